@@ -1,0 +1,168 @@
+/*
+ * helen_hip.h -- C ABI of libhelen_hip.so, the MI355X (gfx950) implementation of the
+ * `helen polish` / `call_consensus` RNN inference path of kishwarshafin/helen.
+ *
+ * Every entry point replaces one Python-level interface of the reference; citations are
+ * file:line into the reference tree.  The library is plain HIP (no torch types): all buffers are
+ * raw pointers, `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *
+ * Conventions
+ *   - every function returns HELEN_OK (0) or a negative HELEN_E* code and never throws;
+ *     helen_last_error() returns a thread-local, NUL-terminated description of the last failure.
+ *   - a HelenModel is bound to one device (one process per GPU, `models/predict_gpu.py:223`);
+ *     calls on one handle must be serialised by the caller (one host thread / one stream at a time).
+ *   - "window" = one MarginPolish pileup image, SEQ_LENGTH(1000) positions x features(90) uint8
+ *     (`Options.py:13-21`); "chunk" = TRAIN_WINDOW(100) consecutive positions, stride
+ *     WINDOW_JUMP(50), 19 per window (`Options.py:24-29`, `models/predict_gpu.py:114-117`).
+ */
+#ifndef HELEN_HIP_H
+#define HELEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HELEN_ABI_VERSION 1
+
+enum {
+    HELEN_OK = 0,
+    HELEN_EINVAL = -1,   /* bad argument (null pointer, size out of range, unsupported geometry) */
+    HELEN_ENOMEM = -2,   /* device or host allocation failed */
+    HELEN_EHIP = -3,     /* a HIP runtime call failed; see helen_last_error() */
+    HELEN_ENODEV = -4    /* no usable gfx950 device / wrong architecture */
+};
+
+/* Geometry constants of the path (`Options.py:13-29`). */
+#define HELEN_SEQ_LENGTH 1000
+#define HELEN_TRAIN_WINDOW 100
+#define HELEN_WINDOW_JUMP 50
+#define HELEN_NUM_CHUNKS 19
+#define HELEN_HIDDEN 128
+#define HELEN_FEATURES 90
+#define HELEN_BASE_LABELS 5
+#define HELEN_RLE_LABELS 11
+
+/*
+ * Host-side view of the TransducerGRU parameter set, exactly the tensors of the reference
+ * model's state_dict (`models/TransducerModel.py:43-58`; loaded by
+ * `models/ModelHander.py:50-78`).  All pointers are HOST pointers to row-major float32.
+ * Index 0 = forward direction (`*_l0`), 1 = reverse (`*_l0_reverse`).  Gate row order inside each
+ * 3H block is PyTorch's r, z, n.
+ */
+typedef struct HelenWeights {
+    int32_t features;          /* F: encoder input width, 90 */
+    int32_t hidden;            /* H: GRU width, 128 */
+    int32_t n_base;            /* 5 */
+    int32_t n_rle;             /* 11 */
+    const float* enc_w_ih[2];  /* [3H, F]   gru_encoder.weight_ih_l0{,_reverse} */
+    const float* enc_w_hh[2];  /* [3H, H]   gru_encoder.weight_hh_l0{,_reverse} */
+    const float* enc_b_ih[2];  /* [3H] */
+    const float* enc_b_hh[2];  /* [3H] */
+    const float* dec_w_ih[2];  /* [3H, 2H]  gru_decoder.weight_ih_l0{,_reverse} */
+    const float* dec_w_hh[2];  /* [3H, H] */
+    const float* dec_b_ih[2];  /* [3H] */
+    const float* dec_b_hh[2];  /* [3H] */
+    const float* base_w;       /* [n_base, 2H]  dense1_base.weight */
+    const float* base_b;       /* [n_base] */
+    const float* rle_w;        /* [n_rle, 2H]   dense2_rle.weight */
+    const float* rle_b;        /* [n_rle] */
+} HelenWeights;
+
+typedef struct HelenModel HelenModel;
+
+/* Arithmetic used for the GRU gate matmuls. */
+enum {
+    HELEN_PRECISION_FP32 = 0,  /* v_mfma_f32_16x16x4_f32, exact fp32 (BASELINE.json configs 1-3) */
+    HELEN_PRECISION_BF16 = 1   /* bf16 MFMA operands, fp32 accumulate/state (config 4) */
+};
+
+/* Kernel classes reported by helen_get_kernel_stats(). */
+enum {
+    HELEN_K_PACK = 0,        /* uint8 image -> fp32 MFMA operand tiles */
+    HELEN_K_GEMM_ENC = 1,    /* encoder input projection  X.W_ih^T + b */
+    HELEN_K_GRU_ENC = 2,     /* encoder recurrence (100 dependent steps, both directions) */
+    HELEN_K_GEMM_DEC = 3,    /* decoder input projection  Y1.W_ih^T + b */
+    HELEN_K_GRU_DEC = 4,     /* decoder recurrence */
+    HELEN_K_HEADS = 5,       /* heads + softmax + accumulate + argmax */
+    HELEN_K_COUNT = 6
+};
+
+/* ABI version of the loaded library (== HELEN_ABI_VERSION of the header it was built from). */
+int helen_abi_version(void);
+
+/* Description of the most recent failure on the calling thread ("" if none). */
+const char* helen_last_error(void);
+
+/*
+ * Build a device-resident model: validates the geometry, packs the weights into the MFMA
+ * fragment layouts the kernels consume and allocates scratch for up to `max_windows` windows per
+ * call.  Replaces `ModelHandler.load_simple_model(...)` + `transducer_model.to(device_id)`
+ * (`models/ModelHander.py:38-82`, `models/predict_gpu.py:58-69`).
+ *   device       HIP device ordinal (`torch.cuda.set_device(device_id)`, predict_gpu.py:67)
+ *   max_windows  capacity in windows of one helen_polish_batch / helen_gru_chunk_forward call
+ *   precision    HELEN_PRECISION_*
+ */
+int helen_model_create(const HelenWeights* weights, int device, int max_windows, int precision,
+                       HelenModel** out_model);
+
+int helen_model_destroy(HelenModel* model);
+
+/* Bytes of device memory the model holds (packed weights + scratch). */
+int helen_model_device_bytes(const HelenModel* model, size_t* out_bytes);
+
+/*
+ * The whole per-batch body of the reference loop (`models/predict_gpu.py:97-159`): uint8 -> f32,
+ * zero initial hidden, 19 chunks of TransducerGRU.forward with the hidden state carried
+ * chunk-to-chunk, per-chunk softmax zero-padded and added into [n,1000,C] accumulators, argmax
+ * (first maximum on ties, like torch.max on CPU, predict_gpu.py:155-156).
+ *   images        DEVICE pointer, uint8 [n_windows, 1000, F] (what SequenceDataset yields per item,
+ *                 `models/dataloader_predict.py:69`, already padded to 1000 positions)
+ *   n_windows     1 .. max_windows; windows are independent, so several loader batches may be
+ *                 coalesced into one call
+ *   bases, rles   DEVICE pointers, uint8 [n_windows, 1000] (what DataStore stores, DataStore.py:126-133)
+ *   acc_base_opt  optional DEVICE pointer float32 [n_windows, 1000, 5]  (prediction_base_tensor)
+ *   acc_rle_opt   optional DEVICE pointer float32 [n_windows, 1000, 11] (prediction_rle_tensor)
+ * Asynchronous with respect to the host: work is enqueued on `stream`.
+ */
+int helen_polish_batch(HelenModel* model, const uint8_t* images, int n_windows, uint8_t* bases,
+                       uint8_t* rles, float* acc_base_opt, float* acc_rle_opt, void* stream);
+
+/*
+ * Same, from HOST memory: `images` is a host pointer (pinned or pageable); the library streams
+ * sub-batches through two pinned staging buffers with hipMemcpyAsync on a copy stream,
+ * overlapped with compute, and writes labels back to host `bases`/`rles`.  Synchronous: returns
+ * when the labels are in host memory.  Replaces the DataLoader -> `.to(device_id)` ->
+ * `.cpu()` hand-offs of `models/predict_gpu.py:94-159`.
+ */
+int helen_polish_host(HelenModel* model, const uint8_t* images, int n_windows, uint8_t* bases,
+                      uint8_t* rles, void* stream);
+
+/*
+ * One TransducerGRU.forward call (`models/TransducerModel.py:60-79`), the operator-level
+ * boundary invoked at `models/predict_gpu.py:129`:
+ *   x      DEVICE float32 [B, T, F]           (T <= 100)
+ *   h_in   DEVICE float32 [B, 2, H]           (index 0 forward, 1 backward)
+ *   base   DEVICE float32 [B, T, 5]   logits  (dense1_base)
+ *   rle    DEVICE float32 [B, T, 11]  logits  (dense2_rle)
+ *   h_out  DEVICE float32 [B, 2, H]           decoder h_n
+ */
+int helen_gru_chunk_forward(HelenModel* model, const float* x, const float* h_in, int B, int T,
+                            float* base, float* rle, float* h_out, void* stream);
+
+/*
+ * Per-kernel-class timing with HIP events on the launch stream.  When enabled, each launch of a
+ * class selected in `class_mask` (bit i = HELEN_K_*) is bracketed by an event pair; stats
+ * accumulate until reset.  helen_get_kernel_stats synchronises the recorded events.
+ */
+int helen_set_profiling(HelenModel* model, unsigned class_mask);
+int helen_reset_kernel_stats(HelenModel* model);
+int helen_get_kernel_stats(HelenModel* model, int kernel_class, double* out_total_ms,
+                           long long* out_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HELEN_HIP_H */

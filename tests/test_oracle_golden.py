@@ -1,0 +1,56 @@
+"""The CPU oracle (oracle/helen_oracle.c) against the golden vectors produced by the reference's
+own TransducerGRU (tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+import oracle
+from golden_cases import (ACC_ATOL, HIDDEN_ATOL, LOGIT_ATOL, LOGIT_RTOL, label_mismatch_report,
+                          load_case)
+
+
+@pytest.mark.parametrize("case", ["trace6", "small_input6"])
+def test_oracle_polish_matches_reference_traces(case):
+    w, img, g = load_case(case)
+    o = oracle.polish_batch(w, img, traces=True)
+    # hidden carried chunk to chunk (predict_gpu.py:129)
+    np.testing.assert_allclose(o["hidden"], g["hidden"], atol=HIDDEN_ATOL, rtol=0)
+    # per-chunk logits of chunks 0, 9, 18
+    np.testing.assert_allclose(o["logit_base"][[0, 9, 18]], g["logit_base"], atol=LOGIT_ATOL,
+                               rtol=LOGIT_RTOL)
+    np.testing.assert_allclose(o["logit_rle"][[0, 9, 18]], g["logit_rle"], atol=LOGIT_ATOL,
+                               rtol=LOGIT_RTOL)
+    # accumulated softmax (first 3 windows stored)
+    np.testing.assert_allclose(o["acc_base"][:3], g["acc_base"], atol=ACC_ATOL, rtol=0)
+    np.testing.assert_allclose(o["acc_rle"][:3], g["acc_rle"], atol=ACC_ATOL, rtol=0)
+    # argmax labels bit-identical
+    nb, rep = label_mismatch_report(g["acc_base"], g["bases"], o["bases"], "base")
+    assert nb == 0, rep
+    nr, rep = label_mismatch_report(g["acc_rle"], g["rles"], o["rles"], "rle")
+    assert nr == 0, rep
+
+
+@pytest.mark.parametrize("case", ["trace6", "small_input6"])
+def test_oracle_forward_matches_reference(case):
+    """One TransducerGRU.forward with T=37 and a non-zero incoming hidden."""
+    w, _, g = load_case(case)
+    base, rle, h = oracle.gru_chunk_forward(w, g["fwd_x"], g["fwd_h0"])
+    np.testing.assert_allclose(base, g["fwd_base"], atol=LOGIT_ATOL, rtol=LOGIT_RTOL)
+    np.testing.assert_allclose(rle, g["fwd_rle"], atol=LOGIT_ATOL, rtol=LOGIT_RTOL)
+    np.testing.assert_allclose(h, g["fwd_h"], atol=HIDDEN_ATOL, rtol=0)
+
+
+def test_oracle_config1_labels():
+    """BASELINE.json configs[0]: 100 windows (reference ran them at batch 4) -> identical labels."""
+    w, img, g = load_case("config1_100")
+    o = oracle.polish_batch(w, img[:24])
+    assert np.array_equal(o["bases"], g["bases"][:24])
+    assert np.array_equal(o["rles"], g["rles"][:24])
+
+
+def test_oracle_batch_independence():
+    """Rows of a batch never interact and hidden is re-zeroed per batch (predict_gpu.py:99)."""
+    w, img, _ = load_case("trace6")
+    a = oracle.polish_batch(w, img[:4])
+    b = oracle.polish_batch(w, img[2:3])
+    assert np.array_equal(a["bases"][2], b["bases"][0])
+    assert np.array_equal(a["acc_rle"][2], b["acc_rle"][0])
