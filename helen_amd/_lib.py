@@ -1,0 +1,96 @@
+"""ctypes binding of libhelen_hip.so (C ABI in include/helen_hip.h).
+
+The HIP library is the product: there is no CPU fallback.  If the shared object is missing or
+fails to load, importing the compute entry points raises -- loudly -- rather than degrading.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhelen_hip.so")
+
+HELEN_ABI_VERSION = 1
+HELEN_OK = 0
+HELEN_PRECISION_FP32 = 0
+HELEN_PRECISION_BF16 = 1
+
+KERNEL_CLASSES = ("pack", "gemm_enc", "gru_enc", "gemm_dec", "gru_dec", "heads")
+
+# every symbol include/helen_hip.h declares
+EXPORTS = (
+    "helen_abi_version", "helen_last_error", "helen_model_create", "helen_model_destroy",
+    "helen_model_device_bytes", "helen_polish_batch", "helen_polish_host",
+    "helen_gru_chunk_forward", "helen_set_profiling", "helen_reset_kernel_stats",
+    "helen_get_kernel_stats",
+)
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+
+
+class HelenWeightsC(ctypes.Structure):
+    """`HelenWeights` of include/helen_hip.h."""
+    _fields_ = [
+        ("features", ctypes.c_int32), ("hidden", ctypes.c_int32),
+        ("n_base", ctypes.c_int32), ("n_rle", ctypes.c_int32),
+        ("enc_w_ih", _f32p * 2), ("enc_w_hh", _f32p * 2),
+        ("enc_b_ih", _f32p * 2), ("enc_b_hh", _f32p * 2),
+        ("dec_w_ih", _f32p * 2), ("dec_w_hh", _f32p * 2),
+        ("dec_b_ih", _f32p * 2), ("dec_b_hh", _f32p * 2),
+        ("base_w", _f32p), ("base_b", _f32p), ("rle_w", _f32p), ("rle_b", _f32p),
+    ]
+
+
+class HelenError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libhelen_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libhelen_hip.so once; raise if it is absent (build with `python __graft_entry__.py`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "helen_amd: %s not found. The HIP library is required (there is no CPU fallback); "
+            "build it with `make -C helen_amd/csrc` or `python __graft_entry__.py`." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.helen_abi_version.restype = ci
+    lib.helen_abi_version.argtypes = []
+    lib.helen_last_error.restype = ctypes.c_char_p
+    lib.helen_last_error.argtypes = []
+    lib.helen_model_create.restype = ci
+    lib.helen_model_create.argtypes = [ctypes.POINTER(HelenWeightsC), ci, ci, ci,
+                                       ctypes.POINTER(vp)]
+    lib.helen_model_destroy.restype = ci
+    lib.helen_model_destroy.argtypes = [vp]
+    lib.helen_model_device_bytes.restype = ci
+    lib.helen_model_device_bytes.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t)]
+    lib.helen_polish_batch.restype = ci
+    lib.helen_polish_batch.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp]
+    lib.helen_polish_host.restype = ci
+    lib.helen_polish_host.argtypes = [vp, vp, ci, vp, vp, vp]
+    lib.helen_gru_chunk_forward.restype = ci
+    lib.helen_gru_chunk_forward.argtypes = [vp, vp, vp, ci, ci, vp, vp, vp, vp]
+    lib.helen_set_profiling.restype = ci
+    lib.helen_set_profiling.argtypes = [vp, ctypes.c_uint]
+    lib.helen_reset_kernel_stats.restype = ci
+    lib.helen_reset_kernel_stats.argtypes = [vp]
+    lib.helen_get_kernel_stats.restype = ci
+    lib.helen_get_kernel_stats.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double),
+                                           ctypes.POINTER(ctypes.c_longlong)]
+    got = lib.helen_abi_version()
+    if got != HELEN_ABI_VERSION:
+        raise ImportError("libhelen_hip.so ABI %d != binding ABI %d; rebuild" % (got, HELEN_ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != HELEN_OK:
+        raise HelenError(rc, load().helen_last_error().decode("utf-8", "replace"))

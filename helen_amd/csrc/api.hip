@@ -1,0 +1,471 @@
+// api.hip -- host side of libhelen_hip.so: the C ABI declared in include/helen_hip.h.
+//
+// Owns the packed weights and the scratch, and issues the launch sequence of the polish path
+// (reference: helen/modules/python/models/predict_gpu.py:97-159 around
+// models/TransducerModel.py:60-79).  No torch, no exceptions across the ABI.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/helen_hip.h"
+#include "kernels.h"
+
+using namespace helen;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(e_ == hipErrorOutOfMemory ? HELEN_ENOMEM : HELEN_EHIP, "%s: %s",   \
+                        #expr, hipGetErrorString(e_));                                      \
+    } while (0)
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct HelenModel {
+    int device = 0;
+    int precision = 0;
+    int max_windows = 0;
+    int max_tiles = 0;
+    size_t device_bytes = 0;
+    // packed parameters (device)
+    f32x4* wp_enc = nullptr;   // [2][24][6][64]
+    f32x4* wp_dec = nullptr;   // [2][24][16][64]
+    f32x4* whp_enc = nullptr;  // [2][4][48][64]
+    f32x4* whp_dec = nullptr;
+    f32x4* whd = nullptr;      // [16][64]
+    float* bias_enc = nullptr; // [2][384]
+    float* bias_dec = nullptr;
+    float* bhn_enc = nullptr;  // [2][128]
+    float* bhn_dec = nullptr;
+    float* bhd = nullptr;      // [16]
+    // scratch (device)
+    f32x4* xa = nullptr;
+    f32x4* gi_enc = nullptr;
+    f32x4* gi_dec = nullptr;
+    f32x4* y1 = nullptr;
+    f32x4* y2 = nullptr;
+    f32x4* hid = nullptr;
+    f32x4* pending = nullptr;
+    // host-streaming path (helen_polish_host)
+    uint8_t* pin_in[2] = {nullptr, nullptr};
+    uint8_t* pin_out[2] = {nullptr, nullptr};
+    uint8_t* dev_in[2] = {nullptr, nullptr};
+    uint8_t* dev_out[2] = {nullptr, nullptr};
+    hipStream_t h2d_stream = nullptr;
+    hipStream_t d2h_stream = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr};
+    hipEvent_t ev_done[2] = {nullptr, nullptr};
+    hipEvent_t ev_out[2] = {nullptr, nullptr};
+    // profiling
+    unsigned prof_mask = 0;
+    std::vector<EventPair> prof[HELEN_K_COUNT];
+    double prof_ms[HELEN_K_COUNT] = {0};
+    long long prof_n[HELEN_K_COUNT] = {0};
+};
+
+namespace {
+
+constexpr long kXaTileStride = (long)kSeq * (kXaStride / 4);        // float4
+constexpr long kGiEncTileStride = (long)kSeq * (kGiStride / 4);
+constexpr long kGiDecTileStride = (long)kWin * (kGiStride / 4);
+constexpr long kYTileStride = (long)kWin * (kYStride / 4);
+
+template <typename T>
+int dev_alloc(HelenModel* m, T** p, size_t count) {
+    HIP_TRY(hipMalloc((void**)p, count * sizeof(T)));
+    m->device_bytes += count * sizeof(T);
+    return HELEN_OK;
+}
+
+template <typename T>
+int upload(HelenModel* m, T** p, const std::vector<T>& host) {
+    int rc = dev_alloc(m, p, host.size());
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(*p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return HELEN_OK;
+}
+
+// B operand of the input projections: Wp[((dir*24 + nt)*MG + m)*64 + lane][e] =
+//   W_ih[dir][16nt + (lane & 15)][k = 16m + 4(lane >> 4) + e], zero past K.
+std::vector<f32x4> pack_w_ih(const float* const w[2], int K, int MG) {
+    std::vector<f32x4> out((size_t)2 * kNTile * MG * 64);
+    for (int dir = 0; dir < 2; ++dir)
+        for (int nt = 0; nt < kNTile; ++nt)
+            for (int m = 0; m < MG; ++m)
+                for (int lane = 0; lane < 64; ++lane) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    const int row = 16 * nt + (lane & 15);
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 16 * m + 4 * (lane >> 4) + e;
+                        if (k < K) v[e] = w[dir][(size_t)row * K + k];
+                    }
+                    out[((size_t)(dir * kNTile + nt) * MG + m) * 64 + lane] = v;
+                }
+    return out;
+}
+
+// B operand of the recurrence, per wave: Whp[((dir*4 + w)*48 + n*8 + m)*64 + lane][e] =
+//   W_hh[dir][g*128 + 32w + 16hh + (lane & 15)][16m + 4(lane >> 4) + e],  n = 2g + hh.
+std::vector<f32x4> pack_w_hh(const float* const w[2]) {
+    std::vector<f32x4> out((size_t)2 * 4 * 48 * 64);
+    for (int dir = 0; dir < 2; ++dir)
+        for (int wv = 0; wv < 4; ++wv)
+            for (int n = 0; n < 6; ++n)
+                for (int m = 0; m < 8; ++m)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int g = n >> 1, hh = n & 1;
+                        const int row = g * kH + 32 * wv + 16 * hh + (lane & 15);
+                        f32x4 v;
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = w[dir][(size_t)row * kH + 16 * m + 4 * (lane >> 4) + e];
+                        out[((size_t)(dir * 4 + wv) * 48 + n * 8 + m) * 64 + lane] = v;
+                    }
+    return out;
+}
+
+void record_begin(HelenModel* m, int cls, hipStream_t s, EventPair* ev, bool* on) {
+    *on = (m->prof_mask >> cls) & 1u;
+    if (!*on) return;
+    if (hipEventCreate(&ev->a) != hipSuccess || hipEventCreate(&ev->b) != hipSuccess) {
+        *on = false;
+        return;
+    }
+    (void)hipEventRecord(ev->a, s);
+}
+void record_end(HelenModel* m, int cls, hipStream_t s, EventPair* ev, bool on) {
+    if (!on) return;
+    (void)hipEventRecord(ev->b, s);
+    m->prof[cls].push_back(*ev);
+}
+
+#define LAUNCH(cls, kernel, grid, block, ...)                                        \
+    do {                                                                             \
+        EventPair ev_;                                                               \
+        bool on_;                                                                    \
+        record_begin(m, cls, s, &ev_, &on_);                                         \
+        hipLaunchKernelGGL(kernel, grid, block, 0, s, __VA_ARGS__);                  \
+        record_end(m, cls, s, &ev_, on_);                                            \
+    } while (0)
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(HELEN_EHIP, "%s: launch failed: %s", what, hipGetErrorString(e));
+    return HELEN_OK;
+}
+
+// One TransducerGRU.forward over `tiles` tiles whose encoder pre-activations are already in
+// gi_enc at positions [pos0, pos0+T): encoder recurrence -> decoder projection -> decoder
+// recurrence.  y2 then holds the decoder output, hid the returned hidden state.
+void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T) {
+    LAUNCH(HELEN_K_GRU_ENC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
+           T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride);
+    LAUNCH(HELEN_K_GEMM_DEC, gemm_gi_kernel<16>, dim3((T + 3) / 4, tiles), dim3(512), m->y1,
+           kYTileStride, m->wp_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T);
+    LAUNCH(HELEN_K_GRU_DEC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, T,
+           m->whp_dec, m->bhn_dec, m->hid, m->y2, kYTileStride);
+}
+
+void free_model(HelenModel* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    void* ptrs[] = {m->wp_enc, m->wp_dec, m->whp_enc, m->whp_dec, m->whd, m->bias_enc, m->bias_dec,
+                    m->bhn_enc, m->bhn_dec, m->bhd, m->xa, m->gi_enc, m->gi_dec, m->y1, m->y2,
+                    m->hid, m->pending, m->dev_in[0], m->dev_in[1], m->dev_out[0], m->dev_out[1]};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (int i = 0; i < 2; ++i) {
+        if (m->pin_in[i]) (void)hipHostFree(m->pin_in[i]);
+        if (m->pin_out[i]) (void)hipHostFree(m->pin_out[i]);
+        if (m->ev_in[i]) (void)hipEventDestroy(m->ev_in[i]);
+        if (m->ev_done[i]) (void)hipEventDestroy(m->ev_done[i]);
+        if (m->ev_out[i]) (void)hipEventDestroy(m->ev_out[i]);
+    }
+    if (m->h2d_stream) (void)hipStreamDestroy(m->h2d_stream);
+    if (m->d2h_stream) (void)hipStreamDestroy(m->d2h_stream);
+    for (int c = 0; c < HELEN_K_COUNT; ++c)
+        for (auto& e : m->prof[c]) {
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
+    delete m;
+}
+
+int create_impl(const HelenWeights* w, int device, int max_windows, int precision, HelenModel* m) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(HELEN_ENODEV, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(HELEN_EINVAL, "device %d out of range (%d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(HELEN_ENODEV, "device %d is %s; this library is built for gfx950 only", device,
+                    prop.gcnArchName);
+    m->device = device;
+    m->precision = precision;
+    m->max_windows = max_windows;
+    m->max_tiles = (max_windows + kTile - 1) / kTile;
+
+    int rc;
+    if ((rc = upload(m, &m->wp_enc, pack_w_ih(w->enc_w_ih, kF, kFPad / 16)))) return rc;
+    if ((rc = upload(m, &m->wp_dec, pack_w_ih(w->dec_w_ih, 2 * kH, 16)))) return rc;
+    if ((rc = upload(m, &m->whp_enc, pack_w_hh(w->enc_w_hh)))) return rc;
+    if ((rc = upload(m, &m->whp_dec, pack_w_hh(w->dec_w_hh)))) return rc;
+    {
+        std::vector<f32x4> whd(16 * 64);
+        for (int mg = 0; mg < 16; ++mg)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int j = lane & 15;
+                f32x4 v;
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 16 * mg + 4 * (lane >> 4) + e;
+                    v[e] = j < kNB ? w->base_w[(size_t)j * 2 * kH + k]
+                                   : w->rle_w[(size_t)(j - kNB) * 2 * kH + k];
+                }
+                whd[mg * 64 + lane] = v;
+            }
+        if ((rc = upload(m, &m->whd, whd))) return rc;
+        std::vector<float> bhd(16);
+        for (int j = 0; j < 16; ++j) bhd[j] = j < kNB ? w->base_b[j] : w->rle_b[j - kNB];
+        if ((rc = upload(m, &m->bhd, bhd))) return rc;
+    }
+    for (int layer = 0; layer < 2; ++layer) {
+        const float* const* b_ih = layer ? w->dec_b_ih : w->enc_b_ih;
+        const float* const* b_hh = layer ? w->dec_b_hh : w->enc_b_hh;
+        std::vector<float> bias(2 * kG), bhn(2 * kH);
+        for (int dir = 0; dir < 2; ++dir) {
+            for (int c = 0; c < kG; ++c)
+                bias[dir * kG + c] = b_ih[dir][c] + (c < 2 * kH ? b_hh[dir][c] : 0.f);
+            for (int u = 0; u < kH; ++u) bhn[dir * kH + u] = b_hh[dir][2 * kH + u];
+        }
+        if ((rc = upload(m, layer ? &m->bias_dec : &m->bias_enc, bias))) return rc;
+        if ((rc = upload(m, layer ? &m->bhn_dec : &m->bhn_enc, bhn))) return rc;
+    }
+    const size_t nt = (size_t)m->max_tiles;
+    if ((rc = dev_alloc(m, &m->xa, nt * kXaTileStride))) return rc;
+    if ((rc = dev_alloc(m, &m->gi_enc, nt * kGiEncTileStride))) return rc;
+    if ((rc = dev_alloc(m, &m->gi_dec, nt * kGiDecTileStride))) return rc;
+    if ((rc = dev_alloc(m, &m->y1, nt * kYTileStride))) return rc;
+    if ((rc = dev_alloc(m, &m->y2, nt * kYTileStride))) return rc;
+    if ((rc = dev_alloc(m, &m->hid, nt * (kHidStride / 4)))) return rc;
+    if ((rc = dev_alloc(m, &m->pending, nt * 2 * kJump * 64))) return rc;
+    return HELEN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int helen_abi_version(void) { return HELEN_ABI_VERSION; }
+
+const char* helen_last_error(void) { return g_err; }
+
+int helen_model_create(const HelenWeights* w, int device, int max_windows, int precision,
+                       HelenModel** out_model) {
+    if (!w || !out_model) return fail(HELEN_EINVAL, "null argument");
+    *out_model = nullptr;
+    if (w->features != kF || w->hidden != kH || w->n_base != kNB || w->n_rle != kNR)
+        return fail(HELEN_EINVAL,
+                    "unsupported geometry F=%d H=%d base=%d rle=%d (built for %d/%d/%d/%d, Options.py:13-29)",
+                    w->features, w->hidden, w->n_base, w->n_rle, kF, kH, kNB, kNR);
+    if (max_windows <= 0) return fail(HELEN_EINVAL, "max_windows must be > 0");
+    if (precision != HELEN_PRECISION_FP32)
+        return fail(HELEN_EINVAL, "precision %d not available in this build", precision);
+    for (int d = 0; d < 2; ++d)
+        if (!w->enc_w_ih[d] || !w->enc_w_hh[d] || !w->enc_b_ih[d] || !w->enc_b_hh[d] ||
+            !w->dec_w_ih[d] || !w->dec_w_hh[d] || !w->dec_b_ih[d] || !w->dec_b_hh[d])
+            return fail(HELEN_EINVAL, "null weight pointer");
+    if (!w->base_w || !w->base_b || !w->rle_w || !w->rle_b) return fail(HELEN_EINVAL, "null head pointer");
+    HelenModel* m = new (std::nothrow) HelenModel();
+    if (!m) return fail(HELEN_ENOMEM, "host allocation failed");
+    int rc = create_impl(w, device, max_windows, precision, m);
+    if (rc != HELEN_OK) {
+        free_model(m);
+        return rc;
+    }
+    *out_model = m;
+    return HELEN_OK;
+}
+
+int helen_model_destroy(HelenModel* m) {
+    free_model(m);
+    return HELEN_OK;
+}
+
+int helen_model_device_bytes(const HelenModel* m, size_t* out_bytes) {
+    if (!m || !out_bytes) return fail(HELEN_EINVAL, "null argument");
+    *out_bytes = m->device_bytes;
+    return HELEN_OK;
+}
+
+int helen_polish_batch(HelenModel* m, const uint8_t* images, int n_windows, uint8_t* bases,
+                       uint8_t* rles, float* acc_base_opt, float* acc_rle_opt, void* stream) {
+    if (!m || !images || !bases || !rles) return fail(HELEN_EINVAL, "null argument");
+    if (n_windows <= 0 || n_windows > m->max_windows)
+        return fail(HELEN_EINVAL, "n_windows %d outside 1..%d", n_windows, m->max_windows);
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = (n_windows + kTile - 1) / kTile;
+
+    // uint8 -> fp32 operand tiles (predict_gpu.py:97)
+    LAUNCH(HELEN_K_PACK, pack_images_kernel, dim3((kSeq * (kXaStride / 4) + 255) / 256, tiles),
+           dim3(256), images, n_windows, kSeq, m->xa);
+    // encoder input projection for all 1000 positions at once: overlapping chunks share it
+    LAUNCH(HELEN_K_GEMM_ENC, gemm_gi_kernel<kFPad / 16>, dim3(kSeq / 4, tiles), dim3(512), m->xa,
+           kXaTileStride, m->wp_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, kSeq);
+    // zero initial hidden per batch (predict_gpu.py:99)
+    HIP_TRY(hipMemsetAsync(m->hid, 0, (size_t)tiles * kHidStride * sizeof(float), s));
+    for (int c = 0; c < kChunks; ++c) {  // predict_gpu.py:114-149
+        launch_chunk(m, s, tiles, c * kJump, kWin);
+        LAUNCH(HELEN_K_HEADS, heads_kernel, dim3(tiles, 2), dim3(256), m->y2, kYTileStride, m->whd,
+               m->bhd, 0, c, kWin, n_windows, m->pending, bases, rles, acc_base_opt, acc_rle_opt,
+               (float*)nullptr, (float*)nullptr);
+    }
+    return check_launch("helen_polish_batch");
+}
+
+int helen_gru_chunk_forward(HelenModel* m, const float* x, const float* h_in, int B, int T,
+                            float* base, float* rle, float* h_out, void* stream) {
+    if (!m || !x || !h_in || !base || !rle || !h_out) return fail(HELEN_EINVAL, "null argument");
+    if (B <= 0 || B > m->max_windows) return fail(HELEN_EINVAL, "B %d outside 1..%d", B, m->max_windows);
+    if (T <= 0 || T > kWin) return fail(HELEN_EINVAL, "T %d outside 1..%d (TRAIN_WINDOW)", T, kWin);
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = (B + kTile - 1) / kTile;
+    LAUNCH(HELEN_K_PACK, pack_x_f32_kernel, dim3((T * (kXaStride / 4) + 255) / 256, tiles), dim3(256),
+           x, B, T, m->xa, kXaTileStride);
+    hipLaunchKernelGGL(pack_hidden_kernel, dim3(tiles), dim3(256), 0, s, h_in, B, (float*)m->hid);
+    LAUNCH(HELEN_K_GEMM_ENC, gemm_gi_kernel<kFPad / 16>, dim3((T + 3) / 4, tiles), dim3(512), m->xa,
+           kXaTileStride, m->wp_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, T);
+    launch_chunk(m, s, tiles, 0, T);
+    LAUNCH(HELEN_K_HEADS, heads_kernel, dim3(tiles, (T + kJump - 1) / kJump), dim3(256), m->y2,
+           kYTileStride, m->whd, m->bhd, 1, 0, T, B, m->pending, (uint8_t*)nullptr, (uint8_t*)nullptr,
+           (float*)nullptr, (float*)nullptr, base, rle);
+    hipLaunchKernelGGL(unpack_hidden_kernel, dim3(tiles), dim3(256), 0, s, (const float*)m->hid, B,
+                       h_out);
+    return check_launch("helen_gru_chunk_forward");
+}
+
+int helen_polish_host(HelenModel* m, const uint8_t* images, int n_windows, uint8_t* bases,
+                      uint8_t* rles, void* stream) {
+    if (!m || !images || !bases || !rles) return fail(HELEN_EINVAL, "null argument");
+    if (n_windows <= 0) return fail(HELEN_EINVAL, "n_windows must be > 0");
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int sub = m->max_windows;
+    const size_t img_bytes = (size_t)kSeq * kF, lab_bytes = (size_t)kSeq;
+    if (!m->h2d_stream) {  // lazily build the two-slot pinned staging ring
+        HIP_TRY(hipStreamCreateWithFlags(&m->h2d_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&m->d2h_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipHostMalloc((void**)&m->pin_in[i], sub * img_bytes, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc((void**)&m->pin_out[i], sub * 2 * lab_bytes, hipHostMallocDefault));
+            int rc;
+            if ((rc = dev_alloc(m, &m->dev_in[i], sub * img_bytes))) return rc;
+            if ((rc = dev_alloc(m, &m->dev_out[i], sub * 2 * lab_bytes))) return rc;
+            HIP_TRY(hipEventCreateWithFlags(&m->ev_in[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&m->ev_done[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&m->ev_out[i], hipEventDisableTiming));
+        }
+    }
+    const int nsub = (n_windows + sub - 1) / sub;
+    auto count = [&](int k) { return (k == nsub - 1) ? n_windows - k * sub : sub; };
+    auto drain = [&](int k) -> int {  // labels of sub-batch k: pinned slot -> caller's arrays
+        const int b = k & 1;
+        HIP_TRY(hipEventSynchronize(m->ev_out[b]));
+        memcpy(bases + (size_t)k * sub * lab_bytes, m->pin_out[b], count(k) * lab_bytes);
+        memcpy(rles + (size_t)k * sub * lab_bytes, m->pin_out[b] + (size_t)sub * lab_bytes,
+               count(k) * lab_bytes);
+        return HELEN_OK;
+    };
+    // Slot b = k & 1.  H2D of sub-batch k+1 (h2d stream) overlaps the kernels of sub-batch k
+    // (caller's stream) and the D2H of sub-batch k-1 (d2h stream).
+    for (int k = 0; k < nsub; ++k) {
+        const int b = k & 1;
+        int rc;
+        if (k >= 2 && (rc = drain(k - 2))) return rc;  // slot b is free again after this
+        memcpy(m->pin_in[b], images + (size_t)k * sub * img_bytes, count(k) * img_bytes);
+        HIP_TRY(hipMemcpyAsync(m->dev_in[b], m->pin_in[b], count(k) * img_bytes,
+                               hipMemcpyHostToDevice, m->h2d_stream));
+        HIP_TRY(hipEventRecord(m->ev_in[b], m->h2d_stream));
+        HIP_TRY(hipStreamWaitEvent(s, m->ev_in[b], 0));
+        rc = helen_polish_batch(m, m->dev_in[b], count(k), m->dev_out[b],
+                                m->dev_out[b] + (size_t)sub * lab_bytes, nullptr, nullptr, s);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(m->ev_done[b], s));
+        HIP_TRY(hipStreamWaitEvent(m->d2h_stream, m->ev_done[b], 0));
+        HIP_TRY(hipMemcpyAsync(m->pin_out[b], m->dev_out[b], (size_t)sub * 2 * lab_bytes,
+                               hipMemcpyDeviceToHost, m->d2h_stream));
+        HIP_TRY(hipEventRecord(m->ev_out[b], m->d2h_stream));
+    }
+    for (int k = (nsub >= 2 ? nsub - 2 : 0); k < nsub; ++k) {
+        int rc = drain(k);
+        if (rc) return rc;
+    }
+    return HELEN_OK;
+}
+
+int helen_set_profiling(HelenModel* m, unsigned class_mask) {
+    if (!m) return fail(HELEN_EINVAL, "null argument");
+    m->prof_mask = class_mask;
+    return HELEN_OK;
+}
+
+static int drain_stats(HelenModel* m) {
+    for (int c = 0; c < HELEN_K_COUNT; ++c) {
+        for (auto& e : m->prof[c]) {
+            HIP_TRY(hipEventSynchronize(e.b));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
+            m->prof_ms[c] += ms;
+            m->prof_n[c] += 1;
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
+        m->prof[c].clear();
+    }
+    return HELEN_OK;
+}
+
+int helen_reset_kernel_stats(HelenModel* m) {
+    if (!m) return fail(HELEN_EINVAL, "null argument");
+    int rc = drain_stats(m);
+    for (int c = 0; c < HELEN_K_COUNT; ++c) {
+        m->prof_ms[c] = 0;
+        m->prof_n[c] = 0;
+    }
+    return rc;
+}
+
+int helen_get_kernel_stats(HelenModel* m, int kernel_class, double* out_total_ms, long long* out_launches) {
+    if (!m || !out_total_ms || !out_launches) return fail(HELEN_EINVAL, "null argument");
+    if (kernel_class < 0 || kernel_class >= HELEN_K_COUNT) return fail(HELEN_EINVAL, "bad kernel class");
+    int rc = drain_stats(m);
+    if (rc) return rc;
+    *out_total_ms = m->prof_ms[kernel_class];
+    *out_launches = m->prof_n[kernel_class];
+    return HELEN_OK;
+}
+
+}  // extern "C"

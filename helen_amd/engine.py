@@ -1,0 +1,172 @@
+"""HelenEngine: a device-resident TransducerGRU behind the C ABI.
+
+PyTorch is plumbing here -- it owns device buffers and the stream; all compute is in
+libhelen_hip.so (helen_amd/csrc).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .options import ImageSizeOptions, TrainOptions
+
+_PAIRS = (
+    ("enc_w_ih", "gru_encoder.weight_ih_l0"), ("enc_w_hh", "gru_encoder.weight_hh_l0"),
+    ("enc_b_ih", "gru_encoder.bias_ih_l0"), ("enc_b_hh", "gru_encoder.bias_hh_l0"),
+    ("dec_w_ih", "gru_decoder.weight_ih_l0"), ("dec_w_hh", "gru_decoder.weight_hh_l0"),
+    ("dec_b_ih", "gru_decoder.bias_ih_l0"), ("dec_b_hh", "gru_decoder.bias_hh_l0"),
+)
+
+
+def _as_numpy(v):
+    if isinstance(v, torch.Tensor):
+        v = v.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(v, dtype=np.float32))
+
+
+def weights_struct(state_dict):
+    """state_dict (reference names, TransducerModel.py:43-58; a leading `module.` left by
+    DataParallel/DDP is stripped as ModelHander.py:70-75 does) -> (HelenWeightsC, keepalive)."""
+    sd = {}
+    for k, v in state_dict.items():
+        sd[k[7:] if k.startswith("module.") else k] = v
+    keep = []
+
+    def arr(name):
+        if name not in sd:
+            raise KeyError("missing parameter '%s' in model state" % name)
+        a = _as_numpy(sd[name])
+        keep.append(a)
+        return a
+
+    s = _lib.HelenWeightsC()
+    s.features = arr("gru_encoder.weight_ih_l0").shape[1]
+    s.hidden = arr("gru_encoder.weight_hh_l0").shape[1]
+    s.n_base = arr("dense1_base.weight").shape[0]
+    s.n_rle = arr("dense2_rle.weight").shape[0]
+    fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))  # noqa: E731
+    for field, name in _PAIRS:
+        pair = getattr(s, field)
+        pair[0] = fp(arr(name))
+        pair[1] = fp(arr(name + "_reverse"))
+    s.base_w = fp(arr("dense1_base.weight"))
+    s.base_b = fp(arr("dense1_base.bias"))
+    s.rle_w = fp(arr("dense2_rle.weight"))
+    s.rle_b = fp(arr("dense2_rle.bias"))
+    return s, keep
+
+
+class HelenEngine(object):
+    """One model replica bound to one GPU (one process per GPU, predict_gpu.py:223)."""
+
+    def __init__(self, state_dict, device=0, max_windows=4096, precision="fp32"):
+        self._lib = _lib.load()
+        self._handle = ctypes.c_void_p()
+        if not torch.cuda.is_available():
+            raise RuntimeError("HelenEngine needs a GPU: torch.cuda.is_available() is False and "
+                               "there is no CPU fallback")
+        self.device = torch.device("cuda", int(device))
+        self.max_windows = int(max_windows)
+        prec = {"fp32": _lib.HELEN_PRECISION_FP32, "bf16": _lib.HELEN_PRECISION_BF16}[precision]
+        s, keep = weights_struct(state_dict)
+        _lib.check(self._lib.helen_model_create(ctypes.byref(s), self.device.index,
+                                                self.max_windows, prec,
+                                                ctypes.byref(self._handle)))
+        del keep
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle:
+            self._lib.helen_model_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_bytes(self):
+        n = ctypes.c_size_t()
+        _lib.check(self._lib.helen_model_device_bytes(self._handle, ctypes.byref(n)))
+        return int(n.value)
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def polish(self, images, want_acc=False):
+        """images: uint8 CUDA tensor [n, 1000, 90] -> (bases u8 [n,1000], rles u8 [n,1000]
+        [, acc_base f32 [n,1000,5], acc_rle f32 [n,1000,11]]).  The per-batch body of the
+        reference loop (predict_gpu.py:97-159); asynchronous on the current stream."""
+        assert images.is_cuda and images.dtype == torch.uint8 and images.is_contiguous()
+        n = images.shape[0]
+        assert tuple(images.shape[1:]) == (ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT)
+        bases = torch.empty((n, ImageSizeOptions.SEQ_LENGTH), dtype=torch.uint8, device=images.device)
+        rles = torch.empty_like(bases)
+        acc_b = acc_r = None
+        pb = pr = None
+        if want_acc:
+            acc_b = torch.zeros((n, ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.TOTAL_BASE_LABELS),
+                                dtype=torch.float32, device=images.device)
+            acc_r = torch.zeros((n, ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.TOTAL_RLE_LABELS),
+                                dtype=torch.float32, device=images.device)
+            pb, pr = acc_b.data_ptr(), acc_r.data_ptr()
+        for s in range(0, n, self.max_windows):
+            e = min(n, s + self.max_windows)
+            _lib.check(self._lib.helen_polish_batch(
+                self._handle, images[s:e].data_ptr(), e - s, bases[s:e].data_ptr(),
+                rles[s:e].data_ptr(),
+                None if pb is None else acc_b[s:e].data_ptr(),
+                None if pr is None else acc_r[s:e].data_ptr(), self._stream()))
+        if want_acc:
+            return bases, rles, acc_b, acc_r
+        return bases, rles
+
+    def polish_host(self, images):
+        """images: uint8 numpy / CPU tensor [n,1000,90] -> (bases, rles) numpy u8 [n,1000]; the
+        library double-buffers H2D/D2H against compute (helen_polish_host)."""
+        if isinstance(images, torch.Tensor):
+            images = images.numpy()
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        n = images.shape[0]
+        bases = np.empty((n, ImageSizeOptions.SEQ_LENGTH), np.uint8)
+        rles = np.empty_like(bases)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.helen_polish_host(
+                self._handle, images.ctypes.data, n, bases.ctypes.data, rles.ctypes.data,
+                self._stream()))
+        return bases, rles
+
+    def chunk_forward(self, x, hidden):
+        """TransducerGRU.forward (TransducerModel.py:60-79): x f32 CUDA [B,T,90], hidden f32 CUDA
+        [B,2,128] -> (base [B,T,5], rle [B,T,11], hidden [B,2,128])."""
+        assert x.is_cuda and hidden.is_cuda
+        x = x.contiguous().float()
+        hidden = hidden.contiguous().float()
+        B, T, _ = x.shape
+        base = torch.empty((B, T, ImageSizeOptions.TOTAL_BASE_LABELS), dtype=torch.float32, device=x.device)
+        rle = torch.empty((B, T, ImageSizeOptions.TOTAL_RLE_LABELS), dtype=torch.float32, device=x.device)
+        h_out = torch.empty((B, 2, TrainOptions.HIDDEN_SIZE), dtype=torch.float32, device=x.device)
+        _lib.check(self._lib.helen_gru_chunk_forward(
+            self._handle, x.data_ptr(), hidden.data_ptr(), B, T, base.data_ptr(), rle.data_ptr(),
+            h_out.data_ptr(), self._stream()))
+        return base, rle, h_out
+
+    # ---- per-kernel-class timing (HIP events inside the library) ----
+    def set_profiling(self, classes):
+        mask = 0
+        for c in classes:
+            mask |= 1 << _lib.KERNEL_CLASSES.index(c)
+        _lib.check(self._lib.helen_set_profiling(self._handle, mask))
+
+    def reset_kernel_stats(self):
+        _lib.check(self._lib.helen_reset_kernel_stats(self._handle))
+
+    def kernel_stats(self):
+        out = {}
+        for i, name in enumerate(_lib.KERNEL_CLASSES):
+            ms, n = ctypes.c_double(), ctypes.c_longlong()
+            _lib.check(self._lib.helen_get_kernel_stats(self._handle, i, ctypes.byref(ms), ctypes.byref(n)))
+            out[name] = (ms.value, int(n.value))
+        return out

@@ -1,0 +1,146 @@
+"""Parity of the HIP path (through the C ABI) against the golden vectors of the reference model
+and against the CPU oracle.  Run on the GPU box: pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from golden_cases import (ACC_ATOL, HIDDEN_ATOL, LOGIT_ATOL, LOGIT_RTOL, label_mismatch_report,
+                          load_case)
+from helen_amd.options import chunk_starts
+from helen_amd.weights import make_images, make_weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engines():
+    from helen_amd.engine import HelenEngine
+    cache = {}
+
+    def get(case):
+        if case not in cache:
+            w, img, g = load_case(case)
+            cache[case] = (HelenEngine(w, device=0, max_windows=256), w, img, g)
+        return cache[case]
+    yield get
+    for e, _, _, _ in cache.values():
+        e.close()
+
+
+@pytest.mark.parametrize("case", ["trace6", "small_input6"])
+def test_polish_matches_reference_golden(engines, case):
+    eng, w, img, g = engines(case)
+    bases, rles, acc_b, acc_r = eng.polish(torch.from_numpy(img).cuda(), want_acc=True)
+    torch.cuda.synchronize()
+    bases, rles = bases.cpu().numpy(), rles.cpu().numpy()
+    np.testing.assert_allclose(acc_b.cpu().numpy()[:3], g["acc_base"], atol=ACC_ATOL, rtol=0)
+    np.testing.assert_allclose(acc_r.cpu().numpy()[:3], g["acc_rle"], atol=ACC_ATOL, rtol=0)
+    nb, rep = label_mismatch_report(g["acc_base"], g["bases"], bases, "base")
+    assert nb == 0, rep
+    nr, rep = label_mismatch_report(g["acc_rle"], g["rles"], rles, "rle")
+    assert nr == 0, rep
+
+
+@pytest.mark.parametrize("case", ["trace6", "small_input6"])
+def test_operator_loop_matches_reference_traces(engines, case):
+    """Drive helen_gru_chunk_forward exactly like predict_gpu.py:114-129 and compare the carried
+    hidden state and per-chunk logits with the reference's."""
+    eng, w, img, g = engines(case)
+    images = torch.from_numpy(img).cuda().float()
+    hidden = torch.zeros(img.shape[0], 2, 128, device="cuda")
+    want_logits = {0: 0, 9: 1, 18: 2}
+    for c, i in enumerate(chunk_starts()):
+        base, rle, hidden = eng.chunk_forward(images[:, i:i + 100].contiguous(), hidden)
+        np.testing.assert_allclose(hidden.cpu().numpy(), g["hidden"][c], atol=HIDDEN_ATOL, rtol=0,
+                                   err_msg="hidden after chunk %d" % c)
+        if c in want_logits:
+            k = want_logits[c]
+            np.testing.assert_allclose(base.cpu().numpy(), g["logit_base"][k], atol=LOGIT_ATOL,
+                                       rtol=LOGIT_RTOL)
+            np.testing.assert_allclose(rle.cpu().numpy(), g["logit_rle"][k], atol=LOGIT_ATOL,
+                                       rtol=LOGIT_RTOL)
+
+
+@pytest.mark.parametrize("case", ["trace6", "small_input6"])
+def test_forward_short_chunk_nonzero_hidden(engines, case):
+    """TransducerGRU.forward with T=37 and a non-zero incoming hidden (golden fwd_*)."""
+    eng, w, img, g = engines(case)
+    base, rle, h = eng.chunk_forward(torch.from_numpy(g["fwd_x"]).cuda(),
+                                     torch.from_numpy(g["fwd_h0"]).cuda())
+    np.testing.assert_allclose(base.cpu().numpy(), g["fwd_base"], atol=LOGIT_ATOL, rtol=LOGIT_RTOL)
+    np.testing.assert_allclose(rle.cpu().numpy(), g["fwd_rle"], atol=LOGIT_ATOL, rtol=LOGIT_RTOL)
+    np.testing.assert_allclose(h.cpu().numpy(), g["fwd_h"], atol=HIDDEN_ATOL, rtol=0)
+
+
+def test_config1_labels(engines):
+    """BASELINE.json configs[0]: 100 windows at batch 4 -> labels identical to the reference."""
+    eng, w, img, g = engines("config1_100")
+    dev = torch.from_numpy(img).cuda()
+    bases = np.empty((100, 1000), np.uint8)
+    rles = np.empty((100, 1000), np.uint8)
+    for s in range(0, 100, 4):   # batch 4, as the reference ran it
+        b, r = eng.polish(dev[s:s + 4].contiguous())
+        bases[s:s + 4], rles[s:s + 4] = b.cpu().numpy(), r.cpu().numpy()
+    assert int((bases != g["bases"]).sum()) == 0
+    assert int((rles != g["rles"]).sum()) == 0
+
+
+@pytest.mark.parametrize("n,mode,input_scale", [(40, "uniform", 1.0), (23, "pileup", 1.0 / 64.0)])
+def test_polish_matches_oracle_ragged(n, mode, input_scale):
+    """Seeded windows, a count that is not a multiple of the 16-window tile, vs the CPU oracle."""
+    import oracle
+    from helen_amd.engine import HelenEngine
+    w = make_weights(seed=5, input_scale=input_scale)
+    img = make_images(n, seed=77, mode=mode)
+    o = oracle.polish_batch(w, img)
+    eng = HelenEngine(w, device=0, max_windows=64)
+    bases, rles, acc_b, acc_r = eng.polish(torch.from_numpy(img).cuda(), want_acc=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(acc_b.cpu().numpy(), o["acc_base"], atol=ACC_ATOL, rtol=0)
+    np.testing.assert_allclose(acc_r.cpu().numpy(), o["acc_rle"], atol=ACC_ATOL, rtol=0)
+    nb, rep = label_mismatch_report(o["acc_base"], o["bases"], bases.cpu().numpy(), "base")
+    nr, rep2 = label_mismatch_report(o["acc_rle"], o["rles"], rles.cpu().numpy(), "rle")
+    assert nb == 0 and nr == 0, rep + "\n" + rep2
+    eng.close()
+
+
+def test_batch_split_invariance():
+    """Windows are independent: one call of 48 == calls of 16+32 == max_windows-limited slices."""
+    from helen_amd.engine import HelenEngine
+    w = make_weights(seed=3, input_scale=1.0 / 64.0)
+    img = torch.from_numpy(make_images(48, seed=8)).cuda()
+    big = HelenEngine(w, device=0, max_windows=64)
+    small = HelenEngine(w, device=0, max_windows=20)   # forces 20+20+8 slices, ragged tiles
+    b0, r0 = big.polish(img)
+    b1, r1 = small.polish(img)
+    b2 = torch.cat([big.polish(img[:16].contiguous())[0], big.polish(img[16:].contiguous())[0]])
+    assert torch.equal(b0, b1) and torch.equal(r0, r1) and torch.equal(b0, b2)
+    big.close()
+    small.close()
+
+
+def test_polish_host_matches_device():
+    from helen_amd.engine import HelenEngine
+    w = make_weights(seed=3, input_scale=1.0 / 64.0)
+    img = make_images(70, seed=9)
+    eng = HelenEngine(w, device=0, max_windows=32)   # 32+32+6: exercises the two-slot ring
+    bh, rh = eng.polish_host(img)
+    bd, rd = eng.polish(torch.from_numpy(img).cuda())
+    assert np.array_equal(bh, bd.cpu().numpy()) and np.array_equal(rh, rd.cpu().numpy())
+    eng.close()
+
+
+def test_errors_are_reported():
+    from helen_amd import _lib
+    from helen_amd.engine import HelenEngine
+    w = make_weights()
+    eng = HelenEngine(w, device=0, max_windows=16)
+    x = torch.zeros(2, 101, 90, device="cuda")
+    with pytest.raises(_lib.HelenError):
+        eng.chunk_forward(x, torch.zeros(2, 2, 128, device="cuda"))   # T > TRAIN_WINDOW
+    bad = dict(w)
+    bad["gru_encoder.weight_ih_l0"] = np.zeros((384, 10), np.float32)   # F=10 is not the model's
+    bad["gru_encoder.weight_ih_l0_reverse"] = np.zeros((384, 10), np.float32)
+    with pytest.raises(_lib.HelenError):
+        HelenEngine(bad, device=0, max_windows=16)
+    eng.close()
