@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- pileup windows / second of the `helen polish` inference path on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N > 1 under torch.distributed.run, one
+rank per GPU).  A "step" is one loader batch of 256 synthetic pileup windows (1000 positions x
+90 features, uint8, already resident in HBM) through the whole hot path: uint8->f32, 19 overlapping
+chunks of the 2-layer bidirectional GRU with carried hidden state, heads, softmax-accumulate and
+argmax labels (reference: models/predict_gpu.py:97-159).  Windows are independent, so consecutive
+batches are coalesced `--coalesce` at a time into one helen_polish_batch call; results are
+identical to per-batch calls (tests/test_gpu_parity.py::test_batch_split_invariance).
+
+Prints ONE JSON line (rank 0) with the whole-job windows/s, the MFMA-roofline figures of the
+dominant kernel (the GRU recurrence, timed with HIP events on the launch stream inside the timed
+region) and a CPU baseline (the repo's oracle, a port of the reference algorithm, on the host
+cores of this box).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_WINDOW = 1772441600.0        # 932,864 FLOP/step x 100 steps x 19 chunks
+GRU_FLOP_PER_WINDOW_LAUNCH = 100 * 2 * 2.0 * 384 * 128   # one recurrence launch, both directions
+FP32_MFMA_PEAK = 157.3e12             # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+
+
+def cpu_baseline(batch, seconds_target=12.0):
+    """Time the CPU oracle (port of the reference path) on this box's host cores, bounded."""
+    import numpy as np
+
+    import oracle
+    from helen_amd.weights import make_images, make_weights
+    threads = oracle.max_threads()
+    w = make_weights(input_scale=1.0 / 64.0)
+    probe = make_images(((threads + 7) // 8) * 8, seed=1)   # one 8-window block per thread
+    t0 = time.time()
+    oracle.polish_batch(w, probe)
+    dt = time.time() - t0
+    rate = probe.shape[0] / dt
+    n = int(min(max(rate * seconds_target, probe.shape[0]), 4 * batch))
+    n = max(8, (n // 8) * 8)
+    img = make_images(n, seed=2)
+    t0 = time.time()
+    oracle.polish_batch(w, img)
+    dt = time.time() - t0
+    return {"value": round(n / dt, 2), "unit": "windows/s", "cores": threads, "kind": "port",
+            "sample": "%d uniform-random windows through oracle/helen_oracle.c (fp32, OpenMP over "
+                      "8-window blocks), %.1f s" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=256, help="windows per step (BASELINE.json: 256)")
+    ap.add_argument("--coalesce", type=int, default=16, help="loader batches per device call")
+    ap.add_argument("--mode", default="uniform", choices=["uniform", "pileup"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from helen_amd.engine import HelenEngine
+    from helen_amd.weights import make_weights
+
+    B, G = args.batch, args.coalesce
+    call_windows = B * G
+    eng = HelenEngine(make_weights(input_scale=1.0 / 64.0), device=local_rank, max_windows=call_windows)
+
+    # synthetic chr20-scale image shard, resident in HBM before the timed region; every rank gets
+    # its own shard (weak scaling: images are sharded by file, CallConsensusInterface.py:138-145)
+    n_res = max(args.steps, args.warmup, 1) * B
+    gen = torch.Generator(device=dev).manual_seed(20260928 + rank)
+    if args.mode == "uniform":
+        images = torch.randint(0, 256, (n_res, 1000, 90), dtype=torch.uint8, device=dev, generator=gen)
+    else:
+        images = torch.zeros((n_res, 1000, 90), dtype=torch.uint8, device=dev)
+        cols = torch.randint(0, 90, (n_res, 1000, 4), device=dev, generator=gen)
+        vals = torch.randint(1, 256, (n_res, 1000, 4), dtype=torch.uint8, device=dev, generator=gen)
+        images.scatter_(2, cols, vals)
+    bases = torch.empty((n_res, 1000), dtype=torch.uint8, device=dev)
+    rles = torch.empty_like(bases)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    import ctypes
+
+    from helen_amd import _lib
+    lib = _lib.load()
+
+    def run(n_steps):
+        n = n_steps * B
+        for s in range(0, n, call_windows):
+            e = min(n, s + call_windows)
+            _lib.check(lib.helen_polish_batch(eng._handle, images[s:e].data_ptr(), e - s,
+                                              bases[s:e].data_ptr(), rles[s:e].data_ptr(), None, None,
+                                              ctypes.c_void_p(stream)))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    if args.warmup > 0:
+        run(args.warmup)
+    barrier()
+    eng.set_profiling(["gru_enc", "gru_dec"])   # HIP events around the dominant kernel only
+    eng.reset_kernel_stats()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stats = eng.kernel_stats()
+    eng.set_profiling([])
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_windows = world * args.steps * B
+        value = total_windows / elapsed
+        gru_ms = stats["gru_enc"][0] + stats["gru_dec"][0]
+        gru_n = stats["gru_enc"][1] + stats["gru_dec"][1]
+        avg_ms = gru_ms / max(gru_n, 1)
+        # launches may process a short last group; use the mean windows per launch
+        calls = (args.steps * B + call_windows - 1) // call_windows
+        win_per_launch = args.steps * B / calls
+        achieved = GRU_FLOP_PER_WINDOW_LAUNCH * win_per_launch / (avg_ms * 1e-3) / 1e12
+        out = {
+            "metric": "pileup windows/sec (batch 256, 1000-pos)",
+            "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (%s uint8 windows, seeded; random-init weights of the reference "
+                    "architecture)" % args.mode,
+            "config": {"workload": "BASELINE.json configs[1]: 1xMI355X, batch 256, fp32, synthetic "
+                                   "chr20-scale image shard resident in HBM",
+                       "batch": B, "coalesce_batches_per_call": G, "positions": 1000, "features": 90,
+                       "windows_per_gpu": args.steps * B, "sharding": "by rank, no collective"},
+            "roofline": {"bound": "mfma", "kernel": "gru_kernel (GRU recurrence, fp32 MFMA)",
+                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK / 1e12,
+                         "unit": "TFLOP/s", "frac": round(achieved * 1e12 / FP32_MFMA_PEAK, 4),
+                         "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": gru_n,
+                         "path_frac": round(value / world * FLOP_PER_WINDOW / FP32_MFMA_PEAK, 4)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhelen_hip.so")
+# HELEN_HIP_LIB: developer override to A/B-test kernel variants built side by side.
+LIB_PATH = os.environ.get("HELEN_HIP_LIB") or os.path.join(_HERE, "csrc", "libhelen_hip.so")
 
 HELEN_ABI_VERSION = 1
 HELEN_OK = 0
@@ -58,6 +59,9 @@ def load():
         raise ImportError(
             "helen_amd: %s not found. The HIP library is required (there is no CPU fallback); "
             "build it with `make -C helen_amd/csrc` or `python __graft_entry__.py`." % LIB_PATH)
+    # PyTorch-ROCm carries its own HIP runtime; import it first so that this process has ONE
+    # libamdhip64 (device buffers and streams are torch's and are handed to the library by pointer).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     vp, ci = ctypes.c_void_p, ctypes.c_int
     lib.helen_abi_version.restype = ci

@@ -177,12 +177,13 @@ int check_launch(const char* what) {
 // One TransducerGRU.forward over `tiles` tiles whose encoder pre-activations are already in
 // gi_enc at positions [pos0, pos0+T): encoder recurrence -> decoder projection -> decoder
 // recurrence.  y2 then holds the decoder output, hid the returned hidden state.
-void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T) {
+void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int enc_npos) {
+    // encoder gi holds `enc_npos` positions; the reverse direction is stored time-reversed
     LAUNCH(HELEN_K_GRU_ENC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
-           T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride);
-    LAUNCH(HELEN_K_GEMM_DEC, gemm_gi_kernel<16>, dim3((T + 3) / 4, tiles), dim3(512), m->y1,
+           enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride);
+    LAUNCH(HELEN_K_GEMM_DEC, (gemm_gi_kernel<16, true>), dim3((T + 3) / 4, tiles, 8 / HELEN_GEMM_WAVES), dim3(HELEN_GEMM_WAVES * 64), m->y1,
            kYTileStride, m->wp_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T);
-    LAUNCH(HELEN_K_GRU_DEC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, T,
+    LAUNCH(HELEN_K_GRU_DEC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, 0, T,
            m->whp_dec, m->bhn_dec, m->hid, m->y2, kYTileStride);
 }
 
@@ -332,12 +333,12 @@ int helen_polish_batch(HelenModel* m, const uint8_t* images, int n_windows, uint
     LAUNCH(HELEN_K_PACK, pack_images_kernel, dim3((kSeq * (kXaStride / 4) + 255) / 256, tiles),
            dim3(256), images, n_windows, kSeq, m->xa);
     // encoder input projection for all 1000 positions at once: overlapping chunks share it
-    LAUNCH(HELEN_K_GEMM_ENC, gemm_gi_kernel<kFPad / 16>, dim3(kSeq / 4, tiles), dim3(512), m->xa,
+    LAUNCH(HELEN_K_GEMM_ENC, (gemm_gi_kernel<kFPad / 16, false>), dim3(kSeq / 4, tiles, 8 / HELEN_GEMM_WAVES), dim3(HELEN_GEMM_WAVES * 64), m->xa,
            kXaTileStride, m->wp_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, kSeq);
     // zero initial hidden per batch (predict_gpu.py:99)
     HIP_TRY(hipMemsetAsync(m->hid, 0, (size_t)tiles * kHidStride * sizeof(float), s));
     for (int c = 0; c < kChunks; ++c) {  // predict_gpu.py:114-149
-        launch_chunk(m, s, tiles, c * kJump, kWin);
+        launch_chunk(m, s, tiles, c * kJump, kWin, kSeq);
         LAUNCH(HELEN_K_HEADS, heads_kernel, dim3(tiles, 2), dim3(256), m->y2, kYTileStride, m->whd,
                m->bhd, 0, c, kWin, n_windows, m->pending, bases, rles, acc_base_opt, acc_rle_opt,
                (float*)nullptr, (float*)nullptr);
@@ -356,9 +357,9 @@ int helen_gru_chunk_forward(HelenModel* m, const float* x, const float* h_in, in
     LAUNCH(HELEN_K_PACK, pack_x_f32_kernel, dim3((T * (kXaStride / 4) + 255) / 256, tiles), dim3(256),
            x, B, T, m->xa, kXaTileStride);
     hipLaunchKernelGGL(pack_hidden_kernel, dim3(tiles), dim3(256), 0, s, h_in, B, (float*)m->hid);
-    LAUNCH(HELEN_K_GEMM_ENC, gemm_gi_kernel<kFPad / 16>, dim3((T + 3) / 4, tiles), dim3(512), m->xa,
+    LAUNCH(HELEN_K_GEMM_ENC, (gemm_gi_kernel<kFPad / 16, false>), dim3((T + 3) / 4, tiles, 8 / HELEN_GEMM_WAVES), dim3(HELEN_GEMM_WAVES * 64), m->xa,
            kXaTileStride, m->wp_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, T);
-    launch_chunk(m, s, tiles, 0, T);
+    launch_chunk(m, s, tiles, 0, T, T);
     LAUNCH(HELEN_K_HEADS, heads_kernel, dim3(tiles, (T + kJump - 1) / kJump), dim3(256), m->y2,
            kYTileStride, m->whd, m->bhd, 1, 0, T, B, m->pending, (uint8_t*)nullptr, (uint8_t*)nullptr,
            (float*)nullptr, (float*)nullptr, base, rle);

@@ -117,24 +117,40 @@ __global__ __launch_bounds__(256) void unpack_hidden_kernel(const float* __restr
 //   Operands come straight from global memory: every load is one contiguous 1 KiB per wave and
 //   the packed weights (<= 786 KB) stay L2-resident; no LDS, no barriers.
 //   bias[dir][col] = b_ih[col] + (col < 2H ? b_hh[col] : 0)   (b_hn is applied inside r*(...)).
-// Output gi[tile][pos][dir][ntile 24][lane 64] float4 (FRAG layout).
+// Output gi[tile][slot][dir][ntile 24][lane 64] float4 (FRAG layout); slot = pos for direction 0,
+// npos-1-pos for direction 1.
 // ------------------------------------------------------------------------------------------------
-template <int MG>
-__global__ __launch_bounds__(512) void gemm_gi_kernel(const f32x4* __restrict__ A, long a_tile_stride,
+#ifndef HELEN_GEMM_WAVES
+#define HELEN_GEMM_WAVES 2
+#endif
+template <int MG, bool REV_A>
+__global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_kernel(const f32x4* __restrict__ A, long a_tile_stride,
                                                       const f32x4* __restrict__ Wp,
                                                       const float* __restrict__ bias,
                                                       f32x4* __restrict__ gi, long gi_tile_stride,
                                                       int npos) {
+    // Output slot: direction 0 -> position p, direction 1 -> npos-1-p (time-reversed), so the
+    // recurrence reads both directions in ascending address order.
+    static_assert(MG % 2 == 0, "operand groups are consumed in ping-pong pairs");
     constexpr int P = 4, N = 6;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = (threadIdx.x >> 6) + blockIdx.z * HELEN_GEMM_WAVES;
     const int dir = wave >> 2;
     const int nt0 = (wave & 3) * N;
     const int tile = blockIdx.y;
     const int pos0 = blockIdx.x * P;
 
-    const f32x4* a_base = A + (size_t)tile * a_tile_stride + lane;
     const f32x4* w_base = Wp + (size_t)((dir * kNTile + nt0) * MG) * 64 + lane;
+    // REV_A: A is a layer output y[tile][slot][fwd | bwd]; the bwd half (groups MG/2..) of
+    // position p sits in slot npos-1-p.
+    const f32x4* a_ptr[P];
+    const f32x4* a_ptr_b[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int pc = min(pos0 + p, npos - 1);
+        a_ptr[p] = A + (size_t)tile * a_tile_stride + (size_t)pc * (MG * 64) + lane;
+        a_ptr_b[p] = A + (size_t)tile * a_tile_stride + (size_t)(npos - 1 - pc) * (MG * 64) + lane;
+    }
 
     f32x4 acc[P][N];
 #pragma unroll
@@ -143,29 +159,70 @@ __global__ __launch_bounds__(512) void gemm_gi_kernel(const f32x4* __restrict__ 
 #pragma unroll
         for (int p = 0; p < P; ++p) acc[p][n] = splat4(b);
     }
-    int posc[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) posc[p] = min(pos0 + p, npos - 1);
 
+    // Register ping-pong: the operands of group m+1 are in flight while group m's 96 MFMAs issue.
+    f32x4 a0[P], b0[N], a1[P], b1[N];
+#define HELEN_LOAD_OPS(a, b, m)                                       \
+    _Pragma("unroll") for (int p = 0; p < P; ++p)                     \
+        a[p] = (REV_A && (m) >= MG / 2) ? a_ptr_b[p][(m) * 64] : a_ptr[p][(m) * 64]; \
+    _Pragma("unroll") for (int n = 0; n < N; ++n) b[n] = w_base[(n * MG + (m)) * 64];
+#define HELEN_MMA_OPS(a, b)                                           \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)                     \
+    _Pragma("unroll") for (int p = 0; p < P; ++p)                     \
+    _Pragma("unroll") for (int n = 0; n < N; ++n) acc[p][n] = mfma4(a[p][e], b[n][e], acc[p][n]);
+
+#ifndef HELEN_GEMM_VARIANT
+#define HELEN_GEMM_VARIANT 3
+#endif
+#if HELEN_GEMM_VARIANT == 0
 #pragma unroll
     for (int m = 0; m < MG; ++m) {
-        f32x4 a[P], b[N];
-#pragma unroll
-        for (int p = 0; p < P; ++p) a[p] = a_base[(size_t)posc[p] * (MG * 64) + m * 64];
-#pragma unroll
-        for (int n = 0; n < N; ++n) b[n] = w_base[(n * MG + m) * 64];
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int p = 0; p < P; ++p)
-#pragma unroll
-                for (int n = 0; n < N; ++n) acc[p][n] = mfma4(a[p][e], b[n][e], acc[p][n]);
+        HELEN_LOAD_OPS(a0, b0, m)
+        HELEN_MMA_OPS(a0, b0)
     }
+#elif HELEN_GEMM_VARIANT == 1 || HELEN_GEMM_VARIANT == 2
+#if HELEN_GEMM_VARIANT == 1
+#define HELEN_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define HELEN_SB()
+#endif
+    HELEN_LOAD_OPS(a0, b0, 0)
+#pragma unroll 1
+    for (int m = 0; m < MG; m += 2) {
+        HELEN_LOAD_OPS(a1, b1, m + 1)
+        HELEN_SB();
+        HELEN_MMA_OPS(a0, b0)
+        HELEN_SB();
+        const int mn = min(m + 2, MG - 1);  // last pass re-reads a resident group (harmless)
+        HELEN_LOAD_OPS(a0, b0, mn)
+        HELEN_SB();
+        HELEN_MMA_OPS(a1, b1)
+        HELEN_SB();
+    }
+#undef HELEN_SB
+#elif HELEN_GEMM_VARIANT == 3
+    // ping-pong, fully unrolled
+    HELEN_LOAD_OPS(a0, b0, 0)
+#pragma unroll
+    for (int m = 0; m < MG; m += 2) {
+        HELEN_LOAD_OPS(a1, b1, m + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        HELEN_MMA_OPS(a0, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (m + 2 < MG) { HELEN_LOAD_OPS(a0, b0, m + 2) }
+        __builtin_amdgcn_sched_barrier(0);
+        HELEN_MMA_OPS(a1, b1)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+#undef HELEN_LOAD_OPS
+#undef HELEN_MMA_OPS
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         if (pos0 + p < npos) {
+            const int slot = dir ? (npos - 1 - (pos0 + p)) : (pos0 + p);
             f32x4* o = gi + (size_t)tile * gi_tile_stride +
-                       ((size_t)(pos0 + p) * 2 + dir) * (kNTile * 64) + nt0 * 64 + lane;
+                       ((size_t)slot * 2 + dir) * (kNTile * 64) + nt0 * 64 + lane;
 #pragma unroll
             for (int n = 0; n < N; ++n) o[n * 64] = acc[p][n];
         }
@@ -175,44 +232,87 @@ __global__ __launch_bounds__(512) void gemm_gi_kernel(const f32x4* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // GRU recurrence for one direction of one layer over T dependent steps (nn.GRU cell, see
 // oracle/helen_oracle.c gru_dir for the scalar statement).
-//   grid (tiles, 2 directions), 4 waves.  Wave w owns hidden units 32w..32w+31: six 16-column
-//   tiles (r, z, n gates x two halves) whose W_hh slice -- 192 floats per lane -- stays in
-//   registers for the whole launch.  h lives in LDS in KB16 layout (double-buffered, one barrier
-//   per step) and is the MFMA A operand of the next step; gate math is fused on the accumulators.
-//   gi for step s+1 is prefetched during step s.  Each step's h is also streamed out as
-//   y[tile][t][dir] (the layer output, KB16) for the next projection.
+//   grid (tiles, 2 directions), 4 waves per workgroup, TWO workgroups per CU (two waves per SIMD
+//   from independent tiles): while one tile is in its gate math / LDS exchange / barrier, the
+//   other tile's MFMAs keep the matrix pipe busy.  That needs <= 256 registers per lane, so:
+//     - wave w owns hidden units 32w..32w+31 = six 16-column tiles (r, z, n gates x two halves);
+//       the W_hh slices of five of them (160 floats per lane) stay in registers for the whole
+//       launch, the sixth is parked in LDS and streamed as a B operand each step;
+//     - h lives in LDS in KB16 layout (double-buffered, ONE barrier per step) and is the MFMA A
+//       operand of the next step;
+//     - the gate pre-activations gi are DMA'd global->LDS (global_load_lds: no registers) one
+//       step ahead into a per-wave, single-buffered slot that is refilled as soon as it is read.
+//   Each step's h is streamed out as y[tile][slot][dir] (KB16) for the next projection, slot =
+//   step index (t for direction 0, T-1-t for direction 1).
 //   Direction 1 walks t = T-1 .. 0 (the `_reverse` weights); its h_n is the state after t = 0.
+//   gi and y are indexed by SLOT = step order for both directions (the reverse direction is
+//   stored time-reversed) so both directions walk memory upwards: descending DMA/store addresses
+//   cost 1000+ cycles of VMEM issue stall per step on gfx950.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void gru_kernel(const f32x4* __restrict__ gi, long gi_tile_stride,
-                                                     int pos0, int T, const f32x4* __restrict__ Whp,
+__device__ __forceinline__ float gru_cell(float ar, float az, float an, float gr, float gz, float gn,
+                                          float hp) {
+    const float rg = fast_sigmoid(ar + gr);
+    const float zg = fast_sigmoid(az + gz);
+    const float ng = fast_tanh(gn + rg * an);
+    return ng + zg * (hp - ng);  // (1-z)*n + z*h
+}
+
+constexpr int kGruLdsF4 = 2 * 512 + 4 * 384 + 4 * 512;  // h[2] | gi[4 waves] | W tile 5[4 waves]
+
+__global__ __launch_bounds__(256, 2) void gru_kernel(const f32x4* __restrict__ gi, long gi_tile_stride,
+                                                     int slot0_fwd, int slot0_bwd, int T,
+                                                     const f32x4* __restrict__ Whp,
                                                      const float* __restrict__ bhn,
                                                      f32x4* __restrict__ hid, f32x4* __restrict__ y,
                                                      long y_tile_stride) {
-    __shared__ f32x4 hbuf[2][kHidDirStride / 4];  // 2 x 8 KiB
+    __shared__ f32x4 smem[kGruLdsF4];  // 72 KiB, one object (two workgroups fit in 160 KiB)
+    f32x4* const hbuf = smem;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int w = tid >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    f32x4* const gbuf = smem + 1024 + w * 384;         // this wave's gi slot: [6][64]
+    f32x4* const w5buf = smem + 1024 + 1536 + w * 512; // this wave's parked W tile: [8][64]
     const int j = lane & 15;
     const int q = lane >> 4;
     const int tile = blockIdx.x;
     const int dir = blockIdx.y;
+    const int slot0 = dir ? slot0_bwd : slot0_fwd;
 
-    // W_hh slice -> registers: W[n = gate*2 + half][m] holds k = 16m + 4q + e, col = unit(half, j)
-    f32x4 W[6][8];
+    // W_hh slice: W[n = gate*2 + half][m] holds k = 16m + 4q + e, col = unit(half, j)
+    f32x4 W[5][8];
     {
         const f32x4* wp = Whp + (size_t)((dir * 4 + w) * 48) * 64 + lane;
 #pragma unroll
-        for (int n = 0; n < 6; ++n)
+        for (int n = 0; n < 5; ++n)
 #pragma unroll
             for (int m = 0; m < 8; ++m) W[n][m] = wp[(n * 8 + m) * 64];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) w5buf[m * 64 + lane] = wp[(5 * 8 + m) * 64];
     }
     float bn[2];
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) bn[hh] = bhn[dir * kH + 32 * w + 16 * hh + j];
 
+    // gi fragments of this wave: column tile of (gate g, half hh) is g*8 + 2w + hh
+    const f32x4* gi_p = gi + (size_t)tile * gi_tile_stride + (size_t)dir * (kNTile * 64) +
+                        (2 * w) * 64 + lane;
+    constexpr long kPosStride = 2 * kNTile * 64;  // float4 per slot
+    auto dma_gi = [&](int slot) {
+        const f32x4* p = gi_p + (size_t)slot * kPosStride;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+                __builtin_amdgcn_global_load_lds(
+                    (const void __attribute__((address_space(1)))*)(p + (g * 8 + hh) * 64),
+                    (void __attribute__((address_space(3)))*)(gbuf + (g * 2 + hh) * 64), 16, 0, 0);
+    };
+
     f32x4* hid_p = hid + ((size_t)tile * 2 + dir) * (kHidDirStride / 4);
-    hbuf[0][tid] = hid_p[tid];
-    hbuf[0][tid + 256] = hid_p[tid + 256];
+    hbuf[tid] = hid_p[tid];
+    hbuf[tid + 256] = hid_p[tid + 256];
+    dma_gi(slot0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     float hprev[2][4];
@@ -222,83 +322,106 @@ __global__ __launch_bounds__(256, 1) void gru_kernel(const f32x4* __restrict__ g
         const int u = 32 * w + 16 * hh + j;
         hoff[hh] = ((u >> 2) * kTile + 4 * q) * 4 + (u & 3);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hprev[hh][r] = ((const float*)hbuf[0])[hoff[hh] + 4 * r];
-    }
-
-    // gi fragment pointers: column tile of (gate g, half hh) is g*8 + 2w + hh
-    const f32x4* gi_p = gi + (size_t)tile * gi_tile_stride + (size_t)dir * (kNTile * 64) +
-                        (2 * w) * 64 + lane;
-    constexpr long kPosStride = 2 * kNTile * 64;  // float4 per position
-    f32x4 G[3][2];
-    {
-        const int t = dir ? (T - 1) : 0;
-        const f32x4* p = gi_p + (size_t)(pos0 + t) * kPosStride;
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) G[g][hh] = p[(g * 8 + hh) * 64];
+        for (int r = 0; r < 4; ++r) hprev[hh][r] = ((const float*)hbuf)[hoff[hh] + 4 * r];
     }
     f32x4* y_p = y + (size_t)tile * y_tile_stride + (size_t)dir * (kHidDirStride / 4);
 
+#ifdef HELEN_GRU_WALL
+    const long long wall0 = wall_clock64();
+#endif
+#ifdef HELEN_GRU_TIMING
+    long long tk[7] = {0, 0, 0, 0, 0, 0, 0};
+#define HELEN_TICK(i) { __builtin_amdgcn_sched_barrier(0); long long now_ = __builtin_readcyclecounter(); tk[i] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
+    long long tlast = __builtin_readcyclecounter();
+#else
+#define HELEN_TICK(i)
+#endif
     for (int s = 0; s < T; ++s) {
-        const int t = dir ? (T - 1 - s) : s;
         const int cur = s & 1;
-        // prefetch next step's gate pre-activations
-        f32x4 Gn[3][2];
-        {
-            const int sn = (s + 1 < T) ? s + 1 : s;
-            const int tn = dir ? (T - 1 - sn) : sn;
-            const f32x4* p = gi_p + (size_t)(pos0 + tn) * kPosStride;
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) Gn[g][hh] = p[(g * 8 + hh) * 64];
-        }
-        // A operand: h(t-1) from LDS
-        f32x4 a[8];
-#pragma unroll
-        for (int m = 0; m < 8; ++m) a[m] = hbuf[cur][m * 64 + lane];
+        const f32x4* hb = hbuf + cur * 512 + lane;
+        const f32x4* wb = w5buf + lane;
 
         f32x4 acc[6];
-        acc[0] = G[0][0];
-        acc[1] = G[0][1];
-        acc[2] = G[1][0];
-        acc[3] = G[1][1];
+        acc[0] = splat4(0.f);
+        acc[1] = splat4(0.f);
+        acc[2] = splat4(0.f);
+        acc[3] = splat4(0.f);
         acc[4] = splat4(bn[0]);
         acc[5] = splat4(bn[1]);
 #pragma unroll
-        for (int m = 0; m < 8; ++m)
+        for (int m = 0; m < 8; ++m) {
+            const f32x4 a = hb[m * 64];   // A operand: h(t-1), k = 16m + 4q + e
+            const f32x4 b5 = wb[m * 64];  // parked W tile (gate n, half 1)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e) {
 #pragma unroll
-                for (int n = 0; n < 6; ++n) acc[n] = mfma4(a[m][e], W[n][m][e], acc[n]);
+                for (int n = 0; n < 5; ++n) acc[n] = mfma4(a[e], W[n][m][e], acc[n]);
+                acc[5] = mfma4(a[e], b5[e], acc[5]);
+            }
+        }
+        HELEN_TICK(0)
+        // gate pre-activations of this step (DMA'd during the previous step), then refill the slot
+        // VMEM queue of this wave, oldest first: 6 gi DMAs (issued last step), 2 y stores (issued
+        // after last step's barrier).  vmcnt(2) = the DMAs have landed; the stores may still fly.
+        // (hipcc does not order these LDS reads behind the DMA by itself.)
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        HELEN_TICK(5)
+        f32x4 G[6];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) G[n] = gbuf[n * 64 + lane];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        HELEN_TICK(6)
+#ifndef HELEN_EXP_NODMA
+        if (s + 1 < T) dma_gi(slot0 + s + 1);
+#endif
+        HELEN_TICK(1)
 
-        // fused gates: r, z, n, h' for this lane's 2 units x 4 windows
-        float* hw = (float*)hbuf[cur ^ 1];
+        float* hw = (float*)(hbuf + (cur ^ 1) * 512);
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
+        for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float rg = fast_sigmoid(acc[0 + hh][r]);
-                const float zg = fast_sigmoid(acc[2 + hh][r]);
-                const float ng = fast_tanh(G[2][hh][r] + rg * acc[4 + hh][r]);
-                const float hn = ng + zg * (hprev[hh][r] - ng);  // (1-z)*n + z*h
+                const float hn = gru_cell(acc[hh][r], acc[2 + hh][r], acc[4 + hh][r], G[hh][r],
+                                          G[2 + hh][r], G[4 + hh][r], hprev[hh][r]);
                 hprev[hh][r] = hn;
                 hw[hoff[hh] + 4 * r] = hn;
             }
-        }
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) G[g][hh] = Gn[g][hh];
-        __syncthreads();
+        HELEN_TICK(2)
+        // raw barrier: only LDS traffic has to be drained, the gi DMA stays in flight across it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        HELEN_TICK(3)
         // stream h(t) out as the layer output
-        f32x4* yo = y_p + (size_t)t * (kYStride / 4);
-        yo[tid] = hbuf[cur ^ 1][tid];
-        yo[tid + 256] = hbuf[cur ^ 1][tid + 256];
+        f32x4* yo = y_p + (size_t)s * (kYStride / 4);  // slot s: t for dir 0, T-1-t for dir 1
+        const f32x4* hn4 = hbuf + (cur ^ 1) * 512;
+#ifndef HELEN_EXP_NOSTORE
+        yo[tid] = hn4[tid];
+        yo[tid + 256] = hn4[tid + 256];
+#else
+        if (T > 100000) { yo[tid] = hn4[tid]; }
+#endif
+        HELEN_TICK(4)
     }
-    hid_p[tid] = hbuf[T & 1][tid];
-    hid_p[tid + 256] = hbuf[T & 1][tid + 256];
+#ifdef HELEN_GRU_TIMING
+    if (tile == 0 && lane == 0) {
+        printf("gru dir %d wave %d: cycles/step  mfma %lld  vmwait %lld  Gread %lld  dma-issue %lld  gates %lld  barrier %lld  ycopy %lld\n",
+               dir, w, tk[0] / T, tk[5] / T, tk[6] / T, tk[1] / T, tk[2] / T, tk[3] / T, tk[4] / T);
+    }
+#endif
+#ifdef HELEN_GRU_WALL
+    if (tid == 0) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        printf("WG tile %d dir %d xcc %u se %u cu %u simd %u start %lld end %lld\n", tile, dir, xcc & 15,
+               (hwid >> 13) & 7, (hwid >> 8) & 15, (hwid >> 4) & 3, wall0, wall_clock64());
+    }
+#endif
+    const f32x4* hl = hbuf + (T & 1) * 512;
+    hid_p[tid] = hl[tid];
+    hid_p[tid + 256] = hl[tid + 256];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -363,13 +486,15 @@ __global__ __launch_bounds__(256) void heads_kernel(
     const bool add_prev = (mode == 0) && (half == 0) && (chunk > 0);
 
     for (int t = t0 + w; t < t1; t += 4) {
+        // y2[tile][slot][fwd | bwd]: the bwd half of position t sits in slot T-1-t
         const f32x4* a_p = y2 + (size_t)tile * y_tile_stride + (size_t)t * (kYStride / 4) + lane;
+        const f32x4* a_pb = y2 + (size_t)tile * y_tile_stride + (size_t)(T - 1 - t) * (kYStride / 4) + lane;
         f32x4 acc0 = splat4(bias);
         f32x4 acc1 = splat4(0.f);
 #pragma unroll
         for (int m = 0; m < 16; m += 2) {
-            const f32x4 a0 = a_p[m * 64];
-            const f32x4 a1 = a_p[(m + 1) * 64];
+            const f32x4 a0 = (m >= 8 ? a_pb : a_p)[m * 64];
+            const f32x4 a1 = (m >= 8 ? a_pb : a_p)[(m + 1) * 64];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc0 = mfma4(a0[e], B[m][e], acc0);

@@ -65,40 +65,51 @@ static void dir_free(Dir* d) {
     free(d->w_hh_t);
 }
 
-/* One GRU direction over T steps for ONE window.
- *   x: [T, K] (row stride xs), h: [H] in/out, y: [T, ys] output written at y[t*ys + yoff .. +H)
- *   reverse: process t = T-1 .. 0 (nn.GRU `_reverse` weights), output stays at index t. */
-static void gru_dir(const Dir* d, const float* x, int xs, int T, int reverse, float* h, float* y,
-                    int ys, int yoff, float* gi, float* gh) {
+/* One GRU direction over T steps for a block of nb <= OB windows (windows never interact; the
+ * block only lets one pass over the weights serve several windows).
+ *   x[b]: [T, K] (row stride xs), h[b]: [H] in/out, y[b]: [T, ys], output at y[t*ys + yoff .. +H)
+ *   reverse: process t = T-1 .. 0 (nn.GRU `_reverse` weights), output stays at index t.
+ *   Per element the k-sum order is fixed (k ascending, then + bias), independent of nb. */
+#define OB 8
+static void gru_dir(const Dir* d, const float* const* x, int xs, int T, int reverse, float* const* h,
+                    float* const* y, int ys, int yoff, int nb, float* gi, float* gh) {
     const int H = d->H, G = 3 * d->H, K = d->K;
     for (int s = 0; s < T; ++s) {
         const int t = reverse ? (T - 1 - s) : s;
-        const float* xt = x + (size_t)t * xs;
-        for (int j = 0; j < G; ++j) {
-            gi[j] = 0.0f;
-            gh[j] = 0.0f;
-        }
+        memset(gi, 0, sizeof(float) * (size_t)nb * G);
+        memset(gh, 0, sizeof(float) * (size_t)nb * G);
         for (int k = 0; k < K; ++k) {
-            const float xv = xt[k];
             const float* w = d->w_ih_t + (size_t)k * G;
-            for (int j = 0; j < G; ++j) gi[j] += xv * w[j];
+            for (int b = 0; b < nb; ++b) {
+                const float xv = x[b][(size_t)t * xs + k];
+                float* g = gi + (size_t)b * G;
+                for (int j = 0; j < G; ++j) g[j] += xv * w[j];
+            }
         }
         for (int k = 0; k < H; ++k) {
-            const float hv = h[k];
             const float* w = d->w_hh_t + (size_t)k * G;
-            for (int j = 0; j < G; ++j) gh[j] += hv * w[j];
+            for (int b = 0; b < nb; ++b) {
+                const float hv = h[b][k];
+                float* g = gh + (size_t)b * G;
+                for (int j = 0; j < G; ++j) g[j] += hv * w[j];
+            }
         }
-        for (int j = 0; j < G; ++j) {
-            gi[j] += d->b_ih[j];
-            gh[j] += d->b_hh[j];
+        for (int b = 0; b < nb; ++b) {
+            float* a = gi + (size_t)b * G;
+            float* c = gh + (size_t)b * G;
+            for (int j = 0; j < G; ++j) {
+                a[j] += d->b_ih[j];
+                c[j] += d->b_hh[j];
+            }
+            float* hb = h[b];
+            for (int j = 0; j < H; ++j) {
+                const float r = sigmoidf_(a[j] + c[j]);
+                const float z = sigmoidf_(a[H + j] + c[H + j]);
+                const float n = tanhf(a[2 * H + j] + r * c[2 * H + j]);
+                hb[j] = (1.0f - z) * n + z * hb[j];
+            }
+            memcpy(y[b] + (size_t)t * ys + yoff, hb, sizeof(float) * H);
         }
-        for (int j = 0; j < H; ++j) {
-            const float r = sigmoidf_(gi[j] + gh[j]);
-            const float z = sigmoidf_(gi[H + j] + gh[H + j]);
-            const float n = tanhf(gi[2 * H + j] + r * gh[2 * H + j]);
-            h[j] = (1.0f - z) * n + z * h[j];
-        }
-        memcpy(y + (size_t)t * ys + yoff, h, sizeof(float) * H);
     }
 }
 
@@ -133,33 +144,42 @@ static void net_free(Net* n) {
     }
 }
 
-/* TransducerGRU.forward for ONE window (`models/TransducerModel.py:60-79`).
- *   x [T,F], hidden [2,H] in/out, base [T,nb], rle [T,nr]; scratch y1,y2 [T,2H], gi,gh [3H]. */
-static void forward_one(const Net* n, const float* x, int T, float* hidden, float* base, float* rle,
-                        float* y1, float* y2, float* gi, float* gh) {
+/* TransducerGRU.forward for a block of nb windows (`models/TransducerModel.py:60-79`).
+ *   x[b] [T,F], hidden[b] [2,H] in/out, base[b] [T,nb_], rle[b] [T,nr];
+ *   scratch y1[b], y2[b] [T,2H]; gi, gh [OB*3H]. */
+static void forward_block(const Net* n, const float* const* x, int T, float* const* hidden,
+                          float* const* base, float* const* rle, float* const* y1,
+                          float* const* y2, int nb, float* gi, float* gh) {
     const int H = n->H;
-    /* encoder: h0 = incoming hidden (index 0 forward, 1 backward) */
-    gru_dir(&n->enc[0], x, n->F, T, 0, hidden, y1, 2 * H, 0, gi, gh);
-    gru_dir(&n->enc[1], x, n->F, T, 1, hidden + H, y1, 2 * H, H, gi, gh);
-    /* decoder: h0 = encoder h_n, input = [h_fwd(t) | h_bwd(t)] */
-    gru_dir(&n->dec[0], y1, 2 * H, T, 0, hidden, y2, 2 * H, 0, gi, gh);
-    gru_dir(&n->dec[1], y1, 2 * H, T, 1, hidden + H, y2, 2 * H, H, gi, gh);
-    /* heads (`TransducerModel.py:75-76`) */
-    for (int t = 0; t < T; ++t) {
-        const float* y = y2 + (size_t)t * 2 * H;
-        for (int c = 0; c < n->nb; ++c) {
-            float a = 0.0f;
-            const float* w = n->base_w + (size_t)c * 2 * H;
-            for (int k = 0; k < 2 * H; ++k) a += y[k] * w[k];
-            base[(size_t)t * n->nb + c] = a + n->base_b[c];
-        }
-        for (int c = 0; c < n->nr; ++c) {
-            float a = 0.0f;
-            const float* w = n->rle_w + (size_t)c * 2 * H;
-            for (int k = 0; k < 2 * H; ++k) a += y[k] * w[k];
-            rle[(size_t)t * n->nr + c] = a + n->rle_b[c];
-        }
+    float* hb[OB];
+    const float* y1c[OB];
+    for (int b = 0; b < nb; ++b) {
+        hb[b] = hidden[b] + H;
+        y1c[b] = y1[b];
     }
+    /* encoder: h0 = incoming hidden (index 0 forward, 1 backward) */
+    gru_dir(&n->enc[0], x, n->F, T, 0, hidden, y1, 2 * H, 0, nb, gi, gh);
+    gru_dir(&n->enc[1], x, n->F, T, 1, hb, y1, 2 * H, H, nb, gi, gh);
+    /* decoder: h0 = encoder h_n, input = [h_fwd(t) | h_bwd(t)] */
+    gru_dir(&n->dec[0], y1c, 2 * H, T, 0, hidden, y2, 2 * H, 0, nb, gi, gh);
+    gru_dir(&n->dec[1], y1c, 2 * H, T, 1, hb, y2, 2 * H, H, nb, gi, gh);
+    /* heads (`TransducerModel.py:75-76`) */
+    for (int b = 0; b < nb; ++b)
+        for (int t = 0; t < T; ++t) {
+            const float* y = y2[b] + (size_t)t * 2 * H;
+            for (int c = 0; c < n->nb; ++c) {
+                float a = 0.0f;
+                const float* w = n->base_w + (size_t)c * 2 * H;
+                for (int k = 0; k < 2 * H; ++k) a += y[k] * w[k];
+                base[b][(size_t)t * n->nb + c] = a + n->base_b[c];
+            }
+            for (int c = 0; c < n->nr; ++c) {
+                float a = 0.0f;
+                const float* w = n->rle_w + (size_t)c * 2 * H;
+                for (int k = 0; k < 2 * H; ++k) a += y[k] * w[k];
+                rle[b][(size_t)t * n->nr + c] = a + n->rle_b[c];
+            }
+        }
 }
 
 static void softmax_add(const float* logits, int C, float* acc) {
@@ -191,18 +211,29 @@ int oracle_gru_chunk_forward(const HelenWeights* w, const float* x, const float*
     Net n;
     if (net_init(&n, w) != 0 || B < 0 || T <= 0) return -1;
     const int H = n.H;
+    const int nblk = (B + OB - 1) / OB;
 #pragma omp parallel
     {
-        float* y1 = (float*)malloc(sizeof(float) * (size_t)T * 2 * H);
-        float* y2 = (float*)malloc(sizeof(float) * (size_t)T * 2 * H);
-        float* gi = (float*)malloc(sizeof(float) * 3 * H);
-        float* gh = (float*)malloc(sizeof(float) * 3 * H);
+        float* y1 = (float*)malloc(sizeof(float) * (size_t)OB * T * 2 * H);
+        float* y2 = (float*)malloc(sizeof(float) * (size_t)OB * T * 2 * H);
+        float* gi = (float*)malloc(sizeof(float) * OB * 3 * H);
+        float* gh = (float*)malloc(sizeof(float) * OB * 3 * H);
 #pragma omp for schedule(dynamic, 1)
-        for (int b = 0; b < B; ++b) {
-            float* hid = h_out + (size_t)b * 2 * H;
-            memcpy(hid, h_in + (size_t)b * 2 * H, sizeof(float) * 2 * H);
-            forward_one(&n, x + (size_t)b * T * n.F, T, hid, base + (size_t)b * T * n.nb,
-                        rle + (size_t)b * T * n.nr, y1, y2, gi, gh);
+        for (int blk = 0; blk < nblk; ++blk) {
+            const int b0 = blk * OB;
+            const int nb = (B - b0 < OB) ? B - b0 : OB;
+            const float* xp[OB];
+            float *hp[OB], *bp[OB], *rp[OB], *y1p[OB], *y2p[OB];
+            for (int b = 0; b < nb; ++b) {
+                hp[b] = h_out + (size_t)(b0 + b) * 2 * H;
+                memcpy(hp[b], h_in + (size_t)(b0 + b) * 2 * H, sizeof(float) * 2 * H);
+                xp[b] = x + (size_t)(b0 + b) * T * n.F;
+                bp[b] = base + (size_t)(b0 + b) * T * n.nb;
+                rp[b] = rle + (size_t)(b0 + b) * T * n.nr;
+                y1p[b] = y1 + (size_t)b * T * 2 * H;
+                y2p[b] = y2 + (size_t)b * T * 2 * H;
+            }
+            forward_block(&n, xp, T, hp, bp, rp, y1p, y2p, nb, gi, gh);
         }
         free(y1);
         free(y2);
@@ -229,49 +260,74 @@ int oracle_polish_batch(const HelenWeights* w, const uint8_t* images, int B, uin
         net_free(&n);
         return -1;
     }
+    const int nblk = (B + OB - 1) / OB;
 #pragma omp parallel
     {
-        float* xf = (float*)malloc(sizeof(float) * (size_t)SEQ * F);
-        float* y1 = (float*)malloc(sizeof(float) * (size_t)WIN * 2 * H);
-        float* y2 = (float*)malloc(sizeof(float) * (size_t)WIN * 2 * H);
-        float* gi = (float*)malloc(sizeof(float) * 3 * H);
-        float* gh = (float*)malloc(sizeof(float) * 3 * H);
-        float* lb = (float*)malloc(sizeof(float) * (size_t)WIN * nb);
-        float* lr = (float*)malloc(sizeof(float) * (size_t)WIN * nr);
-        float* ab = (float*)malloc(sizeof(float) * (size_t)SEQ * nb);
-        float* ar = (float*)malloc(sizeof(float) * (size_t)SEQ * nr);
-        float* hid = (float*)malloc(sizeof(float) * 2 * H);
+        float* xf = (float*)malloc(sizeof(float) * (size_t)OB * SEQ * F);
+        float* y1 = (float*)malloc(sizeof(float) * (size_t)OB * WIN * 2 * H);
+        float* y2 = (float*)malloc(sizeof(float) * (size_t)OB * WIN * 2 * H);
+        float* gi = (float*)malloc(sizeof(float) * OB * 3 * H);
+        float* gh = (float*)malloc(sizeof(float) * OB * 3 * H);
+        float* lb = (float*)malloc(sizeof(float) * (size_t)OB * WIN * nb);
+        float* lr = (float*)malloc(sizeof(float) * (size_t)OB * WIN * nr);
+        float* ab = (float*)malloc(sizeof(float) * (size_t)OB * SEQ * nb);
+        float* ar = (float*)malloc(sizeof(float) * (size_t)OB * SEQ * nr);
+        float* hid = (float*)malloc(sizeof(float) * OB * 2 * H);
 #pragma omp for schedule(dynamic, 1)
-        for (int b = 0; b < B; ++b) {
-            const uint8_t* img = images + (size_t)b * SEQ * F;
-            for (size_t i = 0; i < (size_t)SEQ * F; ++i) xf[i] = (float)img[i]; /* :97 */
-            memset(hid, 0, sizeof(float) * 2 * H);                              /* :99 */
-            memset(ab, 0, sizeof(float) * (size_t)SEQ * nb);                    /* :105 */
-            memset(ar, 0, sizeof(float) * (size_t)SEQ * nr);                    /* :106 */
+        for (int blk = 0; blk < nblk; ++blk) {
+            const int b0 = blk * OB;
+            const int m = (B - b0 < OB) ? B - b0 : OB;
+            const float* xp[OB];
+            float *hp[OB], *bp[OB], *rp[OB], *y1p[OB], *y2p[OB];
+            for (int b = 0; b < m; ++b) {
+                const uint8_t* img = images + (size_t)(b0 + b) * SEQ * F;
+                float* xb = xf + (size_t)b * SEQ * F;
+                for (size_t i = 0; i < (size_t)SEQ * F; ++i) xb[i] = (float)img[i]; /* :97 */
+                hp[b] = hid + (size_t)b * 2 * H;
+                bp[b] = lb + (size_t)b * WIN * nb;
+                rp[b] = lr + (size_t)b * WIN * nr;
+                y1p[b] = y1 + (size_t)b * WIN * 2 * H;
+                y2p[b] = y2 + (size_t)b * WIN * 2 * H;
+            }
+            memset(hid, 0, sizeof(float) * OB * 2 * H);                 /* :99 */
+            memset(ab, 0, sizeof(float) * (size_t)OB * SEQ * nb);       /* :105 */
+            memset(ar, 0, sizeof(float) * (size_t)OB * SEQ * nr);       /* :106 */
             int c = 0;
             for (int i = 0; i < SEQ; i += JUMP) { /* :114-117 */
                 if (i + WIN > SEQ) break;
-                forward_one(&n, xf + (size_t)i * F, WIN, hid, lb, lr, y1, y2, gi, gh); /* :129 */
-                for (int t = 0; t < WIN; ++t) { /* :137-149 */
-                    softmax_add(lb + (size_t)t * nb, nb, ab + (size_t)(i + t) * nb);
-                    softmax_add(lr + (size_t)t * nr, nr, ar + (size_t)(i + t) * nr);
+                for (int b = 0; b < m; ++b) xp[b] = xf + (size_t)b * SEQ * F + (size_t)i * F;
+                forward_block(&n, xp, WIN, hp, bp, rp, y1p, y2p, m, gi, gh); /* :129 */
+                for (int b = 0; b < m; ++b) {
+                    const size_t wb = (size_t)(b0 + b);
+                    for (int t = 0; t < WIN; ++t) { /* :137-149 */
+                        softmax_add(bp[b] + (size_t)t * nb, nb,
+                                    ab + ((size_t)b * SEQ + i + t) * nb);
+                        softmax_add(rp[b] + (size_t)t * nr, nr,
+                                    ar + ((size_t)b * SEQ + i + t) * nr);
+                    }
+                    if (hidden_trace)
+                        memcpy(hidden_trace + ((size_t)c * B + wb) * 2 * H, hp[b],
+                               sizeof(float) * 2 * H);
+                    if (logit_base_trace)
+                        memcpy(logit_base_trace + ((size_t)c * B + wb) * WIN * nb, bp[b],
+                               sizeof(float) * WIN * nb);
+                    if (logit_rle_trace)
+                        memcpy(logit_rle_trace + ((size_t)c * B + wb) * WIN * nr, rp[b],
+                               sizeof(float) * WIN * nr);
                 }
-                if (hidden_trace)
-                    memcpy(hidden_trace + ((size_t)c * B + b) * 2 * H, hid, sizeof(float) * 2 * H);
-                if (logit_base_trace)
-                    memcpy(logit_base_trace + ((size_t)c * B + b) * WIN * nb, lb,
-                           sizeof(float) * WIN * nb);
-                if (logit_rle_trace)
-                    memcpy(logit_rle_trace + ((size_t)c * B + b) * WIN * nr, lr,
-                           sizeof(float) * WIN * nr);
                 ++c;
             }
-            for (int p = 0; p < SEQ; ++p) { /* :155-156 */
-                bases[(size_t)b * SEQ + p] = argmax_first(ab + (size_t)p * nb, nb);
-                rles[(size_t)b * SEQ + p] = argmax_first(ar + (size_t)p * nr, nr);
+            for (int b = 0; b < m; ++b) {
+                const size_t wb = (size_t)(b0 + b);
+                const float* abb = ab + (size_t)b * SEQ * nb;
+                const float* arb = ar + (size_t)b * SEQ * nr;
+                for (int p = 0; p < SEQ; ++p) { /* :155-156 */
+                    bases[wb * SEQ + p] = argmax_first(abb + (size_t)p * nb, nb);
+                    rles[wb * SEQ + p] = argmax_first(arb + (size_t)p * nr, nr);
+                }
+                if (acc_base) memcpy(acc_base + wb * SEQ * nb, abb, sizeof(float) * SEQ * nb);
+                if (acc_rle) memcpy(acc_rle + wb * SEQ * nr, arb, sizeof(float) * SEQ * nr);
             }
-            if (acc_base) memcpy(acc_base + (size_t)b * SEQ * nb, ab, sizeof(float) * SEQ * nb);
-            if (acc_rle) memcpy(acc_rle + (size_t)b * SEQ * nr, ar, sizeof(float) * SEQ * nr);
         }
         free(xf);
         free(y1);
