@@ -1,0 +1,100 @@
+"""call_consensus: argument validation, device planning, file-level sharding and dispatch
+(helen/modules/python/CallConsensusInterface.py:47-156), then `polish_genome`
+(PolishInterface.py:49-105) on top of it."""
+import os
+import sys
+import time
+from datetime import datetime
+
+from . import file_manager
+from .predict import predict_gpu
+
+
+def _err(msg):
+    sys.stderr.write("ERROR: " + msg + "\n")
+
+
+def plan_devices(device_ids, visible_devices):
+    """-> (device list, callers).  None = all visible devices (CallConsensusInterface.py:107-112);
+    otherwise a comma-separated id string (:113-126)."""
+    if device_ids is None:
+        devs = list(range(visible_devices))
+    else:
+        devs = [int(i) for i in str(device_ids).split(",") if i != ""]
+        for d in devs:
+            if d < 0 or d >= visible_devices:
+                raise ValueError("GPU DEVICE: %d IS NOT AVAILABLE (VISIBLE: %d)" % (d, visible_devices))
+    return devs, len(devs)
+
+
+def call_consensus(image_dir, model_path, batch_size, num_workers, threads, output_dir,
+                   output_prefix, gpu_mode, device_ids, callers):
+    if not os.path.isfile(model_path):
+        _err("CAN NOT LOCATE MODEL FILE.")
+        sys.exit(1)
+    if not os.path.isdir(image_dir):
+        _err("CAN NOT LOCATE IMAGE DIRECTORY.")
+        sys.exit(1)
+    if batch_size <= 0:
+        _err("batch_size NEEDS TO BE >0.")
+        sys.exit(1)
+    if num_workers < 0:
+        _err("num_workers NEEDS TO BE >=0.")
+        sys.exit(1)
+    if threads <= 0:
+        _err("THREAD NEEDS TO BE >=0.")
+        sys.exit(1)
+    output_dir = file_manager.handle_output_directory(output_dir)
+    output_filename = os.path.join(output_dir, output_prefix)
+    sys.stderr.write("INFO: OUTPUT FILE: " + output_filename + "\n")
+
+    if not gpu_mode:
+        # The reference's CPU mode is an ONNX Runtime session (models/predict_cpu.py); this build
+        # is the MI355X path only and refuses rather than silently running something else.
+        _err("THIS BUILD HAS NO CPU INFERENCE PATH; RUN WITH --gpu_mode (-g).")
+        sys.exit(1)
+    import torch
+    if not torch.cuda.is_available():
+        _err("NO MI355X VISIBLE (torch.cuda.is_available() IS FALSE).")
+        sys.exit(1)
+    try:
+        device_ids, callers = plan_devices(device_ids, torch.cuda.device_count())
+    except ValueError as e:
+        _err(str(e))
+        sys.exit(1)
+    sys.stderr.write("INFO: AVAILABLE GPU DEVICES: " + str(device_ids) + "\n")
+
+    input_files = file_manager.get_file_paths_from_directory(image_dir)
+    file_chunks = file_manager.shard_round_robin(input_files, callers)
+    callers = len(file_chunks)
+    if callers == 0:
+        _err("NO IMAGE FILES (*.h5) FOUND IN " + image_dir)
+        sys.exit(1)
+    predict_gpu(file_chunks, output_filename, model_path, batch_size, callers, device_ids,
+                num_workers)
+    sys.stderr.write("INFO: PREDICTION GENERATED SUCCESSFULLY.\n")
+
+
+def polish_genome(image_dir, model_path, batch_size, num_workers, threads, output_dir,
+                  output_prefix, gpu_mode, device_ids, callers):
+    """call_consensus into `<output_dir>/predictions_<timestamp>/`, then stitch
+    (PolishInterface.py:49-105).  The stitch step (SSW-anchored FASTA assembly, CPU) is outside
+    this build's scope: the prediction directory is left in the layout the
+    reference's `helen stitch -i <dir>` consumes."""
+    output_dir = file_manager.handle_output_directory(output_dir)
+    timestr = datetime.now().strftime("%m%d%Y_%H%M%S")
+    prediction_dir = file_manager.handle_output_directory(
+        os.path.join(output_dir, "predictions_" + timestr))
+    t0 = time.time()
+    sys.stderr.write("INFO: RUN-ID: " + timestr + "\n")
+    sys.stderr.write("INFO: PREDICTION OUTPUT DIRECTORY: " + prediction_dir + "\n")
+    sys.stderr.write("INFO: CALL CONSENSUS STARTING\n")
+    call_consensus(image_dir, model_path, batch_size, num_workers, threads, prediction_dir,
+                   "helen_predictions", gpu_mode, device_ids, callers)
+    t1 = time.time()
+    sys.stderr.write("INFO: CALL CONSENSUS ELAPSED TIME: %d MINS %d SECS.\n"
+                     % (int((t1 - t0) // 60), int(t1 - t0) % 60))
+    sys.stderr.write("INFO: STITCH IS NOT PART OF THIS BUILD. RUN `helen stitch -i " + prediction_dir
+                     + " -o " + output_dir + " -p " + output_prefix + "` FROM THE REFERENCE "
+                     "PACKAGE TO PRODUCE THE FASTA.\n")
+    return prediction_dir

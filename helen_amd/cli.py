@@ -1,0 +1,75 @@
+"""`helen` command line for the inference path: `polish`, `call_consensus`, `version`, `torch_stat`,
+flag-compatible with helen/helen.py:12-185 (-i -m -b -w -t -o -p -g -d_ids -c)."""
+import argparse
+import sys
+
+from . import __version__
+
+
+def add_polish_arguments(parser, threads_default):
+    parser.add_argument("-i", "--image_dir", type=str, required=True,
+                        help="[REQUIRED] Path to a directory where all MarginPolish generated images are.")
+    parser.add_argument("-m", "--model_path", type=str, required=True,
+                        help="[REQUIRED] Path to a trained model (pkl file).")
+    parser.add_argument("-b", "--batch_size", type=int, required=False, default=512,
+                        help="Batch size for testing, default is 512.")
+    parser.add_argument("-w", "--num_workers", type=int, required=False, default=8,
+                        help="Number of workers to assign to the dataloader. Default is 8.")
+    parser.add_argument("-t", "--threads", type=int, required=False, default=threads_default,
+                        help="Number of PyTorch threads to use, default is %d." % threads_default)
+    parser.add_argument("-o", "--output_dir", type=str, required=False, default="./output/",
+                        help="Path to the output directory.")
+    parser.add_argument("-p", "--output_prefix", type=str, required=False, default="HELEN_prediction",
+                        help="Prefix for the output file. Default is: HELEN_prediction")
+    parser.add_argument("-g", "--gpu_mode", default=False, action="store_true",
+                        help="If set then the MI355X HIP path is used (required: this build has no CPU path).")
+    parser.add_argument("-d_ids", "--device_ids", type=str, required=False, default=None,
+                        help="List of gpu device ids to use for inference, e.g. 0,1,2. Default: all.")
+    parser.add_argument("-c", "--callers", type=int, required=False, default=8,
+                        help="Total number of callers to spawn if doing CPU inference (ignored in gpu mode).")
+    return parser
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(
+        prog="helen", formatter_class=argparse.RawTextHelpFormatter,
+        description="HELEN inference path on MI355X (gfx950): MarginPolish images -> prediction HDF5.")
+    sub = parser.add_subparsers(dest="sub_command")
+    add_polish_arguments(sub.add_parser("polish", help="call_consensus, then (reference) stitch"), 1)
+    add_polish_arguments(sub.add_parser("call_consensus", help="generate the prediction HDF5 files"), 16)
+    sub.add_parser("version", help="show the version")
+    sub.add_parser("torch_stat", help="show torch / device configuration")
+    return parser
+
+
+def main(argv=None):
+    parser = build_parser()
+    flags, unparsed = parser.parse_known_args(argv)
+    if flags.sub_command == "polish":
+        from .call_consensus import polish_genome
+        polish_genome(flags.image_dir, flags.model_path, flags.batch_size, flags.num_workers,
+                      flags.threads, flags.output_dir, flags.output_prefix, flags.gpu_mode,
+                      flags.device_ids, flags.callers)
+    elif flags.sub_command == "call_consensus":
+        from .call_consensus import call_consensus
+        call_consensus(flags.image_dir, flags.model_path, flags.batch_size, flags.num_workers,
+                       flags.threads, flags.output_dir, flags.output_prefix, flags.gpu_mode,
+                       flags.device_ids, flags.callers)
+    elif flags.sub_command == "version":
+        print("HELEN-MI355X VERSION: " + __version__)
+    elif flags.sub_command == "torch_stat":
+        import torch
+        print("TORCH VERSION: " + torch.__version__)
+        print("GPU AVAILABLE: " + str(torch.cuda.is_available()))
+        if torch.cuda.is_available():
+            for i in range(torch.cuda.device_count()):
+                print("DEVICE %d: %s" % (i, torch.cuda.get_device_properties(i).name))
+    else:
+        sys.stderr.write("ERROR: NO SUBCOMMAND PROVIDED. PLEASE USE --help TO SEE THE OPTIONS.\n")
+        parser.print_help(sys.stderr)
+        return 1
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -113,13 +113,18 @@ __global__ __launch_bounds__(256) void unpack_hidden_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------
 // Input projection  gi = A . W_ih^T + bias  for both directions (the non-recurrent half of nn.GRU,
 // TransducerModel.py:70,72).  A is a KB16 operand with MG = K/16 groups per (tile, position).
-//   block = 8 waves: wave w -> direction w>>2, column tiles 6(w&3) .. +5; 4 positions per block.
-//   Operands come straight from global memory: every load is one contiguous 1 KiB per wave and
-//   the packed weights (<= 786 KB) stay L2-resident; no LDS, no barriers.
+//   The 48 column tiles (2 directions x 24) are split over 8 "wave slots": slot v -> direction
+//   v>>2, column tiles 6(v&3) .. +5; a workgroup holds HELEN_GEMM_WAVES slots (grid.z the rest) and
+//   covers 4 positions, so each wave keeps a 4 x 6 block of 16x16 accumulators.
+//   Operands come straight from global memory in a register ping-pong (group m+1 in flight while
+//   group m's 96 MFMAs issue): every load is one contiguous 1 KiB per wave and the packed weights
+//   (<= 786 KB) stay L2-resident; no LDS, no barriers.  Small workgroups (2 waves) measured best:
+//   several independent workgroups per CU overlap each other's prologue/epilogue.
 //   bias[dir][col] = b_ih[col] + (col < 2H ? b_hh[col] : 0)   (b_hn is applied inside r*(...)).
 // Output gi[tile][slot][dir][ntile 24][lane 64] float4 (FRAG layout); slot = pos for direction 0,
 // npos-1-pos for direction 1.
 // ------------------------------------------------------------------------------------------------
+// waves per projection workgroup; 8 / HELEN_GEMM_WAVES workgroups (grid.z) cover the 48 column tiles
 #ifndef HELEN_GEMM_WAVES
 #define HELEN_GEMM_WAVES 2
 #endif
@@ -171,37 +176,6 @@ __global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_kernel(const f3
     _Pragma("unroll") for (int p = 0; p < P; ++p)                     \
     _Pragma("unroll") for (int n = 0; n < N; ++n) acc[p][n] = mfma4(a[p][e], b[n][e], acc[p][n]);
 
-#ifndef HELEN_GEMM_VARIANT
-#define HELEN_GEMM_VARIANT 3
-#endif
-#if HELEN_GEMM_VARIANT == 0
-#pragma unroll
-    for (int m = 0; m < MG; ++m) {
-        HELEN_LOAD_OPS(a0, b0, m)
-        HELEN_MMA_OPS(a0, b0)
-    }
-#elif HELEN_GEMM_VARIANT == 1 || HELEN_GEMM_VARIANT == 2
-#if HELEN_GEMM_VARIANT == 1
-#define HELEN_SB() __builtin_amdgcn_sched_barrier(0)
-#else
-#define HELEN_SB()
-#endif
-    HELEN_LOAD_OPS(a0, b0, 0)
-#pragma unroll 1
-    for (int m = 0; m < MG; m += 2) {
-        HELEN_LOAD_OPS(a1, b1, m + 1)
-        HELEN_SB();
-        HELEN_MMA_OPS(a0, b0)
-        HELEN_SB();
-        const int mn = min(m + 2, MG - 1);  // last pass re-reads a resident group (harmless)
-        HELEN_LOAD_OPS(a0, b0, mn)
-        HELEN_SB();
-        HELEN_MMA_OPS(a1, b1)
-        HELEN_SB();
-    }
-#undef HELEN_SB
-#elif HELEN_GEMM_VARIANT == 3
-    // ping-pong, fully unrolled
     HELEN_LOAD_OPS(a0, b0, 0)
 #pragma unroll
     for (int m = 0; m < MG; m += 2) {
@@ -214,7 +188,6 @@ __global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_kernel(const f3
         HELEN_MMA_OPS(a1, b1)
         __builtin_amdgcn_sched_barrier(0);
     }
-#endif
 #undef HELEN_LOAD_OPS
 #undef HELEN_MMA_OPS
 #pragma unroll
@@ -326,9 +299,6 @@ __global__ __launch_bounds__(256, 2) void gru_kernel(const f32x4* __restrict__ g
     }
     f32x4* y_p = y + (size_t)tile * y_tile_stride + (size_t)dir * (kHidDirStride / 4);
 
-#ifdef HELEN_GRU_WALL
-    const long long wall0 = wall_clock64();
-#endif
 #ifdef HELEN_GRU_TIMING
     long long tk[7] = {0, 0, 0, 0, 0, 0, 0};
 #define HELEN_TICK(i) { __builtin_amdgcn_sched_barrier(0); long long now_ = __builtin_readcyclecounter(); tk[i] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
@@ -371,9 +341,7 @@ __global__ __launch_bounds__(256, 2) void gru_kernel(const f32x4* __restrict__ g
         for (int n = 0; n < 6; ++n) G[n] = gbuf[n * 64 + lane];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         HELEN_TICK(6)
-#ifndef HELEN_EXP_NODMA
         if (s + 1 < T) dma_gi(slot0 + s + 1);
-#endif
         HELEN_TICK(1)
 
         float* hw = (float*)(hbuf + (cur ^ 1) * 512);
@@ -395,28 +363,14 @@ __global__ __launch_bounds__(256, 2) void gru_kernel(const f32x4* __restrict__ g
         // stream h(t) out as the layer output
         f32x4* yo = y_p + (size_t)s * (kYStride / 4);  // slot s: t for dir 0, T-1-t for dir 1
         const f32x4* hn4 = hbuf + (cur ^ 1) * 512;
-#ifndef HELEN_EXP_NOSTORE
         yo[tid] = hn4[tid];
         yo[tid + 256] = hn4[tid + 256];
-#else
-        if (T > 100000) { yo[tid] = hn4[tid]; }
-#endif
         HELEN_TICK(4)
     }
 #ifdef HELEN_GRU_TIMING
     if (tile == 0 && lane == 0) {
         printf("gru dir %d wave %d: cycles/step  mfma %lld  vmwait %lld  Gread %lld  dma-issue %lld  gates %lld  barrier %lld  ycopy %lld\n",
                dir, w, tk[0] / T, tk[5] / T, tk[6] / T, tk[1] / T, tk[2] / T, tk[3] / T, tk[4] / T);
-    }
-#endif
-#ifdef HELEN_GRU_WALL
-    if (tid == 0) {
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        printf("WG tile %d dir %d xcc %u se %u cu %u simd %u start %lld end %lld\n", tile, dir, xcc & 15,
-               (hwid >> 13) & 7, (hwid >> 8) & 15, (hwid >> 4) & 3, wall0, wall_clock64());
     }
 #endif
     const f32x4* hl = hbuf + (T & 1) * 512;

@@ -1,0 +1,135 @@
+"""SequenceDataset: MarginPolish image files -> batches of pileup windows.
+
+Mirrors helen/modules/python/models/dataloader_predict.py:11-95 and the DataLoader around it
+(models/predict_gpu.py:81-85): the index is (file, image name) in file order x HDF5 key order,
+items are the reference's 7-tuple, short images are zero-padded to 1000 positions with (-1,-1,-1)
+position rows, batching is sequential with a short last batch.  Differences in mechanism only:
+files stay open per process (the reference re-opens per item), HDF5 is read through
+helen_amd.hdf5 (ctypes on libhdf5), and batches can be produced by worker processes.
+"""
+import collections
+import sys
+
+import numpy as np
+
+from . import hdf5
+from .file_manager import get_file_paths_from_directory
+from .options import ImageSizeOptions
+
+Batch = collections.namedtuple(
+    "Batch", "contig contig_start contig_end chunk_id images positions filenames")
+
+
+class _FileCache(object):
+    """Per-process cache of open read-only files."""
+
+    def __init__(self, limit=64):
+        self.limit = limit
+        self.files = collections.OrderedDict()
+
+    def get(self, path):
+        f = self.files.get(path)
+        if f is None:
+            if len(self.files) >= self.limit:
+                _, old = self.files.popitem(last=False)
+                old.close()
+            f = hdf5.File(path, "r")
+            self.files[path] = f
+        else:
+            self.files.move_to_end(path)
+        return f
+
+
+_cache = _FileCache()
+
+
+def read_item(hdf5_filepath, image_name):
+    """One image with its bookkeeping, padded to SEQ_LENGTH (dataloader_predict.py:54-88)."""
+    f = _cache.get(hdf5_filepath)
+    base = "images/" + image_name + "/"
+    contig = str(f.read(base + "contig").reshape(-1)[0]).replace("'", "")
+    contig_start = int(f.read(base + "contig_start", np.int64).reshape(-1)[0])
+    contig_end = int(f.read(base + "contig_end", np.int64).reshape(-1)[0])
+    chunk_id = int(f.read(base + "feature_chunk_idx", np.int64).reshape(-1)[0])
+    image = f.read(base + "image", np.uint8)
+    position = f.read(base + "position", np.int64)
+    L, H = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT
+    if image.ndim != 2 or image.shape[1] != H or position.ndim != 2 or position.shape[1] != 3:
+        raise ValueError("IMAGE SIZE ERROR: " + str(hdf5_filepath) + " " + str(image.shape))
+    if image.shape[0] < L:
+        need = L - image.shape[0]
+        image = np.concatenate([image, np.zeros((need, H), np.uint8)], 0)
+        position = np.concatenate([position, np.full((L - position.shape[0], 3), -1, np.int64)], 0)
+    if image.shape[0] != L or position.shape[0] != L:
+        raise ValueError("IMAGE SIZE ERROR: " + str(hdf5_filepath) + " " + str(image.shape))
+    return contig, contig_start, contig_end, chunk_id, image, position, hdf5_filepath
+
+
+def _collate(items):
+    """Default-collate equivalent of torch's DataLoader for the 7-tuple (numpy instead of tensors)."""
+    return Batch(
+        contig=[it[0] for it in items],
+        contig_start=np.array([it[1] for it in items], np.int64),
+        contig_end=np.array([it[2] for it in items], np.int64),
+        chunk_id=np.array([it[3] for it in items], np.int64),
+        images=np.stack([it[4] for it in items]) if items else np.zeros((0, 1000, 90), np.uint8),
+        positions=np.stack([it[5] for it in items]) if items else np.zeros((0, 1000, 3), np.int64),
+        filenames=[it[6] for it in items])
+
+
+def _load_batch(pairs):
+    return _collate([read_item(p, n) for p, n in pairs])
+
+
+class SequenceDataset(object):
+    def __init__(self, image_directory, file_list=None):
+        if file_list is not None:
+            hdf_files = list(file_list)
+        else:
+            hdf_files = get_file_paths_from_directory(image_directory)
+        pairs = []
+        for path in hdf_files:
+            with hdf5.File(path, "r") as f:
+                if "images" in f:
+                    for name in f.keys("images"):
+                        pairs.append((path, name))
+                else:
+                    sys.stderr.write("WARN: NO IMAGES FOUND IN FILE: " + path + "\n")
+        self.all_images = pairs
+
+    def __len__(self):
+        return len(self.all_images)
+
+    def __getitem__(self, index):
+        path, name = self.all_images[index]
+        return read_item(path, name)
+
+    def num_batches(self, batch_size):
+        return (len(self) + batch_size - 1) // batch_size
+
+    def iter_batches(self, batch_size, num_workers=0, prefetch=4):
+        """Sequential batches (shuffle=False, drop_last=False; predict_gpu.py:82-85).  With
+        num_workers > 0 batches are read by a pool of worker processes, `prefetch` batches per
+        worker in flight, and yielded in order."""
+        groups = [self.all_images[i:i + batch_size] for i in range(0, len(self), batch_size)]
+        if num_workers <= 0:
+            for g in groups:
+                yield _load_batch(g)
+            return
+        import concurrent.futures as cf
+        import multiprocessing as mp
+        ctx = mp.get_context("spawn")
+        with cf.ProcessPoolExecutor(num_workers, mp_context=ctx) as pool:
+            window = max(1, num_workers * prefetch)
+            pending = collections.deque()
+            it = iter(groups)
+            for g in it:
+                pending.append(pool.submit(_load_batch, g))
+                if len(pending) >= window:
+                    break
+            while pending:
+                batch = pending.popleft().result()
+                nxt = next(it, None)
+                if nxt is not None:
+                    pending.append(pool.submit(_load_batch, nxt))
+                yield batch

@@ -1,0 +1,57 @@
+"""The N > 1 path on CPU: two processes over gloo.  Ranks take disjoint round-robin shards, never
+exchange data, and only barrier + max-reduce the elapsed time (bench.py's rule)."""
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r)
+from helen_amd import dist_util
+from helen_amd.file_manager import shard_round_robin
+rank, local_rank, world = dist_util.env_world()
+dist = dist_util.init_distributed("gloo")
+assert dist is not None and dist.get_world_size() == 2
+files = ["img_%%02d.h5" %% i for i in range(7)]
+mine = shard_round_robin(files, world)[rank]
+assert mine == dist_util.shard_for_rank(files, rank, world)
+dist_util.barrier(dist)
+t = dist_util.max_over_ranks(dist, 1.0 + rank)          # rank 1 is "slower"
+n = dist_util.sum_over_ranks(dist, len(mine))
+import torch
+gathered = [None, None]
+dist.all_gather_object(gathered, mine)                   # test-only: check the shards
+flat = sorted(sum(gathered, []))
+assert flat == files, flat                               # disjoint and complete
+if rank == 0:
+    print(json.dumps({"max_time": t, "total": n, "shard0": mine}))
+dist_util.barrier(dist)
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_sharding_and_timing_rule(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
+        env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["max_time"] == 2.0 and r["total"] == 7.0
+    assert r["shard0"] == ["img_00.h5", "img_02.h5", "img_04.h5", "img_06.h5"]

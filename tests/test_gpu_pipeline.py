@@ -1,0 +1,107 @@
+"""End-to-end on the GPU box: synthetic MarginPolish image directory -> call_consensus / the CLI ->
+prediction HDF5, checked against the CPU oracle window by window.  pytest -m gpu."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helen_amd import hdf5
+from helen_amd.weights import make_weights
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not hdf5.available(), reason="libhdf5 not loadable")]
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _expected(image_dir, weights):
+    """Oracle labels for every image of the directory, keyed by (contig_start, chunk_id)."""
+    import oracle
+    from helen_amd.sequence_dataset import SequenceDataset
+    ds = SequenceDataset(image_dir)
+    items = [ds[i] for i in range(len(ds))]
+    o = oracle.polish_batch(weights, np.stack([it[4] for it in items]))
+    return {(it[1], it[3]): (o["bases"][i], o["rles"][i], it[5]) for i, it in enumerate(items)}
+
+
+def _check_prediction_files(paths, expected):
+    seen = 0
+    for p in paths:
+        with hdf5.File(p) as f:
+            for contig in f.keys("predictions"):
+                for prefix in f.keys("predictions/" + contig):
+                    root = "predictions/%s/%s" % (contig, prefix)
+                    cs = int(f.read(root + "/contig_start"))
+                    assert prefix == "%s-%d-%d" % (contig, cs, int(f.read(root + "/contig_end")))
+                    for chunk in f.keys(root):
+                        if chunk in ("contig_start", "contig_end"):
+                            continue
+                        eb, er, pos = expected[(cs, int(chunk))]
+                        b = f.read(root + "/" + chunk + "/bases")
+                        r = f.read(root + "/" + chunk + "/rles")
+                        q = f.read(root + "/" + chunk + "/position")
+                        assert b.dtype == np.uint8 and r.dtype == np.uint8 and q.dtype == np.uint32
+                        assert np.array_equal(b, eb) and np.array_equal(r, er)
+                        assert np.array_equal(q, pos.astype(np.uint32))
+                        seen += 1
+    assert seen == len(expected)
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory):
+    from helen_amd.model_handler import ModelHandler
+    from helen_amd.synthetic import write_image_dir
+    d = tmp_path_factory.mktemp("pipe")
+    w = make_weights(seed=31, input_scale=1.0 / 64.0)
+    model = str(d / "synthetic_model.pkl")
+    ModelHandler.save_model(w, None, 128, 1, 0, model)
+    img_dir = str(d / "images")
+    write_image_dir(img_dir, 70, n_files=3, seed=77, short_every=9)
+    return d, w, model, img_dir, _expected(img_dir, w)
+
+
+def test_call_consensus_matches_oracle(workdir):
+    from helen_amd.call_consensus import call_consensus
+    d, w, model, img_dir, expected = workdir
+    out = str(d / "out_api")
+    call_consensus(img_dir, model, 16, 0, 1, out, "pred", True, "0", 1)
+    files = [os.path.join(out, f) for f in sorted(os.listdir(out))]
+    assert [os.path.basename(f) for f in files] == ["pred_0.hdf"]      # <prefix>_<rank>.hdf
+    _check_prediction_files(files, expected)
+
+
+def test_cli_polish_with_workers(workdir):
+    d, w, model, img_dir, expected = workdir
+    out = str(d / "out_cli")
+    r = subprocess.run([sys.executable, "-m", "helen_amd", "polish", "-i", img_dir, "-m", model, "-b", "8",
+                        "-w", "2", "-o", out, "-p", "asm", "-g", "-d_ids", "0"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    pred_dirs = [x for x in os.listdir(out) if x.startswith("predictions_")]
+    assert len(pred_dirs) == 1                                          # PolishInterface.py:65-69
+    pdir = os.path.join(out, pred_dirs[0])
+    files = [os.path.join(pdir, f) for f in sorted(os.listdir(pdir))]
+    assert [os.path.basename(f) for f in files] == ["helen_predictions_0.hdf"]
+    _check_prediction_files(files, expected)
+
+
+def test_drop_in_model_object(workdir):
+    """The reference's operator-level call `transducer_model(image_chunk, hidden)`
+    (predict_gpu.py:129) on the drop-in object loaded from a reference-format checkpoint."""
+    import torch
+
+    import oracle
+    from helen_amd.model_handler import ModelHandler
+    d, w, model, img_dir, expected = workdir
+    m, hs, gl, ep = ModelHandler.load_simple_model(model, 1, 90, 1000, 5, 11)
+    m.eval()
+    m.to(0)
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, 256, size=(5, 100, 90)).astype(np.float32)
+    h = m.init_hidden(5, 1)
+    base, rle, h1 = m(torch.from_numpy(x), h)                # CPU tensors are moved, like DDP did
+    ob, orl, oh = oracle.gru_chunk_forward(w, x, h.numpy())
+    np.testing.assert_allclose(base.cpu().numpy(), ob, atol=2e-4, rtol=2e-4)
+    np.testing.assert_allclose(rle.cpu().numpy(), orl, atol=2e-4, rtol=2e-4)
+    np.testing.assert_allclose(h1.cpu().numpy(), oh, atol=1e-4, rtol=0)

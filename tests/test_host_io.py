@@ -1,0 +1,180 @@
+"""Host-side rows of the path on CPU: HDF5 access, the image reader, the
+prediction writer (8a9), checkpoint I/O (8a8), sharding (8a10) and the CLI surface."""
+import os
+
+import numpy as np
+import pytest
+
+from helen_amd import file_manager, hdf5
+from helen_amd.data_store import DataStore
+from helen_amd.sequence_dataset import SequenceDataset
+from helen_amd.synthetic import write_image_dir, write_image_file
+from helen_amd.weights import make_images, make_weights
+
+pytestmark = pytest.mark.skipif(not hdf5.available(), reason="libhdf5 not loadable")
+
+
+def test_hdf5_roundtrip(tmp_path):
+    p = str(tmp_path / "t.h5")
+    with hdf5.File(p, "w") as f:
+        f.write("a/b/c/u8", np.arange(12, dtype=np.uint8).reshape(3, 4))
+        f.write("a/b/i64", np.array([-5, 7], np.int64))
+        f.write("a/scalar", 42)
+        f.write("a/name", "chr20")
+        f.write("z", np.zeros((0, 3), np.uint32))
+        with pytest.raises(hdf5.Hdf5Error):
+            f.write("a/scalar", 1)          # already exists
+    with hdf5.File(p) as f:
+        assert f.keys("/") == ["a", "z"] and f.keys("a") == ["b", "name", "scalar"]
+        assert "a/b/c/u8" in f and "a/b/nope" not in f and "q/r" not in f
+        u8 = f.read("a/b/c/u8")
+        assert u8.dtype == np.uint8 and u8.tolist() == np.arange(12).reshape(3, 4).tolist()
+        assert f.read("a/b/i64").tolist() == [-5, 7]
+        assert f.read("a/b/i64", np.uint8).dtype == np.uint8
+        s = f.read("a/scalar")
+        assert s.shape == () and s.dtype == np.int64 and int(s) == 42
+        assert f.read("a/name").reshape(-1)[0] == "chr20"
+        assert f.read("z").shape == (0, 3)
+        with pytest.raises(hdf5.Hdf5Error):
+            f.read("missing")
+
+
+def test_dataset_padding_and_order(tmp_path):
+    img = make_images(5, seed=3)
+    lengths = np.array([1000, 613, 1000, 1, 1000])
+    p = str(tmp_path / "one.h5")
+    write_image_file(p, img, lengths=lengths)
+    ds = SequenceDataset(None, file_list=[p])
+    assert len(ds) == 5
+    # HDF5 key order is name order, as h5py's .keys()
+    assert [n for _, n in ds.all_images] == sorted(n for _, n in ds.all_images)
+    by_start = {}
+    for i in range(5):
+        contig, cs, ce, chunk, image, position, path = ds[i]
+        assert contig == "chr20_synth" and ce == cs + 1000 and chunk == 0 and path == p
+        assert image.shape == (1000, 90) and image.dtype == np.uint8
+        assert position.shape == (1000, 3) and position.dtype == np.int64
+        by_start[cs] = (image, position)
+    for k, L in enumerate(lengths):
+        image, position = by_start[800 * k]
+        assert np.array_equal(image[:L], img[k, :L])
+        assert not image[L:].any()                                  # zero rows
+        assert (position[L:] == -1).all()                           # [-1,-1,-1] rows
+        assert np.array_equal(position[:L, 0], 800 * k + np.arange(L))
+
+
+def test_batches_sequential_short_last_and_workers(tmp_path):
+    files = write_image_dir(str(tmp_path / "imgs"), 37, n_files=3, seed=5, short_every=5)
+    ds = SequenceDataset(str(tmp_path / "imgs"))
+    assert len(ds) == 37 and ds.num_batches(8) == 5
+    a = list(ds.iter_batches(8))
+    assert [b.images.shape[0] for b in a] == [8, 8, 8, 8, 5]       # drop_last=False
+    assert a[0].contig_start.dtype == np.int64 and isinstance(a[0].contig[0], str)
+    order = [(f, int(s)) for b in a for f, s in zip(b.filenames, b.contig_start)]
+    want = [(p, int(n.split("-")[1])) for p, n in ds.all_images]
+    assert order == want                                            # index order, no shuffle
+    b = list(ds.iter_batches(8, num_workers=2))
+    assert len(b) == len(a)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.images, y.images) and np.array_equal(x.positions, y.positions)
+        assert x.contig == y.contig and x.filenames == y.filenames
+    assert files == file_manager.get_file_paths_from_directory(str(tmp_path / "imgs"))
+
+
+def test_datastore_layout_dtypes_wrap_and_duplicates(tmp_path):
+    out = str(tmp_path / "pred_0.hdf")
+    pos = np.stack([np.arange(1000), np.zeros(1000), np.zeros(1000)], 1).astype(np.int64)
+    pos[990:] = -1
+    bases = (np.arange(1000) % 5).astype(np.int64)       # labels arrive as int64 from argmax
+    rles = (np.arange(1000) % 11).astype(np.int64)
+    with DataStore(out, "w") as s:
+        s.write_prediction("ctg", np.int64(100), np.int64(1100), np.int64(0), pos, bases, rles, "f")
+        s.write_prediction("ctg", np.int64(100), np.int64(1100), np.int64(1), pos, rles % 5, bases, "f")
+        s.write_prediction("ctg", np.int64(100), np.int64(1100), np.int64(0), pos, bases * 0, rles * 0, "f")
+        s.write_prediction("other", 5, 1005, 0, pos, bases, rles, "f")
+    with hdf5.File(out) as f:
+        assert f.keys("predictions") == ["ctg", "other"]
+        assert f.keys("predictions/ctg") == ["ctg-100-1100"]
+        root = "predictions/ctg/ctg-100-1100"
+        assert f.keys(root) == ["0", "1", "contig_end", "contig_start"]
+        assert int(f.read(root + "/contig_start")) == 100 and int(f.read(root + "/contig_end")) == 1100
+        assert f.read(root + "/contig_start").shape == ()
+        p = f.read(root + "/0/position")
+        assert p.dtype == np.uint32 and p.shape == (1000, 3)
+        assert (p[990:] == 4294967295).all() and p[5, 0] == 5       # -1 wraps (DataStore.py:126)
+        b = f.read(root + "/0/bases")
+        assert b.dtype == np.uint8 and np.array_equal(b, bases)     # duplicate did not overwrite
+        assert f.read(root + "/0/rles").dtype == np.uint8
+        assert np.array_equal(f.read(root + "/1/rles"), bases)
+
+
+def test_round_robin_sharding():
+    files = ["f%d" % i for i in range(7)]
+    assert file_manager.shard_round_robin(files, 3) == [["f0", "f3", "f6"], ["f1", "f4"], ["f2", "f5"]]
+    assert file_manager.shard_round_robin(files[:2], 8) == [["f0"], ["f1"]]   # empties dropped
+    assert file_manager.shard_round_robin([], 4) == []
+    chunks = file_manager.chunk_it(list(range(10)), 3)
+    assert sum(chunks, []) == list(range(10))
+
+
+def test_file_listing_filters_h5(tmp_path):
+    for n in ("b.h5", "a.hdf5", "c.hdf", "d.txt", "e_h5"):
+        (tmp_path / n).write_bytes(b"")
+    got = [os.path.basename(p) for p in file_manager.get_file_paths_from_directory(str(tmp_path))]
+    assert got == ["b.h5", "e_h5"]     # last two characters == 'h5' (CallConsensusInterface.py:43)
+
+
+def test_checkpoint_roundtrip_and_module_prefix(tmp_path):
+    import torch
+
+    from helen_amd.model_handler import ModelHandler
+    from helen_amd.transducer import TransducerGRU
+    w = make_weights(seed=9)
+    path = str(tmp_path / "m.pkl")
+    ModelHandler.save_model(w, None, 128, 1, 3, path)
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) == {"model_state_dict", "model_optimizer", "hidden_size", "gru_layers", "epochs"}
+    model, hidden, layers, epochs = ModelHandler.load_simple_model(path, 1, 90, 1000, 5, 11)
+    assert (hidden, layers, epochs) == (128, 1, 3)
+    sd = model.state_dict()
+    assert all(np.array_equal(sd[k].numpy(), w[k]) for k in w)
+    # a checkpoint saved from a DataParallel/DDP-wrapped model (ModelHander.py:70-75)
+    torch.save({"model_state_dict": {"module." + k: torch.from_numpy(v) for k, v in w.items()},
+                "model_optimizer": {}, "hidden_size": 128, "gru_layers": 1, "epochs": 0}, path)
+    model2, _, _, _ = ModelHandler.load_simple_model(path, 1, 90, 1000, 5, 11)
+    assert np.array_equal(model2.state_dict()["dense2_rle.bias"].numpy(), w["dense2_rle.bias"])
+    m = TransducerGRU(1, 90, 1, 128, 5, 11)
+    assert tuple(m.init_hidden(7, 1).shape) == (7, 2, 128)
+    bad = dict(w)
+    bad.pop("dense1_base.bias")
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad)
+    with pytest.raises(ValueError):
+        TransducerGRU(1, 90, 2, 128, 5, 11)
+
+
+def test_cli_flags_and_validation(tmp_path, capsys):
+    from helen_amd import cli
+    from helen_amd.call_consensus import call_consensus, plan_devices
+    p = cli.build_parser()
+    a = p.parse_args(["polish", "-i", "x", "-m", "y"])
+    assert (a.batch_size, a.num_workers, a.threads, a.output_dir, a.output_prefix, a.gpu_mode,
+            a.device_ids, a.callers) == (512, 8, 1, "./output/", "HELEN_prediction", False, None, 8)
+    b = p.parse_args(["call_consensus", "-i", "x", "-m", "y", "-b", "256", "-g", "-d_ids", "0,2"])
+    assert b.threads == 16 and b.gpu_mode and b.device_ids == "0,2" and b.batch_size == 256
+    assert plan_devices(None, 4) == ([0, 1, 2, 3], 4)
+    assert plan_devices("1,3", 4) == ([1, 3], 2)
+    with pytest.raises(ValueError):
+        plan_devices("5", 4)
+    model = tmp_path / "m.pkl"
+    model.write_bytes(b"x")
+    for kwargs in (dict(model_path=str(tmp_path / "nope.pkl")), dict(image_dir=str(tmp_path / "nodir")),
+                   dict(batch_size=0), dict(num_workers=-1), dict(threads=0), dict(gpu_mode=False)):
+        args = dict(image_dir=str(tmp_path), model_path=str(model), batch_size=4, num_workers=0,
+                    threads=1, output_dir=str(tmp_path / "out"), output_prefix="p", gpu_mode=True,
+                    device_ids=None, callers=1)
+        args.update(kwargs)
+        with pytest.raises(SystemExit) as e:
+            call_consensus(**args)
+        assert e.value.code == 1
+    assert cli.main(["version"]) == 0
