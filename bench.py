@@ -29,6 +29,21 @@ GRU_FLOP_PER_WINDOW_LAUNCH = 100 * 2 * 2.0 * 384 * 128   # one recurrence launch
 FP32_MFMA_PEAK = 157.3e12             # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 
 
+def pmc_traffic(windows_per_launch):
+    """HBM bytes per gru_kernel launch from the committed rocprofv3 PMC summary of this same
+    command (profiles/*_pmc_summary.json, FETCH_SIZE/WRITE_SIZE passes; see scripts/pmc_summary.py),
+    scaled to this run's windows per launch.  None if no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None, None
+    try:
+        k = json.load(open(files[-1]))["kernels"]["helen::gru_kernel"]
+        return int(k["hbm_bytes_per_launch"] * windows_per_launch / 4096.0), os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(batch, seconds_target=12.0):
     """Time the CPU oracle (port of the reference path) on this box's host cores, bounded."""
     import numpy as np
@@ -145,6 +160,7 @@ def main():
         calls = (args.steps * B + call_windows - 1) // call_windows
         win_per_launch = args.steps * B / calls
         achieved = GRU_FLOP_PER_WINDOW_LAUNCH * win_per_launch / (avg_ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(win_per_launch)
         out = {
             "metric": "pileup windows/sec (batch 256, 1000-pos)",
             "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps,
@@ -159,7 +175,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gru_kernel (GRU recurrence, fp32 MFMA)",
                          "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved * 1e12 / FP32_MFMA_PEAK, 4),
-                         "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": gru_n,
+                         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "launches": gru_n,
                          "path_frac": round(value / world * FLOP_PER_WINDOW / FP32_MFMA_PEAK, 4)},
         }
         if not args.no_cpu_baseline:

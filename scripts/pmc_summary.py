@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 PMC passes (gpurun_out/pmc_*/p_counter_collection.csv) into
+profiles/<tag>_pmc_summary.json: per-kernel HBM bytes per launch and MFMA utilisation.
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are
+in KiB and collected in separate passes; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide
+(16 B/lane) coalesced reads, so it is doubled.  Both are calibrated here on kernels whose byte counts
+are known exactly (pack_images writes 1,572,864,000 B per 4096 windows; the recurrence reads gi).
+MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs).
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out")
+
+
+def agg(path):
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+        d[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return d
+
+
+fetch = agg(os.path.join(src, "pmc_FETCH_SIZE", "p_counter_collection.csv"))
+write = agg(os.path.join(src, "pmc_WRITE_SIZE", "p_counter_collection.csv"))
+sq = agg(os.path.join(src, "pmc_sq", "p_counter_collection.csv"))
+out = {"command": "rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 16 --warmup 0 "
+                  "--no-cpu-baseline   (one helen_polish_batch call of 4096 windows)",
+       "notes": "FETCH_SIZE doubled (gfx950 wide-read correction); sizes in bytes per launch",
+       "kernels": {}}
+for k in sorted(sq):
+    if not k.startswith("helen::"):
+        continue
+    mean = lambda d, c: sum(d[k][c]) / len(d[k][c]) if d.get(k, {}).get(c) else None  # noqa: E731
+    f, w = mean(fetch, "FETCH_SIZE"), mean(write, "WRITE_SIZE")
+    gui = mean(sq, "GRBM_GUI_ACTIVE")
+    mf = mean(sq, "SQ_VALU_MFMA_BUSY_CYCLES")
+    wave = mean(sq, "SQ_WAVE_CYCLES")
+    out["kernels"][k] = {
+        "launches_profiled": len(sq[k]["GRBM_GUI_ACTIVE"]),
+        "hbm_read_bytes_per_launch": None if f is None else int(2 * f * 1024),
+        "hbm_write_bytes_per_launch": None if w is None else int(w * 1024),
+        "hbm_bytes_per_launch": None if f is None or w is None else int((2 * f + w) * 1024),
+        "mfma_util": round(mf / (gui / 8 * 1024), 4) if gui else None,
+        "wait_inst_any_frac": round(mean(sq, "SQ_WAIT_INST_ANY") / wave, 4),
+        "wait_any_frac": round(mean(sq, "SQ_WAIT_ANY") / wave, 4),
+        "active_inst_frac": round(mean(sq, "SQ_ACTIVE_INST_ANY") / wave, 4),
+        "lds_bank_conflict_cycles": mean(sq, "SQ_LDS_BANK_CONFLICT"),
+    }
+path = os.path.join(ROOT, "profiles", tag + "_pmc_summary.json")
+json.dump(out, open(path, "w"), indent=1)
+print(open(path).read())
