@@ -59,6 +59,11 @@ struct HelenModel {
     float* bhn_enc = nullptr;  // [2][128]
     float* bhn_dec = nullptr;
     float* bhd = nullptr;      // [16]
+    // bf16 copies of the gate matrices (HELEN_PRECISION_BF16), 4 x bf16 per lane and group
+    bf16x4* wpb_enc = nullptr;
+    bf16x4* wpb_dec = nullptr;
+    bf16x4* whpb_enc = nullptr;
+    bf16x4* whpb_dec = nullptr;
     // scratch (device)
     f32x4* xa = nullptr;
     f32x4* gi_enc = nullptr;
@@ -144,6 +149,20 @@ std::vector<f32x4> pack_w_hh(const float* const w[2]) {
     return out;
 }
 
+// fp32 -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does on the device side)
+short to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (short)(u >> 16);
+}
+std::vector<bf16x4> round_pack(const std::vector<f32x4>& in) {
+    std::vector<bf16x4> out(in.size());
+    for (size_t i = 0; i < in.size(); ++i)
+        for (int e = 0; e < 4; ++e) out[i][e] = to_bf16(in[i][e]);
+    return out;
+}
+
 void record_begin(HelenModel* m, int cls, hipStream_t s, EventPair* ev, bool* on) {
     *on = (m->prof_mask >> cls) & 1u;
     if (!*on) return;
@@ -177,12 +196,35 @@ int check_launch(const char* what) {
 // One TransducerGRU.forward over `tiles` tiles whose encoder pre-activations are already in
 // gi_enc at positions [pos0, pos0+T): encoder recurrence -> decoder projection -> decoder
 // recurrence.  y2 then holds the decoder output, hid the returned hidden state.
+void launch_enc_gemm(HelenModel* m, hipStream_t s, int tiles, int npos) {
+    const dim3 grid((npos + 3) / 4, tiles, 8 / HELEN_GEMM_WAVES), block(HELEN_GEMM_WAVES * 64);
+    if (m->precision == HELEN_PRECISION_BF16)
+        LAUNCH(HELEN_K_GEMM_ENC, (gemm_gi_bf16_kernel<kFPad / 16, false>), grid, block, m->xa,
+               kXaTileStride, m->wpb_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, npos);
+    else
+        LAUNCH(HELEN_K_GEMM_ENC, (gemm_gi_kernel<kFPad / 16, false>), grid, block, m->xa,
+               kXaTileStride, m->wp_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, npos);
+}
+
+// One TransducerGRU.forward over `tiles` tiles whose encoder pre-activations are already in
+// gi_enc at positions [pos0, pos0+T): encoder recurrence -> decoder projection -> decoder
+// recurrence.  y2 then holds the decoder output, hid the returned hidden state.
 void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int enc_npos) {
+    const dim3 ggrid((T + 3) / 4, tiles, 8 / HELEN_GEMM_WAVES), gblock(HELEN_GEMM_WAVES * 64);
     // encoder gi holds `enc_npos` positions; the reverse direction is stored time-reversed
+    if (m->precision == HELEN_PRECISION_BF16) {
+        LAUNCH(HELEN_K_GRU_ENC, gru_bf16_kernel, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride,
+               pos0, enc_npos - pos0 - T, T, m->whpb_enc, m->bhn_enc, m->hid, m->y1, kYTileStride);
+        LAUNCH(HELEN_K_GEMM_DEC, (gemm_gi_bf16_kernel<16, true>), ggrid, gblock, m->y1, kYTileStride,
+               m->wpb_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T);
+        LAUNCH(HELEN_K_GRU_DEC, gru_bf16_kernel, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0,
+               0, T, m->whpb_dec, m->bhn_dec, m->hid, m->y2, kYTileStride);
+        return;
+    }
     LAUNCH(HELEN_K_GRU_ENC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
            enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride);
-    LAUNCH(HELEN_K_GEMM_DEC, (gemm_gi_kernel<16, true>), dim3((T + 3) / 4, tiles, 8 / HELEN_GEMM_WAVES), dim3(HELEN_GEMM_WAVES * 64), m->y1,
-           kYTileStride, m->wp_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T);
+    LAUNCH(HELEN_K_GEMM_DEC, (gemm_gi_kernel<16, true>), ggrid, gblock, m->y1, kYTileStride, m->wp_dec,
+           m->bias_dec, m->gi_dec, kGiDecTileStride, T);
     LAUNCH(HELEN_K_GRU_DEC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, 0, T,
            m->whp_dec, m->bhn_dec, m->hid, m->y2, kYTileStride);
 }
@@ -190,7 +232,7 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
 void free_model(HelenModel* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    void* ptrs[] = {m->wp_enc, m->wp_dec, m->whp_enc, m->whp_dec, m->whd, m->bias_enc, m->bias_dec,
+    void* ptrs[] = {m->wpb_enc, m->wpb_dec, m->whpb_enc, m->whpb_dec, m->wp_enc, m->wp_dec, m->whp_enc, m->whp_dec, m->whd, m->bias_enc, m->bias_dec,
                     m->bhn_enc, m->bhn_dec, m->bhd, m->xa, m->gi_enc, m->gi_dec, m->y1, m->y2,
                     m->hid, m->pending, m->dev_in[0], m->dev_in[1], m->dev_out[0], m->dev_out[1]};
     for (void* p : ptrs)
@@ -233,6 +275,12 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
     if ((rc = upload(m, &m->wp_dec, pack_w_ih(w->dec_w_ih, 2 * kH, 16)))) return rc;
     if ((rc = upload(m, &m->whp_enc, pack_w_hh(w->enc_w_hh)))) return rc;
     if ((rc = upload(m, &m->whp_dec, pack_w_hh(w->dec_w_hh)))) return rc;
+    if (precision == HELEN_PRECISION_BF16) {
+        if ((rc = upload(m, &m->wpb_enc, round_pack(pack_w_ih(w->enc_w_ih, kF, kFPad / 16))))) return rc;
+        if ((rc = upload(m, &m->wpb_dec, round_pack(pack_w_ih(w->dec_w_ih, 2 * kH, 16))))) return rc;
+        if ((rc = upload(m, &m->whpb_enc, round_pack(pack_w_hh(w->enc_w_hh))))) return rc;
+        if ((rc = upload(m, &m->whpb_dec, round_pack(pack_w_hh(w->dec_w_hh))))) return rc;
+    }
     {
         std::vector<f32x4> whd(16 * 64);
         for (int mg = 0; mg < 16; ++mg)
@@ -291,8 +339,8 @@ int helen_model_create(const HelenWeights* w, int device, int max_windows, int p
                     "unsupported geometry F=%d H=%d base=%d rle=%d (built for %d/%d/%d/%d, Options.py:13-29)",
                     w->features, w->hidden, w->n_base, w->n_rle, kF, kH, kNB, kNR);
     if (max_windows <= 0) return fail(HELEN_EINVAL, "max_windows must be > 0");
-    if (precision != HELEN_PRECISION_FP32)
-        return fail(HELEN_EINVAL, "precision %d not available in this build", precision);
+    if (precision != HELEN_PRECISION_FP32 && precision != HELEN_PRECISION_BF16)
+        return fail(HELEN_EINVAL, "unknown precision %d", precision);
     for (int d = 0; d < 2; ++d)
         if (!w->enc_w_ih[d] || !w->enc_w_hh[d] || !w->enc_b_ih[d] || !w->enc_b_hh[d] ||
             !w->dec_w_ih[d] || !w->dec_w_hh[d] || !w->dec_b_ih[d] || !w->dec_b_hh[d])
@@ -333,8 +381,7 @@ int helen_polish_batch(HelenModel* m, const uint8_t* images, int n_windows, uint
     LAUNCH(HELEN_K_PACK, pack_images_kernel, dim3((kSeq * (kXaStride / 4) + 255) / 256, tiles),
            dim3(256), images, n_windows, kSeq, m->xa);
     // encoder input projection for all 1000 positions at once: overlapping chunks share it
-    LAUNCH(HELEN_K_GEMM_ENC, (gemm_gi_kernel<kFPad / 16, false>), dim3(kSeq / 4, tiles, 8 / HELEN_GEMM_WAVES), dim3(HELEN_GEMM_WAVES * 64), m->xa,
-           kXaTileStride, m->wp_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, kSeq);
+    launch_enc_gemm(m, s, tiles, kSeq);
     // zero initial hidden per batch (predict_gpu.py:99)
     HIP_TRY(hipMemsetAsync(m->hid, 0, (size_t)tiles * kHidStride * sizeof(float), s));
     for (int c = 0; c < kChunks; ++c) {  // predict_gpu.py:114-149
@@ -357,8 +404,7 @@ int helen_gru_chunk_forward(HelenModel* m, const float* x, const float* h_in, in
     LAUNCH(HELEN_K_PACK, pack_x_f32_kernel, dim3((T * (kXaStride / 4) + 255) / 256, tiles), dim3(256),
            x, B, T, m->xa, kXaTileStride);
     hipLaunchKernelGGL(pack_hidden_kernel, dim3(tiles), dim3(256), 0, s, h_in, B, (float*)m->hid);
-    LAUNCH(HELEN_K_GEMM_ENC, (gemm_gi_kernel<kFPad / 16, false>), dim3((T + 3) / 4, tiles, 8 / HELEN_GEMM_WAVES), dim3(HELEN_GEMM_WAVES * 64), m->xa,
-           kXaTileStride, m->wp_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, T);
+    launch_enc_gemm(m, s, tiles, T);
     launch_chunk(m, s, tiles, 0, T, T);
     LAUNCH(HELEN_K_HEADS, heads_kernel, dim3(tiles, (T + kJump - 1) / kJump), dim3(256), m->y2,
            kYTileStride, m->whd, m->bhd, 1, 0, T, B, m->pending, (uint8_t*)nullptr, (uint8_t*)nullptr,

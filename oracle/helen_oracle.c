@@ -34,6 +34,22 @@
 
 static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+/* Arithmetic of the gate matmuls: 0 = fp32 (the reference), 1 = operands rounded to bf16 (RNE),
+ * fp32 accumulate/state -- the emulation the bf16 HIP variant (BASELINE.json configs[3]) is
+ * checked against.  Heads, gates and softmax stay fp32 in both. */
+static int g_precision = 0;
+void oracle_set_precision(int p) { g_precision = p ? 1 : 0; }
+int oracle_get_precision(void) { return g_precision; }
+
+static inline float bf16r(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
 /* Transposed copy of a [rows, cols] matrix -> [cols, rows], so the inner loop over output units
  * is contiguous (vectorises without reassociating the k-sum). */
 static float* transpose_(const float* w, int rows, int cols) {
@@ -57,6 +73,10 @@ static void dir_init(Dir* d, const float* w_ih, const float* w_hh, const float* 
     d->H = H;
     d->w_ih_t = transpose_(w_ih, 3 * H, K);
     d->w_hh_t = transpose_(w_hh, 3 * H, H);
+    if (g_precision) {
+        for (size_t i = 0; i < (size_t)3 * H * K; ++i) d->w_ih_t[i] = bf16r(d->w_ih_t[i]);
+        for (size_t i = 0; i < (size_t)3 * H * H; ++i) d->w_hh_t[i] = bf16r(d->w_hh_t[i]);
+    }
     d->b_ih = b_ih;
     d->b_hh = b_hh;
 }
@@ -81,7 +101,8 @@ static void gru_dir(const Dir* d, const float* const* x, int xs, int T, int reve
         for (int k = 0; k < K; ++k) {
             const float* w = d->w_ih_t + (size_t)k * G;
             for (int b = 0; b < nb; ++b) {
-                const float xv = x[b][(size_t)t * xs + k];
+                const float xr = x[b][(size_t)t * xs + k];
+                const float xv = g_precision ? bf16r(xr) : xr;
                 float* g = gi + (size_t)b * G;
                 for (int j = 0; j < G; ++j) g[j] += xv * w[j];
             }
@@ -89,7 +110,7 @@ static void gru_dir(const Dir* d, const float* const* x, int xs, int T, int reve
         for (int k = 0; k < H; ++k) {
             const float* w = d->w_hh_t + (size_t)k * G;
             for (int b = 0; b < nb; ++b) {
-                const float hv = h[b][k];
+                const float hv = g_precision ? bf16r(h[b][k]) : h[b][k];
                 float* g = gh + (size_t)b * G;
                 for (int j = 0; j < G; ++j) g[j] += hv * w[j];
             }

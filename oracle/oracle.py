@@ -56,6 +56,7 @@ def _load():
             ctypes.POINTER(HelenWeightsC), _u8p, ctypes.c_int, _u8p, _u8p, _f32p, _f32p, _f32p,
             _f32p, _f32p]
         lib.oracle_max_threads.restype = ctypes.c_int
+        lib.oracle_set_precision.argtypes = [ctypes.c_int]
         lib.oracle_set_threads.argtypes = [ctypes.c_int]
         _lib = lib
     return _lib
@@ -106,6 +107,12 @@ def max_threads():
 
 def set_threads(n):
     _load().oracle_set_threads(int(n))
+
+
+def set_precision(name):
+    """'fp32' (the reference arithmetic) or 'bf16' (gate-matmul operands rounded to bf16, fp32
+    accumulate/state): the emulation the bf16 HIP variant is checked against."""
+    _load().oracle_set_precision({"fp32": 0, "bf16": 1}[name])
 
 
 def gru_chunk_forward(weights, x, h_in):

@@ -14,11 +14,12 @@ from helen_amd.weights import make_weights  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--windows", type=int, nargs="+", default=[256, 2048, 4096])
 ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--precision", default="fp32")
 args = ap.parse_args()
 
 w = make_weights(input_scale=1.0 / 64.0)
 for n in args.windows:
-    eng = HelenEngine(w, device=0, max_windows=n)
+    eng = HelenEngine(w, device=0, max_windows=n, precision=args.precision)
     g = torch.Generator(device="cuda").manual_seed(1)
     img = torch.randint(0, 256, (n, 1000, 90), dtype=torch.uint8, device="cuda", generator=g)
     eng.polish(img)

@@ -144,3 +144,46 @@ def test_errors_are_reported():
     with pytest.raises(_lib.HelenError):
         HelenEngine(bad, device=0, max_windows=16)
     eng.close()
+
+
+# ---- bf16 gate matmuls (BASELINE.json configs[3]): logits tolerance + argmax parity vs fp32 ----
+BF16_LOGIT_ATOL_VS_EMULATION = 1e-2   # same arithmetic, different summation order / rounding flips
+BF16_LOGIT_ATOL_VS_FP32 = 0.30        # bf16 operands (8-bit mantissa) through 1,900 recurrent steps; |logit| <= 12.5
+BF16_LABEL_MISMATCH_MAX = 0.02        # fraction of positions; random weights have thin margins
+
+
+@pytest.mark.parametrize("case", ["trace6", "small_input6"])
+def test_bf16_variant_against_emulation_and_fp32(case):
+    import oracle
+    from helen_amd.engine import HelenEngine
+    w, img, g = load_case(case)
+    eng = HelenEngine(w, device=0, max_windows=512, precision="bf16")   # config 4 runs at batch 512
+    images = torch.from_numpy(img).cuda()
+    bases, rles, acc_b, acc_r = eng.polish(images, want_acc=True)
+    # operator loop for logits / hidden
+    xf = images.float()
+    hidden = torch.zeros(img.shape[0], 2, 128, device="cuda")
+    logits = {}
+    for c, i in enumerate(chunk_starts()):
+        base, rle, hidden = eng.chunk_forward(xf[:, i:i + 100].contiguous(), hidden)
+        if c in (0, 9, 18):
+            logits[c] = (base.cpu().numpy(), rle.cpu().numpy())
+    oracle.set_precision("bf16")
+    try:
+        emu = oracle.polish_batch(w, img, traces=True)
+    finally:
+        oracle.set_precision("fp32")
+    for k, c in enumerate((0, 9, 18)):
+        np.testing.assert_allclose(logits[c][0], emu["logit_base"][c], atol=BF16_LOGIT_ATOL_VS_EMULATION, rtol=0)
+        np.testing.assert_allclose(logits[c][1], emu["logit_rle"][c], atol=BF16_LOGIT_ATOL_VS_EMULATION, rtol=0)
+        # against the reference's fp32 logits
+        eb = np.abs(logits[c][0] - g["logit_base"][k]).max()
+        er = np.abs(logits[c][1] - g["logit_rle"][k]).max()
+        assert eb < BF16_LOGIT_ATOL_VS_FP32 and er < BF16_LOGIT_ATOL_VS_FP32, (eb, er)
+    b, r = bases.cpu().numpy(), rles.cpu().numpy()
+    mis_emu = ((b != emu["bases"]).mean() + (r != emu["rles"]).mean()) / 2
+    mis_ref = ((b != g["bases"]).mean() + (r != g["rles"]).mean()) / 2
+    print("bf16 %s: label mismatch vs bf16 emulation %.4f%%, vs fp32 reference %.4f%%"
+          % (case, 100 * mis_emu, 100 * mis_ref))
+    assert mis_emu < BF16_LABEL_MISMATCH_MAX and mis_ref < BF16_LABEL_MISMATCH_MAX
+    eng.close()
