@@ -27,6 +27,7 @@ if ROOT not in sys.path:
 FLOP_PER_WINDOW = 1772441600.0        # 932,864 FLOP/step x 100 steps x 19 chunks
 GRU_FLOP_PER_WINDOW_LAUNCH = 100 * 2 * 2.0 * 384 * 128   # one recurrence launch, both directions
 FP32_MFMA_PEAK = 157.3e12             # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+BF16_MFMA_PEAK = 2.5e15               # MI355X_MICROARCH.md: bf16 MFMA, dense
 
 
 def pmc_traffic(windows_per_launch):
@@ -77,6 +78,12 @@ def main():
     ap.add_argument("--coalesce", type=int, default=16, help="loader batches per device call")
     ap.add_argument("--mode", default="uniform", choices=["uniform", "pileup"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="gate-matmul arithmetic; fp32 is BASELINE.json configs[1] (the headline)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for the barrier / max-time reduce (nccl = RCCL)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="testing aid: every rank uses cuda:0 (exercise the N>1 code path on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -84,21 +91,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.single_device:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     else:
         dist = None
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
     from helen_amd.engine import HelenEngine
     from helen_amd.weights import make_weights
 
     B, G = args.batch, args.coalesce
     call_windows = B * G
-    eng = HelenEngine(make_weights(input_scale=1.0 / 64.0), device=local_rank, max_windows=call_windows)
+    eng = HelenEngine(make_weights(input_scale=1.0 / 64.0), device=local_rank, max_windows=call_windows,
+                      precision=args.precision)
 
     # synthetic chr20-scale image shard, resident in HBM before the timed region; every rank gets
     # its own shard (weak scaling: images are sharded by file, CallConsensusInterface.py:138-145)
@@ -146,7 +158,8 @@ def main():
     eng.set_profiling([])
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -161,22 +174,32 @@ def main():
         win_per_launch = args.steps * B / calls
         achieved = GRU_FLOP_PER_WINDOW_LAUNCH * win_per_launch / (avg_ms * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(win_per_launch)
+        peak = FP32_MFMA_PEAK if args.precision == "fp32" else BF16_MFMA_PEAK
+        bound, unit = "mfma", "TFLOP/s"
+        if args.precision == "bf16" and traffic:
+            # with bf16 MFMAs the recurrence is bound by its fp32 gi/y stream, not by the matrix pipe
+            bound, unit, peak = "hbm", "GB/s", 8000e9
+            achieved = traffic / (avg_ms * 1e-3) / 1e9
         out = {
             "metric": "pileup windows/sec (batch 256, 1000-pos)",
             "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 operands, f32 accumulate/state",
             "data": "synthetic (%s uint8 windows, seeded; random-init weights of the reference "
                     "architecture)" % args.mode,
-            "config": {"workload": "BASELINE.json configs[1]: 1xMI355X, batch 256, fp32, synthetic "
-                                   "chr20-scale image shard resident in HBM",
+            "config": {"workload": ("BASELINE.json configs[1]: 1xMI355X, batch 256, fp32, synthetic "
+                                    "chr20-scale image shard resident in HBM") if args.precision == "fp32"
+                       else "BASELINE.json configs[3] variant: bf16 gate matmuls, fp32 accumulate/state",
                        "batch": B, "coalesce_batches_per_call": G, "positions": 1000, "features": 90,
                        "windows_per_gpu": args.steps * B, "sharding": "by rank, no collective"},
-            "roofline": {"bound": "mfma", "kernel": "gru_kernel (GRU recurrence, fp32 MFMA)",
-                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK / 1e12,
-                         "unit": "TFLOP/s", "frac": round(achieved * 1e12 / FP32_MFMA_PEAK, 4),
+            "roofline": {"bound": bound, "kernel": "gru_kernel (GRU recurrence, fp32 MFMA)" if args.precision == "fp32"
+                         else "gru_bf16_kernel (GRU recurrence, bf16 MFMA)",
+                         "achieved": round(achieved, 2),
+                         "peak": peak / (1e12 if bound == "mfma" else 1e9), "unit": unit,
+                         "frac": round(achieved * (1e12 if bound == "mfma" else 1e9) / peak, 4),
                          "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "launches": gru_n,
-                         "path_frac": round(value / world * FLOP_PER_WINDOW / FP32_MFMA_PEAK, 4)},
+                         "path_frac": round(value / world * FLOP_PER_WINDOW /
+                                            (FP32_MFMA_PEAK if args.precision == "fp32" else BF16_MFMA_PEAK), 4)},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B)

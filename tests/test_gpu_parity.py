@@ -187,3 +187,37 @@ def test_bf16_variant_against_emulation_and_fp32(case):
           % (case, 100 * mis_emu, 100 * mis_ref))
     assert mis_emu < BF16_LABEL_MISMATCH_MAX and mis_ref < BF16_LABEL_MISMATCH_MAX
     eng.close()
+
+
+# ---- full-size properties (BASELINE.json configs[1] scale per call: 4096+ windows) ----
+def test_full_size_properties():
+    """At the benchmark's per-call size the oracle is too slow for every window, so check
+    size-independent properties: permutation equivariance (windows never interact), duplicates
+    give identical rows, the host-streaming entry equals the device entry, and a random subset
+    matches the oracle bit for bit."""
+    import oracle
+    from helen_amd.engine import HelenEngine
+    n = 4096 + 40                       # one full device call plus a ragged tail (2.5 tiles)
+    w = make_weights(seed=20260928, input_scale=1.0 / 64.0)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    img = torch.randint(0, 256, (n, 1000, 90), dtype=torch.uint8, device="cuda", generator=g)
+    img[17] = img[4000]                 # duplicates in different tiles / different calls
+    img[4100] = img[5]
+    img[33, 613:] = 0                   # a short window, zero-padded like the reader does
+    eng = HelenEngine(w, device=0, max_windows=4096)
+    bases, rles = eng.polish(img)
+    assert torch.equal(bases[17], bases[4000]) and torch.equal(rles[17], rles[4000])
+    assert torch.equal(bases[4100], bases[5]) and torch.equal(rles[4100], rles[5])
+    perm = torch.randperm(n, device="cuda", generator=g)
+    bp, rp = eng.polish(img[perm].contiguous())
+    assert torch.equal(bp, bases[perm]) and torch.equal(rp, rles[perm])
+    bh, rh = eng.polish_host(img.cpu().numpy())
+    assert np.array_equal(bh, bases.cpu().numpy()) and np.array_equal(rh, rles.cpu().numpy())
+    pick = np.sort(np.random.default_rng(1).choice(n, size=32, replace=False))
+    pick[:3] = [17, 33, 4100]
+    o = oracle.polish_batch(w, img[torch.from_numpy(pick).cuda()].cpu().numpy())
+    nb, rep = label_mismatch_report(o["acc_base"], o["bases"], bases.cpu().numpy()[pick], "base")
+    nr, rep2 = label_mismatch_report(o["acc_rle"], o["rles"], rles.cpu().numpy()[pick], "rle")
+    assert nb == 0 and nr == 0, rep + "\n" + rep2
+    assert int(bases.max()) <= 4 and int(rles.max()) <= 10
+    eng.close()
