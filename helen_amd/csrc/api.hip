@@ -196,27 +196,34 @@ int check_launch(const char* what) {
 // One TransducerGRU.forward over `tiles` tiles whose encoder pre-activations are already in
 // gi_enc at positions [pos0, pos0+T): encoder recurrence -> decoder projection -> decoder
 // recurrence.  y2 then holds the decoder output, hid the returned hidden state.
+// 1-D grid of the projection kernels: units = tiles x position groups, padded to a multiple of 8
+// (the XCD count), times 8 / HELEN_GEMM_WAVES column-group workgroups per unit.
+unsigned gemm_grid(int npos, int tiles) {
+    const int units = tiles * ((npos + 3) / 4);
+    return (unsigned)((units + 7) / 8 * 8) * (8 / HELEN_GEMM_WAVES);
+}
+
 void launch_enc_gemm(HelenModel* m, hipStream_t s, int tiles, int npos) {
-    const dim3 grid((npos + 3) / 4, tiles, 8 / HELEN_GEMM_WAVES), block(HELEN_GEMM_WAVES * 64);
+    const dim3 grid(gemm_grid(npos, tiles)), block(HELEN_GEMM_WAVES * 64);
     if (m->precision == HELEN_PRECISION_BF16)
         LAUNCH(HELEN_K_GEMM_ENC, (gemm_gi_bf16_kernel<kFPad / 16, false>), grid, block, m->xa,
-               kXaTileStride, m->wpb_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, npos);
+               kXaTileStride, m->wpb_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles);
     else
         LAUNCH(HELEN_K_GEMM_ENC, (gemm_gi_kernel<kFPad / 16, false>), grid, block, m->xa,
-               kXaTileStride, m->wp_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, npos);
+               kXaTileStride, m->wp_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles);
 }
 
 // One TransducerGRU.forward over `tiles` tiles whose encoder pre-activations are already in
 // gi_enc at positions [pos0, pos0+T): encoder recurrence -> decoder projection -> decoder
 // recurrence.  y2 then holds the decoder output, hid the returned hidden state.
 void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int enc_npos) {
-    const dim3 ggrid((T + 3) / 4, tiles, 8 / HELEN_GEMM_WAVES), gblock(HELEN_GEMM_WAVES * 64);
+    const dim3 ggrid(gemm_grid(T, tiles)), gblock(HELEN_GEMM_WAVES * 64);
     // encoder gi holds `enc_npos` positions; the reverse direction is stored time-reversed
     if (m->precision == HELEN_PRECISION_BF16) {
         LAUNCH(HELEN_K_GRU_ENC, gru_bf16_kernel, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride,
                pos0, enc_npos - pos0 - T, T, m->whpb_enc, m->bhn_enc, m->hid, m->y1, kYTileStride);
         LAUNCH(HELEN_K_GEMM_DEC, (gemm_gi_bf16_kernel<16, true>), ggrid, gblock, m->y1, kYTileStride,
-               m->wpb_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T);
+               m->wpb_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
         LAUNCH(HELEN_K_GRU_DEC, gru_bf16_kernel, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0,
                0, T, m->whpb_dec, m->bhn_dec, m->hid, m->y2, kYTileStride);
         return;
@@ -224,7 +231,7 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
     LAUNCH(HELEN_K_GRU_ENC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
            enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride);
     LAUNCH(HELEN_K_GEMM_DEC, (gemm_gi_kernel<16, true>), ggrid, gblock, m->y1, kYTileStride, m->wp_dec,
-           m->bias_dec, m->gi_dec, kGiDecTileStride, T);
+           m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
     LAUNCH(HELEN_K_GRU_DEC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, 0, T,
            m->whp_dec, m->bhn_dec, m->hid, m->y2, kYTileStride);
 }
@@ -386,7 +393,7 @@ int helen_polish_batch(HelenModel* m, const uint8_t* images, int n_windows, uint
     HIP_TRY(hipMemsetAsync(m->hid, 0, (size_t)tiles * kHidStride * sizeof(float), s));
     for (int c = 0; c < kChunks; ++c) {  // predict_gpu.py:114-149
         launch_chunk(m, s, tiles, c * kJump, kWin, kSeq);
-        LAUNCH(HELEN_K_HEADS, heads_kernel, dim3(tiles, 2), dim3(256), m->y2, kYTileStride, m->whd,
+        LAUNCH(HELEN_K_HEADS, heads_kernel, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->y2, kYTileStride, m->whd,
                m->bhd, 0, c, kWin, n_windows, m->pending, bases, rles, acc_base_opt, acc_rle_opt,
                (float*)nullptr, (float*)nullptr);
     }
@@ -406,7 +413,7 @@ int helen_gru_chunk_forward(HelenModel* m, const float* x, const float* h_in, in
     hipLaunchKernelGGL(pack_hidden_kernel, dim3(tiles), dim3(256), 0, s, h_in, B, (float*)m->hid);
     launch_enc_gemm(m, s, tiles, T);
     launch_chunk(m, s, tiles, 0, T, T);
-    LAUNCH(HELEN_K_HEADS, heads_kernel, dim3(tiles, (T + kJump - 1) / kJump), dim3(256), m->y2,
+    LAUNCH(HELEN_K_HEADS, heads_kernel, dim3(tiles, (T + kHeadsSpan - 1) / kHeadsSpan), dim3(256), m->y2,
            kYTileStride, m->whd, m->bhd, 1, 0, T, B, m->pending, (uint8_t*)nullptr, (uint8_t*)nullptr,
            (float*)nullptr, (float*)nullptr, base, rle);
     hipLaunchKernelGGL(unpack_hidden_kernel, dim3(tiles), dim3(256), 0, s, (const float*)m->hid, B,

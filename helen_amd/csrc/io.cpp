@@ -1,0 +1,332 @@
+// io.cpp -- libhelen_io.so: native HDF5 reader/writer for the two file formats of the polish path.
+//
+// The per-window work of the reference's loader and writer is a handful of tiny HDF5 datasets
+// (reader: helen/modules/python/models/dataloader_predict.py:64-82; writer:
+// helen/modules/python/DataStore.py:99-133).  Doing that through Python costs ~400 us per window,
+// 30x more than the MI355X needs for the window itself, so the same semantics are restated here
+// against the HDF5 C API: whole batches per call, file handles kept open, types converted by HDF5.
+// C ABI (extern "C"), no exceptions across it; helen_io_last_error() describes the last failure.
+#include <hdf5.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return -1;
+}
+
+constexpr int kSeq = 1000;   // ImageSizeOptions.SEQ_LENGTH  (Options.py:16)
+constexpr int kFeat = 90;    // ImageSizeOptions.IMAGE_HEIGHT (Options.py:14)
+constexpr int kName = 128;   // bytes reserved per contig name in the batch arrays
+
+struct Quiet {
+    Quiet() { H5Eset_auto2(H5E_DEFAULT, nullptr, nullptr); }
+};
+
+// ---- reader side: per-process cache of open files -------------------------------------------
+std::map<std::string, hid_t>& open_files() {
+    static std::map<std::string, hid_t> m;
+    return m;
+}
+
+hid_t get_file(const char* path) {
+    static Quiet q;
+    auto& m = open_files();
+    auto it = m.find(path);
+    if (it != m.end()) return it->second;
+    if (m.size() >= 64) {
+        for (auto& kv : m) H5Fclose(kv.second);
+        m.clear();
+    }
+    hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
+    if (f >= 0) m[path] = f;
+    return f;
+}
+
+// read a 1-element-or-more integer dataset, return element 0 as int64
+int read_i64_first(hid_t loc, const char* name, int64_t* out) {
+    hid_t d = H5Dopen2(loc, name, H5P_DEFAULT);
+    if (d < 0) return -1;
+    hid_t s = H5Dget_space(d);
+    const hssize_t n = H5Sget_simple_extent_npoints(s);
+    H5Sclose(s);
+    int rc = -1;
+    if (n >= 1) {
+        std::vector<int64_t> buf((size_t)n);
+        if (H5Dread(d, H5T_NATIVE_INT64, H5S_ALL, H5S_ALL, H5P_DEFAULT, buf.data()) >= 0) {
+            *out = buf[0];
+            rc = 0;
+        }
+    }
+    H5Dclose(d);
+    return rc;
+}
+
+// first element of a string dataset (fixed- or variable-length), NUL-terminated into out[cap]
+int read_str_first(hid_t loc, const char* name, char* out, size_t cap) {
+    hid_t d = H5Dopen2(loc, name, H5P_DEFAULT);
+    if (d < 0) return -1;
+    hid_t t = H5Dget_type(d);
+    hid_t s = H5Dget_space(d);
+    const hssize_t n = H5Sget_simple_extent_npoints(s);
+    int rc = -1;
+    out[0] = 0;
+    if (H5Tget_class(t) == H5T_STRING && n >= 1) {
+        if (H5Tis_variable_str(t) > 0) {
+            hid_t mt = H5Tcopy(H5T_C_S1);
+            H5Tset_size(mt, H5T_VARIABLE);
+            std::vector<char*> ptrs((size_t)n, nullptr);
+            if (H5Dread(d, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, ptrs.data()) >= 0) {
+                if (ptrs[0]) snprintf(out, cap, "%s", ptrs[0]);
+                H5Dvlen_reclaim(mt, s, H5P_DEFAULT, ptrs.data());
+                rc = 0;
+            }
+            H5Tclose(mt);
+        } else {
+            const size_t sz = H5Tget_size(t);
+            std::vector<char> buf(sz * (size_t)n + 1, 0);
+            hid_t mt = H5Tcopy(t);
+            if (H5Dread(d, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, buf.data()) >= 0) {
+                const size_t len = strnlen(buf.data(), sz);
+                const size_t c = len < cap - 1 ? len : cap - 1;
+                memcpy(out, buf.data(), c);
+                out[c] = 0;
+                rc = 0;
+            }
+            H5Tclose(mt);
+        }
+    }
+    H5Sclose(s);
+    H5Tclose(t);
+    H5Dclose(d);
+    return rc;
+}
+
+// 2-D dataset [rows, cols] -> dst (row-major, `cols` wide) as `memtype`; rows returned
+int read_2d(hid_t loc, const char* name, hid_t memtype, int cols, int max_rows, void* dst, int* rows) {
+    hid_t d = H5Dopen2(loc, name, H5P_DEFAULT);
+    if (d < 0) return -1;
+    hid_t s = H5Dget_space(d);
+    hsize_t dims[2] = {0, 0};
+    int rc = -1;
+    if (H5Sget_simple_extent_ndims(s) == 2) {
+        H5Sget_simple_extent_dims(s, dims, nullptr);
+        if ((int)dims[1] == cols && (int)dims[0] <= max_rows) {
+            *rows = (int)dims[0];
+            rc = (dims[0] == 0 || H5Dread(d, memtype, H5S_ALL, H5S_ALL, H5P_DEFAULT, dst) >= 0) ? 0 : -1;
+        } else {
+            *rows = (int)dims[0];
+            rc = -2;  // shape the path cannot take
+        }
+    }
+    H5Sclose(s);
+    H5Dclose(d);
+    return rc;
+}
+
+// ---- writer side ------------------------------------------------------------------------------
+struct Writer {
+    hid_t file = -1;
+    hid_t lcpl = -1;
+    hid_t space_pos = -1, space_lab = -1, space_scalar = -1;
+    std::set<std::string> regions;   // DataStore.py:115  meta['predictions_contig']
+    std::set<std::string> images;    // DataStore.py:123  meta['predictions']
+    std::vector<uint32_t> pos32;
+};
+
+int write_ds(Writer* w, const std::string& path, hid_t ftype, hid_t mtype, hid_t space, const void* buf) {
+    hid_t d = H5Dcreate2(w->file, path.c_str(), ftype, space, w->lcpl, H5P_DEFAULT, H5P_DEFAULT);
+    if (d < 0) return fail("cannot create dataset '%s'", path.c_str());
+    const herr_t rc = H5Dwrite(d, mtype, H5S_ALL, H5S_ALL, H5P_DEFAULT, buf);
+    H5Dclose(d);
+    return rc < 0 ? fail("cannot write dataset '%s'", path.c_str()) : 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* helen_io_last_error(void) { return g_err; }
+
+int helen_io_abi_version(void) { return 1; }
+
+/* Names of the members of group `images` of one file, in name order (what h5py's .keys() yields;
+ * dataloader_predict.py:41), '\n'-separated into `out` (capacity `cap`).  *n_out = count, or 0 and
+ * return 1 if the file has no `images` group (the reader warns and skips, :47-49).
+ * Returns -1 on error, -2 if `cap` is too small (*n_out then holds the bytes needed). */
+int helen_io_list_images(const char* path, char* out, size_t cap, long long* n_out) {
+    hid_t f = get_file(path);
+    if (f < 0) return fail("cannot open '%s'", path);
+    *n_out = 0;
+    if (H5Lexists(f, "images", H5P_DEFAULT) <= 0) return 1;
+    hid_t g = H5Gopen2(f, "images", H5P_DEFAULT);
+    if (g < 0) return fail("%s: cannot open group 'images'", path);
+    H5G_info_t info;
+    H5Gget_info(g, &info);
+    size_t used = 0;
+    std::vector<char> name(4096);
+    for (hsize_t i = 0; i < info.nlinks; ++i) {
+        ssize_t n = H5Lget_name_by_idx(g, ".", H5_INDEX_NAME, H5_ITER_INC, i, name.data(), name.size(),
+                                       H5P_DEFAULT);
+        if (n < 0) {
+            H5Gclose(g);
+            return fail("%s: cannot list 'images'", path);
+        }
+        if ((size_t)n >= name.size()) {
+            name.resize((size_t)n + 1);
+            H5Lget_name_by_idx(g, ".", H5_INDEX_NAME, H5_ITER_INC, i, name.data(), name.size(), H5P_DEFAULT);
+        }
+        if (used + (size_t)n + 1 <= cap) {
+            memcpy(out + used, name.data(), (size_t)n);
+            out[used + (size_t)n] = '\n';
+        }
+        used += (size_t)n + 1;
+    }
+    H5Gclose(g);
+    if (used > cap) {
+        *n_out = (long long)used;
+        return -2;
+    }
+    *n_out = (long long)info.nlinks;
+    return 0;
+}
+
+/* Read `n` images of one file (names '\n'-separated) with the reader's semantics
+ * (dataloader_predict.py:54-88): image -> uint8 [1000, 90], position -> int64 [1000, 3]; a short image
+ * is padded with zero rows and (-1,-1,-1) position rows; anything that is not [<=1000, 90] / [l, 3]
+ * is the reader's "IMAGE SIZE ERROR".
+ *   images    [n, 1000, 90] uint8      positions [n, 1000, 3] int64
+ *   meta      [n, 3] int64 = contig_start, contig_end, feature_chunk_idx
+ *   contigs   [n, 128] char, NUL-terminated */
+int helen_io_read_images(const char* path, const char* names, int n, uint8_t* images, int64_t* positions,
+                         int64_t* meta, char* contigs) {
+    hid_t f = get_file(path);
+    if (f < 0) return fail("cannot open '%s'", path);
+    const char* p = names;
+    for (int i = 0; i < n; ++i) {
+        const char* e = strchr(p, '\n');
+        std::string name = e ? std::string(p, e - p) : std::string(p);
+        p = e ? e + 1 : p + name.size();
+        const std::string gpath = "images/" + name;
+        hid_t g = H5Gopen2(f, gpath.c_str(), H5P_DEFAULT);
+        if (g < 0) return fail("%s: no image '%s'", path, name.c_str());
+        uint8_t* img = images + (size_t)i * kSeq * kFeat;
+        int64_t* pos = positions + (size_t)i * kSeq * 3;
+        int rows = 0, prow = 0;
+        int rc = read_str_first(g, "contig", contigs + (size_t)i * kName, kName);
+        rc |= read_i64_first(g, "contig_start", meta + (size_t)i * 3 + 0);
+        rc |= read_i64_first(g, "contig_end", meta + (size_t)i * 3 + 1);
+        rc |= read_i64_first(g, "feature_chunk_idx", meta + (size_t)i * 3 + 2);
+        if (rc) {
+            H5Gclose(g);
+            return fail("%s: image '%s' lacks contig / contig_start / contig_end / feature_chunk_idx", path,
+                        name.c_str());
+        }
+        const int r1 = read_2d(g, "image", H5T_NATIVE_UINT8, kFeat, kSeq, img, &rows);
+        const int r2 = read_2d(g, "position", H5T_NATIVE_INT64, 3, kSeq, pos, &prow);
+        H5Gclose(g);
+        if (r1 || r2 || prow != rows)
+            return fail("IMAGE SIZE ERROR: %s (%d, %d)", path, rows, kFeat);   // :85-86
+        if (rows < kSeq) {                                                        // :74-82
+            memset(img + (size_t)rows * kFeat, 0, (size_t)(kSeq - rows) * kFeat);
+            for (int k = rows * 3; k < kSeq * 3; ++k) pos[k] = -1;
+        }
+        // np.array2string(...).replace("'", "") of the reader: strip quotes
+        char* c = contigs + (size_t)i * kName;
+        size_t o = 0;
+        for (size_t k = 0; c[k]; ++k)
+            if (c[k] != '\'') c[o++] = c[k];
+        c[o] = 0;
+    }
+    return 0;
+}
+
+/* Drop every cached read handle of this process. */
+void helen_io_close_readers(void) {
+    for (auto& kv : open_files()) H5Fclose(kv.second);
+    open_files().clear();
+}
+
+/* Prediction file writer (DataStore(filename, 'w'), predict_gpu.py:55). */
+void* helen_io_writer_open(const char* path) {
+    static Quiet q;
+    Writer* w = new Writer();
+    hid_t fapl = H5Pcreate(H5P_FILE_ACCESS);
+    // thousands of tiny objects: allocate metadata in 1 MiB blocks (+10 % writes/s, same format)
+    H5Pset_meta_block_size(fapl, (hsize_t)1 << 20);
+    w->file = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, fapl);
+    H5Pclose(fapl);
+    if (w->file < 0) {
+        fail("cannot create '%s'", path);
+        delete w;
+        return nullptr;
+    }
+    w->lcpl = H5Pcreate(H5P_LINK_CREATE);
+    H5Pset_create_intermediate_group(w->lcpl, 1);
+    hsize_t dp[2] = {kSeq, 3}, dl[1] = {kSeq};
+    w->space_pos = H5Screate_simple(2, dp, nullptr);
+    w->space_lab = H5Screate_simple(1, dl, nullptr);
+    w->space_scalar = H5Screate(H5S_SCALAR);
+    w->pos32.resize((size_t)kSeq * 3);
+    return w;
+}
+
+/* DataStore.write_prediction for `n` windows (DataStore.py:83-133): scalar int64 contig_start /
+ * contig_end once per region, then position uint32 [1000,3] (-1 wraps to 4294967295), bases uint8
+ * [1000], rles uint8 [1000] once per (contig, region, chunk id); repeats are skipped silently. */
+int helen_io_write_predictions(void* handle, int n, const char* contigs, const int64_t* meta,
+                               const int64_t* positions, const uint8_t* bases, const uint8_t* rles) {
+    Writer* w = (Writer*)handle;
+    if (!w) return fail("null writer");
+    char num[64];
+    for (int i = 0; i < n; ++i) {
+        const std::string contig = contigs + (size_t)i * kName;
+        const int64_t cs = meta[(size_t)i * 3], ce = meta[(size_t)i * 3 + 1], chunk = meta[(size_t)i * 3 + 2];
+        snprintf(num, sizeof(num), "-%lld-%lld", (long long)cs, (long long)ce);
+        const std::string prefix = contig + num;
+        snprintf(num, sizeof(num), "%lld", (long long)chunk);
+        const std::string suffix = num;
+        const std::string root = "predictions/" + contig + "/" + prefix;
+        if (w->regions.insert(prefix).second) {
+            if (write_ds(w, root + "/contig_start", H5T_STD_I64LE, H5T_NATIVE_INT64, w->space_scalar, &cs)) return -1;
+            if (write_ds(w, root + "/contig_end", H5T_STD_I64LE, H5T_NATIVE_INT64, w->space_scalar, &ce)) return -1;
+        }
+        if (w->images.insert(contig + prefix + suffix).second) {
+            const int64_t* p = positions + (size_t)i * kSeq * 3;
+            for (int k = 0; k < kSeq * 3; ++k) w->pos32[k] = (uint32_t)p[k];
+            const std::string base = root + "/" + suffix;
+            if (write_ds(w, base + "/position", H5T_STD_U32LE, H5T_NATIVE_UINT32, w->space_pos, w->pos32.data())) return -1;
+            if (write_ds(w, base + "/bases", H5T_STD_U8LE, H5T_NATIVE_UINT8, w->space_lab, bases + (size_t)i * kSeq)) return -1;
+            if (write_ds(w, base + "/rles", H5T_STD_U8LE, H5T_NATIVE_UINT8, w->space_lab, rles + (size_t)i * kSeq)) return -1;
+        }
+    }
+    return 0;
+}
+
+int helen_io_writer_close(void* handle) {
+    Writer* w = (Writer*)handle;
+    if (!w) return 0;
+    H5Sclose(w->space_pos);
+    H5Sclose(w->space_lab);
+    H5Sclose(w->space_scalar);
+    H5Pclose(w->lcpl);
+    const herr_t rc = H5Fclose(w->file);
+    delete w;
+    return rc < 0 ? fail("closing the prediction file failed") : 0;
+}
+
+}  // extern "C"

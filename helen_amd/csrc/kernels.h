@@ -133,17 +133,27 @@ __global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_kernel(const f3
                                                       const f32x4* __restrict__ Wp,
                                                       const float* __restrict__ bias,
                                                       f32x4* __restrict__ gi, long gi_tile_stride,
-                                                      int npos) {
+                                                      int npos, int ntiles) {
     // Output slot: direction 0 -> position p, direction 1 -> npos-1-p (time-reversed), so the
     // recurrence reads both directions in ascending address order.
     static_assert(MG % 2 == 0, "operand groups are consumed in ping-pong pairs");
     constexpr int P = 4, N = 6;
     const int lane = threadIdx.x & 63;
-    const int wave = (threadIdx.x >> 6) + blockIdx.z * HELEN_GEMM_WAVES;
+    // grid.x enumerates (unit, z): unit = (position group, tile), z = which HELEN_GEMM_WAVES wave
+    // slots.  Workgroups are dispatched round-robin over the 8 XCDs (id % 8), so the ZB = 8 /
+    // HELEN_GEMM_WAVES workgroups that share one unit's A operand get ids u, u+8, u+16, ... inside a
+    // block of 8*ZB ids: same XCD, same L2, adjacent in time -> A is fetched from HBM once.
+    constexpr int ZB = 8 / HELEN_GEMM_WAVES;
+    const int bid = blockIdx.x;
+    const int unit = (bid / (8 * ZB)) * 8 + (bid & 7);
+    const int zb = (bid >> 3) % ZB;
+    const int npg = (npos + P - 1) / P;                 // position groups per tile
+    const int tile = unit / npg;
+    const int pos0 = (unit % npg) * P;
+    if (tile >= ntiles) return;                           // grid is padded to a multiple of 8 units
+    const int wave = (threadIdx.x >> 6) + zb * HELEN_GEMM_WAVES;
     const int dir = wave >> 2;
     const int nt0 = (wave & 3) * N;
-    const int tile = blockIdx.y;
-    const int pos0 = blockIdx.x * P;
 
     const f32x4* w_base = Wp + (size_t)((dir * kNTile + nt0) * MG) * 64 + lane;
     // REV_A: A is a layer output y[tile][slot][fwd | bwd]; the bwd half (groups MG/2..) of
@@ -419,14 +429,25 @@ __device__ __forceinline__ f32x4 mfma_bf16(bf16x4 a, bf16x4 b, f32x4 c) {
 template <int MG, bool REV_A>
 __global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_bf16_kernel(
     const f32x4* __restrict__ A, long a_tile_stride, const bf16x4* __restrict__ Wp,
-    const float* __restrict__ bias, f32x4* __restrict__ gi, long gi_tile_stride, int npos) {
+    const float* __restrict__ bias, f32x4* __restrict__ gi, long gi_tile_stride, int npos,
+    int ntiles) {
     constexpr int P = 4, N = 6;
     const int lane = threadIdx.x & 63;
-    const int wave = (threadIdx.x >> 6) + blockIdx.z * HELEN_GEMM_WAVES;
+    // grid.x enumerates (unit, z): unit = (position group, tile), z = which HELEN_GEMM_WAVES wave
+    // slots.  Workgroups are dispatched round-robin over the 8 XCDs (id % 8), so the ZB = 8 /
+    // HELEN_GEMM_WAVES workgroups that share one unit's A operand get ids u, u+8, u+16, ... inside a
+    // block of 8*ZB ids: same XCD, same L2, adjacent in time -> A is fetched from HBM once.
+    constexpr int ZB = 8 / HELEN_GEMM_WAVES;
+    const int bid = blockIdx.x;
+    const int unit = (bid / (8 * ZB)) * 8 + (bid & 7);
+    const int zb = (bid >> 3) % ZB;
+    const int npg = (npos + P - 1) / P;                 // position groups per tile
+    const int tile = unit / npg;
+    const int pos0 = (unit % npg) * P;
+    if (tile >= ntiles) return;                           // grid is padded to a multiple of 8 units
+    const int wave = (threadIdx.x >> 6) + zb * HELEN_GEMM_WAVES;
     const int dir = wave >> 2;
     const int nt0 = (wave & 3) * N;
-    const int tile = blockIdx.y;
-    const int pos0 = blockIdx.x * P;
     const bf16x4* w_base = Wp + (size_t)((dir * kNTile + nt0) * MG) * 64 + lane;
     const f32x4* a_ptr[P];
     const f32x4* a_ptr_b[P];
@@ -584,7 +605,8 @@ __global__ __launch_bounds__(256, 2) void gru_bf16_kernel(const f32x4* __restric
 // ------------------------------------------------------------------------------------------------
 // Heads + softmax + accumulate + argmax (TransducerModel.py:75-76, predict_gpu.py:137-156).
 //   One 16-column MFMA tile is exactly the 5 base + 11 run-length logits of 16 windows.
-//   grid (tiles, halves of 50 positions), 4 waves striding over the positions of the half.
+//   grid (tiles, groups of kHeadsSpan positions), 4 waves striding over the positions of the group
+//   (many small workgroups: the kernel is latency/HBM-bound, so it wants waves in flight).
 //   mode 0 (polish): positions 50c+t; the first half of chunk c receives its second (final)
 //     contribution -> add the pending softmax of chunk c-1, argmax, labels; the second half is
 //     parked in `pending` for chunk c+1 (or is final for the last chunk).  A position gets at most
@@ -616,22 +638,24 @@ __device__ __forceinline__ int group16_argmax(float v, int idx) {
     return idx;
 }
 
+constexpr int kHeadsSpan = 10;  // positions per workgroup; divides kJump so a group never straddles halves
+
 __global__ __launch_bounds__(256) void heads_kernel(
     const f32x4* __restrict__ y2, long y_tile_stride, const f32x4* __restrict__ Whd,
     const float* __restrict__ bhd, int mode, int chunk, int T, int n_windows,
     f32x4* __restrict__ pending, uint8_t* __restrict__ bases, uint8_t* __restrict__ rles,
     float* __restrict__ acc_base, float* __restrict__ acc_rle, float* __restrict__ logit_base,
     float* __restrict__ logit_rle) {
-    __shared__ uint8_t lab[2][kTile][64];
+    __shared__ uint8_t lab[2][kTile][kHeadsSpan];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
     const int j = lane & 15;
     const int q = lane >> 4;
     const int tile = blockIdx.x;
-    const int half = blockIdx.y;
-    const int t0 = half * kJump;
-    const int t1 = min(T, t0 + kJump);
+    const int t0 = blockIdx.y * kHeadsSpan;
+    const int t1 = min(T, t0 + kHeadsSpan);
+    const int half = t0 / kJump;
     const bool isb = j < kNB;
 
     f32x4 B[16];
@@ -713,11 +737,11 @@ __global__ __launch_bounds__(256) void heads_kernel(
     if (mode != 0 || park) return;
     __syncthreads();
     const int span = t1 - t0;
-    for (int g = tid; g < 2 * kTile * kJump; g += 256) {
-        const int kind = g / (kTile * kJump);
-        const int rem = g % (kTile * kJump);
-        const int win = rem / kJump;
-        const int tl = rem % kJump;
+    for (int g = tid; g < 2 * kTile * kHeadsSpan; g += 256) {
+        const int kind = g / (kTile * kHeadsSpan);
+        const int rem = g % (kTile * kHeadsSpan);
+        const int win = rem / kHeadsSpan;
+        const int tl = rem % kHeadsSpan;
         const int window = tile * kTile + win;
         if (window < n_windows && tl < span) {
             uint8_t* out = kind ? rles : bases;

