@@ -77,10 +77,9 @@ def call_consensus(image_dir, model_path, batch_size, num_workers, threads, outp
 
 def polish_genome(image_dir, model_path, batch_size, num_workers, threads, output_dir,
                   output_prefix, gpu_mode, device_ids, callers):
-    """call_consensus into `<output_dir>/predictions_<timestamp>/`, then stitch
-    (PolishInterface.py:49-105).  The stitch step (SSW-anchored FASTA assembly, CPU) is outside
-    this build's scope: the prediction directory is left in the layout the
-    reference's `helen stitch -i <dir>` consumes."""
+    """call_consensus into `<output_dir>/predictions_<timestamp>/`, then stitch the predictions into
+    `<output_dir>/<output_prefix>.fa` (PolishInterface.py:49-105)."""
+    from .stitch import perform_stitch
     output_dir = file_manager.handle_output_directory(output_dir)
     timestr = datetime.now().strftime("%m%d%Y_%H%M%S")
     prediction_dir = file_manager.handle_output_directory(
@@ -90,11 +89,17 @@ def polish_genome(image_dir, model_path, batch_size, num_workers, threads, outpu
     sys.stderr.write("INFO: PREDICTION OUTPUT DIRECTORY: " + prediction_dir + "\n")
     sys.stderr.write("INFO: CALL CONSENSUS STARTING\n")
     call_consensus(image_dir, model_path, batch_size, num_workers, threads, prediction_dir,
-                   "helen_predictions", gpu_mode, device_ids, callers)
+                   output_prefix, gpu_mode, device_ids, callers)
     t1 = time.time()
-    sys.stderr.write("INFO: CALL CONSENSUS ELAPSED TIME: %d MINS %d SECS.\n"
-                     % (int((t1 - t0) // 60), int(t1 - t0) % 60))
-    sys.stderr.write("INFO: STITCH IS NOT PART OF THIS BUILD. RUN `helen stitch -i " + prediction_dir
-                     + " -o " + output_dir + " -p " + output_prefix + "` FROM THE REFERENCE "
-                     "PACKAGE TO PRODUCE THE FASTA.\n")
+    sys.stderr.write("INFO: STITCH STARTING\n")
+    print(prediction_dir)
+    perform_stitch(prediction_dir, output_dir, output_prefix, threads)
+    t2 = time.time()
+
+    def fmt(a, b):
+        return "%d HOURS %d MINS %d SECS" % (int((b - a) // 3600), int((b - a) % 3600 // 60), int(b - a) % 60)
+    sys.stderr.write("INFO: FINISHED PROCESSING.\n")
+    sys.stderr.write("INFO: TOTAL TIME ELAPSED: " + fmt(t0, t2) + "\n")
+    sys.stderr.write("INFO: PREDICTION TIME: " + fmt(t0, t1) + "\n")
+    sys.stderr.write("INFO: STITCH TIME: " + fmt(t1, t2) + "\n")
     return prediction_dir

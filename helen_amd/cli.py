@@ -1,5 +1,5 @@
-"""`helen` command line for the inference path: `polish`, `call_consensus`, `version`, `torch_stat`,
-flag-compatible with helen/helen.py:12-185 (-i -m -b -w -t -o -p -g -d_ids -c)."""
+"""`helen` command line for the inference path: `polish`, `call_consensus`, `stitch`, `version`,
+`torch_stat`, flag-compatible with helen/helen.py:12-222 (-i -m -b -w -t -o -p -g -d_ids -c)."""
 import argparse
 import sys
 
@@ -30,13 +30,25 @@ def add_polish_arguments(parser, threads_default):
     return parser
 
 
+def add_stitch_arguments(parser):
+    parser.add_argument("-i", "--input_dir", type=str, required=True,
+                        help="[REQUIRED] Path to a directory containing prediction files call consensus.")
+    parser.add_argument("-o", "--output_dir", type=str, required=True,
+                        help="[REQUIRED] Path to the output directory.")
+    parser.add_argument("-t", "--threads", type=int, required=True, help="[REQUIRED] Number of threads.")
+    parser.add_argument("-p", "--output_prefix", type=str, required=False, default="HELEN_consensus",
+                        help="Prefix for the output file. Default is: HELEN_consensus")
+    return parser
+
+
 def build_parser():
     parser = argparse.ArgumentParser(
         prog="helen", formatter_class=argparse.RawTextHelpFormatter,
         description="HELEN inference path on MI355X (gfx950): MarginPolish images -> prediction HDF5.")
     sub = parser.add_subparsers(dest="sub_command")
-    add_polish_arguments(sub.add_parser("polish", help="call_consensus, then (reference) stitch"), 1)
+    add_polish_arguments(sub.add_parser("polish", help="call_consensus, then stitch"), 1)
     add_polish_arguments(sub.add_parser("call_consensus", help="generate the prediction HDF5 files"), 16)
+    add_stitch_arguments(sub.add_parser("stitch", help="prediction HDF5 files -> polished FASTA"))
     sub.add_parser("version", help="show the version")
     sub.add_parser("torch_stat", help="show torch / device configuration")
     return parser
@@ -55,6 +67,9 @@ def main(argv=None):
         call_consensus(flags.image_dir, flags.model_path, flags.batch_size, flags.num_workers,
                        flags.threads, flags.output_dir, flags.output_prefix, flags.gpu_mode,
                        flags.device_ids, flags.callers)
+    elif flags.sub_command == "stitch":
+        from .stitch import perform_stitch
+        perform_stitch(flags.input_dir, flags.output_dir, flags.output_prefix, flags.threads)
     elif flags.sub_command == "version":
         print("HELEN-MI355X VERSION: " + __version__)
     elif flags.sub_command == "torch_stat":

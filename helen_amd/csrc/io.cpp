@@ -8,6 +8,7 @@
 // C ABI (extern "C"), no exceptions across it; helen_io_last_error() describes the last failure.
 #include <hdf5.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -315,6 +316,105 @@ int helen_io_write_predictions(void* handle, int n, const char* contigs, const i
         }
     }
     return 0;
+}
+
+/* Sequence of one region of a prediction file, as Stitch.small_chunk_stitch builds it
+ * (helen/modules/python/Stitch.py:204-247): the region's chunk ids are visited in STRING-sorted order;
+ * every (pos, indx, split) position key keeps its first writer; keys are sorted numerically and each
+ * contributes label_decoder[base] repeated rle times ('' A C G T for 0..4, Options.py:3).  Positions
+ * are stored as uint32, so the (-1,-1,-1) rows of padded images arrive as 4294967295 and are NOT
+ * skipped by the reference's `< 0` test: all of them share one key, which sorts last -- reproduced.
+ * Writes the NUL-terminated sequence into out (capacity cap); returns its length, -2 if cap is too
+ * small (call again with a larger buffer), -1 on error. */
+long long helen_io_region_sequence(const char* path, const char* contig, const char* region, char* out,
+                                   long long cap) {
+    hid_t f = get_file(path);
+    if (f < 0) return fail("cannot open '%s'", path);
+    const std::string gpath = std::string("predictions/") + contig + "/" + region;
+    hid_t g = H5Gopen2(f, gpath.c_str(), H5P_DEFAULT);
+    if (g < 0) return fail("%s: no region '%s'", path, gpath.c_str());
+    H5G_info_t info;
+    H5Gget_info(g, &info);
+    std::vector<std::string> chunks;
+    std::vector<char> name(256);
+    for (hsize_t i = 0; i < info.nlinks; ++i) {
+        ssize_t n = H5Lget_name_by_idx(g, ".", H5_INDEX_NAME, H5_ITER_INC, i, name.data(), name.size(), H5P_DEFAULT);
+        if (n < 0 || (size_t)n >= name.size()) continue;
+        std::string s(name.data());
+        if (s != "contig_start" && s != "contig_end") chunks.push_back(s);
+    }
+    std::sort(chunks.begin(), chunks.end());   // sorted(set of str): lexicographic
+    struct Rec {
+        int64_t pos, indx, split;
+        uint8_t base, rle;
+        uint32_t order;
+    };
+    std::vector<Rec> recs;
+    std::vector<uint32_t> pos;
+    std::vector<uint8_t> bases, rles;
+    uint32_t order = 0;
+    for (const std::string& c : chunks) {
+        hid_t cg = H5Gopen2(g, c.c_str(), H5P_DEFAULT);
+        if (cg < 0) continue;
+        hid_t d = H5Dopen2(cg, "bases", H5P_DEFAULT);
+        hssize_t n = 0;
+        if (d >= 0) {
+            hid_t sp = H5Dget_space(d);
+            n = H5Sget_simple_extent_npoints(sp);
+            H5Sclose(sp);
+        }
+        bool ok = d >= 0 && n > 0;
+        if (ok) {
+            pos.resize((size_t)n * 3);
+            bases.resize((size_t)n);
+            rles.resize((size_t)n);
+            ok = H5Dread(d, H5T_NATIVE_UINT8, H5S_ALL, H5S_ALL, H5P_DEFAULT, bases.data()) >= 0;
+        }
+        if (d >= 0) H5Dclose(d);
+        if (ok) {
+            hid_t dr = H5Dopen2(cg, "rles", H5P_DEFAULT);
+            hid_t dp = H5Dopen2(cg, "position", H5P_DEFAULT);
+            ok = dr >= 0 && dp >= 0 &&
+                 H5Dread(dr, H5T_NATIVE_UINT8, H5S_ALL, H5S_ALL, H5P_DEFAULT, rles.data()) >= 0 &&
+                 H5Dread(dp, H5T_NATIVE_UINT32, H5S_ALL, H5S_ALL, H5P_DEFAULT, pos.data()) >= 0;
+            if (dr >= 0) H5Dclose(dr);
+            if (dp >= 0) H5Dclose(dp);
+        }
+        H5Gclose(cg);
+        if (!ok) {
+            H5Gclose(g);
+            return fail("%s: cannot read chunk '%s/%s'", path, gpath.c_str(), c.c_str());
+        }
+        for (hssize_t k = 0; k < n; ++k)
+            recs.push_back({(int64_t)pos[(size_t)k * 3], (int64_t)pos[(size_t)k * 3 + 1],
+                            (int64_t)pos[(size_t)k * 3 + 2], bases[(size_t)k], rles[(size_t)k], order++});
+    }
+    H5Gclose(g);
+    std::sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) {
+        if (a.pos != b.pos) return a.pos < b.pos;
+        if (a.indx != b.indx) return a.indx < b.indx;
+        if (a.split != b.split) return a.split < b.split;
+        return a.order < b.order;
+    });
+    static const char kDecode[5] = {0, 'A', 'C', 'G', 'T'};
+    long long len = 0;
+    for (size_t k = 0; k < recs.size(); ++k) {
+        if (k > 0 && recs[k].pos == recs[k - 1].pos && recs[k].indx == recs[k - 1].indx &&
+            recs[k].split == recs[k - 1].split)
+            continue;   // first writer wins
+        const char ch = recs[k].base < 5 ? kDecode[recs[k].base] : 0;
+        if (!ch) continue;
+        for (int r = 0; r < recs[k].rle; ++r) {
+            if (len < cap - 1) out[len] = ch;
+            ++len;
+        }
+    }
+    if (len >= cap) {
+        fail("buffer too small: need %lld", len + 1);
+        return -2;
+    }
+    out[len] = 0;
+    return len;
 }
 
 int helen_io_writer_close(void* handle) {

@@ -1,0 +1,365 @@
+// ssw.cpp -- local alignment for `stitch`, written from scratch to give the SAME answers as the
+// striped Smith-Waterman library the reference vendors and calls through its HELEN.Aligner binding
+// (reference: helen/modules/src/local_reassembly/ssw.c `ssw_align`, ssw_cpp.cpp `Aligner::Align_cpp`,
+// used at helen/modules/python/Stitch.py:111-134).
+//
+// Why not "any" Smith-Waterman: stitch anchors two overlapping sequences at the first long match
+// run of the reported alignment, so ties must break the same way and the reference's quirks matter:
+//   * the score / end cell come from a STRIPED pass (query split into L interleaved lanes, L = 16 for
+//     the 8-bit pass, 8 for the 16-bit pass that is used once the 8-bit score saturates at 255) whose
+//     E (gap in the query direction) is updated from H *before* the lazy-F correction, and whose best
+//     cell is the first reference column that raises the maximum, smallest query index in it;
+//   * the begin cell comes from the same pass run backwards from the end cell until a column
+//     reaches the forward score;
+//   * the CIGAR comes from a banded global-in-the-box DP (band doubled until the score is reached)
+//     with a fixed preference order in its traceback (diagonal on ties, deletion over insertion).
+// No SIMD is needed here (stitch aligns ~200-base overlaps); the lanes are emulated with plain
+// loops so that the arithmetic, including its saturation behaviour, is the library's.
+// Checked cell-for-cell against the reference library itself (oracle/_ref/libssw_ref.so, built from
+// the reference's own sources) on randomised inputs: tests/test_stitch.py.
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+// A,C,G,T -> 0..3 (either case), everything else 4 -- the reference's translation table
+// (ssw_cpp.cpp:9-19; note that U/u also map to 0 there).
+int8_t base_code(char c) {
+    switch (c) {
+        case 'A': case 'a': case 'U': case 'u': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+        default: return 4;
+    }
+}
+
+struct Best {
+    int score = 0, ref = 0, read = 0;
+};
+
+inline int sat_sub_u(int a, int b) { return a > b ? a - b : 0; }  // unsigned saturating subtract
+
+// One striped pass over ref[begin..end) (forward) or backwards, query `read` of length m.
+//   lanes 16: the 8-bit pass (scores biased by `bias`, saturating at 255);
+//   lanes 8:  the 16-bit pass (signed saturating add).
+// terminate < 0: never stop early.  Returns the best score, its reference index and query index.
+Best striped_pass(const int8_t* ref, bool backwards, int n, const int8_t* read, int m, int gap_open,
+                  int gap_ext, const int8_t* mat, int lanes, int bias, int terminate) {
+    const int seg = (m + lanes - 1) / lanes;
+    const int cells = seg * lanes;
+    // profile[r][cell]: substitution score of ref base r against the query position of that cell;
+    // cell index c = s * lanes + lane  <->  query position lane * seg + s; padding scores 0.
+    std::vector<int> prof((size_t)5 * cells);
+    for (int r = 0; r < 5; ++r)
+        for (int s = 0; s < seg; ++s)
+            for (int l = 0; l < lanes; ++l) {
+                const int q = l * seg + s;
+                prof[(size_t)r * cells + s * lanes + l] = q < m ? mat[r * 5 + read[q]] : 0;
+            }
+    std::vector<int> Hs(cells, 0), Hl(cells, 0), E(cells, 0), Hbest(cells, 0), F(lanes), Hv(lanes);
+    const int cap = lanes == 16 ? 255 : 32767;
+    int best = 0, best_ref = lanes == 16 ? -1 : 0, best_read = m - 1;
+    bool overflow = false;
+
+    auto shift_lanes = [&](std::vector<int>& v) {  // lane l takes lane l-1's value, lane 0 gets 0
+        for (int l = lanes - 1; l > 0; --l) v[l] = v[l - 1];
+        v[0] = 0;
+    };
+
+    for (int step = 0; step < n; ++step) {
+        const int i = backwards ? n - 1 - step : step;
+        const int* P = &prof[(size_t)ref[i] * cells];
+        int col_max = 0;
+        std::fill(F.begin(), F.end(), 0);
+        for (int l = 0; l < lanes; ++l) Hv[l] = Hs[(seg - 1) * lanes + l];
+        shift_lanes(Hv);  // diagonal predecessors of the first segment
+        std::swap(Hs, Hl);
+        for (int s = 0; s < seg; ++s) {
+            for (int l = 0; l < lanes; ++l) {
+                const int c = s * lanes + l;
+                int h;
+                if (lanes == 16) {
+                    h = std::min(Hv[l] + P[c] + bias, 255);  // adds_epu8 with the biased profile
+                    h = sat_sub_u(h, bias);
+                } else {
+                    h = std::min(Hv[l] + P[c], 32767);        // adds_epi16 (never underflows here)
+                }
+                h = std::max(h, E[c]);
+                h = std::max(h, F[l]);
+                col_max = std::max(col_max, h);
+                Hs[c] = h;
+                const int open = sat_sub_u(h, gap_open);
+                E[c] = std::max(sat_sub_u(E[c], gap_ext), open);   // from H before the lazy-F fix-up
+                F[l] = std::max(sat_sub_u(F[l], gap_ext), open);
+                Hv[l] = Hl[c];
+            }
+        }
+        // lazy F: carry gaps across lane boundaries; E is deliberately left alone
+        if (lanes == 16) {
+            int s = 0;
+            shift_lanes(F);
+            auto settled = [&](int seg_i) {
+                for (int l = 0; l < lanes; ++l)
+                    if (sat_sub_u(F[l], sat_sub_u(Hs[seg_i * lanes + l], gap_open)) != 0) return false;
+                return true;
+            };
+            while (!settled(s)) {
+                for (int l = 0; l < lanes; ++l) {
+                    int& h = Hs[s * lanes + l];
+                    h = std::max(h, F[l]);
+                    col_max = std::max(col_max, h);
+                    F[l] = sat_sub_u(F[l], gap_ext);
+                }
+                if (++s >= seg) {
+                    s = 0;
+                    shift_lanes(F);
+                }
+            }
+        } else {
+            bool done = false;
+            for (int k = 0; k < lanes && !done; ++k) {
+                shift_lanes(F);
+                for (int s = 0; s < seg && !done; ++s) {
+                    bool any = false;
+                    for (int l = 0; l < lanes; ++l) {
+                        int& h = Hs[s * lanes + l];
+                        h = std::max(h, F[l]);
+                        col_max = std::max(col_max, h);
+                        F[l] = sat_sub_u(F[l], gap_ext);
+                        if (F[l] > sat_sub_u(h, gap_open)) any = true;
+                    }
+                    if (!any) done = true;
+                }
+            }
+        }
+        if (col_max > best) {
+            best = col_max;
+            if (lanes == 16 && best + bias >= 255) {
+                overflow = true;
+                break;
+            }
+            best_ref = i;
+            Hbest = Hs;
+        }
+        if (col_max == terminate) break;
+    }
+    for (int c = 0; c < cells; ++c)
+        if (Hbest[c] == best) {
+            const int q = c / lanes + (c % lanes) * seg;
+            if (q < best_read) best_read = q;
+        }
+    Best b;
+    b.score = (lanes == 16 && (overflow || best + bias >= 255)) ? 255 : std::min(best, cap);
+    b.ref = best_ref;
+    b.read = best_read;
+    return b;
+}
+
+struct Op {
+    char op;
+    int len;
+};
+
+// Banded DP inside the box ref[0..n) x read[0..m) that reproduces `score`, then the traceback.
+// Row i = query position, column j = reference position; the band of row i is
+// [max(0, i-w), min(n-1, i+w)].  dir packs, per cell, the choices for E (query gap continues /
+// opens), F (reference gap) and H.
+bool banded_cigar(const int8_t* ref, const int8_t* read, int n, int m, int score, int gap_open,
+                  int gap_ext, int w, const int8_t* mat, std::vector<Op>* out) {
+    std::vector<int> hb, eb, hc;
+    std::vector<int8_t> dir;
+    int best = 0;
+    int width_d = 0;
+    auto left = [&](int i) { return std::max(0, i - w); };
+    do {
+        const int width = 2 * w + 3;
+        width_d = 2 * w + 1;
+        hb.assign(width + 1, 0);
+        eb.assign(width + 1, 0);
+        hc.assign(width + 1, 0);
+        dir.assign((size_t)width_d * m * 3 + 3, 0);
+        best = 0;
+        for (int i = 0; i < m; ++i) {
+            const int beg = std::max(0, i - w);
+            const int end = std::min(n - 1, i + w);
+            const int edge = std::min(end + 1, width - 1);
+            int f = 0, u = 0;
+            hb[0] = eb[0] = hb[edge] = eb[edge] = hc[0] = 0;
+            int8_t* d = &dir[(size_t)width_d * i * 3];
+            for (int j = beg; j <= end; ++j) {
+                u = j - left(i) + 1;                       // this cell in this row's band
+                const int up = j - left(i - 1) + 1;        // (i-1, j)   in the previous row's band
+                const int lf = j - 1 - left(i) + 1;        // (i, j-1)
+                const int dg = j - 1 - left(i - 1) + 1;    // (i-1, j-1)
+                const int x = (j - left(i)) * 3;
+                int a = (i == 0 ? 0 : hb[up]) - gap_open;
+                int b = (i == 0 ? 0 : eb[up]) - gap_ext;
+                if (i == 0) {
+                    a = -gap_open;
+                    b = -gap_ext;
+                }
+                eb[u] = std::max(a, b);
+                d[x + 0] = a > b ? 3 : 2;
+                a = hc[lf] - gap_open;
+                b = f - gap_ext;
+                f = std::max(a, b);
+                d[x + 1] = a > b ? 5 : 4;
+                const int e1 = std::max(eb[u], 0), f1 = std::max(f, 0);
+                const int gap = std::max(e1, f1);
+                const int diag = hb[dg] + mat[ref[j] * 5 + read[i]];
+                hc[u] = std::max(gap, diag);
+                best = std::max(best, hc[u]);
+                if (gap <= diag)
+                    d[x + 2] = 1;
+                else
+                    d[x + 2] = e1 > f1 ? d[x + 0] : d[x + 1];
+            }
+            for (int j = 1; j <= u; ++j) hb[j] = hc[j];
+        }
+        w *= 2;
+    } while (best < score);
+    w /= 2;
+
+    // traceback from the box's far corner; stops when the query is used up
+    std::vector<Op> rev;
+    int i = m - 1, j = n - 1, run = 0, which = 2;
+    char op = 'M', prev = 'M';
+    while (i > 0) {
+        const int x = (j - left(i)) * 3 + which;
+        if (j - left(i) < 0 || j - left(i) >= width_d) return false;
+        const int8_t t = dir[(size_t)width_d * i * 3 + x];
+        switch (t) {
+            case 1: --i; --j; which = 2; op = 'M'; break;
+            case 2: --i; which = 0; op = 'I'; break;
+            case 3: --i; which = 2; op = 'I'; break;
+            case 4: --j; which = 1; op = 'D'; break;
+            case 5: --j; which = 2; op = 'D'; break;
+            default: return false;
+        }
+        if (op == prev) {
+            ++run;
+        } else {
+            rev.push_back({prev, run});
+            prev = op;
+            run = 1;
+        }
+    }
+    if (op == 'M') {
+        rev.push_back({'M', run + 1});
+    } else {
+        rev.push_back({op, run});
+        rev.push_back({'M', 1});
+    }
+    out->assign(rev.rbegin(), rev.rend());
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* Local alignment of `query` against `ref` with the reference library's semantics
+ * (Aligner(match, mismatch, gap_open, gap_extend); SetReferenceSequence; Align_cpp(query, Filter(), al, 0)).
+ *   out[6] = best score, ref_begin, ref_end, query_begin, query_end, mismatches (0-based, inclusive)
+ *   cigar  = extended CIGAR (=, X, I, D, with S soft clips), NUL-terminated, truncated to cap
+ * Returns 0; 1 if either sequence is empty (the reference's Align_cpp returns false); -1 on an
+ * internal inconsistency. */
+int helen_ssw_align(const char* ref_seq, int ref_len, const char* query_seq, int query_len, int match,
+                    int mismatch, int gap_open, int gap_extend, int* out, char* cigar, int cigar_cap) {
+    for (int k = 0; k < 6; ++k) out[k] = 0;
+    if (cigar_cap > 0) cigar[0] = 0;
+    if (ref_len <= 0 || query_len <= 0) return 1;
+    int8_t mat[25];
+    for (int a = 0; a < 5; ++a)
+        for (int b = 0; b < 5; ++b) mat[a * 5 + b] = (a < 4 && b < 4 && a == b) ? (int8_t)match : (int8_t)-mismatch;
+    std::vector<int8_t> ref(ref_len), read(query_len);
+    for (int k = 0; k < ref_len; ++k) ref[k] = base_code(ref_seq[k]);
+    for (int k = 0; k < query_len; ++k) read[k] = base_code(query_seq[k]);
+
+    // 8-bit pass first; the 16-bit pass replaces it when the score saturates
+    const int bias = mismatch;  // |most negative matrix entry|
+    int lanes = 16;
+    Best fwd = striped_pass(ref.data(), false, ref_len, read.data(), query_len, gap_open, gap_extend,
+                            mat, 16, bias, -1);
+    if (fwd.score == 255) {
+        lanes = 8;
+        fwd = striped_pass(ref.data(), false, ref_len, read.data(), query_len, gap_open, gap_extend, mat,
+                           8, 0, -1);
+    }
+    const int score = fwd.score, ref_end = fwd.ref, read_end = fwd.read;
+    // begin cell: reversed query prefix against the reference prefix, walked backwards
+    std::vector<int8_t> rq(read.begin(), read.begin() + read_end + 1);
+    std::reverse(rq.begin(), rq.end());
+    const Best bwd = striped_pass(ref.data(), true, ref_end + 1, rq.data(), read_end + 1, gap_open,
+                                  gap_extend, mat, lanes, lanes == 16 ? bias : 0, score);
+    const int ref_begin = bwd.ref, read_begin = read_end - bwd.read;
+    out[0] = score;
+    out[1] = ref_begin;
+    out[2] = ref_end;
+    out[3] = read_begin;
+    out[4] = read_end;
+    if (ref_begin < 0 || read_begin < 0 || ref_end < ref_begin || read_end < read_begin) return 0;
+
+    const int n = ref_end - ref_begin + 1, m = read_end - read_begin + 1;
+    std::vector<Op> ops;
+    if (!banded_cigar(ref.data() + ref_begin, read.data() + read_begin, n, m, score, gap_open, gap_extend,
+                      std::abs(n - m) + 1, mat, &ops))
+        return -1;
+
+    // M runs -> '=' / 'X' runs, soft clips at both ends, mismatch count (ssw_cpp.cpp:97-180)
+    std::string s;
+    char buf[32];
+    auto emit = [&](int len, char op) {
+        snprintf(buf, sizeof(buf), "%d%c", len, op);
+        s += buf;
+    };
+    if (read_begin > 0) emit(read_begin, 'S');
+    const int8_t* rp = ref.data() + ref_begin;
+    const int8_t* qp = read.data() + read_begin;
+    int mism = 0, run_eq = 0, run_x = 0;
+    auto flush = [&]() {
+        if (run_eq) emit(run_eq, '=');
+        else if (run_x) emit(run_x, 'X');
+        run_eq = run_x = 0;
+    };
+    for (const Op& o : ops) {
+        if (o.op == 'M') {
+            for (int k = 0; k < o.len; ++k, ++rp, ++qp) {
+                if (*rp != *qp) {
+                    ++mism;
+                    if (run_eq) emit(run_eq, '=');
+                    run_eq = 0;
+                    ++run_x;
+                } else {
+                    if (run_x) emit(run_x, 'X');
+                    run_x = 0;
+                    ++run_eq;
+                }
+            }
+        } else if (o.op == 'I') {
+            qp += o.len;
+            mism += o.len;
+            flush();
+            emit(o.len, 'I');
+        } else {
+            rp += o.len;
+            mism += o.len;
+            flush();
+            emit(o.len, 'D');
+        }
+    }
+    flush();
+    const int tail = query_len - read_end - 1;
+    if (tail > 0) emit(tail, 'S');
+    out[5] = mism;
+    if (cigar_cap > 0) snprintf(cigar, cigar_cap, "%s", s.c_str());
+    return 0;
+}
+
+}  // extern "C"

@@ -39,6 +39,13 @@ def load():
     lib.helen_io_write_predictions.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp]
     lib.helen_io_writer_close.restype = ctypes.c_int
     lib.helen_io_writer_close.argtypes = [vp]
+    lib.helen_io_region_sequence.restype = ctypes.c_longlong
+    lib.helen_io_region_sequence.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
+                                             ctypes.c_char_p, ctypes.c_longlong]
+    lib.helen_ssw_align.restype = ctypes.c_int
+    lib.helen_ssw_align.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_int]
     _lib = lib
     return lib
 
@@ -124,3 +131,41 @@ class Writer(object):
         if self._h:
             self._lib.helen_io_writer_close(self._h)
             self._h = None
+
+
+def region_sequence(path, contig, region):
+    """Decoded sequence of one region of a prediction file (Stitch.small_chunk_stitch's inner loop)."""
+    lib = load()
+    cap = 1 << 16
+    while True:
+        buf = ctypes.create_string_buffer(cap)
+        n = lib.helen_io_region_sequence(os.fsencode(path), contig.encode(), region.encode(), buf, cap)
+        if n == -2:
+            cap *= 4
+            continue
+        if n < 0:
+            raise IOError(_err(lib))
+        return buf.raw[:n].decode()
+
+
+class Alignment(object):
+    """What the reference's HELEN.Alignment exposes to Stitch (pybind_api.h:18-31)."""
+    __slots__ = ("best_score", "reference_begin", "reference_end", "query_begin", "query_end",
+                 "mismatches", "cigar_string")
+
+
+def ssw_align(reference, query, match, mismatch, gap_open, gap_extend):
+    """Aligner(match, mismatch, gap_open, gap_extend).SetReferenceSequence(reference);
+    Align_cpp(query, Filter(), alignment, 0) -> Alignment (same numbers as the reference's SSW)."""
+    lib = load()
+    r, q = reference.encode(), query.encode()
+    out = (ctypes.c_int * 6)()
+    cap = 16 * (len(r) + len(q)) + 64
+    cig = ctypes.create_string_buffer(cap)
+    rc = lib.helen_ssw_align(r, len(r), q, len(q), match, mismatch, gap_open, gap_extend, out, cig, cap)
+    if rc < 0:
+        raise RuntimeError("helen_ssw_align: internal inconsistency")
+    a = Alignment()
+    (a.best_score, a.reference_begin, a.reference_end, a.query_begin, a.query_end, a.mismatches) = list(out)
+    a.cigar_string = cig.value.decode()
+    return a

@@ -1,0 +1,221 @@
+"""stitch: prediction HDF5 files -> polished FASTA.
+
+Same procedure and the same outputs as helen/modules/python/Stitch.py:14-301 and
+StitchInterface.py:40-106:
+  1. per region (`predictions/<contig>/<contig-start-end>`), the images' labels are merged by position
+     key (first writer wins) and decoded base x run-length (`small_chunk_stitch`);
+  2. neighbouring regions overlap (SEQ_OVERLAP): the tail of the running sequence and the head of the
+     next one are aligned with striped Smith-Waterman (match 4, mismatch 6, gap 8/2, Options.py:4-7),
+     the first match run of >= 8 is the anchor, and the sequences are joined there
+     (`get_confident_positions`, `alignment_stitch`); 10 N's fill where no anchor exists.
+What differs is mechanism only: the per-position merge and the aligner are native
+(helen_amd/csrc/io.cpp, ssw.cpp -- the aligner reproduces the reference's SSW cell for cell), the
+running sequence is a bytearray (the reference re-allocates the whole string at every join), and
+worker processes are fed (file, region) lists.
+"""
+import concurrent.futures
+import os
+import re
+import sys
+
+from . import file_manager, hdf5, native_io
+
+
+class StitchOptions(object):   # Options.py:1-10
+    BASE_ERROR_RATE = 0.0
+    label_decoder = {1: 'A', 2: 'C', 3: 'G', 4: 'T', 0: ''}
+    MATCH_PENALTY = 4
+    MISMATCH_PENALTY = 6
+    GAP_PENALTY = 8
+    GAP_EXTEND_PENALTY = 2
+    MIN_SEQUENCE_REQUIRED_FOR_MULTITHREADING = 2
+    OVERLAP_THRESHOLD = 8
+    KMER_SIZE = 15
+
+
+_CIGAR = re.compile(r'(\d+)(\w)')
+
+
+def get_confident_positions(alignment):
+    """(reference index, query index) of the first M run (= and X merged) of at least
+    OVERLAP_THRESHOLD, or (-1, -1) (Stitch.py:34-94)."""
+    cigar = alignment.cigar_string.replace('=', 'M').replace('X', 'M')
+    grouped = []
+    for length, op in _CIGAR.findall(cigar):
+        if grouped and grouped[-1][0] == op:
+            grouped[-1][1] += int(length)
+        else:
+            grouped.append([op, int(length)])
+    ref_index = alignment.reference_begin
+    read_index = 0
+    for op, length in grouped:
+        if op == 'M' and length >= StitchOptions.OVERLAP_THRESHOLD:
+            return ref_index, read_index
+        if op == 'S' or op == 'I':
+            read_index += length
+        elif op == 'D':
+            ref_index += length
+        elif op == 'M':
+            ref_index += length
+            read_index += length
+        else:
+            raise ValueError("ERROR: INVALID CIGAR OPERATION ENCOUNTERED WHILTE STITCHING: " + str(op) + "\n")
+    return -1, -1
+
+
+def alignment_stitch(sequence_chunks):
+    """Join (contig, start, end, sequence) chunks in position order (Stitch.py:96-190)."""
+    sequence_chunks = sorted(sequence_chunks, key=lambda e: (e[1], e[2]))
+    contig, running_start, running_end, first = sequence_chunks[0]
+    running = bytearray(first.encode())
+    fill = b'N' * 10
+    for i in range(1, len(sequence_chunks)):
+        _, this_start, this_end, this_sequence = sequence_chunks[i]
+        if this_start < running_end:
+            overlap_bases = running_end - this_start
+            overlap_bases = overlap_bases + int(overlap_bases * StitchOptions.BASE_ERROR_RATE)
+            # python slicing semantics of the reference: s[-n:] is all of s when n >= len(s)
+            left_chunk = bytes(running[-overlap_bases:]).decode()
+            right_chunk = this_sequence[:overlap_bases]
+            if len(left_chunk) > 0 and len(right_chunk) > 0:
+                alignment = native_io.ssw_align(left_chunk, right_chunk, StitchOptions.MATCH_PENALTY,
+                                                StitchOptions.MISMATCH_PENALTY, StitchOptions.GAP_PENALTY,
+                                                StitchOptions.GAP_EXTEND_PENALTY)
+                best_score, pos = alignment.best_score, None
+            else:
+                best_score = 0      # Align_cpp returns false on an empty sequence: score stays 0
+            if best_score == 0:
+                sys.stderr.write("WARNING: NO ALIGNMENT FOUND: " + str(this_start) + " " + str(this_end) + "\n")
+                if len(right_chunk) > 10:
+                    running += fill
+                    running += right_chunk.encode()
+                    running_end = this_end
+            else:
+                pos_a, pos_b = get_confident_positions(alignment)
+                if pos_a == -1 or pos_b == -1:
+                    sys.stderr.write("WARNING: NO OVERLAPS IN ALIGNMENT : \n")
+                    sys.stderr.write("LEFT : " + left_chunk + "\n")
+                    sys.stderr.write("RIGHT: " + right_chunk + "\n")
+                    sys.stderr.write("CIGAR: " + alignment.cigar_string + "\n")
+                    if len(this_sequence) > 10:
+                        # left_sequence + overlap_sequence is the running sequence itself
+                        running += fill
+                        running += this_sequence.encode()
+                        running_end = this_end
+                else:
+                    # running[:-overlap] + left_chunk[:pos_a] + this[pos_b:]
+                    keep = len(running) - len(left_chunk) + pos_a
+                    del running[keep:]
+                    running += this_sequence[pos_b:].encode()
+                    running_end = this_end
+        else:
+            sys.stderr.write("WARNING: NO OVERLAP IN CHUNKS:  " + str(contig) + " " + str(this_start) + " "
+                             + str(running_end) + "\n")
+            if len(this_sequence) > 10:
+                running += fill
+                running += this_sequence.encode()
+                running_end = this_end
+    return contig, running_start, running_end, running.decode()
+
+
+def _region_sequence_py(file_name, contig, chunk_name):
+    """Pure-Python fallback of native_io.region_sequence (no libhelen_io.so)."""
+    with hdf5.File(file_name, "r") as f:
+        root = "predictions/%s/%s" % (contig, chunk_name)
+        chunks = sorted(set(f.keys(root)) - {"contig_start", "contig_end"})
+        base_d, rle_d = {}, {}
+        for chunk in chunks:
+            bases = f.read(root + "/" + chunk + "/bases")
+            rles = f.read(root + "/" + chunk + "/rles")
+            positions = f.read(root + "/" + chunk + "/position", "int64")
+            for (pos, indx, split), b, r in zip(positions.tolist(), bases.tolist(), rles.tolist()):
+                if indx < 0 or pos < 0:
+                    continue
+                if (pos, indx, split) not in base_d:
+                    base_d[(pos, indx, split)] = b
+                    rle_d[(pos, indx, split)] = r
+        return ''.join(StitchOptions.label_decoder[base_d[k]] * int(rle_d[k]) for k in sorted(base_d))
+
+
+def small_chunk_stitch(contig, small_chunk_keys):
+    """Decode every region of `small_chunk_keys` = [(contig, file, region name, start, end)] and stitch
+    them (Stitch.py:192-255)."""
+    name_sequence_tuples = []
+    for contig_name, file_name, chunk_name, contig_start, contig_end in small_chunk_keys:
+        if native_io.available():
+            sequence = native_io.region_sequence(file_name, contig, chunk_name)
+        else:
+            sequence = _region_sequence_py(file_name, contig, chunk_name)
+        name_sequence_tuples.append((contig, contig_start, contig_end, sequence))
+    name_sequence_tuples = sorted(name_sequence_tuples, key=lambda e: (e[1], e[2]))
+    return alignment_stitch(name_sequence_tuples)
+
+
+def create_consensus_sequence(contig, sequence_chunk_keys, threads):
+    """(Stitch.py:257-301): sort the regions, stitch runs of them in worker processes, then stitch the
+    partial sequences."""
+    key_list = sorted(((contig, f, key, int(st), int(end)) for f, key, st, end in sequence_chunk_keys),
+                      key=lambda e: (e[3], e[4]))
+    if not key_list:
+        return ""
+    n = max(StitchOptions.MIN_SEQUENCE_REQUIRED_FOR_MULTITHREADING, int(len(key_list) / threads) + 1)
+    file_chunks = [key_list[i:i + n] for i in range(0, len(key_list), n)]   # FileManager.chunks
+    sequence_chunks = []
+    if threads <= 1 or len(file_chunks) == 1:
+        for fc in file_chunks:
+            sequence_chunks.append(small_chunk_stitch(contig, fc))
+    else:
+        import multiprocessing as mp
+        with concurrent.futures.ProcessPoolExecutor(max_workers=threads,
+                                                    mp_context=mp.get_context("spawn")) as ex:
+            futures = [ex.submit(small_chunk_stitch, contig, fc) for fc in file_chunks]
+            for fut in concurrent.futures.as_completed(futures):
+                if fut.exception() is None:
+                    sequence_chunks.append(fut.result())
+                else:
+                    sys.stderr.write("ERROR: " + str(fut.exception()) + "\n")
+    sequence_chunks = sorted(sequence_chunks, key=lambda e: (e[1], e[2]))
+    return alignment_stitch(sequence_chunks)[3]
+
+
+def get_file_paths_from_directory(directory_path):
+    """`*hdf` files of a directory (StitchInterface.py:30-37)."""
+    return [os.path.abspath(os.path.join(directory_path, f)) for f in os.listdir(directory_path)
+            if os.path.isfile(os.path.join(directory_path, f)) and f[-3:] == 'hdf']
+
+
+def perform_stitch(input_directory, output_path, output_prefix, threads):
+    """Every contig of every prediction file -> `<output_path>/<output_prefix>.fa`
+    (StitchInterface.py:40-106)."""
+    all_prediction_files = get_file_paths_from_directory(input_directory)
+    all_contigs = set()
+    for prediction_file in sorted(all_prediction_files):
+        with hdf5.File(prediction_file, "r") as f:
+            if "predictions" in f:
+                all_contigs.update(f.keys("predictions"))
+            else:
+                raise ValueError("ERROR: INVALID HDF5 FILE, FILE DOES NOT CONTAIN predictions KEY.\n")
+    output_dir = file_manager.handle_output_directory(output_path)
+    output_filename = os.path.join(output_dir, output_prefix + '.fa')
+    sys.stderr.write("INFO: OUTPUT FILE: " + output_filename + "\n")
+    with open(output_filename, 'w') as fasta:
+        for i, contig in enumerate(sorted(all_contigs)):
+            prefix = "{:04d}/{:04d}:".format(i, len(all_contigs))
+            sys.stderr.write("INFO: " + prefix + " PROCESSING CONTIG: " + contig + "\n")
+            chunk_name_tuple = []
+            for prediction_file in all_prediction_files:
+                with hdf5.File(prediction_file, "r") as f:
+                    if contig not in f.keys("predictions"):
+                        continue
+                    for chunk_key in sorted(f.keys("predictions/" + contig)):
+                        root = "predictions/%s/%s/" % (contig, chunk_key)
+                        chunk_name_tuple.append((prediction_file, chunk_key,
+                                                 int(f.read(root + "contig_start")),
+                                                 int(f.read(root + "contig_end"))))
+            consensus_sequence = create_consensus_sequence(contig, chunk_name_tuple, threads)
+            sys.stderr.write("INFO: " + prefix + " FINISHED PROCESSING " + contig
+                             + ", POLISHED SEQUENCE LENGTH: " + str(len(consensus_sequence)) + ".\n")
+            if consensus_sequence is not None and len(consensus_sequence) > 0:
+                fasta.write('>' + contig + "\n")
+                fasta.write(consensus_sequence + "\n")
+    return output_filename

@@ -1,0 +1,187 @@
+"""stitch: the aligner against the reference's own SSW (oracle/_ref, built from the
+reference sources), the anchor logic, the region decode (native == Python restatement), and
+end-to-end reconstruction of a known sequence from overlapping regions."""
+import ctypes
+import os
+import random
+
+import numpy as np
+import pytest
+
+from helen_amd import hdf5, native_io
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SSW = os.path.join(ROOT, "oracle", "_ref", "libssw_ref.so")
+
+pytestmark = pytest.mark.skipif(not (hdf5.available() and native_io.available()),
+                                reason="libhdf5 / libhelen_io.so not available")
+
+
+def _mutate(s, rate, rng):
+    out = []
+    for c in s:
+        x = rng.random()
+        if x < rate / 3:
+            continue
+        if x < 2 * rate / 3:
+            out.append(rng.choice("ACGT"))
+            out.append(c)
+        elif x < rate:
+            out.append(rng.choice("ACGTN"))
+        else:
+            out.append(c)
+    return "".join(out)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SSW), reason="oracle/_ref/libssw_ref.so not built (make -C oracle ref)")
+def test_aligner_equals_reference_ssw_on_random_pairs():
+    """Score, begin/end cells, extended CIGAR and mismatch count, cell for cell, with stitch's
+    penalties (4, 6, 8, 2; Options.py:4-7).  Score-0 results are compared on the score only: the
+    reference library reads out of bounds there and stitch looks at nothing else (Stitch.py:137)."""
+    ref = ctypes.CDLL(REF_SSW)
+    rng = random.Random(12345)
+    checked = 0
+    for t in range(2500):
+        L = rng.choice([1, 2, 3, 5, 8, 13, 30, 60, 100, 200, 200, 200, 400])
+        base = "".join(rng.choice("ACGT") for _ in range(L))
+        mode = rng.random()
+        if mode < 0.5:
+            r, q = base, _mutate(base, rng.choice([0, 0.01, 0.05, 0.15, 0.4]), rng)
+            if rng.random() < 0.5 and len(q) > 10:
+                k = rng.randrange(0, min(40, len(q) // 2))
+                q = q[k:] + "".join(rng.choice("ACGT") for _ in range(k))
+        elif mode < 0.7:
+            r, q = base, "".join(rng.choice("ACGT") for _ in range(rng.choice([1, 5, 20, 100, 200])))
+        elif mode < 0.85:
+            r = "".join(rng.choice("AC") * rng.randrange(1, 6) for _ in range(L // 3 + 1))
+            q = _mutate(r, 0.1, rng)
+        else:
+            r, q = _mutate(base, 0.05, rng), base[rng.randrange(0, max(1, L // 2)):]
+        if not r or not q:
+            continue
+        out = (ctypes.c_int * 6)()
+        cig = ctypes.create_string_buffer(1 << 16)
+        ref.ssw_ref_align(r.encode(), len(r), q.encode(), 4, 6, 8, 2, out, cig, 1 << 16)
+        a = native_io.ssw_align(r, q, 4, 6, 8, 2)
+        assert a.best_score == out[0], (r, q)
+        if out[0] > 0:
+            assert (a.reference_begin, a.reference_end, a.query_begin, a.query_end, a.mismatches) == \
+                tuple(out[1:6]), (r, q)
+            assert a.cigar_string == cig.value.decode(), (r, q)
+            checked += 1
+    assert checked > 2000
+
+
+def test_aligner_known_answers():
+    a = native_io.ssw_align("ACGTTGCATGCATGCAAGGCTTAGGACCATTTACGGCATG", "TGCATGCATGCAGGCTTAGGACCTTTTACGGC", 4, 6, 8, 2)
+    # produced by the reference library (oracle/_ref) for this pair
+    assert (a.best_score, a.reference_begin, a.reference_end, a.query_begin, a.query_end) == (110, 4, 36, 0, 31)
+    assert a.cigar_string == "11=1D12=1X8=" and a.mismatches == 2
+    z = native_io.ssw_align("AAAA", "", 4, 6, 8, 2)
+    assert z.best_score == 0
+
+
+def test_confident_positions():
+    from helen_amd.stitch import get_confident_positions
+
+    class A(object):
+        pass
+    a = A()
+    a.cigar_string, a.reference_begin = "3S5=1X2=4D9=2I7=", 10
+    # groups: S3 M8 D4 M9 ...: the first M run >= 8 is the merged 5=1X2= at ref 10, read 3
+    assert get_confident_positions(a) == (10, 3)
+    a.cigar_string, a.reference_begin = "2S4=1I3=2D5=1X6=", 7
+    # M4 I1 M3 D2 M12 -> anchor at ref 7+4+3+2 = 16, read 2+4+1+3 = 10
+    assert get_confident_positions(a) == (16, 10)
+    a.cigar_string, a.reference_begin = "3=1I3=1D2=", 0
+    assert get_confident_positions(a) == (-1, -1)
+
+
+def _write_predictions(path, contig, regions):
+    """regions: list of (start, end, [(chunk_id, positions int64 [n,3], bases, rles)])."""
+    from helen_amd.data_store import DataStore
+    with DataStore(path, "w") as s:
+        for start, end, chunks in regions:
+            for chunk_id, pos, bases, rles in chunks:
+                n = len(bases)
+                P = np.full((1000, 3), -1, np.int64)
+                B = np.zeros(1000, np.uint8)
+                R = np.zeros(1000, np.uint8)
+                P[:n], B[:n], R[:n] = pos, bases, rles
+                s.write_prediction(contig, start, end, chunk_id, P, B, R)
+
+
+def test_region_decode_native_equals_python(tmp_path):
+    """First writer wins over chunk ids visited in STRING order ('0','1','10','2',...), numeric key
+    order, rle repetition, base 0 = nothing, and the uint32-wrapped padding rows that the
+    reference's `< 0` test lets through (they share one key that sorts last)."""
+    from helen_amd.stitch import _region_sequence_py
+    rng = np.random.default_rng(5)
+    chunks = []
+    for cid in range(12):                                # ids 0..11 -> '10','11' sort before '2'
+        n = 40
+        pos = np.stack([rng.integers(0, 60, n), rng.integers(0, 3, n), rng.integers(0, 2, n)], 1)
+        chunks.append((cid, pos, rng.integers(0, 5, n), rng.integers(0, 11, n)))
+    path = str(tmp_path / "p_0.hdf")
+    _write_predictions(path, "ctg", [(0, 1000, chunks)])
+    a = native_io.region_sequence(path, "ctg", "ctg-0-1000")
+    b = _region_sequence_py(path, "ctg", "ctg-0-1000")
+    assert a == b and len(a) > 50
+    # the padding rows contribute the first padded row's label once, at the very end
+    first = chunks[0]
+    tail_base, tail_rle = 0, 0          # padded labels written as zeros by _write_predictions
+    assert a.endswith("ACGT"[tail_base - 1] * tail_rle if tail_base else "")
+
+
+@pytest.mark.parametrize("threads", [1, 3])
+def test_stitch_reconstructs_a_known_sequence(tmp_path, threads):
+    """Overlapping regions (stride 800, length 1000, like MarginPolish's) whose labels are the run-
+    length encoding of a known sequence must stitch back to exactly that sequence; regions are
+    spread over two prediction files and images are split into two chunk ids."""
+    from helen_amd.stitch import perform_stitch
+    rng = random.Random(7)
+    runs = []
+    prev = None
+    while len(runs) < 5000:
+        b = rng.choice("ACGT")
+        if b == prev:
+            continue
+        runs.append((b, 1 if rng.random() < 0.7 else rng.randrange(2, 6)))
+        prev = b
+    truth = "".join(b * r for b, r in runs)
+    code = {"A": 1, "C": 2, "G": 3, "T": 4}
+    regions = []
+    for k in range((len(runs) - 200) // 800):
+        lo, hi = 800 * k, min(len(runs), 800 * k + 1000)
+        pos = np.stack([np.arange(lo, hi), np.zeros(hi - lo, np.int64), np.zeros(hi - lo, np.int64)], 1)
+        bases = np.array([code[b] for b, _ in runs[lo:hi]])
+        rles = np.array([r for _, r in runs[lo:hi]])
+        half = (hi - lo) // 2
+        regions.append((lo, hi, [(0, pos[:half], bases[:half], rles[:half]),
+                                 (1, pos[half:], bases[half:], rles[half:])]))
+    d = tmp_path / "pred"
+    d.mkdir()
+    _write_predictions(str(d / "p_0.hdf"), "chrS", regions[0::2])
+    _write_predictions(str(d / "p_1.hdf"), "chrS", regions[1::2])
+    out = perform_stitch(str(d), str(tmp_path / "out"), "asm", threads)
+    lines = open(out).read().split("\n")
+    assert lines[0] == ">chrS" and lines[2] == ""
+    covered = "".join(b * r for b, r in runs[:regions[-1][1]])
+    assert lines[1] == covered and covered == truth[:len(covered)]
+
+
+def test_stitch_gap_and_no_alignment_paths():
+    from helen_amd.stitch import alignment_stitch
+    rng = random.Random(3)
+    s1 = "".join(rng.choice("ACGT") for _ in range(300))
+    s2 = "".join(rng.choice("ACGT") for _ in range(300))
+    # no coordinate overlap -> 10 N filler (Stitch.py:180-188)
+    c, st, en, seq = alignment_stitch([("c", 0, 300, s1), ("c", 400, 700, s2)])
+    assert (st, en) == (0, 700) and seq == s1 + "N" * 10 + s2
+    # coordinate overlap but unrelated sequence: either no anchor (filler + whole next chunk) or an
+    # anchor by chance; both keep every base of s1 up to the overlap
+    c, st, en, seq = alignment_stitch([("c", 0, 300, s1), ("c", 250, 550, s2)])
+    assert seq.startswith(s1[:250]) and en == 550
+    # a short chunk (<= 10 bases) without an anchor is dropped (Stitch.py:163)
+    c, st, en, seq = alignment_stitch([("c", 0, 300, s1), ("c", 400, 405, "ACGTA")])
+    assert seq == s1 and en == 300
