@@ -2,12 +2,14 @@
 """bench.py -- pileup windows / second of the `helen polish` inference path on MI355X.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` (N > 1 under torch.distributed.run, one
-rank per GPU).  A "step" is one loader batch of 256 synthetic pileup windows (1000 positions x
-90 features, uint8, already resident in HBM) through the whole hot path: uint8->f32, 19 overlapping
-chunks of the 2-layer bidirectional GRU with carried hidden state, heads, softmax-accumulate and
-argmax labels (reference: models/predict_gpu.py:97-159).  Windows are independent, so consecutive
-batches are coalesced `--coalesce` at a time into one helen_polish_batch call; results are
-identical to per-batch calls (tests/test_gpu_parity.py::test_batch_split_invariance).
+rank per GPU).  A "step" is one pass of the hot path -- one helen_polish_batch call -- over
+`--coalesce` (16) loader batches of 256 synthetic pileup windows (1000 positions x 90 features,
+uint8, already resident in HBM): uint8->f32, 19 overlapping chunks of the 2-layer bidirectional GRU
+with carried hidden state, heads, softmax-accumulate and argmax labels (reference:
+models/predict_gpu.py:97-159).  Windows are independent and hidden is zeroed per window, so handing
+the device 16 loader batches at once gives the same labels as 16 separate calls
+(tests/test_gpu_parity.py::test_batch_split_invariance); 4096 windows = 256 tiles is what fills
+256 CUs x 2 workgroups.  `value` is windows per second over all ranks.
 
 Prints ONE JSON line (rank 0) with the whole-job windows/s, the MFMA-roofline figures of the
 dominant kernel (the GRU recurrence, timed with HIP events on the launch stream inside the timed
@@ -72,8 +74,8 @@ def cpu_baseline(batch, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=16, help="timed device calls per rank")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed device calls per rank")
     ap.add_argument("--batch", type=int, default=256, help="windows per step (BASELINE.json: 256)")
     ap.add_argument("--coalesce", type=int, default=16, help="loader batches per device call")
     ap.add_argument("--mode", default="uniform", choices=["uniform", "pileup"])
@@ -114,7 +116,7 @@ def main():
 
     # synthetic chr20-scale image shard, resident in HBM before the timed region; every rank gets
     # its own shard (weak scaling: images are sharded by file, CallConsensusInterface.py:138-145)
-    n_res = max(args.steps, args.warmup, 1) * B
+    n_res = min(max(args.steps, args.warmup, 1), 8) * call_windows   # resident shard (re-walked if shorter)
     gen = torch.Generator(device=dev).manual_seed(20260928 + rank)
     if args.mode == "uniform":
         images = torch.randint(0, 256, (n_res, 1000, 90), dtype=torch.uint8, device=dev, generator=gen)
@@ -132,11 +134,13 @@ def main():
     from helen_amd import _lib
     lib = _lib.load()
 
+    n_calls_res = n_res // call_windows
+
     def run(n_steps):
-        n = n_steps * B
-        for s in range(0, n, call_windows):
-            e = min(n, s + call_windows)
-            _lib.check(lib.helen_polish_batch(eng._handle, images[s:e].data_ptr(), e - s,
+        for k in range(n_steps):
+            s = (k % n_calls_res) * call_windows
+            e = s + call_windows
+            _lib.check(lib.helen_polish_batch(eng._handle, images[s:e].data_ptr(), call_windows,
                                               bases[s:e].data_ptr(), rles[s:e].data_ptr(), None, None,
                                               ctypes.c_void_p(stream)))
 
@@ -164,14 +168,12 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        total_windows = world * args.steps * B
+        total_windows = world * args.steps * call_windows
         value = total_windows / elapsed
         gru_ms = stats["gru_enc"][0] + stats["gru_dec"][0]
         gru_n = stats["gru_enc"][1] + stats["gru_dec"][1]
         avg_ms = gru_ms / max(gru_n, 1)
-        # launches may process a short last group; use the mean windows per launch
-        calls = (args.steps * B + call_windows - 1) // call_windows
-        win_per_launch = args.steps * B / calls
+        win_per_launch = call_windows
         achieved = GRU_FLOP_PER_WINDOW_LAUNCH * win_per_launch / (avg_ms * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(win_per_launch)
         peak = FP32_MFMA_PEAK if args.precision == "fp32" else BF16_MFMA_PEAK
@@ -190,8 +192,9 @@ def main():
             "config": {"workload": ("BASELINE.json configs[1]: 1xMI355X, batch 256, fp32, synthetic "
                                     "chr20-scale image shard resident in HBM") if args.precision == "fp32"
                        else "BASELINE.json configs[3] variant: bf16 gate matmuls, fp32 accumulate/state",
-                       "batch": B, "coalesce_batches_per_call": G, "positions": 1000, "features": 90,
-                       "windows_per_gpu": args.steps * B, "sharding": "by rank, no collective"},
+                       "batch": B, "batches_per_step": G, "windows_per_step": call_windows,
+                       "positions": 1000, "features": 90, "windows_per_gpu": args.steps * call_windows,
+                       "resident_windows_per_gpu": n_res, "sharding": "by rank, no collective"},
             "roofline": {"bound": bound, "kernel": "gru_kernel (GRU recurrence, fp32 MFMA)" if args.precision == "fp32"
                          else "gru_bf16_kernel (GRU recurrence, bf16 MFMA)",
                          "achieved": round(achieved, 2),
@@ -201,7 +204,7 @@ def main():
                          "path_frac": round(value / world * FLOP_PER_WINDOW /
                                             (FP32_MFMA_PEAK if args.precision == "fp32" else BF16_MFMA_PEAK), 4)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B)
         print(json.dumps(out))
     if dist is not None:

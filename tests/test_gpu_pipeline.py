@@ -111,3 +111,22 @@ def test_drop_in_model_object(workdir):
     np.testing.assert_allclose(base.cpu().numpy(), ob, atol=2e-4, rtol=2e-4)
     np.testing.assert_allclose(rle.cpu().numpy(), orl, atol=2e-4, rtol=2e-4)
     np.testing.assert_allclose(h1.cpu().numpy(), oh, atol=1e-4, rtol=0)
+
+
+def test_two_callers_shard_files_round_robin(workdir):
+    """Two callers (both on GPU 0 here; one per GPU in production): files are dealt round-robin
+    (CallConsensusInterface.py:138-145), each rank writes <prefix>_<rank>.hdf, the union is complete."""
+    from helen_amd.call_consensus import call_consensus
+    from helen_amd.file_manager import get_file_paths_from_directory, shard_round_robin
+    d, w, model, img_dir, expected = workdir
+    out = str(d / "out_two")
+    call_consensus(img_dir, model, 16, 0, 1, out, "pred", True, "0,0", 2)
+    files = [os.path.join(out, f) for f in sorted(os.listdir(out))]
+    assert [os.path.basename(f) for f in files] == ["pred_0.hdf", "pred_1.hdf"]
+    _check_prediction_files(files, expected)
+    # rank 0 holds exactly the windows of its file shard
+    shards = shard_round_robin(get_file_paths_from_directory(img_dir), 2)
+    from helen_amd.sequence_dataset import SequenceDataset
+    n0 = len(SequenceDataset(None, file_list=shards[0]))
+    with hdf5.File(files[0]) as f:
+        assert len(f.keys("predictions/chr20_synth")) == n0
