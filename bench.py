@@ -60,7 +60,7 @@ def cpu_baseline(batch, seconds_target=12.0):
     oracle.polish_batch(w, probe)
     dt = time.time() - t0
     rate = probe.shape[0] / dt
-    n = int(min(max(rate * seconds_target, probe.shape[0]), 4 * batch))
+    n = int(min(max(rate * seconds_target, probe.shape[0]), 16 * batch))
     n = max(8, (n // 8) * 8)
     img = make_images(n, seed=2)
     t0 = time.time()
