@@ -198,15 +198,15 @@ int check_launch(const char* what) {
 // recurrence.  y2 then holds the decoder output, hid the returned hidden state.
 // 1-D grid of the projection kernels: units = tiles x position groups, padded to a multiple of 8
 // (the XCD count), times 8 / HELEN_GEMM_WAVES column-group workgroups per unit.
-unsigned gemm_grid(int npos, int tiles) {
-    const int units = tiles * ((npos + 3) / 4);
+unsigned gemm_grid(int npos, int tiles, int positions_per_wave = 4) {
+    const int units = tiles * ((npos + positions_per_wave - 1) / positions_per_wave);
     return (unsigned)((units + 7) / 8 * 8) * (8 / HELEN_GEMM_WAVES);
 }
 
 void launch_enc_gemm(HelenModel* m, hipStream_t s, int tiles, int npos) {
     const dim3 grid(gemm_grid(npos, tiles)), block(HELEN_GEMM_WAVES * 64);
     if (m->precision == HELEN_PRECISION_BF16)
-        LAUNCH(HELEN_K_GEMM_ENC, (gemm_gi_bf16_kernel<kFPad / 16, false>), grid, block, m->xa,
+        LAUNCH(HELEN_K_GEMM_ENC, (gemm_gi_bf16_kernel<kFPad / 16, false, 4, false>), dim3(gemm_grid(npos, tiles, 4)), block, m->xa,
                kXaTileStride, m->wpb_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles);
     else
         LAUNCH(HELEN_K_GEMM_ENC, (gemm_gi_kernel<kFPad / 16, false>), grid, block, m->xa,
@@ -222,7 +222,7 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
     if (m->precision == HELEN_PRECISION_BF16) {
         LAUNCH(HELEN_K_GRU_ENC, gru_bf16_kernel, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride,
                pos0, enc_npos - pos0 - T, T, m->whpb_enc, m->bhn_enc, m->hid, m->y1, kYTileStride);
-        LAUNCH(HELEN_K_GEMM_DEC, (gemm_gi_bf16_kernel<16, true>), ggrid, gblock, m->y1, kYTileStride,
+        LAUNCH(HELEN_K_GEMM_DEC, (gemm_gi_bf16_kernel<16, true, 2, true>), dim3(gemm_grid(T, tiles, 2)), gblock, m->y1, kYTileStride,
                m->wpb_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
         LAUNCH(HELEN_K_GRU_DEC, gru_bf16_kernel, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0,
                0, T, m->whpb_dec, m->bhn_dec, m->hid, m->y2, kYTileStride);

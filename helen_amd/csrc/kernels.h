@@ -426,37 +426,31 @@ __device__ __forceinline__ f32x4 mfma_bf16(bf16x4 a, bf16x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
 
-template <int MG, bool REV_A>
+// With bf16 MFMAs the projection is memory-bound (fp32 gi out: 24.5 KB per tile/position/direction),
+// so the loop is built for bytes in flight, not for MFMA issue: each wave takes P positions (2 for the
+// decoder's K = 256, 4 for the encoder's K = 96) and issues ALL of their A loads up front (P x MG x 1 KiB
+// per wave), then streams the packed bf16 W_ih
+// from L2 one group ahead; 8+ waves per CU hide what is left.
+template <int MG, bool REV_A, int P, bool UPFRONT>
 __global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_bf16_kernel(
     const f32x4* __restrict__ A, long a_tile_stride, const bf16x4* __restrict__ Wp,
     const float* __restrict__ bias, f32x4* __restrict__ gi, long gi_tile_stride, int npos,
     int ntiles) {
-    constexpr int P = 4, N = 6;
-    const int lane = threadIdx.x & 63;
-    // grid.x enumerates (unit, z): unit = (position group, tile), z = which HELEN_GEMM_WAVES wave
-    // slots.  Workgroups are dispatched round-robin over the 8 XCDs (id % 8), so the ZB = 8 /
-    // HELEN_GEMM_WAVES workgroups that share one unit's A operand get ids u, u+8, u+16, ... inside a
-    // block of 8*ZB ids: same XCD, same L2, adjacent in time -> A is fetched from HBM once.
+    constexpr int N = 6;
     constexpr int ZB = 8 / HELEN_GEMM_WAVES;
+    const int lane = threadIdx.x & 63;
     const int bid = blockIdx.x;
-    const int unit = (bid / (8 * ZB)) * 8 + (bid & 7);
+    const int unit = (bid / (8 * ZB)) * 8 + (bid & 7);   // same XCD-aware enumeration as gemm_gi_kernel
     const int zb = (bid >> 3) % ZB;
-    const int npg = (npos + P - 1) / P;                 // position groups per tile
+    const int npg = (npos + P - 1) / P;
     const int tile = unit / npg;
     const int pos0 = (unit % npg) * P;
-    if (tile >= ntiles) return;                           // grid is padded to a multiple of 8 units
+    if (tile >= ntiles) return;
     const int wave = (threadIdx.x >> 6) + zb * HELEN_GEMM_WAVES;
     const int dir = wave >> 2;
     const int nt0 = (wave & 3) * N;
     const bf16x4* w_base = Wp + (size_t)((dir * kNTile + nt0) * MG) * 64 + lane;
-    const f32x4* a_ptr[P];
-    const f32x4* a_ptr_b[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        const int pc = min(pos0 + p, npos - 1);
-        a_ptr[p] = A + (size_t)tile * a_tile_stride + (size_t)pc * (MG * 64) + lane;
-        a_ptr_b[p] = A + (size_t)tile * a_tile_stride + (size_t)(npos - 1 - pc) * (MG * 64) + lane;
-    }
+
     f32x4 acc[P][N];
 #pragma unroll
     for (int n = 0; n < N; ++n) {
@@ -464,21 +458,62 @@ __global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_bf16_kernel(
 #pragma unroll
         for (int p = 0; p < P; ++p) acc[p][n] = splat4(b);
     }
+    const f32x4* fwd[P];
+    const f32x4* bwd[P];
 #pragma unroll
-    for (int m = 0; m < MG; ++m) {
-        f32x4 a[P];
-        bf16x4 b[N];
+    for (int p = 0; p < P; ++p) {
+        const int pc = min(pos0 + p, npos - 1);
+        fwd[p] = A + (size_t)tile * a_tile_stride + (size_t)pc * (MG * 64) + lane;
+        bwd[p] = A + (size_t)tile * a_tile_stride + (size_t)(npos - 1 - pc) * (MG * 64) + lane;
+    }
+    if constexpr (!UPFRONT) {
+        // short K (encoder): the kernel is bound by its output stream; plain per-group loads measured best
 #pragma unroll
-        for (int p = 0; p < P; ++p) a[p] = (REV_A && m >= MG / 2) ? a_ptr_b[p][m * 64] : a_ptr[p][m * 64];
+        for (int m = 0; m < MG; ++m) {
+            f32x4 am[P];
+            bf16x4 bm[N];
 #pragma unroll
-        for (int n = 0; n < N; ++n) b[n] = w_base[(n * MG + m) * 64];
+            for (int p = 0; p < P; ++p) am[p] = (REV_A && m >= MG / 2) ? bwd[p][m * 64] : fwd[p][m * 64];
+#pragma unroll
+            for (int n = 0; n < N; ++n) bm[n] = w_base[(n * MG + m) * 64];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const bf16x4 ab = to_bf16x4(am[p]);
+#pragma unroll
+                for (int n = 0; n < N; ++n) acc[p][n] = mfma_bf16(ab, bm[n], acc[p][n]);
+            }
+        }
+    } else {
+    f32x4 a[P][MG];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int m = 0; m < MG; ++m) a[p][m] = (REV_A && m >= MG / 2) ? bwd[p][m * 64] : fwd[p][m * 64];
+    bf16x4 b0[N], b1[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) b0[n] = w_base[(n * MG) * 64];
+#pragma unroll
+    for (int m = 0; m < MG; m += 2) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) b1[n] = w_base[(n * MG + m + 1) * 64];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            const bf16x4 ab = to_bf16x4(a[p]);
+            const bf16x4 ab = to_bf16x4(a[p][m]);
 #pragma unroll
-            for (int n = 0; n < N; ++n) acc[p][n] = mfma_bf16(ab, b[n], acc[p][n]);
+            for (int n = 0; n < N; ++n) acc[p][n] = mfma_bf16(ab, b0[n], acc[p][n]);
+        }
+        if (m + 2 < MG) {
+#pragma unroll
+            for (int n = 0; n < N; ++n) b0[n] = w_base[(n * MG + m + 2) * 64];
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const bf16x4 ab = to_bf16x4(a[p][m + 1]);
+#pragma unroll
+            for (int n = 0; n < N; ++n) acc[p][n] = mfma_bf16(ab, b1[n], acc[p][n]);
         }
     }
+    }  // UPFRONT
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         if (pos0 + p < npos) {
