@@ -50,11 +50,26 @@ class HelenError(RuntimeError):
 _lib = None
 
 
+def _try_build(target):
+    """The .so files are build products kept out of git; if one is missing (fresh clone) and the
+    toolchain is here, build it in-tree once.  Failure is silent here -- the caller raises."""
+    import shutil
+    import subprocess
+    if shutil.which("make") and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        try:
+            subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), target], check=False,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        except Exception:
+            pass
+
+
 def load():
     """Load libhelen_hip.so once; raise if it is absent (build with `python __graft_entry__.py`)."""
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and not os.environ.get("HELEN_HIP_LIB"):
+        _try_build("libhelen_hip.so")
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "helen_amd: %s not found. The HIP library is required (there is no CPU fallback); "

@@ -20,7 +20,12 @@ def load():
     if _tried:
         return _lib
     _tried = True
-    if os.environ.get("HELEN_NO_NATIVE_IO") or not os.path.exists(LIB_PATH):
+    if os.environ.get("HELEN_NO_NATIVE_IO"):
+        return None
+    if not os.path.exists(LIB_PATH):
+        from ._lib import _try_build
+        _try_build("libhelen_io.so")
+    if not os.path.exists(LIB_PATH):
         return None
     try:
         lib = ctypes.CDLL(LIB_PATH)
