@@ -97,7 +97,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torch.distributed.run (any world size) the process group is used for the barrier and the
+    # max-over-ranks time; a plain `python bench.py` needs none
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         import torch.distributed as dist
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
