@@ -14,6 +14,7 @@ HELEN_ABI_VERSION = 1
 HELEN_OK = 0
 HELEN_PRECISION_FP32 = 0
 HELEN_PRECISION_BF16 = 1
+HELEN_PRECISION_FP32X3 = 2
 
 KERNEL_CLASSES = ("pack", "gemm_enc", "gru_enc", "gemm_dec", "gru_dec", "heads")
 

@@ -64,6 +64,9 @@ struct HelenModel {
     bf16x4* wpb_dec = nullptr;
     bf16x4* whpb_enc = nullptr;
     bf16x4* whpb_dec = nullptr;
+    // three-term bf16 split of W_hh for the fp32x3 recurrence: [2 dirs][8 waves][3 gates][4 M][3 terms][64]
+    bf16x8* w3h_enc = nullptr;
+    bf16x8* w3h_dec = nullptr;
     // scratch (device)
     f32x4* xa = nullptr;
     f32x4* gi_enc = nullptr;
@@ -163,6 +166,41 @@ std::vector<bf16x4> round_pack(const std::vector<f32x4>& in) {
     return out;
 }
 
+float from_bf16(short b) {
+    uint32_t u = (uint32_t)(uint16_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// W_hh -> W3[((dir*8 + v)*36 + (g*4 + M)*3 + t)*64 + lane][e] = term t of
+//   W_hh[dir][g*128 + 16v + (lane & 15)][32M + 8(lane >> 4) + e], with w == t0 + t1 + t2 exactly.
+std::vector<bf16x8> pack_w_hh_x3(const float* const w[2]) {
+    std::vector<bf16x8> out((size_t)2 * 8 * 36 * 64);
+    for (int dir = 0; dir < 2; ++dir)
+        for (int v = 0; v < 8; ++v)
+            for (int g = 0; g < 3; ++g)
+                for (int M = 0; M < 4; ++M)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int row = g * kH + 16 * v + (lane & 15);
+                        for (int e = 0; e < 8; ++e) {
+                            const float x = w[dir][(size_t)row * kH + 32 * M + 8 * (lane >> 4) + e];
+                            const short t1 = to_bf16(x);
+                            const float r1 = x - from_bf16(t1);
+                            const short t2 = to_bf16(r1);
+                            const float r2 = r1 - from_bf16(t2);
+                            const short t3 = to_bf16(r2);
+                            const size_t base = ((size_t)(dir * 8 + v) * 36 + (g * 4 + M) * 3) * 64 + lane;
+                            short terms[3] = {t1, t2, t3};
+                            for (int t = 0; t < 3; ++t) {
+                                __bf16 val;
+                                memcpy(&val, &terms[t], 2);
+                                out[base + (size_t)t * 64][e] = val;
+                            }
+                        }
+                    }
+    return out;
+}
+
 void record_begin(HelenModel* m, int cls, hipStream_t s, EventPair* ev, bool* on) {
     *on = (m->prof_mask >> cls) & 1u;
     if (!*on) return;
@@ -228,18 +266,27 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
                0, T, m->whpb_dec, m->bhn_dec, m->hid, m->y2, kYTileStride);
         return;
     }
-    LAUNCH(HELEN_K_GRU_ENC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
-           enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride);
+    const bool x3 = m->precision == HELEN_PRECISION_FP32X3;
+    if (x3)
+        LAUNCH(HELEN_K_GRU_ENC, gru_x3_kernel, dim3(tiles, 2), dim3(512), m->gi_enc, kGiEncTileStride, pos0,
+               enc_npos - pos0 - T, T, m->w3h_enc, m->bhn_enc, m->hid, m->y1, kYTileStride);
+    else
+        LAUNCH(HELEN_K_GRU_ENC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
+               enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride);
     LAUNCH(HELEN_K_GEMM_DEC, (gemm_gi_kernel<16, true>), ggrid, gblock, m->y1, kYTileStride, m->wp_dec,
            m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
-    LAUNCH(HELEN_K_GRU_DEC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, 0, T,
-           m->whp_dec, m->bhn_dec, m->hid, m->y2, kYTileStride);
+    if (x3)
+        LAUNCH(HELEN_K_GRU_DEC, gru_x3_kernel, dim3(tiles, 2), dim3(512), m->gi_dec, kGiDecTileStride, 0, 0,
+               T, m->w3h_dec, m->bhn_dec, m->hid, m->y2, kYTileStride);
+    else
+        LAUNCH(HELEN_K_GRU_DEC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, 0, T,
+               m->whp_dec, m->bhn_dec, m->hid, m->y2, kYTileStride);
 }
 
 void free_model(HelenModel* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    void* ptrs[] = {m->wpb_enc, m->wpb_dec, m->whpb_enc, m->whpb_dec, m->wp_enc, m->wp_dec, m->whp_enc, m->whp_dec, m->whd, m->bias_enc, m->bias_dec,
+    void* ptrs[] = {m->w3h_enc, m->w3h_dec, m->wpb_enc, m->wpb_dec, m->whpb_enc, m->whpb_dec, m->wp_enc, m->wp_dec, m->whp_enc, m->whp_dec, m->whd, m->bias_enc, m->bias_dec,
                     m->bhn_enc, m->bhn_dec, m->bhd, m->xa, m->gi_enc, m->gi_dec, m->y1, m->y2,
                     m->hid, m->pending, m->dev_in[0], m->dev_in[1], m->dev_out[0], m->dev_out[1]};
     for (void* p : ptrs)
@@ -282,6 +329,10 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
     if ((rc = upload(m, &m->wp_dec, pack_w_ih(w->dec_w_ih, 2 * kH, 16)))) return rc;
     if ((rc = upload(m, &m->whp_enc, pack_w_hh(w->enc_w_hh)))) return rc;
     if ((rc = upload(m, &m->whp_dec, pack_w_hh(w->dec_w_hh)))) return rc;
+    if (precision == HELEN_PRECISION_FP32X3) {
+        if ((rc = upload(m, &m->w3h_enc, pack_w_hh_x3(w->enc_w_hh)))) return rc;
+        if ((rc = upload(m, &m->w3h_dec, pack_w_hh_x3(w->dec_w_hh)))) return rc;
+    }
     if (precision == HELEN_PRECISION_BF16) {
         if ((rc = upload(m, &m->wpb_enc, round_pack(pack_w_ih(w->enc_w_ih, kF, kFPad / 16))))) return rc;
         if ((rc = upload(m, &m->wpb_dec, round_pack(pack_w_ih(w->dec_w_ih, 2 * kH, 16))))) return rc;
@@ -346,7 +397,8 @@ int helen_model_create(const HelenWeights* w, int device, int max_windows, int p
                     "unsupported geometry F=%d H=%d base=%d rle=%d (built for %d/%d/%d/%d, Options.py:13-29)",
                     w->features, w->hidden, w->n_base, w->n_rle, kF, kH, kNB, kNR);
     if (max_windows <= 0) return fail(HELEN_EINVAL, "max_windows must be > 0");
-    if (precision != HELEN_PRECISION_FP32 && precision != HELEN_PRECISION_BF16)
+    if (precision != HELEN_PRECISION_FP32 && precision != HELEN_PRECISION_BF16 &&
+        precision != HELEN_PRECISION_FP32X3)
         return fail(HELEN_EINVAL, "unknown precision %d", precision);
     for (int d = 0; d < 2; ++d)
         if (!w->enc_w_ih[d] || !w->enc_w_hh[d] || !w->enc_b_ih[d] || !w->enc_b_hh[d] ||

@@ -638,6 +638,149 @@ __global__ __launch_bounds__(256, 2) void gru_bf16_kernel(const f32x4* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp32x3 recurrence (HELEN_PRECISION_FP32X3, opt-in): fp32-class h . W_hh^T on the bf16 matrix cores.
+//   Every fp32 value is the exact sum of three bf16 terms (3 x 8 significand bits): h = h1 + h2 + h3,
+//   w = w1 + w2 + w3.  Each partial product hi*wj is exact in fp32, and the six leading ones
+//   (i + j <= 4) reproduce h*w to 2^-32 relative -- below fp32's own rounding -- so
+//       sum_k h_k w_k = sum over the 6 products of (bf16 MFMA, fp32 accumulate)
+//   is an fp32 dot product up to summation order, at 6 x 16.7 cycles per 32 k on
+//   v_mfma_f32_16x16x32_bf16 instead of 8 x 32 cycles on v_mfma_f32_16x16x4_f32.
+//   W_hh's three terms for a wave's columns must stay in registers (3 x the bf16 kernel's), so the
+//   workgroup is 8 waves, wave v owning hidden units 16v..16v+15 (one 16-column tile per gate).
+//   The new h is split once, by the lane that produced it, into three bf16 planes in LDS laid out as
+//   the A fragment of the K = 32 MFMA (unit (k/8, row) of 8 bf16 = 16 bytes; group M of lane (row, q)
+//   is unit 4M + q); an fp32 copy feeds the layer output y and the carried state, which keep the
+//   fp32 path's layouts -- only this kernel changes, the projections stay on fp32 MFMAs.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short bf16_bits(float f) {   // RNE, via the hardware convert
+    const bf16x2_t p = __builtin_convertvector((f32x2){f, 0.f}, bf16x2_t);
+    return (unsigned short)(__builtin_bit_cast(unsigned, p) & 0xffffu);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) {
+    return __builtin_bit_cast(float, (unsigned)b << 16);
+}
+
+__global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ gi, long gi_tile_stride,
+                                                     int slot0_fwd, int slot0_bwd, int T,
+                                                     const bf16x8* __restrict__ W3,
+                                                     const float* __restrict__ bhn,
+                                                     f32x4* __restrict__ hid, f32x4* __restrict__ y,
+                                                     long y_tile_stride) {
+    // LDS (one object): fp32 h [2][512 f4] | bf16 planes [2 buffers][3 terms][256 units of 16 B] |
+    // gi slots [8 waves][3][64 f4]
+    __shared__ f32x4 smem[2 * 512 + 2 * 3 * 256 + 8 * 192];
+    f32x4* const hbuf = smem;
+    f32x4* const planes = smem + 1024;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int v = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7: hidden units 16v..16v+15
+    f32x4* const gbuf = smem + 1024 + 1536 + v * 192;
+    const int j = lane & 15;
+    const int q = lane >> 4;
+    const int tile = blockIdx.x;
+    const int dir = blockIdx.y;
+    const int slot0 = dir ? slot0_bwd : slot0_fwd;
+    const int u = 16 * v + j;                                  // this lane's hidden unit
+
+    // W[g][M][t]: term t of W_hh[row g*128 + u][k = 32M + 8q + e], e = 0..7
+    bf16x8 W[3][4][3];
+    {
+        const bf16x8* wp = W3 + (size_t)((dir * 8 + v) * 36) * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int M = 0; M < 4; ++M)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) W[g][M][t] = wp[((g * 4 + M) * 3 + t) * 64];
+    }
+    const float bn = bhn[dir * kH + u];
+
+    const f32x4* gi_p = gi + (size_t)tile * gi_tile_stride + (size_t)dir * (kNTile * 64) + v * 64 + lane;
+    constexpr long kPosStride = 2 * kNTile * 64;
+    auto dma_gi = [&](int slot) {
+        const f32x4* p = gi_p + (size_t)slot * kPosStride;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+            __builtin_amdgcn_global_load_lds(
+                (const void __attribute__((address_space(1)))*)(p + (g * 8) * 64),
+                (void __attribute__((address_space(3)))*)(gbuf + g * 64), 16, 0, 0);
+    };
+    // this lane's 4 values: rows 4q + r of unit u.  fp32 h: float index ((u>>2)*16 + 4q + r)*4 + (u&3);
+    // planes: bf16 index ((u>>3)*16 + 4q + r)*8 + (u&7) inside a 256-unit plane
+    const int hoff = ((u >> 2) * kTile + 4 * q) * 4 + (u & 3);
+    const int poff = ((u >> 3) * kTile + 4 * q) * 8 + (u & 7);
+    auto store_h = [&](int buf, int r, float h) {
+        ((float*)(hbuf + buf * 512))[hoff + 4 * r] = h;
+        unsigned short* pl = (unsigned short*)(planes + buf * 768);
+        const unsigned short t1 = bf16_bits(h);
+        const float r1 = h - bf16_to_f32(t1);
+        const unsigned short t2 = bf16_bits(r1);
+        const float r2 = r1 - bf16_to_f32(t2);
+        const unsigned short t3 = bf16_bits(r2);
+        pl[0 * 2048 + poff + 8 * r] = t1;
+        pl[1 * 2048 + poff + 8 * r] = t2;
+        pl[2 * 2048 + poff + 8 * r] = t3;
+    };
+
+    f32x4* hid_p = hid + ((size_t)tile * 2 + dir) * (kHidDirStride / 4);
+    hbuf[tid] = hid_p[tid];
+    dma_gi(slot0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float hprev[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hprev[r] = ((const float*)hbuf)[hoff + 4 * r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) store_h(0, r, hprev[r]);     // planes of h0 (fp32 copy rewritten in place)
+    __syncthreads();
+    f32x4* y_p = y + (size_t)tile * y_tile_stride + (size_t)dir * (kHidDirStride / 4);
+
+    for (int s = 0; s < T; ++s) {
+        const int cur = s & 1;
+        const bf16x8* pa = (const bf16x8*)(planes + cur * 768) + lane;
+        f32x4 acc[3];
+        acc[0] = splat4(0.f);
+        acc[1] = splat4(0.f);
+        acc[2] = splat4(bn);
+#pragma unroll
+        for (int M = 0; M < 4; ++M) {
+            const bf16x8 a1 = pa[0 * 256 + M * 64], a2 = pa[1 * 256 + M * 64], a3 = pa[2 * 256 + M * 64];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {   // six leading products, smallest first
+                f32x4 c = acc[g];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, W[g][M][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, W[g][M][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, W[g][M][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, W[g][M][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, W[g][M][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, W[g][M][0], c, 0, 0, 0);
+                acc[g] = c;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // VMEM queue: 3 gi DMAs, then 1 y store
+        f32x4 G[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) G[g] = gbuf[g * 64 + lane];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (s + 1 < T) dma_gi(slot0 + s + 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float hn = gru_cell(acc[0][r], acc[1][r], acc[2][r], G[0][r], G[1][r], G[2][r], hprev[r]);
+            hprev[r] = hn;
+            store_h(cur ^ 1, r, hn);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        f32x4* yo = y_p + (size_t)s * (kYStride / 4);
+        yo[tid] = (hbuf + (cur ^ 1) * 512)[tid];
+    }
+    hid_p[tid] = (hbuf + (T & 1) * 512)[tid];
+}
+
+// ------------------------------------------------------------------------------------------------
 // Heads + softmax + accumulate + argmax (TransducerModel.py:75-76, predict_gpu.py:137-156).
 //   One 16-column MFMA tile is exactly the 5 base + 11 run-length logits of 16 windows.
 //   grid (tiles, groups of kHeadsSpan positions), 4 waves striding over the positions of the group

@@ -68,7 +68,8 @@ class HelenEngine(object):
                                "there is no CPU fallback")
         self.device = torch.device("cuda", int(device))
         self.max_windows = int(max_windows)
-        prec = {"fp32": _lib.HELEN_PRECISION_FP32, "bf16": _lib.HELEN_PRECISION_BF16}[precision]
+        prec = {"fp32": _lib.HELEN_PRECISION_FP32, "bf16": _lib.HELEN_PRECISION_BF16,
+                "fp32x3": _lib.HELEN_PRECISION_FP32X3}[precision]
         s, keep = weights_struct(state_dict)
         _lib.check(self._lib.helen_model_create(ctypes.byref(s), self.device.index,
                                                 self.max_windows, prec,

@@ -237,3 +237,31 @@ def test_run_to_run_determinism():
         for a, b in zip(first, again):
             assert torch.equal(a, b)
     eng.close()
+
+
+# ---- fp32x3 (opt-in): the recurrence as exact bf16 partial products -- judged by the fp32 bar ----
+@pytest.mark.parametrize("case", ["trace6", "small_input6", "config1_100"])
+def test_fp32x3_meets_the_fp32_bar(case):
+    """Same tolerances and the same label identity as the fp32 path, against the reference goldens."""
+    from helen_amd.engine import HelenEngine
+    w, img, g = load_case(case)
+    eng = HelenEngine(w, device=0, max_windows=128, precision="fp32x3")
+    images = torch.from_numpy(img).cuda()
+    bases, rles, acc_b, acc_r = eng.polish(images, want_acc=True)
+    assert int((bases.cpu().numpy() != g["bases"]).sum()) == 0
+    assert int((rles.cpu().numpy() != g["rles"]).sum()) == 0
+    if "acc_base" in g:
+        np.testing.assert_allclose(acc_b.cpu().numpy()[:3], g["acc_base"], atol=ACC_ATOL, rtol=0)
+        np.testing.assert_allclose(acc_r.cpu().numpy()[:3], g["acc_rle"], atol=ACC_ATOL, rtol=0)
+        xf = images.float()
+        hidden = torch.zeros(img.shape[0], 2, 128, device="cuda")
+        want = {0: 0, 9: 1, 18: 2}
+        for c, i in enumerate(chunk_starts()):
+            base, rle, hidden = eng.chunk_forward(xf[:, i:i + 100].contiguous(), hidden)
+            np.testing.assert_allclose(hidden.cpu().numpy(), g["hidden"][c], atol=HIDDEN_ATOL, rtol=0)
+            if c in want:
+                np.testing.assert_allclose(base.cpu().numpy(), g["logit_base"][want[c]], atol=LOGIT_ATOL,
+                                           rtol=LOGIT_RTOL)
+                np.testing.assert_allclose(rle.cpu().numpy(), g["logit_rle"][want[c]], atol=LOGIT_ATOL,
+                                           rtol=LOGIT_RTOL)
+    eng.close()
