@@ -80,8 +80,9 @@ def main():
     ap.add_argument("--coalesce", type=int, default=16, help="loader batches per device call")
     ap.add_argument("--mode", default="uniform", choices=["uniform", "pileup"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
-                    help="gate-matmul arithmetic; fp32 is BASELINE.json configs[1] (the headline)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp32x3"],
+                    help="gate-matmul arithmetic; fp32 (true fp32 MFMA) is BASELINE.json configs[1], the "
+                         "headline; fp32x3 = fp32-class via three-term bf16 splits (opt-in experiment)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier / max-time reduce (nccl = RCCL)")
     ap.add_argument("--single-device", action="store_true",
@@ -178,7 +179,7 @@ def main():
         win_per_launch = call_windows
         achieved = GRU_FLOP_PER_WINDOW_LAUNCH * win_per_launch / (avg_ms * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(win_per_launch)
-        peak = FP32_MFMA_PEAK if args.precision == "fp32" else BF16_MFMA_PEAK
+        peak = BF16_MFMA_PEAK if args.precision == "bf16" else FP32_MFMA_PEAK
         bound, unit = "mfma", "TFLOP/s"
         if args.precision == "bf16" and traffic:
             # with bf16 MFMAs the recurrence is bound by its fp32 gi/y stream, not by the matrix pipe
@@ -188,23 +189,27 @@ def main():
             "metric": "pileup windows/sec (batch 256, 1000-pos)",
             "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 operands, f32 accumulate/state",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16 operands, f32 accumulate/state",
+                      "fp32x3": "f32 emulated as 3-term bf16 splits (6 exact partial products), f32 "
+                                "accumulate/state"}[args.precision],
             "data": "synthetic (%s uint8 windows, seeded; random-init weights of the reference "
                     "architecture)" % args.mode,
             "config": {"workload": ("BASELINE.json configs[1]: 1xMI355X, batch 256, fp32, synthetic "
-                                    "chr20-scale image shard resident in HBM") if args.precision == "fp32"
+                                    "chr20-scale image shard resident in HBM") if args.precision != "bf16"
                        else "BASELINE.json configs[3] variant: bf16 gate matmuls, fp32 accumulate/state",
                        "batch": B, "batches_per_step": G, "windows_per_step": call_windows,
                        "positions": 1000, "features": 90, "windows_per_gpu": args.steps * call_windows,
                        "resident_windows_per_gpu": n_res, "sharding": "by rank, no collective"},
-            "roofline": {"bound": bound, "kernel": "gru_kernel (GRU recurrence, fp32 MFMA)" if args.precision == "fp32"
-                         else "gru_bf16_kernel (GRU recurrence, bf16 MFMA)",
+            "roofline": {"bound": bound, "kernel": {"fp32": "gru_kernel (GRU recurrence, fp32 MFMA)",
+                                    "bf16": "gru_bf16_kernel (GRU recurrence, bf16 MFMA)",
+                                    "fp32x3": "gru_x3_kernel (GRU recurrence, 6 bf16 MFMAs per fp32 product "
+                                              "group; fraction is of the fp32 MFMA peak)"}[args.precision],
                          "achieved": round(achieved, 2),
                          "peak": peak / (1e12 if bound == "mfma" else 1e9), "unit": unit,
                          "frac": round(achieved * (1e12 if bound == "mfma" else 1e9) / peak, 4),
                          "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "launches": gru_n,
                          "path_frac": round(value / world * FLOP_PER_WINDOW /
-                                            (FP32_MFMA_PEAK if args.precision == "fp32" else BF16_MFMA_PEAK), 4)},
+                                            (BF16_MFMA_PEAK if args.precision == "bf16" else FP32_MFMA_PEAK), 4)},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B)

@@ -67,6 +67,8 @@ struct HelenModel {
     // three-term bf16 split of W_hh for the fp32x3 recurrence: [2 dirs][8 waves][3 gates][4 M][3 terms][64]
     bf16x8* w3h_enc = nullptr;
     bf16x8* w3h_dec = nullptr;
+    bf16x8* w3i_dec = nullptr;   // decoder W_ih split: [2 dirs][24 tiles][8 M][3 terms][64]
+    f32x4* y1p = nullptr;        // encoder output as three bf16 planes: [tile][slot][dir][3][256] x 16 B
     // scratch (device)
     f32x4* xa = nullptr;
     f32x4* gi_enc = nullptr;
@@ -98,6 +100,7 @@ constexpr long kXaTileStride = (long)kSeq * (kXaStride / 4);        // float4
 constexpr long kGiEncTileStride = (long)kSeq * (kGiStride / 4);
 constexpr long kGiDecTileStride = (long)kWin * (kGiStride / 4);
 constexpr long kYTileStride = (long)kWin * (kYStride / 4);
+constexpr long kY1pTileStride = (long)kWin * 2 * 768;                // three bf16 planes per (slot, dir)
 
 template <typename T>
 int dev_alloc(HelenModel* m, T** p, size_t count) {
@@ -201,6 +204,33 @@ std::vector<bf16x8> pack_w_hh_x3(const float* const w[2]) {
     return out;
 }
 
+// decoder W_ih -> W3d[(((dir*24 + nt)*8 + M)*3 + t)*64 + lane][e] = term t of
+//   W_ih[dir][16nt + (lane & 15)][32M + 8(lane >> 4) + e]   (K = 256 = [fwd 128 | bwd 128])
+std::vector<bf16x8> pack_w_ih_x3(const float* const w[2]) {
+    std::vector<bf16x8> out((size_t)2 * kNTile * 8 * 3 * 64);
+    for (int dir = 0; dir < 2; ++dir)
+        for (int nt = 0; nt < kNTile; ++nt)
+            for (int M = 0; M < 8; ++M)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int row = 16 * nt + (lane & 15);
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = w[dir][(size_t)row * 2 * kH + 32 * M + 8 * (lane >> 4) + e];
+                        const short t1 = to_bf16(x);
+                        const float r1 = x - from_bf16(t1);
+                        const short t2 = to_bf16(r1);
+                        const float r2 = r1 - from_bf16(t2);
+                        const short t3 = to_bf16(r2);
+                        short terms[3] = {t1, t2, t3};
+                        for (int t = 0; t < 3; ++t) {
+                            __bf16 val;
+                            memcpy(&val, &terms[t], 2);
+                            out[((size_t)((dir * kNTile + nt) * 8 + M) * 3 + t) * 64 + lane][e] = val;
+                        }
+                    }
+                }
+    return out;
+}
+
 void record_begin(HelenModel* m, int cls, hipStream_t s, EventPair* ev, bool* on) {
     *on = (m->prof_mask >> cls) & 1u;
     if (!*on) return;
@@ -266,27 +296,31 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
                0, T, m->whpb_dec, m->bhn_dec, m->hid, m->y2, kYTileStride);
         return;
     }
-    const bool x3 = m->precision == HELEN_PRECISION_FP32X3;
-    if (x3)
+    if (m->precision == HELEN_PRECISION_FP32X3) {
+        // encoder output goes out as three bf16 planes only; the projection consumes them directly
         LAUNCH(HELEN_K_GRU_ENC, gru_x3_kernel, dim3(tiles, 2), dim3(512), m->gi_enc, kGiEncTileStride, pos0,
-               enc_npos - pos0 - T, T, m->w3h_enc, m->bhn_enc, m->hid, m->y1, kYTileStride);
-    else
-        LAUNCH(HELEN_K_GRU_ENC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
-               enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride);
+               enc_npos - pos0 - T, T, m->w3h_enc, m->bhn_enc, m->hid, (f32x4*)nullptr, kYTileStride,
+               m->y1p, kY1pTileStride);
+        const int units = tiles * ((T + 15) / 16);
+        LAUNCH(HELEN_K_GEMM_DEC, gemm_dec_x3_kernel, dim3((unsigned)((units + 7) / 8 * 8) * 6), dim3(512),
+               m->y1p, kY1pTileStride, (const f32x4*)m->w3i_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T,
+               tiles);
+        LAUNCH(HELEN_K_GRU_DEC, gru_x3_kernel, dim3(tiles, 2), dim3(512), m->gi_dec, kGiDecTileStride, 0, 0,
+               T, m->w3h_dec, m->bhn_dec, m->hid, m->y2, kYTileStride, (f32x4*)nullptr, kY1pTileStride);
+        return;
+    }
+    LAUNCH(HELEN_K_GRU_ENC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
+           enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride);
     LAUNCH(HELEN_K_GEMM_DEC, (gemm_gi_kernel<16, true>), ggrid, gblock, m->y1, kYTileStride, m->wp_dec,
            m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
-    if (x3)
-        LAUNCH(HELEN_K_GRU_DEC, gru_x3_kernel, dim3(tiles, 2), dim3(512), m->gi_dec, kGiDecTileStride, 0, 0,
-               T, m->w3h_dec, m->bhn_dec, m->hid, m->y2, kYTileStride);
-    else
-        LAUNCH(HELEN_K_GRU_DEC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, 0, T,
-               m->whp_dec, m->bhn_dec, m->hid, m->y2, kYTileStride);
+    LAUNCH(HELEN_K_GRU_DEC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, 0, T,
+           m->whp_dec, m->bhn_dec, m->hid, m->y2, kYTileStride);
 }
 
 void free_model(HelenModel* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    void* ptrs[] = {m->w3h_enc, m->w3h_dec, m->wpb_enc, m->wpb_dec, m->whpb_enc, m->whpb_dec, m->wp_enc, m->wp_dec, m->whp_enc, m->whp_dec, m->whd, m->bias_enc, m->bias_dec,
+    void* ptrs[] = {m->w3i_dec, m->y1p, m->w3h_enc, m->w3h_dec, m->wpb_enc, m->wpb_dec, m->whpb_enc, m->whpb_dec, m->wp_enc, m->wp_dec, m->whp_enc, m->whp_dec, m->whd, m->bias_enc, m->bias_dec,
                     m->bhn_enc, m->bhn_dec, m->bhd, m->xa, m->gi_enc, m->gi_dec, m->y1, m->y2,
                     m->hid, m->pending, m->dev_in[0], m->dev_in[1], m->dev_out[0], m->dev_out[1]};
     for (void* p : ptrs)
@@ -332,6 +366,8 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
     if (precision == HELEN_PRECISION_FP32X3) {
         if ((rc = upload(m, &m->w3h_enc, pack_w_hh_x3(w->enc_w_hh)))) return rc;
         if ((rc = upload(m, &m->w3h_dec, pack_w_hh_x3(w->dec_w_hh)))) return rc;
+        if ((rc = upload(m, &m->w3i_dec, pack_w_ih_x3(w->dec_w_ih)))) return rc;
+        if ((rc = dev_alloc(m, &m->y1p, (size_t)m->max_tiles * kY1pTileStride))) return rc;
     }
     if (precision == HELEN_PRECISION_BF16) {
         if ((rc = upload(m, &m->wpb_enc, round_pack(pack_w_ih(w->enc_w_ih, kF, kFPad / 16))))) return rc;

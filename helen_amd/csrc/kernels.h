@@ -667,7 +667,10 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
                                                      const bf16x8* __restrict__ W3,
                                                      const float* __restrict__ bhn,
                                                      f32x4* __restrict__ hid, f32x4* __restrict__ y,
-                                                     long y_tile_stride) {
+                                                     long y_tile_stride, f32x4* __restrict__ yplanes,
+                                                     long yp_tile_stride) {
+    // Layer output: fp32 y[tile][slot][dir] (KB16, for the heads) when `y` is given, and/or the three
+    // bf16 planes yplanes[tile][slot][dir][plane][256 units] (for gemm_dec_x3_kernel) when given.
     // LDS (one object): fp32 h [2][512 f4] | bf16 planes [2 buffers][3 terms][256 units of 16 B] |
     // gi slots [8 waves][3][64 f4]
     __shared__ f32x4 smem[2 * 512 + 2 * 3 * 256 + 8 * 192];
@@ -747,17 +750,14 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
 #pragma unroll
         for (int M = 0; M < 4; ++M) {
             const bf16x8 a1 = pa[0 * 256 + M * 64], a2 = pa[1 * 256 + M * 64], a3 = pa[2 * 256 + M * 64];
+            const bf16x8 at[3] = {a1, a2, a3};
+            constexpr int TA[6] = {0, 2, 1, 0, 1, 0};   // six leading products, smallest first;
+            constexpr int TB[6] = {2, 0, 1, 1, 0, 0};   // product index outermost: 3 accumulators rotate
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {   // six leading products, smallest first
-                f32x4 c = acc[g];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, W[g][M][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, W[g][M][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, W[g][M][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, W[g][M][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, W[g][M][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, W[g][M][0], c, 0, 0, 0);
-                acc[g] = c;
-            }
+            for (int k = 0; k < 6; ++k)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[TA[k]], W[g][M][TB[k]], acc[g], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // VMEM queue: 3 gi DMAs, then 1 y store
         f32x4 G[3];
@@ -774,10 +774,129 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        f32x4* yo = y_p + (size_t)s * (kYStride / 4);
-        yo[tid] = (hbuf + (cur ^ 1) * 512)[tid];
+        if (y != nullptr) {
+            f32x4* yo = y_p + (size_t)s * (kYStride / 4);
+            yo[tid] = (hbuf + (cur ^ 1) * 512)[tid];
+        }
+        if (yplanes != nullptr) {   // 768 units of 16 B per (tile, slot, dir)
+            f32x4* po = yplanes + (size_t)tile * yp_tile_stride + ((size_t)s * 2 + dir) * 768;
+            const f32x4* ps = planes + (cur ^ 1) * 768;
+            po[tid] = ps[tid];
+            if (tid < 256) po[512 + tid] = ps[512 + tid];
+        }
     }
     hid_p[tid] = (hbuf + (T & 1) * 512)[tid];
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32x3 decoder projection: gi = Y1 . W_ih^T + b with both operands as three bf16 terms (six exact
+// partial products per term pair, fp32 accumulate; see gru_x3_kernel).  Y1 arrives already split
+// (the encoder recurrence wrote the planes), W_ih was split on the host.
+//   Workgroup = 8 waves = (tile, 8 positions, direction, 8 of its 24 column tiles).  For each group M
+//   of 32 k the 24 A rows (8 positions x 3 planes) and 24 B rows (8 tiles x 3 terms), 1 KiB each,
+//   are DMA'd global->LDS through a 3-deep ring (3 x 48 KiB): a group's compute time (~0.7 us) is
+//   shorter than the memory latency, so two groups are kept in flight behind counted vmcnt waits and
+//   one raw barrier per group.  Wave w multiplies positions 2(w&3)..+1 by column tiles 4(w>>2)..+3:
+//   48 MFMAs per group against 18 ds_read_b128.  k < 128 comes from the forward encoder direction at slot p, k >= 128 from the
+//   backward one at slot npos-1-p; output slot order as gemm_gi_kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gemm_dec_x3_kernel(const f32x4* __restrict__ yplanes,
+                                                          long yp_tile_stride,
+                                                          const f32x4* __restrict__ W3d,
+                                                          const float* __restrict__ bias,
+                                                          f32x4* __restrict__ gi, long gi_tile_stride,
+                                                          int npos, int ntiles) {
+    constexpr int PB = 16, NB = 8, ROWS = PB * 3 + NB * 3;   // 72 rows of 1 KiB per stage
+    constexpr int STAGES = 2;                                  // 144 KiB
+    constexpr int RPW = ROWS / 8;                              // 9 DMA rows per wave and stage
+    __shared__ f32x4 smem[STAGES * ROWS * 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // block id -> (unit, z): the 6 workgroups (2 directions x 3 thirds of the column tiles) of one
+    // unit share its A rows; ids u, u+8, ... inside a block of 48 land on the same XCD
+    const int bid = blockIdx.x;
+    const int unit = (bid / 48) * 8 + (bid & 7);
+    const int z = (bid >> 3) % 6;
+    const int npg = (npos + PB - 1) / PB;
+    const int tile = unit / npg;
+    const int pos0 = (unit % npg) * PB;
+    if (tile >= ntiles) return;
+    const int dir = z / 3;
+    const int nt0 = (z % 3) * NB;
+
+    // DMA of group M into buffer b: row r of the stage is copied by wave r % 8
+    auto stage = [&](int M, int b) {
+        f32x4* dst = smem + b * (ROWS * 64);
+        const int part = M >> 2, sub = M & 3;                  // fwd / bwd half of k, group inside it
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int r = w + 8 * i;
+            const f32x4* src;
+            if (r < PB * 3) {
+                const int p = r / 3, plane = r % 3;
+                const int pc = min(pos0 + p, npos - 1);
+                const int slot = part ? (npos - 1 - pc) : pc;
+                src = yplanes + (size_t)tile * yp_tile_stride + ((size_t)slot * 2 + part) * 768 + plane * 256 +
+                      sub * 64 + lane;
+            } else {
+                const int q = r - PB * 3, n = q / 3, t = q % 3;
+                src = W3d + ((size_t)((dir * kNTile + nt0 + n) * 8 + M) * 3 + t) * 64 + lane;
+            }
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                             (void __attribute__((address_space(3)))*)(dst + r * 64), 16, 0, 0);
+        }
+    };
+
+    const int pw = (w & 3) * 4;     // this wave's first position within the block (4 positions)
+    const int tw = (w >> 2) * 4;    // this wave's first column tile within the block (4 tiles)
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const float b = bias[dir * kG + (nt0 + tw + n) * 16 + (lane & 15)];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p][n] = splat4(b);
+    }
+    constexpr int TA[6] = {0, 2, 1, 0, 1, 0};   // six leading products, smallest first: term of A
+    constexpr int TB[6] = {2, 0, 1, 1, 0, 0};   //                                        term of B
+    stage(0, 0);
+#pragma unroll
+    for (int M = 0; M < 8; ++M) {
+        // group M has landed for this wave, then (barrier) for everyone; the other buffer, read
+        // during group M-1, is free again -> refill it with group M+1 while group M is multiplied
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (M + 1 < 8) stage(M + 1, (M + 1) & 1);
+        const bf16x8* L = (const bf16x8*)(smem + (M & 1) * (ROWS * 64)) + lane;
+        bf16x8 fa[4][3], fb[4][3];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) fa[p][t] = L[((pw + p) * 3 + t) * 64];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) fb[n][t] = L[(PB * 3 + (tw + n) * 3 + t) * 64];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    acc[p][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[p][TA[k]], fb[n][TB[k]], acc[p][n], 0, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int pos = pos0 + pw + p;
+        if (pos < npos) {
+            const int slot = dir ? (npos - 1 - pos) : pos;
+            f32x4* o = gi + (size_t)tile * gi_tile_stride + ((size_t)slot * 2 + dir) * (kNTile * 64) +
+                       (nt0 + tw) * 64 + lane;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) o[n * 64] = acc[p][n];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
