@@ -32,6 +32,10 @@ class TransducerGRU(object):
         self._engine = None
         self._device = None
         self._max_windows = 4096
+        # arithmetic of the gate matmuls: "fp32" (default, true fp32 MFMA), "fp32x3" (fp32-class via
+        # three-term bf16 splits) or "bf16"; $HELEN_PRECISION selects it for the CLI
+        import os
+        self.precision = os.environ.get("HELEN_PRECISION", "fp32")
         self.training = False
 
     # ---- nn.Module-like surface used by the reference's callers ----
@@ -91,7 +95,7 @@ class TransducerGRU(object):
             from .engine import HelenEngine
             dev = self._device if self._device is not None else torch.device("cuda", 0)
             self._engine = HelenEngine(self._params, device=dev.index or 0,
-                                       max_windows=self._max_windows)
+                                       max_windows=self._max_windows, precision=self.precision)
             self._device = dev
         return self._engine
 
