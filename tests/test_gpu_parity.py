@@ -265,3 +265,17 @@ def test_fp32x3_meets_the_fp32_bar(case):
                 np.testing.assert_allclose(rle.cpu().numpy(), g["logit_rle"][want[c]], atol=LOGIT_ATOL,
                                            rtol=LOGIT_RTOL)
     eng.close()
+
+
+@pytest.mark.parametrize("case", ["trace6", "small_input6"])
+def test_fp32x3_short_chunk_nonzero_hidden(case):
+    """T = 37 (not a multiple of the projection's 16-position block), B = 3 (ragged tile), non-zero
+    incoming hidden -- through the fp32x3 kernels, held to the fp32 tolerances."""
+    from helen_amd.engine import HelenEngine
+    w, img, g = load_case(case)
+    eng = HelenEngine(w, device=0, max_windows=32, precision="fp32x3")
+    base, rle, h = eng.chunk_forward(torch.from_numpy(g["fwd_x"]).cuda(), torch.from_numpy(g["fwd_h0"]).cuda())
+    np.testing.assert_allclose(base.cpu().numpy(), g["fwd_base"], atol=LOGIT_ATOL, rtol=LOGIT_RTOL)
+    np.testing.assert_allclose(rle.cpu().numpy(), g["fwd_rle"], atol=LOGIT_ATOL, rtol=LOGIT_RTOL)
+    np.testing.assert_allclose(h.cpu().numpy(), g["fwd_h"], atol=HIDDEN_ATOL, rtol=0)
+    eng.close()
