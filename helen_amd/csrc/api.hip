@@ -301,10 +301,8 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
         LAUNCH(HELEN_K_GRU_ENC, gru_x3_kernel, dim3(tiles, 2), dim3(512), m->gi_enc, kGiEncTileStride, pos0,
                enc_npos - pos0 - T, T, m->w3h_enc, m->bhn_enc, m->hid, (f32x4*)nullptr, kYTileStride,
                m->y1p, kY1pTileStride);
-        const int units = tiles * ((T + 15) / 16);
-        LAUNCH(HELEN_K_GEMM_DEC, gemm_dec_x3_kernel, dim3((unsigned)((units + 7) / 8 * 8) * 6), dim3(512),
-               m->y1p, kY1pTileStride, (const f32x4*)m->w3i_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T,
-               tiles);
+        LAUNCH(HELEN_K_GEMM_DEC, gemm_dec_x3_kernel, dim3(3, tiles), dim3(512), m->y1p, kY1pTileStride,
+               (const f32x4*)m->w3i_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
         LAUNCH(HELEN_K_GRU_DEC, gru_x3_kernel, dim3(tiles, 2), dim3(512), m->gi_dec, kGiDecTileStride, 0, 0,
                T, m->w3h_dec, m->bhn_dec, m->hid, m->y2, kYTileStride, (f32x4*)nullptr, kY1pTileStride);
         return;

@@ -792,13 +792,15 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
 // fp32x3 decoder projection: gi = Y1 . W_ih^T + b with both operands as three bf16 terms (six exact
 // partial products per term pair, fp32 accumulate; see gru_x3_kernel).  Y1 arrives already split
 // (the encoder recurrence wrote the planes), W_ih was split on the host.
-//   Workgroup = 8 waves = (tile, 8 positions, direction, 8 of its 24 column tiles).  For each group M
-//   of 32 k the 24 A rows (8 positions x 3 planes) and 24 B rows (8 tiles x 3 terms), 1 KiB each,
-//   are DMA'd global->LDS through a 3-deep ring (3 x 48 KiB): a group's compute time (~0.7 us) is
-//   shorter than the memory latency, so two groups are kept in flight behind counted vmcnt waits and
-//   one raw barrier per group.  Wave w multiplies positions 2(w&3)..+1 by column tiles 4(w>>2)..+3:
-//   48 MFMAs per group against 18 ds_read_b128.  k < 128 comes from the forward encoder direction at slot p, k >= 128 from the
-//   backward one at slot npos-1-p; output slot order as gemm_gi_kernel.
+//   With MFMAs this cheap the kernel lives or dies by operand traffic, so it is WEIGHT-STATIONARY:
+//   a workgroup (8 waves) owns 16 of the 48 column tiles (2 per wave) and keeps all three terms of
+//   their W_ih slice -- 2 tiles x 8 groups x 3 terms = 192 registers per lane -- for its whole life,
+//   walking the 100 positions of one window tile two at a time.  Per stage only A moves: 2 positions
+//   x 3 planes x 8 groups = 48 rows of 1 KiB, DMA'd global->LDS into a 2-deep ring while the previous
+//   stage is multiplied (192 MFMAs per wave and stage, one barrier per stage): 32 MFMAs per KiB
+//   staged instead of 8-11 for a block-tiled kernel that also stages the weights.
+//   k < 128 comes from the forward encoder direction at slot p, k >= 128 from the backward one at
+//   slot npos-1-p; output slot order as gemm_gi_kernel.  grid (3 column sets, window tiles).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void gemm_dec_x3_kernel(const f32x4* __restrict__ yplanes,
                                                           long yp_tile_stride,
@@ -806,95 +808,94 @@ __global__ __launch_bounds__(512) void gemm_dec_x3_kernel(const f32x4* __restric
                                                           const float* __restrict__ bias,
                                                           f32x4* __restrict__ gi, long gi_tile_stride,
                                                           int npos, int ntiles) {
-    constexpr int PB = 16, NB = 8, ROWS = PB * 3 + NB * 3;   // 72 rows of 1 KiB per stage
-    constexpr int STAGES = 2;                                  // 144 KiB
-    constexpr int RPW = ROWS / 8;                              // 9 DMA rows per wave and stage
-    __shared__ f32x4 smem[STAGES * ROWS * 64];
+    constexpr int ROWS = 2 * 3 * 8;   // rows of 1 KiB per stage: (position, plane, group)
+    __shared__ f32x4 smem[2 * ROWS * 64];   // 96 KiB
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // block id -> (unit, z): the 6 workgroups (2 directions x 3 thirds of the column tiles) of one
-    // unit share its A rows; ids u, u+8, ... inside a block of 48 land on the same XCD
-    const int bid = blockIdx.x;
-    const int unit = (bid / 48) * 8 + (bid & 7);
-    const int z = (bid >> 3) % 6;
-    const int npg = (npos + PB - 1) / PB;
-    const int tile = unit / npg;
-    const int pos0 = (unit % npg) * PB;
+    const int set = blockIdx.x;
+    const int tile = blockIdx.y;
     if (tile >= ntiles) return;
-    const int dir = z / 3;
-    const int nt0 = (z % 3) * NB;
+    const int gt0 = 16 * set + 2 * w;          // first of this wave's two global column tiles (dir*24 + nt)
+    const int dir = gt0 / kNTile;
+    const int nt = gt0 % kNTile;
 
-    // DMA of group M into buffer b: row r of the stage is copied by wave r % 8
-    auto stage = [&](int M, int b) {
-        f32x4* dst = smem + b * (ROWS * 64);
-        const int part = M >> 2, sub = M & 3;                  // fwd / bwd half of k, group inside it
+    // weight terms -> registers: B[ti][M][t]
+    bf16x8 B[2][8][3];
+    {
+        const bf16x8* wp = (const bf16x8*)W3d + lane;
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) {
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int M = 0; M < 8; ++M)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) B[ti][M][t] = wp[((size_t)((gt0 + ti) * 8 + M) * 3 + t) * 64];
+    }
+    float bs[2];
+    bs[0] = bias[dir * kG + nt * 16 + (lane & 15)];
+    bs[1] = bias[dir * kG + (nt + 1) * 16 + (lane & 15)];
+
+    const f32x4* yp = yplanes + (size_t)tile * yp_tile_stride + lane;
+    // DMA of position pair g into buffer b; row r = (p*3 + plane)*8 + M is copied by wave r % 8
+    auto stage = [&](int g, int b) {
+        f32x4* dst = smem + b * (ROWS * 64);
+#pragma unroll
+        for (int i = 0; i < ROWS / 8; ++i) {
             const int r = w + 8 * i;
-            const f32x4* src;
-            if (r < PB * 3) {
-                const int p = r / 3, plane = r % 3;
-                const int pc = min(pos0 + p, npos - 1);
-                const int slot = part ? (npos - 1 - pc) : pc;
-                src = yplanes + (size_t)tile * yp_tile_stride + ((size_t)slot * 2 + part) * 768 + plane * 256 +
-                      sub * 64 + lane;
-            } else {
-                const int q = r - PB * 3, n = q / 3, t = q % 3;
-                src = W3d + ((size_t)((dir * kNTile + nt0 + n) * 8 + M) * 3 + t) * 64 + lane;
-            }
+            const int M = r & 7, plane = (r >> 3) % 3, p = r / 24;
+            const int part = M >> 2;
+            const int pc = min(2 * g + p, npos - 1);
+            const int slot = part ? (npos - 1 - pc) : pc;
+            const f32x4* src = yp + ((size_t)slot * 2 + part) * 768 + plane * 256 + (M & 3) * 64;
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                              (void __attribute__((address_space(3)))*)(dst + r * 64), 16, 0, 0);
         }
     };
-
-    const int pw = (w & 3) * 4;     // this wave's first position within the block (4 positions)
-    const int tw = (w >> 2) * 4;    // this wave's first column tile within the block (4 tiles)
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const float b = bias[dir * kG + (nt0 + tw + n) * 16 + (lane & 15)];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc[p][n] = splat4(b);
-    }
     constexpr int TA[6] = {0, 2, 1, 0, 1, 0};   // six leading products, smallest first: term of A
     constexpr int TB[6] = {2, 0, 1, 1, 0, 0};   //                                        term of B
+    const int ng = (npos + 1) / 2;
     stage(0, 0);
-#pragma unroll
-    for (int M = 0; M < 8; ++M) {
-        // group M has landed for this wave, then (barrier) for everyone; the other buffer, read
-        // during group M-1, is free again -> refill it with group M+1 while group M is multiplied
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    for (int g = 0; g < ng; ++g) {
+        // this wave's rows of pair g have landed; after the barrier everybody's have, and the
+        // other buffer (read during pair g-1) is free for pair g+1.  VMEM queue, oldest first: the 6
+        // DMA rows of pair g, then the 4 output stores of pair g-1 -- which may stay in flight.
+        if (g == 0)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (M + 1 < 8) stage(M + 1, (M + 1) & 1);
-        const bf16x8* L = (const bf16x8*)(smem + (M & 1) * (ROWS * 64)) + lane;
-        bf16x8 fa[4][3], fb[4][3];
+        if (g + 1 < ng) stage(g + 1, (g + 1) & 1);
+        const bf16x8* L = (const bf16x8*)(smem + (g & 1) * (ROWS * 64)) + lane;
+        f32x4 acc[2][2];
+        acc[0][0] = acc[1][0] = splat4(bs[0]);
+        acc[0][1] = acc[1][1] = splat4(bs[1]);
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int M = 0; M < 8; ++M) {
+            bf16x8 a[2][3];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) fa[p][t] = L[((pw + p) * 3 + t) * 64];
+            for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+                for (int t = 0; t < 3; ++t) a[p][t] = L[((p * 3 + t) * 8 + M) * 64];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) fb[n][t] = L[(PB * 3 + (tw + n) * 3 + t) * 64];
+            for (int k = 0; k < 6; ++k)
 #pragma unroll
-        for (int k = 0; k < 6; ++k)
+                for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+                    for (int p = 0; p < 2; ++p)
+                        acc[p][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p][TA[k]], B[ti][M][TB[k]],
+                                                                            acc[p][ti], 0, 0, 0);
+        }
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
-                    acc[p][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[p][TA[k]], fb[n][TB[k]], acc[p][n], 0, 0, 0);
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int pos = pos0 + pw + p;
-        if (pos < npos) {
-            const int slot = dir ? (npos - 1 - pos) : pos;
-            f32x4* o = gi + (size_t)tile * gi_tile_stride + ((size_t)slot * 2 + dir) * (kNTile * 64) +
-                       (nt0 + tw) * 64 + lane;
-#pragma unroll
-            for (int n = 0; n < 4; ++n) o[n * 64] = acc[p][n];
+        for (int p = 0; p < 2; ++p) {
+            const int pos = 2 * g + p;
+            if (pos < npos) {
+                const int slot = dir ? (npos - 1 - pos) : pos;
+                f32x4* o = gi + (size_t)tile * gi_tile_stride + ((size_t)slot * 2 + dir) * (kNTile * 64) + nt * 64 +
+                           lane;
+                o[0] = acc[p][0];
+                o[64] = acc[p][1];
+            }
         }
     }
 }
