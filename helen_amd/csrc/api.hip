@@ -68,6 +68,8 @@ struct HelenModel {
     bf16x8* w3h_enc = nullptr;
     bf16x8* w3h_dec = nullptr;
     bf16x8* w3i_dec = nullptr;   // decoder W_ih split: [2 dirs][24 tiles][8 M][3 terms][64]
+    bf16x8* w3i_enc = nullptr;   // encoder W_ih split: [2 dirs][24 tiles][3 M][3 terms][64] (K padded to 96)
+    f32x4* xb = nullptr;         // pileup counts as bf16 A fragments: [tile][pos][192] x 16 B
     f32x4* y1p = nullptr;        // encoder output as three bf16 planes: [tile][slot][dir][3][256] x 16 B
     // scratch (device)
     f32x4* xa = nullptr;
@@ -206,15 +208,17 @@ std::vector<bf16x8> pack_w_hh_x3(const float* const w[2]) {
 
 // decoder W_ih -> W3d[(((dir*24 + nt)*8 + M)*3 + t)*64 + lane][e] = term t of
 //   W_ih[dir][16nt + (lane & 15)][32M + 8(lane >> 4) + e]   (K = 256 = [fwd 128 | bwd 128])
-std::vector<bf16x8> pack_w_ih_x3(const float* const w[2]) {
-    std::vector<bf16x8> out((size_t)2 * kNTile * 8 * 3 * 64);
+std::vector<bf16x8> pack_w_ih_x3(const float* const w[2], int K = 2 * kH) {
+    const int NM = (K + 31) / 32;
+    std::vector<bf16x8> out((size_t)2 * kNTile * NM * 3 * 64);
     for (int dir = 0; dir < 2; ++dir)
         for (int nt = 0; nt < kNTile; ++nt)
-            for (int M = 0; M < 8; ++M)
+            for (int M = 0; M < NM; ++M)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int row = 16 * nt + (lane & 15);
                     for (int e = 0; e < 8; ++e) {
-                        const float x = w[dir][(size_t)row * 2 * kH + 32 * M + 8 * (lane >> 4) + e];
+                        const int k = 32 * M + 8 * (lane >> 4) + e;
+                        const float x = k < K ? w[dir][(size_t)row * K + k] : 0.f;
                         const short t1 = to_bf16(x);
                         const float r1 = x - from_bf16(t1);
                         const short t2 = to_bf16(r1);
@@ -224,7 +228,7 @@ std::vector<bf16x8> pack_w_ih_x3(const float* const w[2]) {
                         for (int t = 0; t < 3; ++t) {
                             __bf16 val;
                             memcpy(&val, &terms[t], 2);
-                            out[((size_t)((dir * kNTile + nt) * 8 + M) * 3 + t) * 64 + lane][e] = val;
+                            out[((size_t)((dir * kNTile + nt) * NM + M) * 3 + t) * 64 + lane][e] = val;
                         }
                     }
                 }
@@ -318,7 +322,7 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
 void free_model(HelenModel* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    void* ptrs[] = {m->w3i_dec, m->y1p, m->w3h_enc, m->w3h_dec, m->wpb_enc, m->wpb_dec, m->whpb_enc, m->whpb_dec, m->wp_enc, m->wp_dec, m->whp_enc, m->whp_dec, m->whd, m->bias_enc, m->bias_dec,
+    void* ptrs[] = {m->w3i_enc, m->xb, m->w3i_dec, m->y1p, m->w3h_enc, m->w3h_dec, m->wpb_enc, m->wpb_dec, m->whpb_enc, m->whpb_dec, m->wp_enc, m->wp_dec, m->whp_enc, m->whp_dec, m->whd, m->bias_enc, m->bias_dec,
                     m->bhn_enc, m->bhn_dec, m->bhd, m->xa, m->gi_enc, m->gi_dec, m->y1, m->y2,
                     m->hid, m->pending, m->dev_in[0], m->dev_in[1], m->dev_out[0], m->dev_out[1]};
     for (void* p : ptrs)
@@ -365,6 +369,8 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
         if ((rc = upload(m, &m->w3h_enc, pack_w_hh_x3(w->enc_w_hh)))) return rc;
         if ((rc = upload(m, &m->w3h_dec, pack_w_hh_x3(w->dec_w_hh)))) return rc;
         if ((rc = upload(m, &m->w3i_dec, pack_w_ih_x3(w->dec_w_ih)))) return rc;
+        if ((rc = upload(m, &m->w3i_enc, pack_w_ih_x3(w->enc_w_ih, kF)))) return rc;
+        if ((rc = dev_alloc(m, &m->xb, (size_t)m->max_tiles * kSeq * 192))) return rc;
         if ((rc = dev_alloc(m, &m->y1p, (size_t)m->max_tiles * kY1pTileStride))) return rc;
     }
     if (precision == HELEN_PRECISION_BF16) {
@@ -470,11 +476,19 @@ int helen_polish_batch(HelenModel* m, const uint8_t* images, int n_windows, uint
     hipStream_t s = (hipStream_t)stream;
     const int tiles = (n_windows + kTile - 1) / kTile;
 
-    // uint8 -> fp32 operand tiles (predict_gpu.py:97)
-    LAUNCH(HELEN_K_PACK, pack_images_kernel, dim3((kSeq * (kXaStride / 4) + 255) / 256, tiles),
-           dim3(256), images, n_windows, kSeq, m->xa);
-    // encoder input projection for all 1000 positions at once: overlapping chunks share it
-    launch_enc_gemm(m, s, tiles, kSeq);
+    if (m->precision == HELEN_PRECISION_FP32X3) {
+        // pileup counts are exact in bf16: pack them straight into A fragments, three exact products per w
+        LAUNCH(HELEN_K_PACK, pack_images_x3_kernel, dim3((kSeq * 192 + 255) / 256, tiles), dim3(256), images,
+               n_windows, kSeq, m->xb);
+        LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_x3_kernel, dim3(3, tiles), dim3(512), m->xb, (long)kSeq * 192,
+               (const f32x4*)m->w3i_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, kSeq, tiles);
+    } else {
+        // uint8 -> fp32 operand tiles (predict_gpu.py:97)
+        LAUNCH(HELEN_K_PACK, pack_images_kernel, dim3((kSeq * (kXaStride / 4) + 255) / 256, tiles),
+               dim3(256), images, n_windows, kSeq, m->xa);
+        // encoder input projection for all 1000 positions at once: overlapping chunks share it
+        launch_enc_gemm(m, s, tiles, kSeq);
+    }
     // zero initial hidden per batch (predict_gpu.py:99)
     HIP_TRY(hipMemsetAsync(m->hid, 0, (size_t)tiles * kHidStride * sizeof(float), s));
     for (int c = 0; c < kChunks; ++c) {  // predict_gpu.py:114-149

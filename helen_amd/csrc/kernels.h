@@ -901,6 +901,126 @@ __global__ __launch_bounds__(512) void gemm_dec_x3_kernel(const f32x4* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp32x3 encoder projection.  The encoder input is raw pileup counts 0..255 (predict_gpu.py:97): every x
+// is EXACTLY one bf16 term, so x*w = x*w1 + x*w2 + x*w3 with exact partial products -- three bf16 MFMAs
+// per 32 k.  pack_images_x3_kernel writes the counts straight as bf16 A fragments (K padded 90 -> 96 =
+// 3 groups), gemm_enc_x3_kernel is weight-stationary like gemm_dec_x3_kernel: 2 column tiles per
+// wave (72 registers of weight terms), 8 positions per stage (24 KiB of A), and it runs at the speed
+// of its fp32 output stream (3 MB per window).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_images_x3_kernel(const uint8_t* __restrict__ img, int n_windows,
+                                                             int npos, f32x4* __restrict__ xb) {
+    // one 16-byte unit (8 bf16) per thread: unit index within (tile, pos) = M*64 + q*16 + row
+    const int tile = blockIdx.y;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= npos * 192) return;
+    const int row = g & 15;
+    const int o = (g >> 4) % 12;          // octet of k: k = 8*o + e
+    const int pos = g / 192;
+    const int window = tile * kTile + row;
+    unsigned short v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0;
+    if (window < n_windows) {
+        const uint8_t* p = img + ((size_t)window * npos + pos) * kF + o * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (o * 8 + e < kF) v[e] = bf16_bits((float)p[e]);   // exact: integers <= 255
+    }
+    uint4 u;
+    u.x = v[0] | ((unsigned)v[1] << 16);
+    u.y = v[2] | ((unsigned)v[3] << 16);
+    u.z = v[4] | ((unsigned)v[5] << 16);
+    u.w = v[6] | ((unsigned)v[7] << 16);
+    xb[((size_t)tile * npos + pos) * 192 + o * 16 + row] = __builtin_bit_cast(f32x4, u);
+}
+
+__global__ __launch_bounds__(512) void gemm_enc_x3_kernel(const f32x4* __restrict__ xb, long xb_tile_stride,
+                                                          const f32x4* __restrict__ W3e,
+                                                          const float* __restrict__ bias,
+                                                          f32x4* __restrict__ gi, long gi_tile_stride,
+                                                          int npos, int ntiles) {
+    constexpr int PB = 8, ROWS = PB * 3;    // rows of 1 KiB per stage: (position, group)
+    __shared__ f32x4 smem[2 * ROWS * 64];   // 48 KiB
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int set = blockIdx.x;
+    const int tile = blockIdx.y;
+    if (tile >= ntiles) return;
+    const int gt0 = 16 * set + 2 * w;
+    const int dir = gt0 / kNTile;
+    const int nt = gt0 % kNTile;
+    bf16x8 B[2][3][3];
+    {
+        const bf16x8* wp = (const bf16x8*)W3e + lane;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int M = 0; M < 3; ++M)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) B[ti][M][t] = wp[((size_t)((gt0 + ti) * 3 + M) * 3 + t) * 64];
+    }
+    float bs[2];
+    bs[0] = bias[dir * kG + nt * 16 + (lane & 15)];
+    bs[1] = bias[dir * kG + (nt + 1) * 16 + (lane & 15)];
+    const f32x4* xp = xb + (size_t)tile * xb_tile_stride + lane;
+    auto stage = [&](int g, int b) {    // positions 8g..8g+7: 24 rows, 3 per wave; row r = p*3 + M
+        f32x4* dst = smem + b * (ROWS * 64);
+#pragma unroll
+        for (int i = 0; i < ROWS / 8; ++i) {
+            const int r = w + 8 * i;
+            const int pc = min(PB * g + r / 3, npos - 1);
+            const f32x4* src = xp + (size_t)pc * 192 + (r % 3) * 64;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                             (void __attribute__((address_space(3)))*)(dst + r * 64), 16, 0, 0);
+        }
+    };
+    const int ng = (npos + PB - 1) / PB;
+    stage(0, 0);
+    for (int g = 0; g < ng; ++g) {
+        // VMEM queue, oldest first: 3 DMA rows of group g, then 16 output stores of group g-1
+        if (g == 0)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (g + 1 < ng) stage(g + 1, (g + 1) & 1);
+        const bf16x8* L = (const bf16x8*)(smem + (g & 1) * (ROWS * 64)) + lane;
+        f32x4 acc[PB][2];
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            acc[p][0] = splat4(bs[0]);
+            acc[p][1] = splat4(bs[1]);
+        }
+#pragma unroll
+        for (int M = 0; M < 3; ++M) {
+            bf16x8 a[PB];
+#pragma unroll
+            for (int p = 0; p < PB; ++p) a[p] = L[(p * 3 + M) * 64];
+#pragma unroll
+            for (int t = 2; t >= 0; --t)   // smallest term first
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int p = 0; p < PB; ++p)
+                        acc[p][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p], B[ti][M][t], acc[p][ti], 0, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            // every stage issues exactly 16 stores per lane (counted above): out-of-range positions of the
+            // last stage rewrite the last valid one with identical values
+            const int pos = min(PB * g + p, npos - 1);
+            const int slot = dir ? (npos - 1 - pos) : pos;
+            f32x4* o = gi + (size_t)tile * gi_tile_stride + ((size_t)slot * 2 + dir) * (kNTile * 64) + nt * 64 + lane;
+            o[0] = acc[p][0];
+            o[64] = acc[p][1];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Heads + softmax + accumulate + argmax (TransducerModel.py:75-76, predict_gpu.py:137-156).
 //   One 16-column MFMA tile is exactly the 5 base + 11 run-length logits of 16 windows.
 //   grid (tiles, groups of kHeadsSpan positions), 4 waves striding over the positions of the group
