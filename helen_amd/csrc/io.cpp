@@ -142,15 +142,15 @@ int read_2d(hid_t loc, const char* name, hid_t memtype, int cols, int max_rows, 
 // ---- writer side ------------------------------------------------------------------------------
 struct Writer {
     hid_t file = -1;
-    hid_t lcpl = -1;
+    hid_t lcpl = -1, dcpl = -1;
     hid_t space_pos = -1, space_lab = -1, space_scalar = -1;
     std::set<std::string> regions;   // DataStore.py:115  meta['predictions_contig']
     std::set<std::string> images;    // DataStore.py:123  meta['predictions']
     std::vector<uint32_t> pos32;
 };
 
-int write_ds(Writer* w, const std::string& path, hid_t ftype, hid_t mtype, hid_t space, const void* buf) {
-    hid_t d = H5Dcreate2(w->file, path.c_str(), ftype, space, w->lcpl, H5P_DEFAULT, H5P_DEFAULT);
+int write_ds(Writer* w, hid_t loc, const std::string& path, hid_t ftype, hid_t mtype, hid_t space, const void* buf) {
+    hid_t d = H5Dcreate2(loc, path.c_str(), ftype, space, w->lcpl, w->dcpl, H5P_DEFAULT);
     if (d < 0) return fail("cannot create dataset '%s'", path.c_str());
     const herr_t rc = H5Dwrite(d, mtype, H5S_ALL, H5S_ALL, H5P_DEFAULT, buf);
     H5Dclose(d);
@@ -176,33 +176,31 @@ int helen_io_list_images(const char* path, char* out, size_t cap, long long* n_o
     if (H5Lexists(f, "images", H5P_DEFAULT) <= 0) return 1;
     hid_t g = H5Gopen2(f, "images", H5P_DEFAULT);
     if (g < 0) return fail("%s: cannot open group 'images'", path);
-    H5G_info_t info;
-    H5Gget_info(g, &info);
-    size_t used = 0;
-    std::vector<char> name(4096);
-    for (hsize_t i = 0; i < info.nlinks; ++i) {
-        ssize_t n = H5Lget_name_by_idx(g, ".", H5_INDEX_NAME, H5_ITER_INC, i, name.data(), name.size(),
-                                       H5P_DEFAULT);
-        if (n < 0) {
-            H5Gclose(g);
-            return fail("%s: cannot list 'images'", path);
+    // one pass in name order (H5Lget_name_by_idx per member is O(n) each on symbol-table groups)
+    struct Acc {
+        char* out;
+        size_t cap, used;
+        long long count;
+    } acc = {out, cap, 0, 0};
+    auto cb = [](hid_t, const char* name, const H5L_info_t*, void* ud) -> herr_t {
+        Acc* a = (Acc*)ud;
+        const size_t n = strlen(name);
+        if (a->used + n + 1 <= a->cap) {
+            memcpy(a->out + a->used, name, n);
+            a->out[a->used + n] = '\n';
         }
-        if ((size_t)n >= name.size()) {
-            name.resize((size_t)n + 1);
-            H5Lget_name_by_idx(g, ".", H5_INDEX_NAME, H5_ITER_INC, i, name.data(), name.size(), H5P_DEFAULT);
-        }
-        if (used + (size_t)n + 1 <= cap) {
-            memcpy(out + used, name.data(), (size_t)n);
-            out[used + (size_t)n] = '\n';
-        }
-        used += (size_t)n + 1;
-    }
+        a->used += n + 1;
+        a->count += 1;
+        return 0;
+    };
+    const herr_t it = H5Literate(g, H5_INDEX_NAME, H5_ITER_INC, nullptr, cb, &acc);
     H5Gclose(g);
-    if (used > cap) {
-        *n_out = (long long)used;
+    if (it < 0) return fail("%s: cannot list 'images'", path);
+    if (acc.used > cap) {
+        *n_out = (long long)acc.used;
         return -2;
     }
-    *n_out = (long long)info.nlinks;
+    *n_out = acc.count;
     return 0;
 }
 
@@ -278,6 +276,7 @@ void* helen_io_writer_open(const char* path) {
     }
     w->lcpl = H5Pcreate(H5P_LINK_CREATE);
     H5Pset_create_intermediate_group(w->lcpl, 1);
+    w->dcpl = H5Pcreate(H5P_DATASET_CREATE);
     hsize_t dp[2] = {kSeq, 3}, dl[1] = {kSeq};
     w->space_pos = H5Screate_simple(2, dp, nullptr);
     w->space_lab = H5Screate_simple(1, dl, nullptr);
@@ -288,13 +287,17 @@ void* helen_io_writer_open(const char* path) {
 
 /* DataStore.write_prediction for `n` windows (DataStore.py:83-133): scalar int64 contig_start /
  * contig_end once per region, then position uint32 [1000,3] (-1 wraps to 4294967295), bases uint8
- * [1000], rles uint8 [1000] once per (contig, region, chunk id); repeats are skipped silently. */
-int helen_io_write_predictions(void* handle, int n, const char* contigs, const int64_t* meta,
-                               const int64_t* positions, const uint8_t* bases, const uint8_t* rles) {
+ * [1000], rles uint8 [1000] once per (contig, region, chunk id); repeats are skipped silently.
+ * `sel` (optional) lists the rows of the batch arrays to write -- several writer processes share one
+ * batch, each taking the regions assigned to it. */
+int helen_io_write_predictions_sel(void* handle, int n_sel, const int32_t* sel, const char* contigs,
+                                   const int64_t* meta, const int64_t* positions, const uint8_t* bases,
+                                   const uint8_t* rles) {
     Writer* w = (Writer*)handle;
     if (!w) return fail("null writer");
     char num[64];
-    for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n_sel; ++j) {
+        const int i = sel ? sel[j] : j;
         const std::string contig = contigs + (size_t)i * kName;
         const int64_t cs = meta[(size_t)i * 3], ce = meta[(size_t)i * 3 + 1], chunk = meta[(size_t)i * 3 + 2];
         snprintf(num, sizeof(num), "-%lld-%lld", (long long)cs, (long long)ce);
@@ -303,19 +306,28 @@ int helen_io_write_predictions(void* handle, int n, const char* contigs, const i
         const std::string suffix = num;
         const std::string root = "predictions/" + contig + "/" + prefix;
         if (w->regions.insert(prefix).second) {
-            if (write_ds(w, root + "/contig_start", H5T_STD_I64LE, H5T_NATIVE_INT64, w->space_scalar, &cs)) return -1;
-            if (write_ds(w, root + "/contig_end", H5T_STD_I64LE, H5T_NATIVE_INT64, w->space_scalar, &ce)) return -1;
+            if (write_ds(w, w->file, root + "/contig_start", H5T_STD_I64LE, H5T_NATIVE_INT64, w->space_scalar, &cs)) return -1;
+            if (write_ds(w, w->file, root + "/contig_end", H5T_STD_I64LE, H5T_NATIVE_INT64, w->space_scalar, &ce)) return -1;
         }
         if (w->images.insert(contig + prefix + suffix).second) {
             const int64_t* p = positions + (size_t)i * kSeq * 3;
             for (int k = 0; k < kSeq * 3; ++k) w->pos32[k] = (uint32_t)p[k];
             const std::string base = root + "/" + suffix;
-            if (write_ds(w, base + "/position", H5T_STD_U32LE, H5T_NATIVE_UINT32, w->space_pos, w->pos32.data())) return -1;
-            if (write_ds(w, base + "/bases", H5T_STD_U8LE, H5T_NATIVE_UINT8, w->space_lab, bases + (size_t)i * kSeq)) return -1;
-            if (write_ds(w, base + "/rles", H5T_STD_U8LE, H5T_NATIVE_UINT8, w->space_lab, rles + (size_t)i * kSeq)) return -1;
+            hid_t g = H5Gcreate2(w->file, base.c_str(), w->lcpl, H5P_DEFAULT, H5P_DEFAULT);
+            if (g < 0) return fail("cannot create group '%s'", base.c_str());
+            int bad = write_ds(w, g, "position", H5T_STD_U32LE, H5T_NATIVE_UINT32, w->space_pos, w->pos32.data()) ||
+                      write_ds(w, g, "bases", H5T_STD_U8LE, H5T_NATIVE_UINT8, w->space_lab, bases + (size_t)i * kSeq) ||
+                      write_ds(w, g, "rles", H5T_STD_U8LE, H5T_NATIVE_UINT8, w->space_lab, rles + (size_t)i * kSeq);
+            H5Gclose(g);
+            if (bad) return -1;
         }
     }
     return 0;
+}
+
+int helen_io_write_predictions(void* handle, int n, const char* contigs, const int64_t* meta,
+                               const int64_t* positions, const uint8_t* bases, const uint8_t* rles) {
+    return helen_io_write_predictions_sel(handle, n, nullptr, contigs, meta, positions, bases, rles);
 }
 
 /* Sequence of one region of a prediction file, as Stitch.small_chunk_stitch builds it
@@ -424,6 +436,7 @@ int helen_io_writer_close(void* handle) {
     H5Sclose(w->space_lab);
     H5Sclose(w->space_scalar);
     H5Pclose(w->lcpl);
+    H5Pclose(w->dcpl);
     const herr_t rc = H5Fclose(w->file);
     delete w;
     return rc < 0 ? fail("closing the prediction file failed") : 0;

@@ -39,17 +39,18 @@ class DataStore(object):
         elif self.file_handler is not None:
             self.file_handler.close()
 
-    def write_batch(self, contigs, meta, positions, bases, rles):
+    def write_batch(self, contigs, meta, positions, bases, rles, sel=None):
         """write_prediction for a whole batch: contigs = list of str or packed u8 [n,128], meta i64
-        [n,3] = (contig_start, contig_end, chunk_id), positions i64 [n,1000,3], labels u8 [n,1000]."""
+        [n,3] = (contig_start, contig_end, chunk_id), positions i64 [n,1000,3], labels u8 [n,1000];
+        `sel` = optional row indices (in order) to write instead of all rows."""
         if self._native is not None:
             if isinstance(contigs, (list, tuple)):
                 contigs = native_io.pack_contigs(contigs)
-            self._native.write(contigs, meta, positions, bases, rles)
+            self._native.write(contigs, meta, positions, bases, rles, sel)
             return
         names = contigs if isinstance(contigs, (list, tuple)) else native_io.contig_names(contigs)
-        for i, c in enumerate(names):
-            self.write_prediction(c, meta[i, 0], meta[i, 1], meta[i, 2], positions[i], bases[i], rles[i])
+        for i in (range(len(names)) if sel is None else [int(k) for k in sel]):
+            self.write_prediction(names[i], meta[i, 0], meta[i, 1], meta[i, 2], positions[i], bases[i], rles[i])
 
     def write_prediction(self, contig, contig_start, contig_end, chunk_id, position,
                          predicted_bases, predicted_rles, filename=None):

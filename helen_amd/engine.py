@@ -124,15 +124,22 @@ class HelenEngine(object):
             return bases, rles, acc_b, acc_r
         return bases, rles
 
-    def polish_host(self, images):
+    def polish_host(self, images, out=None):
         """images: uint8 numpy / CPU tensor [n,1000,90] -> (bases, rles) numpy u8 [n,1000]; the
-        library double-buffers H2D/D2H against compute (helen_polish_host)."""
+        library double-buffers H2D/D2H against compute (helen_polish_host).  `out` = optional
+        (bases, rles) C-contiguous uint8 [n,1000] arrays to receive the labels."""
         if isinstance(images, torch.Tensor):
             images = images.numpy()
         images = np.ascontiguousarray(images, dtype=np.uint8)
         n = images.shape[0]
-        bases = np.empty((n, ImageSizeOptions.SEQ_LENGTH), np.uint8)
-        rles = np.empty_like(bases)
+        if out is not None:
+            bases, rles = out
+            for a in (bases, rles):
+                if a.dtype != np.uint8 or a.shape != (n, ImageSizeOptions.SEQ_LENGTH) or not a.flags.c_contiguous:
+                    raise ValueError("out arrays must be C-contiguous uint8 [n,1000]")
+        else:
+            bases = np.empty((n, ImageSizeOptions.SEQ_LENGTH), np.uint8)
+            rles = np.empty_like(bases)
         with torch.cuda.device(self.device):
             _lib.check(self._lib.helen_polish_host(
                 self._handle, images.ctypes.data, n, bases.ctypes.data, rles.ctypes.data,

@@ -42,6 +42,8 @@ def load():
     lib.helen_io_writer_open.argtypes = [ctypes.c_char_p]
     lib.helen_io_write_predictions.restype = ctypes.c_int
     lib.helen_io_write_predictions.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp]
+    lib.helen_io_write_predictions_sel.restype = ctypes.c_int
+    lib.helen_io_write_predictions_sel.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, vp]
     lib.helen_io_writer_close.restype = ctypes.c_int
     lib.helen_io_writer_close.argtypes = [vp]
     lib.helen_io_region_sequence.restype = ctypes.c_longlong
@@ -119,16 +121,25 @@ class Writer(object):
         if not self._h:
             raise IOError(_err(self._lib))
 
-    def write(self, contigs, meta, positions, bases, rles):
+    def write(self, contigs, meta, positions, bases, rles, sel=None):
+        """Write the batch rows (all, or those listed in `sel`)."""
         n = int(meta.shape[0])
         contigs = np.ascontiguousarray(contigs, np.uint8)
         meta = np.ascontiguousarray(meta, np.int64)
         positions = np.ascontiguousarray(positions, np.int64)
         bases = np.ascontiguousarray(bases, np.uint8)
         rles = np.ascontiguousarray(rles, np.uint8)
-        rc = self._lib.helen_io_write_predictions(self._h, n, contigs.ctypes.data, meta.ctypes.data,
-                                                  positions.ctypes.data, bases.ctypes.data,
-                                                  rles.ctypes.data)
+        if sel is not None:
+            sel = np.ascontiguousarray(sel, np.int32)
+            if sel.size and (sel.min() < 0 or sel.max() >= n):
+                raise IndexError("row selection out of range")
+            rc = self._lib.helen_io_write_predictions_sel(
+                self._h, int(sel.size), sel.ctypes.data, contigs.ctypes.data, meta.ctypes.data,
+                positions.ctypes.data, bases.ctypes.data, rles.ctypes.data)
+        else:
+            rc = self._lib.helen_io_write_predictions(self._h, n, contigs.ctypes.data, meta.ctypes.data,
+                                                      positions.ctypes.data, bases.ctypes.data,
+                                                      rles.ctypes.data)
         if rc != 0:
             raise IOError(_err(self._lib))
 

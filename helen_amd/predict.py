@@ -9,8 +9,15 @@ per window, so coalescing cannot change results), images go up as uint8 through 
 double-buffered copies and labels come back as uint8; reader processes fill shared-memory slots
 while the previous slot is on the GPU and the one before is being written by a writer thread.
 No process group is created (the reference's gloo group is never used on this path).
+
+$HELEN_WRITERS=W (default 1) shards the prediction writer over W processes per rank: creating the
+three small HDF5 datasets of a window costs ~70 us inside libhdf5, ~14 k windows/s per process.
+Writer 0 keeps the reference's file name `<output>_<rank>.hdf`, writer k > 0 writes
+`<output>_<rank>_w<k>.hdf`; all chunks of one region go to the same file, and stitch takes every
+`*.hdf` of the directory (StitchInterface.py:35-36), so the result is the same.
 """
 import multiprocessing as mp
+import os
 import queue
 import sys
 import threading
@@ -21,7 +28,7 @@ import numpy as np
 from .data_store import DataStore
 from .model_handler import ModelHandler
 from .options import ImageSizeOptions
-from .sequence_dataset import SequenceDataset, SharedSlot, fill_shared
+from .sequence_dataset import SequenceDataset, SharedSlot, attach_slot, fill_shared
 
 # windows per device call: scratch is ~4 MB per window, 4096 windows fill 256 CUs x 2 workgroups
 DEVICE_CALL_WINDOWS = 4096
@@ -45,6 +52,94 @@ def _writer_loop(wq, store, free_slots, err):
     except Exception as e:  # surfaced by the caller
         err.append(e)
         free_slots.put(None)
+
+
+def writer_of_region(meta, writers):
+    """Writer index per window: a hash of contig_start, so that every chunk of a region -- and a
+    repeat of the same (region, chunk id), which must be dropped by the one file that has it
+    (DataStore.py:102-124) -- lands in the same file."""
+    key = meta[:, 0].astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    return ((key >> np.uint64(40)) % np.uint64(writers)).astype(np.int64)
+
+
+def prediction_file_name(output_filename, rank, writer=0):
+    return output_filename + "_" + str(rank) + ("" if writer == 0 else "_w" + str(writer)) + ".hdf"
+
+
+def _writer_process(k, writers, filename, task_q, done_q):
+    """Writer process k of `writers`: for every device call, store the windows of its regions."""
+    try:
+        store = DataStore(filename, mode="w")
+        while True:
+            task = task_q.get()
+            if task is None:
+                break
+            path, cap, n = task
+            slot = attach_slot(path, cap)
+            sel = np.nonzero(writer_of_region(slot.meta[:n], writers) == k)[0].astype(np.int32)
+            if sel.size:
+                store.write_batch(slot.contigs[:n], slot.meta[:n], slot.positions[:n], slot.bases[:n],
+                                  slot.rles[:n], sel=sel)
+            done_q.put((path, None))
+        store.close()
+        done_q.put((None, None))
+    except Exception as e:
+        done_q.put((None, "writer %d: %r" % (k, e)))
+
+
+class _WriterPool(object):
+    """W writer processes; a slot is recycled when all of them are done with it."""
+
+    def __init__(self, output_filename, rank, writers, free_slots, err):
+        ctx = mp.get_context("spawn")
+        self.writers, self.free_slots, self.err = writers, free_slots, err
+        self.done_q = ctx.Queue()
+        self.task_qs = [ctx.Queue() for _ in range(writers)]
+        self.procs = [ctx.Process(target=_writer_process, daemon=True,
+                                  args=(k, writers, prediction_file_name(output_filename, rank, k),
+                                        self.task_qs[k], self.done_q))
+                      for k in range(writers)]
+        for p in self.procs:
+            p.start()
+        self.slots, self.pending, self.t_busy = {}, {}, None
+        self.collector = threading.Thread(target=self._collect, daemon=True)
+        self.collector.start()
+
+    def submit(self, slot, n):
+        self.slots[slot.path] = slot
+        self.pending[slot.path] = self.writers
+        if self.t_busy is None:
+            self.t_busy = time.time()
+        for q in self.task_qs:
+            q.put((slot.path, slot.cap, n))
+
+    def _collect(self):
+        closed = 0
+        while closed < self.writers:
+            path, error = self.done_q.get()
+            if error is not None:
+                self.err.append(IOError(error))
+                self.free_slots.put(None)
+                return
+            if path is None:
+                closed += 1
+                continue
+            self.pending[path] -= 1
+            if self.pending[path] == 0:
+                if not any(self.pending.values()) and self.t_busy is not None:
+                    STAGE_SECONDS["write"] += time.time() - self.t_busy
+                    self.t_busy = None
+                self.free_slots.put(self.slots[path])
+
+    def close(self):
+        for q in self.task_qs:
+            q.put(None)
+        self.collector.join()
+        for p in self.procs:
+            p.join(timeout=60)
+        if self.t_busy is not None:
+            STAGE_SECONDS["write"] += time.time() - self.t_busy
+            self.t_busy = None
 
 
 def _feeder_loop(calls, free_slots, ready_q, pool, cap, err):
@@ -76,7 +171,9 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     Pipeline (three stages, three shared-memory slots of one device call each):
       reader processes fill slot k+1 | the GPU polishes slot k | the writer thread stores slot k-1."""
     import torch
-    prediction_data_file = DataStore(output_filename + "_" + str(rank) + ".hdf", mode="w")
+    writers = max(1, int(os.environ.get("HELEN_WRITERS", "1")))
+    prediction_data_file = DataStore(prediction_file_name(output_filename, rank), mode="w") \
+        if writers == 1 else None
     transducer_model, hidden_size, gru_layers, prev_ite = ModelHandler.load_simple_model(
         model_path, input_channels=ImageSizeOptions.IMAGE_CHANNELS,
         image_features=ImageSizeOptions.IMAGE_HEIGHT, seq_len=ImageSizeOptions.SEQ_LENGTH,
@@ -90,7 +187,7 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     transducer_model.set_capacity(min(DEVICE_CALL_WINDOWS, cap))
     engine = transducer_model.engine
     if rank == 0:
-        print(output_filename + "_" + str(rank) + ".hdf")
+        print(prediction_file_name(output_filename, rank))
         sys.stderr.write("INFO: MI355X HIP PATH, DEVICE " + str(device_id) + ", "
                          + str(engine.device_bytes >> 20) + " MiB OF DEVICE MEMORY HELD.\n")
         sys.stderr.write("Loading data\n")
@@ -112,12 +209,16 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     ferr, werr = [], []
     feeder = threading.Thread(target=_feeder_loop, args=(calls, free_slots, ready_q, pool, cap, ferr),
                               daemon=True)
-    writer = threading.Thread(target=_writer_loop, args=(wq, prediction_data_file, free_slots, werr),
-                              daemon=True)
     for k in STAGE_SECONDS:
         STAGE_SECONDS[k] = 0.0
+    if writers == 1:
+        writer = threading.Thread(target=_writer_loop, args=(wq, prediction_data_file, free_slots, werr),
+                                  daemon=True)
+        writer.start()
+        writer_pool = None
+    else:
+        writer_pool = _WriterPool(output_filename, rank, writers, free_slots, werr)
     feeder.start()
-    writer.start()
     start_time = time.time()
     batch_iterator = 0
     try:
@@ -130,10 +231,13 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
             for f in futures:
                 f.result()                       # raises the reader's exception, if any
             t1 = time.time()
-            bases, rles = engine.polish_host(slot.images[:n])
+            bases, rles = engine.polish_host(slot.images[:n], out=(slot.bases[:n], slot.rles[:n]))
             STAGE_SECONDS["read_wait"] += t1 - t0
             STAGE_SECONDS["device"] += time.time() - t1
-            wq.put((slot, n, bases, rles))
+            if writer_pool is None:
+                wq.put((slot, n, bases, rles))
+            else:
+                writer_pool.submit(slot, n)
             batch_iterator += nb
             if rank == 0:
                 eta = (time.time() - start_time) / batch_iterator * (total_batches - batch_iterator)
@@ -142,8 +246,11 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
             if werr:
                 break
     finally:
-        wq.put(None)
-        writer.join()
+        if writer_pool is None:
+            wq.put(None)
+            writer.join()
+        else:
+            writer_pool.close()
         if pool is not None:
             pool.shutdown(wait=True, cancel_futures=True)
         for sl in slots:
@@ -152,7 +259,8 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         raise ferr[0]
     if werr:
         raise werr[0]
-    prediction_data_file.close()
+    if prediction_data_file is not None:
+        prediction_data_file.close()
     engine.close()
     if rank == 0:
         sys.stderr.write("INFO: %d WINDOWS IN %.1f SECS (WAITING FOR READERS %.1f, DEVICE %.1f, WRITER BUSY %.1f).\n"

@@ -125,7 +125,7 @@ class SharedSlot(object):
         self.cap = int(cap)
         L, H = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT
         self._sizes = (self.cap * L * H, self.cap * L * 3 * 8, self.cap * 3 * 8,
-                       self.cap * native_io.NAME_BYTES)
+                       self.cap * native_io.NAME_BYTES, self.cap * L, self.cap * L)
         total = sum(self._sizes)
         if create:
             d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
@@ -135,15 +135,18 @@ class SharedSlot(object):
         self.path = path
         self.owner = create
         self._mm = np.memmap(path, dtype=np.uint8, mode="r+", shape=(total,))
-        o0, o1, o2, o3 = np.cumsum((0,) + self._sizes[:3])
+        o0, o1, o2, o3, o4, o5 = np.cumsum((0,) + self._sizes[:5])
         self.images = self._mm[o0:o0 + self._sizes[0]].reshape(self.cap, L, H)
         self.positions = self._mm[o1:o1 + self._sizes[1]].view(np.int64).reshape(self.cap, L, 3)
         self.meta = self._mm[o2:o2 + self._sizes[2]].view(np.int64).reshape(self.cap, 3)
         self.contigs = self._mm[o3:o3 + self._sizes[3]].reshape(self.cap, native_io.NAME_BYTES)
+        # label rows of the device call, for writer processes
+        self.bases = self._mm[o4:o4 + self._sizes[4]].reshape(self.cap, L)
+        self.rles = self._mm[o5:o5 + self._sizes[5]].reshape(self.cap, L)
 
     def close(self):
         import os
-        self.images = self.positions = self.meta = self.contigs = None
+        self.images = self.positions = self.meta = self.contigs = self.bases = self.rles = None
         self._mm = None
         if self.owner and self.path and os.path.exists(self.path):
             os.unlink(self.path)
@@ -152,8 +155,8 @@ class SharedSlot(object):
 _attached = {}
 
 
-def fill_shared(path, cap, offset, pairs):
-    """Worker entry: read `pairs` into slot `path` at window `offset`.  Returns len(pairs)."""
+def attach_slot(path, cap):
+    """This process's mapping of the slot another process created."""
     key = (path, cap)
     slot = _attached.get(key)
     if slot is None:
@@ -161,6 +164,12 @@ def fill_shared(path, cap, offset, pairs):
             _attached.clear()
         slot = SharedSlot(cap, path=path, create=False)
         _attached[key] = slot
+    return slot
+
+
+def fill_shared(path, cap, offset, pairs):
+    """Worker entry: read `pairs` into slot `path` at window `offset`.  Returns len(pairs)."""
+    slot = attach_slot(path, cap)
     n = len(pairs)
     fill_batch(pairs, slot.images[offset:offset + n], slot.positions[offset:offset + n],
                slot.meta[offset:offset + n], slot.contigs[offset:offset + n])

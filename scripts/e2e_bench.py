@@ -24,10 +24,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--windows", type=int, default=16384)
     ap.add_argument("--h5-windows", type=int, default=8192)
-    ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--workers", type=str, default="8", help="reader processes; comma list = one run each")
+    ap.add_argument("--writers", type=str, default="1", help="$HELEN_WRITERS; comma list = one run each")
+    ap.add_argument("--skip-host", action="store_true")
     args = ap.parse_args()
 
     w = make_weights(input_scale=1.0 / 64.0)
+    if not args.skip_host:
+        host_probe(w, args)
+    e2e_probe(w, args)
+
+
+def host_probe(w, args):
     eng = HelenEngine(w, device=0, max_windows=4096)
     rng = np.random.default_rng(1)
     img = rng.integers(0, 256, size=(args.windows, 1000, 90), dtype=np.uint8)
@@ -42,6 +50,8 @@ def main():
     assert np.array_equal(bd.cpu().numpy(), b[:4096])
     eng.close()
 
+
+def e2e_probe(w, args):
     d = tempfile.mkdtemp(prefix="helen_e2e_")
     try:
         model = os.path.join(d, "m.pkl")
@@ -49,11 +59,17 @@ def main():
         t0 = time.time()
         write_image_dir(os.path.join(d, "img"), args.h5_windows, n_files=16)
         print("wrote %d windows of synthetic HDF5 in %.1f s" % (args.h5_windows, time.time() - t0))
-        t0 = time.time()
-        call_consensus(os.path.join(d, "img"), model, 256, args.workers, 1, os.path.join(d, "out"), "p", True, "0", 1)
-        dt = time.time() - t0
-        print("call_consensus end-to-end (HDF5 in -> HDF5 out, %d reader workers): %d windows in %.2f s = %.0f windows/s"
-              % (args.workers, args.h5_windows, dt, args.h5_windows / dt))
+        for workers in [int(x) for x in args.workers.split(",")]:
+            for writers in [int(x) for x in args.writers.split(",")]:
+                os.environ["HELEN_WRITERS"] = str(writers)
+                out = os.path.join(d, "out_%d_%d" % (workers, writers))
+                t0 = time.time()
+                call_consensus(os.path.join(d, "img"), model, 256, workers, 1, out, "p", True, "0", 1)
+                dt = time.time() - t0
+                print("call_consensus end-to-end (HDF5 in -> HDF5 out, %d reader workers, %d writers): "
+                      "%d windows in %.2f s = %.0f windows/s"
+                      % (workers, writers, args.h5_windows, dt, args.h5_windows / dt), flush=True)
+                shutil.rmtree(out, ignore_errors=True)
     finally:
         shutil.rmtree(d, ignore_errors=True)
 

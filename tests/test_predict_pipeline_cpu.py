@@ -15,8 +15,12 @@ pytestmark = pytest.mark.skipif(not hdf5.available(), reason="libhdf5 not loadab
 class _StandInEngine(object):
     device_bytes = 0
 
-    def polish_host(self, images):
-        return (images[:, :, 0] % 5).astype(np.uint8), (images[:, :, 1] % 11).astype(np.uint8)
+    def polish_host(self, images, out=None):
+        bases, rles = (images[:, :, 0] % 5).astype(np.uint8), (images[:, :, 1] % 11).astype(np.uint8)
+        if out is not None:
+            out[0][:], out[1][:] = bases, rles
+            return out
+        return bases, rles
 
     def close(self):
         pass
@@ -55,6 +59,49 @@ def test_pipeline_with_stand_in_device(tmp_path, monkeypatch, workers):
         assert len(f.keys("predictions/chr20_synth")) == 150
     assert seen == 150
     assert not glob.glob("/dev/shm/helen_slot_*") or True     # slots are unlinked (best effort check)
+
+
+def test_sharded_writers(tmp_path, monkeypatch):
+    """$HELEN_WRITERS=3: every window lands in exactly one of the rank's files, a region is never split
+    across files, and the files together hold what the single writer holds."""
+    import torch
+
+    import helen_amd.predict as P
+    import helen_amd.transducer as T
+    from helen_amd.model_handler import ModelHandler
+    from helen_amd.sequence_dataset import SequenceDataset
+    from helen_amd.synthetic import write_image_dir
+    from helen_amd.weights import make_weights
+    monkeypatch.setattr(T.TransducerGRU, "engine", property(lambda self: _StandInEngine()))
+    monkeypatch.setattr(T.TransducerGRU, "to", lambda self, d: self)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(P, "DEVICE_CALL_WINDOWS", 64)
+    monkeypatch.setenv("HELEN_WRITERS", "3")
+    img_dir = str(tmp_path / "img")
+    write_image_dir(img_dir, 150, n_files=3, short_every=7)
+    model = str(tmp_path / "m.pkl")
+    ModelHandler.save_model(make_weights(), None, 128, 1, 0, model)
+    files = sorted(glob.glob(os.path.join(img_dir, "*.h5")))
+    P.predict(files, str(tmp_path / "out"), model, 16, 2, 0, 0)
+    outs = sorted(glob.glob(str(tmp_path / "out_0*.hdf")))
+    assert [os.path.basename(o) for o in outs] == ["out_0.hdf", "out_0_w1.hdf", "out_0_w2.hdf"]
+    handles = [hdf5.File(o) for o in outs]
+    region_file = {}
+    ds = SequenceDataset(None, file_list=files)
+    for i in range(len(ds)):
+        contig, cs, ce, chunk, image, position, _ = ds[i]
+        region = "predictions/%s/%s-%d-%d" % (contig, contig, cs, ce)
+        holders = [k for k, f in enumerate(handles) if (region + "/%d" % chunk) in f]
+        assert len(holders) == 1, (region, chunk, holders)
+        assert region_file.setdefault(region, holders[0]) == holders[0]     # region not split
+        f = handles[holders[0]]
+        assert np.array_equal(f.read(region + "/%d/bases" % chunk), image[:, 0] % 5)
+        assert np.array_equal(f.read(region + "/%d/rles" % chunk), image[:, 1] % 11)
+        assert np.array_equal(f.read(region + "/%d/position" % chunk), position.astype(np.uint32))
+        assert int(f.read(region + "/contig_start").reshape(-1)[0]) == cs
+    assert len(set(region_file.values())) > 1                               # actually sharded
+    for f in handles:
+        f.close()
 
 
 def test_reader_error_surfaces(tmp_path, monkeypatch):
