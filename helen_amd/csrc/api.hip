@@ -275,11 +275,18 @@ unsigned gemm_grid(int npos, int tiles, int positions_per_wave = 4) {
     return (unsigned)((units + 7) / 8 * 8) * (8 / HELEN_GEMM_WAVES);
 }
 
+constexpr int kWsMinWorkgroups = 384;   // 1.5 workgroups per CU-slot pair: below this the position-parallel kernel wins
+
 void launch_enc_gemm(HelenModel* m, hipStream_t s, int tiles, int npos) {
     const dim3 grid(gemm_grid(npos, tiles)), block(HELEN_GEMM_WAVES * 64);
     if (m->precision == HELEN_PRECISION_BF16)
         LAUNCH(HELEN_K_GEMM_ENC, (gemm_gi_bf16_kernel<kFPad / 16, false, 4, false>), dim3(gemm_grid(npos, tiles, 4)), block, m->xa,
                kXaTileStride, m->wpb_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles);
+    else if (3 * tiles >= kWsMinWorkgroups)
+        // enough tiles to fill the chip with one workgroup per (tile, column set): weights stay in
+        // registers, same MFMA order per accumulator as gemm_gi_kernel (bit-identical gi)
+        LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_ws_kernel, dim3(3 * ((tiles + 7) / 8 * 8)), dim3(256), m->xa,
+               kXaTileStride, m->wp_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles);
     else
         LAUNCH(HELEN_K_GEMM_ENC, (gemm_gi_kernel<kFPad / 16, false>), grid, block, m->xa,
                kXaTileStride, m->wp_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles);
@@ -288,6 +295,10 @@ void launch_enc_gemm(HelenModel* m, hipStream_t s, int tiles, int npos) {
 // One TransducerGRU.forward over `tiles` tiles whose encoder pre-activations are already in
 // gi_enc at positions [pos0, pos0+T): encoder recurrence -> decoder projection -> decoder
 // recurrence.  y2 then holds the decoder output, hid the returned hidden state.
+#ifndef HELEN_X3_NT
+#define HELEN_X3_NT 1   // window tiles per workgroup of the fp32x3 recurrence (2: no faster, see kernel)
+#endif
+
 void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int enc_npos) {
     const dim3 ggrid(gemm_grid(T, tiles)), gblock(HELEN_GEMM_WAVES * 64);
     // encoder gi holds `enc_npos` positions; the reverse direction is stored time-reversed
@@ -302,13 +313,14 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
     }
     if (m->precision == HELEN_PRECISION_FP32X3) {
         // encoder output goes out as three bf16 planes only; the projection consumes them directly
-        LAUNCH(HELEN_K_GRU_ENC, gru_x3_kernel, dim3(tiles, 2), dim3(512), m->gi_enc, kGiEncTileStride, pos0,
-               enc_npos - pos0 - T, T, m->w3h_enc, m->bhn_enc, m->hid, (f32x4*)nullptr, kYTileStride,
-               m->y1p, kY1pTileStride);
-        LAUNCH(HELEN_K_GEMM_DEC, gemm_dec_x3_kernel, dim3(3, tiles), dim3(512), m->y1p, kY1pTileStride,
+        LAUNCH(HELEN_K_GRU_ENC, gru_x3_kernel<HELEN_X3_NT>, dim3((tiles + HELEN_X3_NT - 1) / HELEN_X3_NT, 2),
+               dim3(512), m->gi_enc, kGiEncTileStride, pos0, enc_npos - pos0 - T, T, m->w3h_enc, m->bhn_enc,
+               m->hid, (f32x4*)nullptr, kYTileStride, m->y1p, kY1pTileStride, tiles);
+        LAUNCH(HELEN_K_GEMM_DEC, gemm_dec_x3_kernel, dim3(3 * ((tiles + 7) / 8 * 8)), dim3(512), m->y1p, kY1pTileStride,
                (const f32x4*)m->w3i_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
-        LAUNCH(HELEN_K_GRU_DEC, gru_x3_kernel, dim3(tiles, 2), dim3(512), m->gi_dec, kGiDecTileStride, 0, 0,
-               T, m->w3h_dec, m->bhn_dec, m->hid, m->y2, kYTileStride, (f32x4*)nullptr, kY1pTileStride);
+        LAUNCH(HELEN_K_GRU_DEC, gru_x3_kernel<HELEN_X3_NT>, dim3((tiles + HELEN_X3_NT - 1) / HELEN_X3_NT, 2),
+               dim3(512), m->gi_dec, kGiDecTileStride, 0, 0, T, m->w3h_dec, m->bhn_dec, m->hid, m->y2,
+               kYTileStride, (f32x4*)nullptr, kY1pTileStride, tiles);
         return;
     }
     LAUNCH(HELEN_K_GRU_ENC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
@@ -480,7 +492,7 @@ int helen_polish_batch(HelenModel* m, const uint8_t* images, int n_windows, uint
         // pileup counts are exact in bf16: pack them straight into A fragments, three exact products per w
         LAUNCH(HELEN_K_PACK, pack_images_x3_kernel, dim3((kSeq * 192 + 255) / 256, tiles), dim3(256), images,
                n_windows, kSeq, m->xb);
-        LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_x3_kernel, dim3(3, tiles), dim3(512), m->xb, (long)kSeq * 192,
+        LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_x3_kernel, dim3(3 * ((tiles + 7) / 8 * 8)), dim3(512), m->xb, (long)kSeq * 192,
                (const f32x4*)m->w3i_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, kSeq, tiles);
     } else {
         // uint8 -> fp32 operand tiles (predict_gpu.py:97)

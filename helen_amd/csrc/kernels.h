@@ -213,6 +213,96 @@ __global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_kernel(const f3
 }
 
 // ------------------------------------------------------------------------------------------------
+// Encoder input projection, weight-stationary (fp32 MFMA): gi = X . W_ih^T + bias for all `npos` positions.
+//   K is only 96, so a wave can hold its whole slice of W_ih in registers: 4 column tiles x 6 groups =
+//   96 registers, loaded once.  Workgroup = 4 waves = one third of the 48 column tiles; grid = 3 column
+//   sets x tiles, enumerated so that the three sets of a tile run on one XCD (its xa stream comes from HBM
+//   once).  Only the activations move: a stage is 4 positions (24 KiB of KB16 fragments) brought in by
+//   LDS-DMA into a 2-deep ring, 384 MFMAs per wave per barrier, and the 16 output stores of a stage stay
+//   in flight across the next barrier.  Two workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemm_enc_ws_kernel(const f32x4* __restrict__ A, long a_tile_stride,
+                                                             const f32x4* __restrict__ Wp,
+                                                             const float* __restrict__ bias,
+                                                             f32x4* __restrict__ gi, long gi_tile_stride,
+                                                             int npos, int ntiles) {
+    constexpr int MG = kFPad / 16;          // 6 operand groups of 16 k
+    constexpr int PB = 4, N = 4;
+    constexpr int ROWS = PB * MG;           // 24 rows of 1 KiB per stage
+    __shared__ f32x4 smem[2 * ROWS * 64];   // 48 KiB
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int local = blockIdx.x >> 3;
+    const int set = local % 3;
+    const int tile = (local / 3) * 8 + (blockIdx.x & 7);
+    if (tile >= ntiles) return;
+    const int gt0 = 16 * set + N * w;       // first of this wave's global column tiles (dir*24 + nt)
+    const int dir = gt0 / kNTile;
+    const int nt0 = gt0 % kNTile;
+    f32x4 B[N][MG];
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int m = 0; m < MG; ++m) B[n][m] = Wp[(size_t)((gt0 + n) * MG + m) * 64 + lane];
+    float bs[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) bs[n] = bias[dir * kG + (nt0 + n) * 16 + (lane & 15)];
+    const f32x4* ap = A + (size_t)tile * a_tile_stride + lane;
+    auto stage = [&](int g, int b) {        // positions 4g..4g+3: row r = p*6 + m, 6 rows per wave
+        f32x4* dst = smem + b * (ROWS * 64);
+#pragma unroll
+        for (int i = 0; i < ROWS / 4; ++i) {
+            const int r = w + 4 * i;
+            const int pc = min(PB * g + r / MG, npos - 1);
+            const f32x4* src = ap + (size_t)pc * (MG * 64) + (r % MG) * 64;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                             (void __attribute__((address_space(3)))*)(dst + r * 64), 16, 0, 0);
+        }
+    };
+    const int ng = (npos + PB - 1) / PB;
+    stage(0, 0);
+    for (int g = 0; g < ng; ++g) {
+        // VMEM queue, oldest first: 6 DMA rows of group g, then the 16 output stores of group g-1
+        if (g == 0)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (g + 1 < ng) stage(g + 1, (g + 1) & 1);
+        const f32x4* L = smem + (g & 1) * (ROWS * 64) + lane;
+        f32x4 acc[PB][N];
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+#pragma unroll
+            for (int n = 0; n < N; ++n) acc[p][n] = splat4(bs[n]);
+#pragma unroll
+        for (int m = 0; m < MG; ++m) {
+            f32x4 a[PB];
+#pragma unroll
+            for (int p = 0; p < PB; ++p) a[p] = L[(p * MG + m) * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int p = 0; p < PB; ++p)
+#pragma unroll
+                    for (int n = 0; n < N; ++n) acc[p][n] = mfma4(a[p][e], B[n][m][e], acc[p][n]);
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            // exactly 16 stores per lane per stage (counted above): positions past the end of the last
+            // stage rewrite the last valid one with identical values
+            const int pos = min(PB * g + p, npos - 1);
+            const int slot = dir ? (npos - 1 - pos) : pos;
+            f32x4* o = gi + (size_t)tile * gi_tile_stride + ((size_t)slot * 2 + dir) * (kNTile * 64) + nt0 * 64 + lane;
+#pragma unroll
+            for (int n = 0; n < N; ++n) o[n * 64] = acc[p][n];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // GRU recurrence for one direction of one layer over T dependent steps (nn.GRU cell, see
 // oracle/helen_oracle.c gru_dir for the scalar statement).
 //   grid (tiles, 2 directions), 4 waves per workgroup, TWO workgroups per CU (two waves per SIMD
@@ -662,30 +752,36 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short b) {
     return __builtin_bit_cast(float, (unsigned)b << 16);
 }
 
+template <int NT>
 __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ gi, long gi_tile_stride,
                                                      int slot0_fwd, int slot0_bwd, int T,
                                                      const bf16x8* __restrict__ W3,
                                                      const float* __restrict__ bhn,
                                                      f32x4* __restrict__ hid, f32x4* __restrict__ y,
                                                      long y_tile_stride, f32x4* __restrict__ yplanes,
-                                                     long yp_tile_stride) {
+                                                     long yp_tile_stride, int ntiles) {
+    // NT window tiles per workgroup share the resident W_hh terms and one barrier per step.  Measured:
+    // NT = 2 is no faster than NT = 1 (0.459 vs 0.449 ms) -- a step is 2 x 1200 cycles of MFMA issue plus
+    // 2 x 940 cycles of gate/split VALU work per SIMD, which do not overlap, not barrier latency -- so
+    // NT = 1 (more workgroups, half the LDS) is what is launched.  A workgroup past the last tile
+    // recomputes the last one (identical stores).
     // Layer output: fp32 y[tile][slot][dir] (KB16, for the heads) when `y` is given, and/or the three
     // bf16 planes yplanes[tile][slot][dir][plane][256 units] (for gemm_dec_x3_kernel) when given.
-    // LDS (one object): fp32 h [2][512 f4] | bf16 planes [2 buffers][3 terms][256 units of 16 B] |
+    // LDS per tile: fp32 h [2][512 f4] | bf16 planes [2 buffers][3 terms][256 units of 16 B] |
     // gi slots [8 waves][3][64 f4]
-    __shared__ f32x4 smem[2 * 512 + 2 * 3 * 256 + 8 * 192];
-    f32x4* const hbuf = smem;
-    f32x4* const planes = smem + 1024;
+    constexpr int kPerTile = 2 * 512 + 2 * 3 * 256 + 8 * 192;   // 4096 f4 = 64 KiB
+    __shared__ f32x4 smem[NT * kPerTile];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int v = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7: hidden units 16v..16v+15
-    f32x4* const gbuf = smem + 1024 + 1536 + v * 192;
     const int j = lane & 15;
     const int q = lane >> 4;
-    const int tile = blockIdx.x;
     const int dir = blockIdx.y;
     const int slot0 = dir ? slot0_bwd : slot0_fwd;
     const int u = 16 * v + j;                                  // this lane's hidden unit
+    int tile[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) tile[n] = min((int)blockIdx.x * NT + n, ntiles - 1);
 
     // W[g][M][t]: term t of W_hh[row g*128 + u][k = 32M + 8q + e], e = 0..7
     bf16x8 W[3][4][3];
@@ -700,23 +796,26 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
     }
     const float bn = bhn[dir * kH + u];
 
-    const f32x4* gi_p = gi + (size_t)tile * gi_tile_stride + (size_t)dir * (kNTile * 64) + v * 64 + lane;
     constexpr long kPosStride = 2 * kNTile * 64;
-    auto dma_gi = [&](int slot) {
-        const f32x4* p = gi_p + (size_t)slot * kPosStride;
+    auto hbuf = [&](int n) { return smem + n * kPerTile; };
+    auto planes = [&](int n) { return smem + n * kPerTile + 1024; };
+    auto gbuf = [&](int n) { return smem + n * kPerTile + 1024 + 1536 + v * 192; };
+    auto dma_gi = [&](int n, int slot) {
+        const f32x4* p = gi + (size_t)tile[n] * gi_tile_stride + (size_t)dir * (kNTile * 64) + v * 64 + lane +
+                         (size_t)slot * kPosStride;
 #pragma unroll
         for (int g = 0; g < 3; ++g)
             __builtin_amdgcn_global_load_lds(
                 (const void __attribute__((address_space(1)))*)(p + (g * 8) * 64),
-                (void __attribute__((address_space(3)))*)(gbuf + g * 64), 16, 0, 0);
+                (void __attribute__((address_space(3)))*)(gbuf(n) + g * 64), 16, 0, 0);
     };
     // this lane's 4 values: rows 4q + r of unit u.  fp32 h: float index ((u>>2)*16 + 4q + r)*4 + (u&3);
     // planes: bf16 index ((u>>3)*16 + 4q + r)*8 + (u&7) inside a 256-unit plane
     const int hoff = ((u >> 2) * kTile + 4 * q) * 4 + (u & 3);
     const int poff = ((u >> 3) * kTile + 4 * q) * 8 + (u & 7);
-    auto store_h = [&](int buf, int r, float h) {
-        ((float*)(hbuf + buf * 512))[hoff + 4 * r] = h;
-        unsigned short* pl = (unsigned short*)(planes + buf * 768);
+    auto store_h = [&](int n, int buf, int r, float h) {
+        ((float*)(hbuf(n) + buf * 512))[hoff + 4 * r] = h;
+        unsigned short* pl = (unsigned short*)(planes(n) + buf * 768);
         const unsigned short t1 = bf16_bits(h);
         const float r1 = h - bf16_to_f32(t1);
         const unsigned short t2 = bf16_bits(r1);
@@ -727,65 +826,104 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
         pl[2 * 2048 + poff + 8 * r] = t3;
     };
 
-    f32x4* hid_p = hid + ((size_t)tile * 2 + dir) * (kHidDirStride / 4);
-    hbuf[tid] = hid_p[tid];
-    dma_gi(slot0);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        hbuf(n)[tid] = (hid + ((size_t)tile[n] * 2 + dir) * (kHidDirStride / 4))[tid];
+        dma_gi(n, slot0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    float hprev[4];
+    float hprev[NT][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) hprev[r] = ((const float*)hbuf)[hoff + 4 * r];
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) store_h(0, r, hprev[r]);     // planes of h0 (fp32 copy rewritten in place)
+        for (int r = 0; r < 4; ++r) hprev[n][r] = ((const float*)hbuf(n))[hoff + 4 * r];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) store_h(n, 0, r, hprev[n][r]);   // planes of h0 (fp32 copy rewritten in place)
     __syncthreads();
-    f32x4* y_p = y + (size_t)tile * y_tile_stride + (size_t)dir * (kHidDirStride / 4);
-
+#ifdef HELEN_GRU_TIMING
+    long long tk[7] = {0, 0, 0, 0, 0, 0, 0};
+    long long tlast = __builtin_readcyclecounter();
+#endif
     for (int s = 0; s < T; ++s) {
         const int cur = s & 1;
-        const bf16x8* pa = (const bf16x8*)(planes + cur * 768) + lane;
-        f32x4 acc[3];
-        acc[0] = splat4(0.f);
-        acc[1] = splat4(0.f);
-        acc[2] = splat4(bn);
+        f32x4 acc[NT][3];
 #pragma unroll
-        for (int M = 0; M < 4; ++M) {
-            const bf16x8 a1 = pa[0 * 256 + M * 64], a2 = pa[1 * 256 + M * 64], a3 = pa[2 * 256 + M * 64];
-            const bf16x8 at[3] = {a1, a2, a3};
-            constexpr int TA[6] = {0, 2, 1, 0, 1, 0};   // six leading products, smallest first;
-            constexpr int TB[6] = {2, 0, 1, 1, 0, 0};   // product index outermost: 3 accumulators rotate
+        for (int n = 0; n < NT; ++n) {
+            const bf16x8* pa = (const bf16x8*)(planes(n) + cur * 768) + lane;
+            acc[n][0] = splat4(0.f);
+            acc[n][1] = splat4(0.f);
+            acc[n][2] = splat4(bn);
 #pragma unroll
-            for (int k = 0; k < 6; ++k)
+            for (int M = 0; M < 4; ++M) {
+                const bf16x8 a1 = pa[0 * 256 + M * 64], a2 = pa[1 * 256 + M * 64], a3 = pa[2 * 256 + M * 64];
+                const bf16x8 at[3] = {a1, a2, a3};
+                constexpr int TA[6] = {0, 2, 1, 0, 1, 0};   // six leading products, smallest first;
+                constexpr int TB[6] = {2, 0, 1, 1, 0, 0};   // product index outermost: 3 accumulators rotate
 #pragma unroll
-                for (int g = 0; g < 3; ++g)
-                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[TA[k]], W[g][M][TB[k]], acc[g], 0, 0, 0);
+                for (int k = 0; k < 6; ++k)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        acc[n][g] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[TA[k]], W[g][M][TB[k]], acc[n][g], 0, 0, 0);
+            }
         }
-        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // VMEM queue: 3 gi DMAs, then 1 y store
-        f32x4 G[3];
+        HELEN_TICK(0)
+#ifdef HELEN_GRU_TIMING
+        asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]));
+        HELEN_TICK(1)
+#endif
+        // VMEM queue, oldest first: 3 gi DMAs per tile, then the previous step's output stores (at least
+        // one per tile): the DMAs have landed once no more than NT operations are outstanding
+        if (NT == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        HELEN_TICK(2)
 #pragma unroll
-        for (int g = 0; g < 3; ++g) G[g] = gbuf[g * 64 + lane];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (s + 1 < T) dma_gi(slot0 + s + 1);
+        for (int n = 0; n < NT; ++n) {
+            f32x4 G[3];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float hn = gru_cell(acc[0][r], acc[1][r], acc[2][r], G[0][r], G[1][r], G[2][r], hprev[r]);
-            hprev[r] = hn;
-            store_h(cur ^ 1, r, hn);
+            for (int g = 0; g < 3; ++g) G[g] = gbuf(n)[g * 64 + lane];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (s + 1 < T) dma_gi(n, slot0 + s + 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float hn = gru_cell(acc[n][0][r], acc[n][1][r], acc[n][2][r], G[0][r], G[1][r], G[2][r],
+                                          hprev[n][r]);
+                hprev[n][r] = hn;
+                store_h(n, cur ^ 1, r, hn);
+            }
         }
+        HELEN_TICK(3)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        HELEN_TICK(4)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (y != nullptr) {
-            f32x4* yo = y_p + (size_t)s * (kYStride / 4);
-            yo[tid] = (hbuf + (cur ^ 1) * 512)[tid];
-        }
-        if (yplanes != nullptr) {   // 768 units of 16 B per (tile, slot, dir)
-            f32x4* po = yplanes + (size_t)tile * yp_tile_stride + ((size_t)s * 2 + dir) * 768;
-            const f32x4* ps = planes + (cur ^ 1) * 768;
-            po[tid] = ps[tid];
-            if (tid < 256) po[512 + tid] = ps[512 + tid];
+        HELEN_TICK(5)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            if (y != nullptr) {
+                f32x4* yo = y + (size_t)tile[n] * y_tile_stride + (size_t)dir * (kHidDirStride / 4) +
+                            (size_t)s * (kYStride / 4);
+                yo[tid] = (hbuf(n) + (cur ^ 1) * 512)[tid];
+            }
+            if (yplanes != nullptr) {   // 768 units of 16 B per (tile, slot, dir)
+                f32x4* po = yplanes + (size_t)tile[n] * yp_tile_stride + ((size_t)s * 2 + dir) * 768;
+                const f32x4* ps = planes(n) + (cur ^ 1) * 768;
+                po[tid] = ps[tid];
+                if (tid < 256) po[512 + tid] = ps[512 + tid];
+            }
         }
     }
-    hid_p[tid] = (hbuf + (T & 1) * 512)[tid];
+#ifdef HELEN_GRU_TIMING
+    if (blockIdx.x == 0 && lane == 0 && (v == 0 || v == 5))
+        printf("gru_x3 dir %d wave %d: cycles/step  mfma-issue %lld  mfma-drain %lld  vmwait %lld  G+gates+stores %lld  lgkm %lld  barrier %lld  (ycopy in mfma-issue)\n",
+               dir, v, tk[0] / T, tk[1] / T, tk[2] / T, tk[3] / T, tk[4] / T, tk[5] / T);
+#endif
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+        (hid + ((size_t)tile[n] * 2 + dir) * (kHidDirStride / 4))[tid] = (hbuf(n) + (T & 1) * 512)[tid];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -813,8 +951,12 @@ __global__ __launch_bounds__(512) void gemm_dec_x3_kernel(const f32x4* __restric
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int set = blockIdx.x;
-    const int tile = blockIdx.y;
+    // 1-D grid of 3 * roundup8(ntiles) ids.  Workgroups go round-robin over the 8 XCDs (id % 8): the three
+    // column sets of a tile get consecutive local slots of ONE XCD, so its A stream is fetched from HBM
+    // once and served from that XCD's L2 to the other two.
+    const int local = blockIdx.x >> 3;
+    const int set = local % 3;
+    const int tile = (local / 3) * 8 + (blockIdx.x & 7);
     if (tile >= ntiles) return;
     const int gt0 = 16 * set + 2 * w;          // first of this wave's two global column tiles (dir*24 + nt)
     const int dir = gt0 / kNTile;
@@ -945,8 +1087,12 @@ __global__ __launch_bounds__(512) void gemm_enc_x3_kernel(const f32x4* __restric
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int set = blockIdx.x;
-    const int tile = blockIdx.y;
+    // 1-D grid of 3 * roundup8(ntiles) ids.  Workgroups go round-robin over the 8 XCDs (id % 8): the three
+    // column sets of a tile get consecutive local slots of ONE XCD, so its A stream is fetched from HBM
+    // once and served from that XCD's L2 to the other two.
+    const int local = blockIdx.x >> 3;
+    const int set = local % 3;
+    const int tile = (local / 3) * 8 + (blockIdx.x & 7);
     if (tile >= ntiles) return;
     const int gt0 = 16 * set + 2 * w;
     const int dir = gt0 / kNTile;
