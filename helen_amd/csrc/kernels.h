@@ -731,7 +731,8 @@ __global__ __launch_bounds__(256, 2) void gru_bf16_kernel(const f32x4* __restric
 // fp32x3 recurrence (HELEN_PRECISION_FP32X3, opt-in): fp32-class h . W_hh^T on the bf16 matrix cores.
 //   Every fp32 value is the exact sum of three bf16 terms (3 x 8 significand bits): h = h1 + h2 + h3,
 //   w = w1 + w2 + w3.  Each partial product hi*wj is exact in fp32, and the six leading ones
-//   (i + j <= 4) reproduce h*w to 2^-32 relative -- below fp32's own rounding -- so
+//   (i + j <= 4) reproduce h*w to ~2^-26 relative (RNE splits: |h2| <= 2^-9 |h|, |h3| <= 2^-18 |h|; the
+//   dropped h2*w3, h3*w2, h3*w3 are <= 2 * 2^-27) -- a quarter of fp32's own rounding unit -- so
 //       sum_k h_k w_k = sum over the 6 products of (bf16 MFMA, fp32 accumulate)
 //   is an fp32 dot product up to summation order, at 6 x 16.7 cycles per 32 k on
 //   v_mfma_f32_16x16x32_bf16 instead of 8 x 32 cycles on v_mfma_f32_16x16x4_f32.
