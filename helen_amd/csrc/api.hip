@@ -70,7 +70,7 @@ struct HelenModel {
     bf16x8* w3i_dec = nullptr;   // decoder W_ih split: [2 dirs][24 tiles][8 M][3 terms][64]
     bf16x8* w3i_enc = nullptr;   // encoder W_ih split: [2 dirs][24 tiles][3 M][3 terms][64] (K padded to 96)
     f32x4* xb = nullptr;         // pileup counts as bf16 A fragments: [tile][pos][192] x 16 B
-    f32x4* y1p = nullptr;        // encoder output as three bf16 planes: [tile][slot][dir][3][256] x 16 B
+    f32x4* y1p = nullptr;        // encoder output as bf16 planes: [tile][slot][dir][3 (fp32x3) | 1 (bf16)][256] x 16 B
     // scratch (device)
     f32x4* xa = nullptr;
     f32x4* gi_enc = nullptr;
@@ -103,6 +103,7 @@ constexpr long kGiEncTileStride = (long)kSeq * (kGiStride / 4);
 constexpr long kGiDecTileStride = (long)kWin * (kGiStride / 4);
 constexpr long kYTileStride = (long)kWin * (kYStride / 4);
 constexpr long kY1pTileStride = (long)kWin * 2 * 768;                // three bf16 planes per (slot, dir)
+constexpr long kY1bTileStride = (long)kWin * 2 * 256;                // one bf16 plane per (slot, dir)
 
 template <typename T>
 int dev_alloc(HelenModel* m, T** p, size_t count) {
@@ -303,12 +304,14 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
     const dim3 ggrid(gemm_grid(T, tiles)), gblock(HELEN_GEMM_WAVES * 64);
     // encoder gi holds `enc_npos` positions; the reverse direction is stored time-reversed
     if (m->precision == HELEN_PRECISION_BF16) {
+        // encoder output goes out as one bf16 plane (what the projection would round it to anyway)
         LAUNCH(HELEN_K_GRU_ENC, gru_bf16_kernel, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride,
-               pos0, enc_npos - pos0 - T, T, m->whpb_enc, m->bhn_enc, m->hid, m->y1, kYTileStride);
-        LAUNCH(HELEN_K_GEMM_DEC, (gemm_gi_bf16_kernel<16, true, 2, true>), dim3(gemm_grid(T, tiles, 2)), gblock, m->y1, kYTileStride,
-               m->wpb_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
+               pos0, enc_npos - pos0 - T, T, m->whpb_enc, m->bhn_enc, m->hid, (f32x4*)nullptr, kYTileStride,
+               m->y1p, kY1bTileStride);
+        LAUNCH(HELEN_K_GEMM_DEC, (gemm_dec_x3_kernel<1, 6>), dim3(3 * ((tiles + 7) / 8 * 8)), dim3(512), m->y1p,
+               kY1bTileStride, (const f32x4*)m->w3i_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
         LAUNCH(HELEN_K_GRU_DEC, gru_bf16_kernel, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0,
-               0, T, m->whpb_dec, m->bhn_dec, m->hid, m->y2, kYTileStride);
+               0, T, m->whpb_dec, m->bhn_dec, m->hid, m->y2, kYTileStride, (f32x4*)nullptr, kY1bTileStride);
         return;
     }
     if (m->precision == HELEN_PRECISION_FP32X3) {
@@ -316,7 +319,7 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
         LAUNCH(HELEN_K_GRU_ENC, gru_x3_kernel<HELEN_X3_NT>, dim3((tiles + HELEN_X3_NT - 1) / HELEN_X3_NT, 2),
                dim3(512), m->gi_enc, kGiEncTileStride, pos0, enc_npos - pos0 - T, T, m->w3h_enc, m->bhn_enc,
                m->hid, (f32x4*)nullptr, kYTileStride, m->y1p, kY1pTileStride, tiles);
-        LAUNCH(HELEN_K_GEMM_DEC, gemm_dec_x3_kernel, dim3(3 * ((tiles + 7) / 8 * 8)), dim3(512), m->y1p, kY1pTileStride,
+        LAUNCH(HELEN_K_GEMM_DEC, (gemm_dec_x3_kernel<3, 2>), dim3(3 * ((tiles + 7) / 8 * 8)), dim3(512), m->y1p, kY1pTileStride,
                (const f32x4*)m->w3i_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
         LAUNCH(HELEN_K_GRU_DEC, gru_x3_kernel<HELEN_X3_NT>, dim3((tiles + HELEN_X3_NT - 1) / HELEN_X3_NT, 2),
                dim3(512), m->gi_dec, kGiDecTileStride, 0, 0, T, m->w3h_dec, m->bhn_dec, m->hid, m->y2,
@@ -390,6 +393,11 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
         if ((rc = upload(m, &m->wpb_dec, round_pack(pack_w_ih(w->dec_w_ih, 2 * kH, 16))))) return rc;
         if ((rc = upload(m, &m->whpb_enc, round_pack(pack_w_hh(w->enc_w_hh))))) return rc;
         if ((rc = upload(m, &m->whpb_dec, round_pack(pack_w_hh(w->dec_w_hh))))) return rc;
+        // weight-stationary projections read term 0 (= RNE(w)) of the three-term packing
+        if ((rc = upload(m, &m->w3i_dec, pack_w_ih_x3(w->dec_w_ih)))) return rc;
+        if ((rc = upload(m, &m->w3i_enc, pack_w_ih_x3(w->enc_w_ih, kF)))) return rc;
+        if ((rc = dev_alloc(m, &m->xb, (size_t)m->max_tiles * kSeq * 192))) return rc;
+        if ((rc = dev_alloc(m, &m->y1p, (size_t)m->max_tiles * kY1bTileStride))) return rc;
     }
     {
         std::vector<f32x4> whd(16 * 64);
@@ -488,12 +496,18 @@ int helen_polish_batch(HelenModel* m, const uint8_t* images, int n_windows, uint
     hipStream_t s = (hipStream_t)stream;
     const int tiles = (n_windows + kTile - 1) / kTile;
 
-    if (m->precision == HELEN_PRECISION_FP32X3) {
-        // pileup counts are exact in bf16: pack them straight into A fragments, three exact products per w
+    if (m->precision == HELEN_PRECISION_FP32X3 || m->precision == HELEN_PRECISION_BF16) {
+        // pileup counts are exact in bf16: pack them straight into A fragments; three exact products per w
+        // (fp32x3) or the one product with w rounded to bf16 (bf16)
         LAUNCH(HELEN_K_PACK, pack_images_x3_kernel, dim3((kSeq * 192 + 255) / 256, tiles), dim3(256), images,
                n_windows, kSeq, m->xb);
-        LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_x3_kernel, dim3(3 * ((tiles + 7) / 8 * 8)), dim3(512), m->xb, (long)kSeq * 192,
-               (const f32x4*)m->w3i_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, kSeq, tiles);
+        const dim3 egrid(3 * ((tiles + 7) / 8 * 8));
+        if (m->precision == HELEN_PRECISION_FP32X3)
+            LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_x3_kernel<3>, egrid, dim3(512), m->xb, (long)kSeq * 192,
+                   (const f32x4*)m->w3i_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, kSeq, tiles);
+        else
+            LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_x3_kernel<1>, egrid, dim3(512), m->xb, (long)kSeq * 192,
+                   (const f32x4*)m->w3i_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, kSeq, tiles);
     } else {
         // uint8 -> fp32 operand tiles (predict_gpu.py:97)
         LAUNCH(HELEN_K_PACK, pack_images_kernel, dim3((kSeq * (kXaStride / 4) + 255) / 256, tiles),

@@ -624,7 +624,11 @@ __global__ __launch_bounds__(256, 2) void gru_bf16_kernel(const f32x4* __restric
                                                           const bf16x4* __restrict__ Whp,
                                                           const float* __restrict__ bhn,
                                                           f32x4* __restrict__ hid, f32x4* __restrict__ y,
-                                                          long y_tile_stride) {
+                                                          long y_tile_stride, f32x4* __restrict__ yplane,
+                                                          long yp_tile_stride) {
+    // Layer output: fp32 y (KB16, for the heads) when `yplane` is null, otherwise ONE bf16 plane
+    // yplane[tile][slot][dir][256 units of 16 B] = h rounded to bf16 (RNE) in the K = 32 A-fragment
+    // layout gemm_dec_x3_kernel<1, .> consumes (unit (k/8)*16 + row holds 8 consecutive k of a row).
     __shared__ f32x4 smem[2 * 512 + 4 * 384];
     f32x4* const hbuf = smem;
     const int tid = threadIdx.x;
@@ -697,7 +701,11 @@ __global__ __launch_bounds__(256, 2) void gru_bf16_kernel(const f32x4* __restric
 #pragma unroll
             for (int n = 0; n < 6; ++n) acc[n] = mfma_bf16(a, W[n][m], acc[n]);
         }
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // gi DMA landed (see gru_kernel)
+        // gi DMA landed (see gru_kernel): behind the 6 DMAs sit this step's output stores, 2 (y) or 1 (plane)
+        if (yplane != nullptr)
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         f32x4 G[6];
 #pragma unroll
         for (int n = 0; n < 6; ++n) G[n] = gbuf[n * 64 + lane];
@@ -717,10 +725,20 @@ __global__ __launch_bounds__(256, 2) void gru_bf16_kernel(const f32x4* __restric
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        f32x4* yo = y_p + (size_t)s * (kYStride / 4);
         const f32x4* hn4 = hbuf + (cur ^ 1) * 512;
-        yo[tid] = hn4[tid];
-        yo[tid + 256] = hn4[tid + 256];
+        if (yplane != nullptr) {
+            // thread = unit (octet o = tid >> 4, row = tid & 15): KB16 float4s 2o and 2o+1 of the row
+            const int row = tid & 15, o = tid >> 4;
+            const f32x4 lo = hn4[(2 * o) * 16 + row], hi = hn4[(2 * o + 1) * 16 + row];
+            const bf16x4 l4 = to_bf16x4(lo), h4 = to_bf16x4(hi);
+            uint2 a = __builtin_bit_cast(uint2, l4), b = __builtin_bit_cast(uint2, h4);
+            uint4 u = {a.x, a.y, b.x, b.y};
+            (yplane + (size_t)tile * yp_tile_stride + ((size_t)s * 2 + dir) * 256)[tid] = __builtin_bit_cast(f32x4, u);
+        } else {
+            f32x4* yo = y_p + (size_t)s * (kYStride / 4);
+            yo[tid] = hn4[tid];
+            yo[tid + 256] = hn4[tid + 256];
+        }
     }
     const f32x4* hl = hbuf + (T & 1) * 512;
     hid_p[tid] = hl[tid];
@@ -940,15 +958,20 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
 //   staged instead of 8-11 for a block-tiled kernel that also stages the weights.
 //   k < 128 comes from the forward encoder direction at slot p, k >= 128 from the backward one at
 //   slot npos-1-p; output slot order as gemm_gi_kernel.  grid (3 column sets, window tiles).
+//   NP = 3 planes / weight terms (fp32x3: six products) or 1 (HELEN_PRECISION_BF16: Y1 and W_ih rounded to
+//   bf16, one product); PB = positions per stage (NP * PB * 8 rows of 1 KiB).
 // ------------------------------------------------------------------------------------------------
+template <int NP, int PB>
 __global__ __launch_bounds__(512) void gemm_dec_x3_kernel(const f32x4* __restrict__ yplanes,
                                                           long yp_tile_stride,
                                                           const f32x4* __restrict__ W3d,
                                                           const float* __restrict__ bias,
                                                           f32x4* __restrict__ gi, long gi_tile_stride,
                                                           int npos, int ntiles) {
-    constexpr int ROWS = 2 * 3 * 8;   // rows of 1 KiB per stage: (position, plane, group)
-    __shared__ f32x4 smem[2 * ROWS * 64];   // 96 KiB
+    static_assert(NP == 1 || NP == 3, "one bf16 plane or the three-term split");
+    constexpr int ROWS = PB * NP * 8;       // rows of 1 KiB per stage: (position, plane, group)
+    static_assert(ROWS % 8 == 0 && 2 * ROWS <= 96, "two stages must fit 96 KiB");
+    __shared__ f32x4 smem[2 * ROWS * 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -963,8 +986,8 @@ __global__ __launch_bounds__(512) void gemm_dec_x3_kernel(const f32x4* __restric
     const int dir = gt0 / kNTile;
     const int nt = gt0 % kNTile;
 
-    // weight terms -> registers: B[ti][M][t]
-    bf16x8 B[2][8][3];
+    // weight terms -> registers: B[ti][M][t]  (W3d always holds three terms; term 0 = RNE(w))
+    bf16x8 B[2][8][NP];
     {
         const bf16x8* wp = (const bf16x8*)W3d + lane;
 #pragma unroll
@@ -972,73 +995,76 @@ __global__ __launch_bounds__(512) void gemm_dec_x3_kernel(const f32x4* __restric
 #pragma unroll
             for (int M = 0; M < 8; ++M)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) B[ti][M][t] = wp[((size_t)((gt0 + ti) * 8 + M) * 3 + t) * 64];
+                for (int t = 0; t < NP; ++t) B[ti][M][t] = wp[((size_t)((gt0 + ti) * 8 + M) * 3 + t) * 64];
     }
     float bs[2];
     bs[0] = bias[dir * kG + nt * 16 + (lane & 15)];
     bs[1] = bias[dir * kG + (nt + 1) * 16 + (lane & 15)];
 
     const f32x4* yp = yplanes + (size_t)tile * yp_tile_stride + lane;
-    // DMA of position pair g into buffer b; row r = (p*3 + plane)*8 + M is copied by wave r % 8
+    // DMA of position group g into buffer b; row r = (p*NP + plane)*8 + M is copied by wave r % 8
     auto stage = [&](int g, int b) {
         f32x4* dst = smem + b * (ROWS * 64);
 #pragma unroll
         for (int i = 0; i < ROWS / 8; ++i) {
             const int r = w + 8 * i;
-            const int M = r & 7, plane = (r >> 3) % 3, p = r / 24;
+            const int M = r & 7, plane = (r >> 3) % NP, p = r / (8 * NP);
             const int part = M >> 2;
-            const int pc = min(2 * g + p, npos - 1);
+            const int pc = min(PB * g + p, npos - 1);
             const int slot = part ? (npos - 1 - pc) : pc;
-            const f32x4* src = yp + ((size_t)slot * 2 + part) * 768 + plane * 256 + (M & 3) * 64;
+            const f32x4* src = yp + ((size_t)slot * 2 + part) * (NP * 256) + plane * 256 + (M & 3) * 64;
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                              (void __attribute__((address_space(3)))*)(dst + r * 64), 16, 0, 0);
         }
     };
-    constexpr int TA[6] = {0, 2, 1, 0, 1, 0};   // six leading products, smallest first: term of A
-    constexpr int TB[6] = {2, 0, 1, 1, 0, 0};   //                                        term of B
-    const int ng = (npos + 1) / 2;
+    constexpr int NPROD = NP == 3 ? 6 : 1;
+    constexpr int TA[6] = {NP == 3 ? 0 : 0, 2, 1, 0, 1, 0};   // leading products, smallest first: term of A
+    constexpr int TB[6] = {NP == 3 ? 2 : 0, 0, 1, 1, 0, 0};   //                                   term of B
+    const int ng = (npos + PB - 1) / PB;
     stage(0, 0);
     for (int g = 0; g < ng; ++g) {
-        // this wave's rows of pair g have landed; after the barrier everybody's have, and the
-        // other buffer (read during pair g-1) is free for pair g+1.  VMEM queue, oldest first: the 6
-        // DMA rows of pair g, then the 4 output stores of pair g-1 -- which may stay in flight.
+        // this wave's rows of group g have landed; after the barrier everybody's have, and the
+        // other buffer (read during group g-1) is free for group g+1.  VMEM queue, oldest first: the
+        // DMA rows of group g, then the 2 * PB output stores of group g-1 -- which may stay in flight.
         if (g == 0)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PB) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (g + 1 < ng) stage(g + 1, (g + 1) & 1);
         const bf16x8* L = (const bf16x8*)(smem + (g & 1) * (ROWS * 64)) + lane;
-        f32x4 acc[2][2];
-        acc[0][0] = acc[1][0] = splat4(bs[0]);
-        acc[0][1] = acc[1][1] = splat4(bs[1]);
+        f32x4 acc[PB][2];
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            acc[p][0] = splat4(bs[0]);
+            acc[p][1] = splat4(bs[1]);
+        }
 #pragma unroll
         for (int M = 0; M < 8; ++M) {
-            bf16x8 a[2][3];
+            bf16x8 a[PB][NP];
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
+            for (int p = 0; p < PB; ++p)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) a[p][t] = L[((p * 3 + t) * 8 + M) * 64];
+                for (int t = 0; t < NP; ++t) a[p][t] = L[((p * NP + t) * 8 + M) * 64];
 #pragma unroll
-            for (int k = 0; k < 6; ++k)
+            for (int k = 0; k < NPROD; ++k)
 #pragma unroll
                 for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-                    for (int p = 0; p < 2; ++p)
+                    for (int p = 0; p < PB; ++p)
                         acc[p][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p][TA[k]], B[ti][M][TB[k]],
                                                                             acc[p][ti], 0, 0, 0);
         }
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int pos = 2 * g + p;
-            if (pos < npos) {
-                const int slot = dir ? (npos - 1 - pos) : pos;
-                f32x4* o = gi + (size_t)tile * gi_tile_stride + ((size_t)slot * 2 + dir) * (kNTile * 64) + nt * 64 +
-                           lane;
-                o[0] = acc[p][0];
-                o[64] = acc[p][1];
-            }
+        for (int p = 0; p < PB; ++p) {
+            // exactly 2 * PB stores per lane per stage (counted above): positions past the end of the last
+            // stage rewrite the last valid one with identical values
+            const int pos = min(PB * g + p, npos - 1);
+            const int slot = dir ? (npos - 1 - pos) : pos;
+            f32x4* o = gi + (size_t)tile * gi_tile_stride + ((size_t)slot * 2 + dir) * (kNTile * 64) + nt * 64 + lane;
+            o[0] = acc[p][0];
+            o[64] = acc[p][1];
         }
     }
 }
@@ -1078,6 +1104,8 @@ __global__ __launch_bounds__(256) void pack_images_x3_kernel(const uint8_t* __re
     xb[((size_t)tile * npos + pos) * 192 + o * 16 + row] = __builtin_bit_cast(f32x4, u);
 }
 
+//   TERMS = 3 (fp32x3) or 1 (HELEN_PRECISION_BF16: W_ih rounded to bf16, i.e. the first term only).
+template <int TERMS>
 __global__ __launch_bounds__(512) void gemm_enc_x3_kernel(const f32x4* __restrict__ xb, long xb_tile_stride,
                                                           const f32x4* __restrict__ W3e,
                                                           const float* __restrict__ bias,
@@ -1098,7 +1126,7 @@ __global__ __launch_bounds__(512) void gemm_enc_x3_kernel(const f32x4* __restric
     const int gt0 = 16 * set + 2 * w;
     const int dir = gt0 / kNTile;
     const int nt = gt0 % kNTile;
-    bf16x8 B[2][3][3];
+    bf16x8 B[2][3][TERMS];
     {
         const bf16x8* wp = (const bf16x8*)W3e + lane;
 #pragma unroll
@@ -1106,7 +1134,7 @@ __global__ __launch_bounds__(512) void gemm_enc_x3_kernel(const f32x4* __restric
 #pragma unroll
             for (int M = 0; M < 3; ++M)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) B[ti][M][t] = wp[((size_t)((gt0 + ti) * 3 + M) * 3 + t) * 64];
+                for (int t = 0; t < TERMS; ++t) B[ti][M][t] = wp[((size_t)((gt0 + ti) * 3 + M) * 3 + t) * 64];
     }
     float bs[2];
     bs[0] = bias[dir * kG + nt * 16 + (lane & 15)];
@@ -1147,7 +1175,7 @@ __global__ __launch_bounds__(512) void gemm_enc_x3_kernel(const f32x4* __restric
 #pragma unroll
             for (int p = 0; p < PB; ++p) a[p] = L[(p * 3 + M) * 64];
 #pragma unroll
-            for (int t = 2; t >= 0; --t)   // smallest term first
+            for (int t = TERMS - 1; t >= 0; --t)   // smallest term first
 #pragma unroll
                 for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
