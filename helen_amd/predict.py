@@ -10,12 +10,14 @@ double-buffered copies and labels come back as uint8; reader processes fill shar
 while the previous slot is on the GPU and the one before is being written by a writer thread.
 No process group is created (the reference's gloo group is never used on this path).
 
-$HELEN_WRITERS=W (default 1) shards the prediction writer over W processes per rank: creating the
-three small HDF5 datasets of a window costs ~70 us inside libhdf5, ~14 k windows/s per process.
+The prediction writer is sharded over W processes per rank (W = $HELEN_WRITERS, default one per four
+reader workers, 1..8): creating the three small HDF5 datasets of a window costs ~70 us inside
+libhdf5, ~10-14 k windows/s per process, against ~75 k windows/s of device throughput.
 Writer 0 keeps the reference's file name `<output>_<rank>.hdf`, writer k > 0 writes
 `<output>_<rank>_w<k>.hdf`; all chunks of one region go to the same file, and stitch takes every
 `*.hdf` of the directory (StitchInterface.py:35-36), so the result is the same.
 """
+import collections
 import multiprocessing as mp
 import os
 import queue
@@ -26,9 +28,9 @@ import time
 import numpy as np
 
 from .data_store import DataStore
-from .model_handler import ModelHandler
 from .options import ImageSizeOptions
-from .sequence_dataset import SequenceDataset, SharedSlot, attach_slot, fill_shared
+from .prediction_writer import prediction_file_name, writer_of_region, writer_process  # noqa: F401
+from .sequence_dataset import SequenceDataset, SharedSlot, fill_shared
 
 # windows per device call: scratch is ~4 MB per window, 4096 windows fill 256 CUs x 2 workgroups
 DEVICE_CALL_WINDOWS = 4096
@@ -54,37 +56,73 @@ def _writer_loop(wq, store, free_slots, err):
         free_slots.put(None)
 
 
-def writer_of_region(meta, writers):
-    """Writer index per window: a hash of contig_start, so that every chunk of a region -- and a
-    repeat of the same (region, chunk id), which must be dropped by the one file that has it
-    (DataStore.py:102-124) -- lands in the same file."""
-    key = meta[:, 0].astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
-    return ((key >> np.uint64(40)) % np.uint64(writers)).astype(np.int64)
+class _DeviceStage(object):
+    """The device stage as a three-stream pipeline: H2D of slot k+1 | kernels of slot k | D2H of slot
+    k-1, two device image buffers.  The slots' shared mappings are page-locked in place
+    (hipHostRegister, through torch's runtime binding) so both copies are plain DMA from / into the
+    memory the readers fill and the writers read -- no staging copy, nothing blocks the host until
+    `pop()` waits for the oldest slot's labels.  helen_polish_batch (device pointers, asynchronous
+    on the current stream) does the work."""
+
+    def __init__(self, engine, slots, cap, device):
+        import torch
+        self.torch, self.engine = torch, engine
+        self.dev = torch.device("cuda", device)
+        self.rt = torch.cuda.cudart()
+        self.registered = []
+        for sl in slots:
+            ptr, nbytes = sl.base_address()
+            rc = self.rt.cudaHostRegister(ptr, nbytes, 0)
+            if int(rc) != 0:
+                self.close()
+                raise RuntimeError("hipHostRegister failed (%s)" % (rc,))
+            self.registered.append(ptr)
+        self.s_in, self.s_out = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
+        L, H = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT
+        self.img = [torch.empty((cap, L, H), dtype=torch.uint8, device=self.dev) for _ in range(2)]
+        self.busy = [None, None]          # event after which img[i] may be overwritten
+        self.k = 0
+        self.inflight = collections.deque()
+
+    def submit(self, slot, n):
+        torch = self.torch
+        i = self.k & 1
+        self.k += 1
+        compute = torch.cuda.current_stream(self.dev)
+        with torch.cuda.stream(self.s_in):
+            if self.busy[i] is not None:
+                self.s_in.wait_event(self.busy[i])
+            self.img[i][:n].copy_(torch.from_numpy(slot.images[:n]), non_blocking=True)
+            ev_in = self.s_in.record_event()
+        compute.wait_event(ev_in)
+        bases, rles = self.engine.polish(self.img[i][:n])
+        ev_c = compute.record_event()
+        self.busy[i] = ev_c
+        with torch.cuda.stream(self.s_out):
+            self.s_out.wait_event(ev_c)
+            torch.from_numpy(slot.bases[:n]).copy_(bases, non_blocking=True)
+            torch.from_numpy(slot.rles[:n]).copy_(rles, non_blocking=True)
+            ev_out = self.s_out.record_event()
+        self.inflight.append((slot, n, ev_out, (bases, rles)))     # keep the device labels alive
+
+    def pop(self):
+        slot, n, ev, _ = self.inflight.popleft()
+        ev.synchronize()
+        return slot, n
+
+    def close(self):
+        for ptr in self.registered:
+            self.rt.cudaHostUnregister(ptr)
+        self.registered = []
 
 
-def prediction_file_name(output_filename, rank, writer=0):
-    return output_filename + "_" + str(rank) + ("" if writer == 0 else "_w" + str(writer)) + ".hdf"
-
-
-def _writer_process(k, writers, filename, task_q, done_q):
-    """Writer process k of `writers`: for every device call, store the windows of its regions."""
-    try:
-        store = DataStore(filename, mode="w")
-        while True:
-            task = task_q.get()
-            if task is None:
-                break
-            path, cap, n = task
-            slot = attach_slot(path, cap)
-            sel = np.nonzero(writer_of_region(slot.meta[:n], writers) == k)[0].astype(np.int32)
-            if sel.size:
-                store.write_batch(slot.contigs[:n], slot.meta[:n], slot.positions[:n], slot.bases[:n],
-                                  slot.rles[:n], sel=sel)
-            done_q.put((path, None))
-        store.close()
-        done_q.put((None, None))
-    except Exception as e:
-        done_q.put((None, "writer %d: %r" % (k, e)))
+def writer_count(num_workers):
+    """Writer processes per rank: $HELEN_WRITERS if set, else one per four reader workers (1..8) --
+    `-w 0..7` keeps the reference's single `<output>_<rank>.hdf`."""
+    env = os.environ.get("HELEN_WRITERS")
+    if env:
+        return max(1, int(env))
+    return min(8, max(1, int(num_workers) // 4))
 
 
 class _WriterPool(object):
@@ -95,7 +133,7 @@ class _WriterPool(object):
         self.writers, self.free_slots, self.err = writers, free_slots, err
         self.done_q = ctx.Queue()
         self.task_qs = [ctx.Queue() for _ in range(writers)]
-        self.procs = [ctx.Process(target=_writer_process, daemon=True,
+        self.procs = [ctx.Process(target=writer_process, daemon=True,
                                   args=(k, writers, prediction_file_name(output_filename, rank, k),
                                         self.task_qs[k], self.done_q))
                       for k in range(writers)]
@@ -142,22 +180,24 @@ class _WriterPool(object):
             self.t_busy = None
 
 
-def _feeder_loop(calls, free_slots, ready_q, pool, cap, err):
-    """Feeder thread: for each device call take a free slot and get its loader batches read into
-    it -- by the worker pool (one task per loader batch) or inline when num_workers == 0."""
+def _feeder_loop(calls, free_slots, ready_q, pool, cap, err, num_workers=0):
+    """Feeder thread: for each device call take a free slot and get its windows read into it -- by
+    the worker pool, in about two contiguous tasks per worker so that every worker has something
+    to do whatever the loader batch size is, or inline when num_workers == 0."""
     try:
         for batches in calls:
             slot = free_slots.get()
             if slot is None:
                 return
-            futures, off = [], 0
-            for pairs in batches:
-                if pool is not None:
-                    futures.append(pool.submit(fill_shared, slot.path, cap, off, pairs))
-                else:
-                    fill_shared(slot.path, cap, off, pairs)
-                off += len(pairs)
-            ready_q.put((slot, off, futures, len(batches)))
+            pairs = [p for b in batches for p in b]
+            futures = []
+            if pool is not None:
+                step = max(16, -(-len(pairs) // max(1, 2 * num_workers)))
+                for off in range(0, len(pairs), step):
+                    futures.append(pool.submit(fill_shared, slot.path, cap, off, pairs[off:off + step]))
+            else:
+                fill_shared(slot.path, cap, 0, pairs)
+            ready_q.put((slot, len(pairs), futures, len(batches)))
         ready_q.put(None)
     except Exception as e:
         err.append(e)
@@ -168,10 +208,12 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     """Run inference over the image files `test_file` (a list) on device `device_id` and write
     `<output_filename>_<rank>.hdf` (predict_gpu.py:38-179).
 
-    Pipeline (three stages, three shared-memory slots of one device call each):
-      reader processes fill slot k+1 | the GPU polishes slot k | the writer thread stores slot k-1."""
+    Pipeline over shared-memory slots of one device call each:
+      reader processes fill slot k+2 | H2D k+1 | kernels k | D2H k-1 | writer(s) store slot k-2."""
     import torch
-    writers = max(1, int(os.environ.get("HELEN_WRITERS", "1")))
+
+    from .model_handler import ModelHandler
+    writers = writer_count(num_workers)
     prediction_data_file = DataStore(prediction_file_name(output_filename, rank), mode="w") \
         if writers == 1 else None
     transducer_model, hidden_size, gru_layers, prev_ite = ModelHandler.load_simple_model(
@@ -198,7 +240,8 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     calls = [batches[i:i + group] for i in range(0, len(batches), group)]           # short last batch
     total_batches = len(batches)
 
-    slots = [SharedSlot(cap) for _ in range(min(3, max(1, len(calls))))]
+    # reader filling | H2D | kernels | D2H | writer: five slots keep every stage busy
+    slots = [SharedSlot(cap) for _ in range(min(5, max(1, len(calls))))]
     free_slots, ready_q, wq = queue.Queue(), queue.Queue(maxsize=2), queue.Queue()
     for sl in slots:
         free_slots.put(sl)
@@ -207,7 +250,7 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         import concurrent.futures as cf
         pool = cf.ProcessPoolExecutor(num_workers, mp_context=mp.get_context("spawn"))
     ferr, werr = [], []
-    feeder = threading.Thread(target=_feeder_loop, args=(calls, free_slots, ready_q, pool, cap, ferr),
+    feeder = threading.Thread(target=_feeder_loop, args=(calls, free_slots, ready_q, pool, cap, ferr, num_workers),
                               daemon=True)
     for k in STAGE_SECONDS:
         STAGE_SECONDS[k] = 0.0
@@ -219,6 +262,20 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     else:
         writer_pool = _WriterPool(output_filename, rank, writers, free_slots, werr)
     feeder.start()
+    stage = None
+    if os.environ.get("HELEN_DEVICE_STAGE", "async") != "sync" and hasattr(engine, "polish") \
+            and torch.cuda.is_available() and calls:
+        try:
+            stage = _DeviceStage(engine, slots, cap, device_id)
+        except Exception as e:      # page-locking refused (ulimit -l, container policy): staged copies
+            sys.stderr.write("INFO: SLOTS NOT PAGE-LOCKED (" + str(e) + "), USING STAGED COPIES.\n")
+
+    def to_writer(slot, n):
+        if writer_pool is None:
+            wq.put((slot, n, slot.bases[:n], slot.rles[:n]))
+        else:
+            writer_pool.submit(slot, n)
+
     start_time = time.time()
     batch_iterator = 0
     try:
@@ -231,13 +288,15 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
             for f in futures:
                 f.result()                       # raises the reader's exception, if any
             t1 = time.time()
-            bases, rles = engine.polish_host(slot.images[:n], out=(slot.bases[:n], slot.rles[:n]))
+            if stage is not None:
+                stage.submit(slot, n)
+                while len(stage.inflight) > 1:   # keep one call in flight behind the one just queued
+                    to_writer(*stage.pop())
+            else:
+                engine.polish_host(slot.images[:n], out=(slot.bases[:n], slot.rles[:n]))
+                to_writer(slot, n)
             STAGE_SECONDS["read_wait"] += t1 - t0
             STAGE_SECONDS["device"] += time.time() - t1
-            if writer_pool is None:
-                wq.put((slot, n, bases, rles))
-            else:
-                writer_pool.submit(slot, n)
             batch_iterator += nb
             if rank == 0:
                 eta = (time.time() - start_time) / batch_iterator * (total_batches - batch_iterator)
@@ -245,12 +304,18 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
                                  % (batch_iterator, total_batches, int(eta // 60), int(eta) % 60))
             if werr:
                 break
+        t1 = time.time()
+        while stage is not None and stage.inflight and not werr:
+            to_writer(*stage.pop())
+        STAGE_SECONDS["device"] += time.time() - t1
     finally:
         if writer_pool is None:
             wq.put(None)
             writer.join()
         else:
             writer_pool.close()
+        if stage is not None:
+            stage.close()
         if pool is not None:
             pool.shutdown(wait=True, cancel_futures=True)
         for sl in slots:

@@ -144,6 +144,10 @@ class SharedSlot(object):
         self.bases = self._mm[o4:o4 + self._sizes[4]].reshape(self.cap, L)
         self.rles = self._mm[o5:o5 + self._sizes[5]].reshape(self.cap, L)
 
+    def base_address(self):
+        """(address, bytes) of the whole mapping, for page-locking it in place."""
+        return self._mm.ctypes.data, int(self._mm.nbytes)
+
     def close(self):
         import os
         self.images = self.positions = self.meta = self.contigs = self.bases = self.rles = None

@@ -10,14 +10,10 @@ import tempfile
 import time
 
 import numpy as np
-import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from helen_amd.engine import HelenEngine  # noqa: E402
-from helen_amd.weights import make_weights  # noqa: E402
-from helen_amd.call_consensus import call_consensus  # noqa: E402
-from helen_amd.model_handler import ModelHandler  # noqa: E402
-from helen_amd.synthetic import write_image_dir  # noqa: E402
+# torch and the engine are imported inside the probes: reader / writer processes re-import this file
+# (spawn) and must stay as light as they are under `python -m helen_amd`
 
 
 def main():
@@ -29,6 +25,7 @@ def main():
     ap.add_argument("--skip-host", action="store_true")
     args = ap.parse_args()
 
+    from helen_amd.weights import make_weights
     w = make_weights(input_scale=1.0 / 64.0)
     if not args.skip_host:
         host_probe(w, args)
@@ -36,6 +33,8 @@ def main():
 
 
 def host_probe(w, args):
+    import torch
+    from helen_amd.engine import HelenEngine
     eng = HelenEngine(w, device=0, max_windows=4096)
     rng = np.random.default_rng(1)
     img = rng.integers(0, 256, size=(args.windows, 1000, 90), dtype=np.uint8)
@@ -52,6 +51,9 @@ def host_probe(w, args):
 
 
 def e2e_probe(w, args):
+    from helen_amd.call_consensus import call_consensus
+    from helen_amd.model_handler import ModelHandler
+    from helen_amd.synthetic import write_image_dir
     d = tempfile.mkdtemp(prefix="helen_e2e_")
     try:
         model = os.path.join(d, "m.pkl")
