@@ -41,6 +41,19 @@ def add_stitch_arguments(parser):
     return parser
 
 
+def add_test_arguments(parser):
+    """`helen_train test` (helen/helen_train.py:87-136)."""
+    parser.add_argument("--test_image_dir", type=str, required=True,
+                        help="Path to directory containing labeled images for testing the models.")
+    parser.add_argument("--batch_size", type=int, required=False, default=100, help="Batch size, default is 100.")
+    parser.add_argument("--model_path", type=str, required=False, default="./model", help="Path of the model to load")
+    parser.add_argument("--gpu_mode", action="store_true", help="Run on the MI355X HIP path (required).")
+    parser.add_argument("--print_details", action="store_true", help="Accepted for compatibility.")
+    parser.add_argument("--output_dir", type=str, required=False, default="./debug_output", help="Output directory.")
+    parser.add_argument("--num_workers", type=int, required=False, default=40, help="Accepted for compatibility.")
+    return parser
+
+
 def build_parser():
     parser = argparse.ArgumentParser(
         prog="helen", formatter_class=argparse.RawTextHelpFormatter,
@@ -49,6 +62,7 @@ def build_parser():
     add_polish_arguments(sub.add_parser("polish", help="call_consensus, then stitch"), 1)
     add_polish_arguments(sub.add_parser("call_consensus", help="generate the prediction HDF5 files"), 16)
     add_stitch_arguments(sub.add_parser("stitch", help="prediction HDF5 files -> polished FASTA"))
+    add_test_arguments(sub.add_parser("test", help="evaluate a model on labeled images (helen_train test)"))
     sub.add_parser("version", help="show the version")
     sub.add_parser("torch_stat", help="show torch / device configuration")
     return parser
@@ -70,6 +84,11 @@ def main(argv=None):
     elif flags.sub_command == "stitch":
         from .stitch import perform_stitch
         perform_stitch(flags.input_dir, flags.output_dir, flags.output_prefix, flags.threads)
+    elif flags.sub_command == "test":
+        from .evaluate import test_interface
+        sys.stderr.write("INFO: TEST MODULE SELECTED\n")
+        test_interface(flags.test_image_dir, flags.batch_size, flags.gpu_mode, flags.num_workers,
+                       flags.model_path, flags.output_dir, flags.print_details)
     elif flags.sub_command == "version":
         print("HELEN-MI355X VERSION: " + __version__)
     elif flags.sub_command == "torch_stat":

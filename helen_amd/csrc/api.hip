@@ -487,15 +487,9 @@ int helen_model_device_bytes(const HelenModel* m, size_t* out_bytes) {
     return HELEN_OK;
 }
 
-int helen_polish_batch(HelenModel* m, const uint8_t* images, int n_windows, uint8_t* bases,
-                       uint8_t* rles, float* acc_base_opt, float* acc_rle_opt, void* stream) {
-    if (!m || !images || !bases || !rles) return fail(HELEN_EINVAL, "null argument");
-    if (n_windows <= 0 || n_windows > m->max_windows)
-        return fail(HELEN_EINVAL, "n_windows %d outside 1..%d", n_windows, m->max_windows);
-    HIP_TRY(hipSetDevice(m->device));
-    hipStream_t s = (hipStream_t)stream;
-    const int tiles = (n_windows + kTile - 1) / kTile;
-
+// uint8 windows -> operand tiles -> encoder input projection for all 1000 positions (overlapping chunks
+// share it) -> zero initial hidden (predict_gpu.py:97-99): everything before the chunk loop.
+static int launch_front(HelenModel* m, hipStream_t s, const uint8_t* images, int n_windows, int tiles) {
     if (m->precision == HELEN_PRECISION_FP32X3 || m->precision == HELEN_PRECISION_BF16) {
         // pileup counts are exact in bf16: pack them straight into A fragments; three exact products per w
         // (fp32x3) or the one product with w rounded to bf16 (bf16)
@@ -512,11 +506,23 @@ int helen_polish_batch(HelenModel* m, const uint8_t* images, int n_windows, uint
         // uint8 -> fp32 operand tiles (predict_gpu.py:97)
         LAUNCH(HELEN_K_PACK, pack_images_kernel, dim3((kSeq * (kXaStride / 4) + 255) / 256, tiles),
                dim3(256), images, n_windows, kSeq, m->xa);
-        // encoder input projection for all 1000 positions at once: overlapping chunks share it
         launch_enc_gemm(m, s, tiles, kSeq);
     }
     // zero initial hidden per batch (predict_gpu.py:99)
     HIP_TRY(hipMemsetAsync(m->hid, 0, (size_t)tiles * kHidStride * sizeof(float), s));
+    return HELEN_OK;
+}
+
+int helen_polish_batch(HelenModel* m, const uint8_t* images, int n_windows, uint8_t* bases,
+                       uint8_t* rles, float* acc_base_opt, float* acc_rle_opt, void* stream) {
+    if (!m || !images || !bases || !rles) return fail(HELEN_EINVAL, "null argument");
+    if (n_windows <= 0 || n_windows > m->max_windows)
+        return fail(HELEN_EINVAL, "n_windows %d outside 1..%d", n_windows, m->max_windows);
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = (n_windows + kTile - 1) / kTile;
+    int rc = launch_front(m, s, images, n_windows, tiles);
+    if (rc) return rc;
     for (int c = 0; c < kChunks; ++c) {  // predict_gpu.py:114-149
         launch_chunk(m, s, tiles, c * kJump, kWin, kSeq);
         LAUNCH(HELEN_K_HEADS, heads_kernel, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->y2, kYTileStride, m->whd,
@@ -524,6 +530,31 @@ int helen_polish_batch(HelenModel* m, const uint8_t* images, int n_windows, uint
                (float*)nullptr, (float*)nullptr);
     }
     return check_launch("helen_polish_batch");
+}
+
+int helen_evaluate_batch(HelenModel* m, const uint8_t* images, const uint8_t* label_base,
+                         const uint8_t* label_rle, int n_windows, const float* rle_class_weights,
+                         float* chunk_stats, unsigned long long* base_confusion,
+                         unsigned long long* rle_confusion, void* stream) {
+    if (!m || !images || !label_base || !label_rle || !rle_class_weights || !chunk_stats || !base_confusion ||
+        !rle_confusion)
+        return fail(HELEN_EINVAL, "null argument");
+    if (n_windows <= 0 || n_windows > m->max_windows)
+        return fail(HELEN_EINVAL, "n_windows %d outside 1..%d", n_windows, m->max_windows);
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = (n_windows + kTile - 1) / kTile;
+    RleClassWeights cw;
+    for (int i = 0; i < kNR; ++i) cw.w[i] = rle_class_weights[i];
+    int rc = launch_front(m, s, images, n_windows, tiles);
+    if (rc) return rc;
+    for (int c = 0; c < kChunks; ++c) {  // models/test.py:95-121
+        launch_chunk(m, s, tiles, c * kJump, kWin, kSeq);
+        LAUNCH(HELEN_K_HEADS, heads_eval_kernel, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->y2, kYTileStride,
+               m->whd, m->bhd, c, kWin, n_windows, label_base, label_rle, cw, chunk_stats, base_confusion,
+               rle_confusion);
+    }
+    return check_launch("helen_evaluate_batch");
 }
 
 int helen_gru_chunk_forward(HelenModel* m, const float* x, const float* h_in, int B, int T,

@@ -1343,4 +1343,104 @@ __global__ __launch_bounds__(256) void heads_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Heads + cross-entropy + confusion counts: the per-chunk body of the reference's evaluation loop
+// (models/test.py:104-121) for chunk `chunk` of 16-window tiles.
+//   logits as in heads_kernel; per position: nll_base = logsumexp(base) - base[label_base],
+//   nll_rle likewise (nn.CrossEntropyLoss = log_softmax + nll), predictions = first-maximum argmax of
+//   the LOGITS (torchnet ConfusionMeter: np.argmax), confusion[target][predicted] += 1.
+//   Outputs: stats[window][chunk][group of kHeadsSpan positions][3] = (sum nll_base, sum w[l]*nll_rle,
+//   sum w[l]) summed over the group's positions in position order (deterministic; the host finishes
+//   the per-batch means), and the two confusion matrices accumulated with integer atomics.
+//   Labels outside 0..4 / 0..10 are the caller's error (torch raises); they are clamped here only
+//   to keep the accesses in range.
+// ------------------------------------------------------------------------------------------------
+struct RleClassWeights {
+    float w[kNR];
+};
+
+__global__ __launch_bounds__(256) void heads_eval_kernel(
+    const f32x4* __restrict__ y2, long y_tile_stride, const f32x4* __restrict__ Whd,
+    const float* __restrict__ bhd, int chunk, int T, int n_windows,
+    const uint8_t* __restrict__ label_base, const uint8_t* __restrict__ label_rle, RleClassWeights cw,
+    float* __restrict__ stats, unsigned long long* __restrict__ conf_base,
+    unsigned long long* __restrict__ conf_rle) {
+    __shared__ float vals[3][kTile][kHeadsSpan];
+    __shared__ unsigned hist_b[kNB * kNB], hist_r[kNR * kNR];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int j = lane & 15;
+    const int q = lane >> 4;
+    const int tile = blockIdx.x;
+    const int t0 = blockIdx.y * kHeadsSpan;
+    const int t1 = min(T, t0 + kHeadsSpan);
+    const bool isb = j < kNB;
+    for (int g = tid; g < 3 * kTile * kHeadsSpan; g += 256) (&vals[0][0][0])[g] = 0.f;
+    if (tid < kNB * kNB) hist_b[tid] = 0;
+    if (tid < kNR * kNR) hist_r[tid] = 0;
+    __syncthreads();
+
+    f32x4 B[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) B[m] = Whd[m * 64 + lane];
+    const float bias = bhd[j];
+
+    for (int t = t0 + w; t < t1; t += 4) {
+        const f32x4* a_p = y2 + (size_t)tile * y_tile_stride + (size_t)t * (kYStride / 4) + lane;
+        const f32x4* a_pb = y2 + (size_t)tile * y_tile_stride + (size_t)(T - 1 - t) * (kYStride / 4) + lane;
+        f32x4 acc0 = splat4(bias);
+        f32x4 acc1 = splat4(0.f);
+#pragma unroll
+        for (int m = 0; m < 16; m += 2) {
+            const f32x4 a0 = (m >= 8 ? a_pb : a_p)[m * 64];
+            const f32x4 a1 = (m >= 8 ? a_pb : a_p)[(m + 1) * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = mfma4(a0[e], B[m][e], acc0);
+                acc1 = mfma4(a1[e], B[m + 1][e], acc1);
+            }
+        }
+        const f32x4 logit = acc0 + acc1;  // row 4q+r (window), col j (class)
+        const int pos = chunk * kJump + t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int window = tile * kTile + 4 * q + r;
+            const bool valid = window < n_windows;
+            const int lb = valid ? min((int)label_base[(size_t)window * kSeq + pos], kNB - 1) : 0;
+            const int lr = valid ? min((int)label_rle[(size_t)window * kSeq + pos], kNR - 1) : 0;
+            const float x = logit[r];
+            const float mb = group16_max(isb ? x : -INFINITY);
+            const float mr = group16_max(isb ? -INFINITY : x);
+            const float e = expf(x - (isb ? mb : mr));
+            const float sb = group16_sum(isb ? e : 0.f);
+            const float sr = group16_sum(isb ? 0.f : e);
+            const float xb = group16_sum((isb && j == lb) ? x : 0.f);
+            const float xr = group16_sum((!isb && j - kNB == lr) ? x : 0.f);
+            const int pb = group16_argmax(isb ? x : -INFINITY, isb ? j : 99);
+            const int pr = group16_argmax(isb ? -INFINITY : x, isb ? 99 : j) - kNB;
+            if (j == 0 && valid) {
+                const float wr = cw.w[lr];
+                vals[0][4 * q + r][t - t0] = (mb + logf(sb)) - xb;
+                vals[1][4 * q + r][t - t0] = wr * ((mr + logf(sr)) - xr);
+                vals[2][4 * q + r][t - t0] = wr;
+                atomicAdd(&hist_b[lb * kNB + pb], 1u);
+                atomicAdd(&hist_r[lr * kNR + pr], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 3 * kTile) {
+        const int k = tid / kTile, win = tid % kTile;
+        const int window = tile * kTile + win;
+        if (window < n_windows) {
+            float sum = 0.f;
+            for (int tl = 0; tl < t1 - t0; ++tl) sum += vals[k][win][tl];
+            stats[(((size_t)window * kChunks + chunk) * (kWin / kHeadsSpan) + blockIdx.y) * 3 + k] = sum;
+        }
+    }
+    if (tid < kNB * kNB && hist_b[tid]) atomicAdd(&conf_base[tid], (unsigned long long)hist_b[tid]);
+    if (tid < kNR * kNR && hist_r[tid]) atomicAdd(&conf_rle[tid], (unsigned long long)hist_r[tid]);
+}
+
 }  // namespace helen

@@ -146,6 +146,30 @@ class HelenEngine(object):
                 self._stream()))
         return bases, rles
 
+    def evaluate(self, images, label_base, label_rle, class_weights, base_confusion, rle_confusion):
+        """The per-batch body of the reference's evaluation loop (models/test.py:78-126) for uint8 CUDA
+        tensors images [n,1000,90], label_base / label_rle [n,1000].  Returns chunk_stats f32 CUDA
+        [n,19,10,3] (sum nll_base, sum w*nll_rle, sum w per window, chunk and group of 10 positions) and
+        adds the chunk predictions into the int64 CUDA confusion matrices [5,5] / [11,11]
+        ([target][predicted]).  Asynchronous on the current stream."""
+        assert images.is_cuda and images.dtype == torch.uint8 and images.is_contiguous()
+        n = images.shape[0]
+        L = ImageSizeOptions.SEQ_LENGTH
+        for lab in (label_base, label_rle):
+            assert lab.is_cuda and lab.dtype == torch.uint8 and lab.is_contiguous() and tuple(lab.shape) == (n, L)
+        assert base_confusion.dtype == torch.int64 and base_confusion.is_contiguous() and base_confusion.is_cuda
+        assert rle_confusion.dtype == torch.int64 and rle_confusion.is_contiguous() and rle_confusion.is_cuda
+        cw = np.ascontiguousarray(class_weights, np.float32)
+        assert cw.shape == (ImageSizeOptions.TOTAL_RLE_LABELS,)
+        stats = torch.empty((n, 19, 10, 3), dtype=torch.float32, device=images.device)
+        for s in range(0, n, self.max_windows):
+            e = min(n, s + self.max_windows)
+            _lib.check(self._lib.helen_evaluate_batch(
+                self._handle, images[s:e].data_ptr(), label_base[s:e].data_ptr(), label_rle[s:e].data_ptr(),
+                e - s, cw.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), stats[s:e].data_ptr(),
+                base_confusion.data_ptr(), rle_confusion.data_ptr(), self._stream()))
+        return stats
+
     def chunk_forward(self, x, hidden):
         """TransducerGRU.forward (TransducerModel.py:60-79): x f32 CUDA [B,T,90], hidden f32 CUDA
         [B,2,128] -> (base [B,T,5], rle [B,T,11], hidden [B,2,128])."""

@@ -22,6 +22,8 @@ class TrainOptions(object):
     WINDOW_JUMP = 50           # chunk stride (Options.py:26)
     GRU_LAYERS = 1
     HIDDEN_SIZE = 128
+    # run-length class weights of the evaluation / training loss (Options.py:29)
+    CLASS_WEIGHTS = [0.3, 0.5, 0.5, 0.5, 0.5, 0.8, 0.9, 1.0, 1.0, 1.0, 0.9]
 
 
 def chunk_starts(seq_length=ImageSizeOptions.SEQ_LENGTH,

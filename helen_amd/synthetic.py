@@ -14,10 +14,11 @@ from .weights import make_images
 
 
 def write_image_file(path, images, contig="chr20_synth", first_window=0, lengths=None,
-                     chunks_per_region=1):
+                     chunks_per_region=1, labels=None):
     """Write `images` (uint8 [n, 1000, 90]) as n images of one file.  Window k covers
     contig_start = 800*k .. +1000 (SEQ_OVERLAP 200, Options.py:17); `lengths[i] < 1000` stores a
-    short image (the reader pads it)."""
+    short image (the reader pads it).  labels = (label_base, label_run_length) uint8 [n, 1000] makes
+    it a labeled file as the evaluation loader reads it (models/dataloader.py:59-61)."""
     n = images.shape[0]
     with hdf5.File(path, "w") as f:
         for i in range(n):
@@ -36,6 +37,9 @@ def write_image_file(path, images, contig="chr20_synth", first_window=0, lengths
             pos = np.zeros((L, 3), np.int64)
             pos[:, 0] = start + np.arange(L)
             f.write(base + "position", pos, np.int64)
+            if labels is not None:
+                f.write(base + "label_base", labels[0][i, :L], np.uint8)
+                f.write(base + "label_run_length", labels[1][i, :L], np.uint8)
 
 
 def write_image_dir(directory, n_windows, n_files=4, seed=20260928, mode="uniform", short_every=0):

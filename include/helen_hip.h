@@ -89,7 +89,7 @@ enum {
     HELEN_K_GRU_ENC = 2,     /* encoder recurrence (100 dependent steps, both directions) */
     HELEN_K_GEMM_DEC = 3,    /* decoder input projection  Y1.W_ih^T + b */
     HELEN_K_GRU_DEC = 4,     /* decoder recurrence */
-    HELEN_K_HEADS = 5,       /* heads + softmax + accumulate + argmax */
+    HELEN_K_HEADS = 5,       /* heads + softmax + accumulate + argmax (or + cross-entropy terms) */
     HELEN_K_COUNT = 6
 };
 
@@ -154,6 +154,28 @@ int helen_polish_host(HelenModel* model, const uint8_t* images, int n_windows, u
  */
 int helen_gru_chunk_forward(HelenModel* model, const float* x, const float* h_in, int B, int T,
                             float* base, float* rle, float* h_out, void* stream);
+
+/*
+ * The per-batch body of the reference's evaluation loop on labeled images (`models/test.py:78-126`,
+ * `helen_train test`): the same 19-chunk forward as helen_polish_batch, but each
+ * chunk's logits go into nn.CrossEntropyLoss terms and torchnet-ConfusionMeter counts instead of the
+ * softmax accumulators.
+ *   images             DEVICE uint8 [n_windows, 1000, F]
+ *   label_base         DEVICE uint8 [n_windows, 1000], values 0..4   (`models/dataloader.py:60`)
+ *   label_rle          DEVICE uint8 [n_windows, 1000], values 0..10  (`models/dataloader.py:61`)
+ *   rle_class_weights  HOST float[11]: TrainOptions.CLASS_WEIGHTS (`Options.py:29`, `models/test.py:55-58`)
+ *   chunk_stats        DEVICE float32 [n_windows, 19, 10, 3], overwritten: for window, chunk and group of
+ *                      10 consecutive chunk positions: sum of nll_base, sum of w[label]*nll_rle, sum of
+ *                      w[label].  A loader batch's chunk losses (`models/test.py:108-113`) are
+ *                      sum(nll_base)/(B*100) and sum(w*nll_rle)/sum(w) over its windows.
+ *   base_confusion     DEVICE uint64 [5, 5],   ADDED to: [target][predicted], predicted = first-maximum
+ *   rle_confusion      DEVICE uint64 [11, 11]  argmax of the chunk's logits (`models/test.py:116-119`)
+ * Asynchronous on `stream`.  Labels out of range are the caller's error (torch raises on them).
+ */
+int helen_evaluate_batch(HelenModel* model, const uint8_t* images, const uint8_t* label_base,
+                         const uint8_t* label_rle, int n_windows, const float* rle_class_weights,
+                         float* chunk_stats, unsigned long long* base_confusion,
+                         unsigned long long* rle_confusion, void* stream);
 
 /*
  * Per-kernel-class timing with HIP events on the launch stream.  When enabled, each launch of a

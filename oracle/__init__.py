@@ -4,6 +4,6 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 nothing under helen_amd/ does (tests/test_layout.py checks that).
 """
 from .oracle import (  # noqa: F401
-    HelenWeightsC, build, gru_chunk_forward, polish_batch, max_threads, set_precision, set_threads,
+    HelenWeightsC, build, evaluate, gru_chunk_forward, polish_batch, max_threads, set_precision, set_threads,
     weights_struct,
 )

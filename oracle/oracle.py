@@ -158,3 +158,45 @@ def polish_batch(weights, images, traces=False):
     if rc != 0:
         raise RuntimeError("oracle_polish_batch failed: %d" % rc)
     return out
+
+
+def evaluate(weights, images, label_base, label_rle, batch_size, class_weights):
+    """The reference's evaluation loop (helen/modules/python/models/test.py:78-126, 150) on the CPU
+    restatement's per-chunk logits: per loader batch and chunk nn.CrossEntropyLoss (mean) on the base
+    logits + class-weighted nn.CrossEntropyLoss (sum w*nll / sum w) on the run-length logits, and
+    torchnet ConfusionMeter counts conf[target][argmax(logits)].  float64 bookkeeping."""
+    images = np.ascontiguousarray(images, np.uint8)
+    n = images.shape[0]
+    cw = np.asarray(class_weights, np.float64)
+    total_loss = total_loss_rle = 0.0
+    total_images = 0
+    conf_b = np.zeros((5, 5), np.int64)
+    conf_r = np.zeros((11, 11), np.int64)
+    chunk_losses = []
+
+    def nll(logits, labels):
+        x = logits.astype(np.float64)
+        m = x.max(axis=-1, keepdims=True)
+        lse = m[..., 0] + np.log(np.exp(x - m).sum(axis=-1))
+        return lse - np.take_along_axis(x, labels[..., None].astype(np.int64), axis=-1)[..., 0]
+
+    for lo in range(0, n, batch_size):
+        hi = min(n, lo + batch_size)
+        tr = polish_batch(weights, images[lo:hi], traces=True)
+        for c in range(19):
+            lb = label_base[lo:hi, 50 * c:50 * c + 100]
+            lr = label_rle[lo:hi, 50 * c:50 * c + 100]
+            ob, orl = tr["logit_base"][c], tr["logit_rle"][c]          # [B,100,C]
+            loss_b = nll(ob, lb).mean()
+            w = cw[lr.astype(np.int64)]
+            loss_r = (w * nll(orl, lr)).sum() / w.sum()
+            total_loss += loss_b + loss_r
+            total_loss_rle += loss_r
+            total_images += hi - lo
+            chunk_losses.append((loss_b, loss_r))
+            np.add.at(conf_b, (lb.astype(np.int64).ravel(), ob.argmax(axis=-1).ravel()), 1)
+            np.add.at(conf_r, (lr.astype(np.int64).ravel(), orl.argmax(axis=-1).ravel()), 1)
+    return {"loss": total_loss / total_images if total_images else 0.0, "total_loss": total_loss,
+            "total_loss_rle": total_loss_rle, "total_images": total_images,
+            "base_confusion_matrix": conf_b, "rle_confusion_matrix": conf_r,
+            "chunk_losses": np.array(chunk_losses)}

@@ -12,6 +12,7 @@ from helen_amd.weights import make_images, make_weights
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 CASE_WEIGHTS = {
+    "eval10": dict(seed=20260928, head_scale=8.0, input_scale=1.0 / 64.0),
     "trace6": dict(seed=20260928, head_scale=8.0, input_scale=1.0),
     "small_input6": dict(seed=7, head_scale=8.0, input_scale=1.0 / 64.0),
     "config1_100": dict(seed=20260928, head_scale=8.0, input_scale=1.0 / 64.0),
@@ -27,7 +28,14 @@ def case_images(case):
     if case == "config1_100":
         return np.concatenate([make_images(60, seed=21, mode="uniform"),
                                make_images(40, seed=22, mode="pileup")])
+    if case == "eval10":   # tests/golden/make_golden_eval.py: labeled evaluation, loader batch 4
+        return np.concatenate([make_images(7, seed=31, mode="uniform"), make_images(3, seed=32, mode="pileup")])
     raise KeyError(case)
+
+
+EVAL_BATCH = 4
+# evaluation loss (models/test.py): sums of ~1e5 fp32 log-softmax terms, compared in relative terms
+EVAL_LOSS_RTOL = 2e-5
 
 
 def load_case(case):

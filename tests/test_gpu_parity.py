@@ -279,3 +279,61 @@ def test_fp32x3_short_chunk_nonzero_hidden(case):
     np.testing.assert_allclose(rle.cpu().numpy(), g["fwd_rle"], atol=LOGIT_ATOL, rtol=LOGIT_RTOL)
     np.testing.assert_allclose(h.cpu().numpy(), g["fwd_h"], atol=HIDDEN_ATOL, rtol=0)
     eng.close()
+
+
+# ---- evaluation on labeled images (models/test.py) ----
+def _eval_on_gpu(eng, img, lb, lr, sizes):
+    from helen_amd.evaluate import batch_losses
+    from helen_amd.options import TrainOptions
+    cm_b = torch.zeros((5, 5), dtype=torch.int64, device="cuda")
+    cm_r = torch.zeros((11, 11), dtype=torch.int64, device="cuda")
+    stats = eng.evaluate(torch.from_numpy(img).cuda(), torch.from_numpy(lb).cuda(), torch.from_numpy(lr).cuda(),
+                         TrainOptions.CLASS_WEIGHTS, cm_b, cm_r)
+    torch.cuda.synchronize()
+    loss_b, loss_r = batch_losses(stats.cpu().numpy(), sizes)
+    return loss_b, loss_r, cm_b.cpu().numpy(), cm_r.cpu().numpy()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
+def test_evaluation_matches_reference_golden(precision):
+    """helen_evaluate_batch against torch's CrossEntropyLoss on the reference model's logits
+    (tests/golden/make_golden_eval.py): per-(batch, chunk) losses, loss sums, confusion matrices."""
+    from golden_cases import EVAL_BATCH, EVAL_LOSS_RTOL
+    from helen_amd.engine import HelenEngine
+    w, img, g = load_case("eval10")
+    eng = HelenEngine(w, device=0, max_windows=16, precision=precision)
+    sizes = [EVAL_BATCH, EVAL_BATCH, 2]
+    loss_b, loss_r, cm_b, cm_r = _eval_on_gpu(eng, img, g["label_base"], g["label_rle"], sizes)
+    eng.close()
+    got = np.stack([loss_b.ravel(), loss_r.ravel()], axis=1)            # (batch, chunk) order of test.py
+    np.testing.assert_allclose(got, g["chunk_losses"], rtol=2e-4, atol=1e-6)
+    total = float((loss_b + loss_r).sum())
+    np.testing.assert_allclose(total, g["total_loss"][0], rtol=EVAL_LOSS_RTOL)
+    np.testing.assert_allclose(float(loss_r.sum()), g["total_loss_rle"][0], rtol=EVAL_LOSS_RTOL)
+    assert np.array_equal(cm_b, g["base_confusion_matrix"])
+    assert np.array_equal(cm_r, g["rle_confusion_matrix"])
+
+
+def test_evaluation_ragged_batch_vs_oracle():
+    """37 windows (not a multiple of the 16-window tile), engine capacity 16 (three device calls),
+    loader batch 5: same losses and counts as the CPU restatement; padded tile rows contribute nothing."""
+    import oracle
+    from helen_amd.engine import HelenEngine
+    from helen_amd.options import TrainOptions
+    w = make_weights(seed=3, head_scale=8.0, input_scale=1.0 / 64.0)
+    img = make_images(37, seed=41, mode="uniform")
+    rng = np.random.default_rng(8)
+    lb = rng.integers(0, 5, (37, 1000), dtype=np.uint8)
+    lr = rng.integers(0, 11, (37, 1000), dtype=np.uint8)
+    ref = oracle.evaluate(w, img, lb, lr, 5, TrainOptions.CLASS_WEIGHTS)
+    eng = HelenEngine(w, device=0, max_windows=16)
+    sizes = [5] * 7 + [2]
+    loss_b, loss_r, cm_b, cm_r = _eval_on_gpu(eng, img, lb, lr, sizes)
+    eng.close()
+    np.testing.assert_allclose(np.stack([loss_b.ravel(), loss_r.ravel()], axis=1), ref["chunk_losses"],
+                               rtol=2e-4, atol=1e-6)
+    assert cm_b.sum() == cm_r.sum() == 37 * 19 * 100
+    # random labels against peaked predictions: a handful of argmax near-ties may flip between two
+    # correct fp32 implementations; the matrices must agree up to that
+    assert np.abs(cm_b - ref["base_confusion_matrix"]).sum() <= 4
+    assert np.abs(cm_r - ref["rle_confusion_matrix"]).sum() <= 4

@@ -130,3 +130,33 @@ def test_two_callers_shard_files_round_robin(workdir):
     n0 = len(SequenceDataset(None, file_list=shards[0]))
     with hdf5.File(files[0]) as f:
         assert len(f.keys("predictions/chr20_synth")) == n0
+
+
+def test_evaluation_interface_end_to_end(tmp_path):
+    """helen_amd.evaluate.test_interface (TestInterface.py:93-141 / models/test.py) on a labeled image
+    directory holding the eval10 golden case: loss, loss sums and both confusion matrices equal what
+    torch's CrossEntropyLoss + the reference model gave; the matrices are saved."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from golden_cases import EVAL_BATCH, EVAL_LOSS_RTOL, load_case
+    from helen_amd.evaluate import SequenceDataset, test_interface
+    from helen_amd.model_handler import ModelHandler
+    from helen_amd.synthetic import write_image_file
+    w, img, g = load_case("eval10")
+    img_dir = tmp_path / "labeled"
+    img_dir.mkdir()
+    # two files; names sort in window order so the loader batches are the golden's
+    write_image_file(str(img_dir / "a.h5"), img[:6], first_window=100, labels=(g["label_base"][:6], g["label_rle"][:6]))
+    write_image_file(str(img_dir / "b.h5"), img[6:], first_window=106, labels=(g["label_base"][6:], g["label_rle"][6:]))
+    ds = SequenceDataset(str(img_dir))
+    assert len(ds) == 10 and np.array_equal(ds[7][0], img[7]) and np.array_equal(ds[7][2], g["label_rle"][7])
+    model = str(tmp_path / "m.pkl")
+    ModelHandler.save_model(w, None, 128, 1, 0, model)
+    out = str(tmp_path / "eval_out")
+    stats = test_interface(str(img_dir), EVAL_BATCH, True, 0, model, out, False)
+    np.testing.assert_allclose(stats["loss"], g["loss"][0], rtol=EVAL_LOSS_RTOL)
+    np.testing.assert_allclose(stats["total_loss_rle"], g["total_loss_rle"][0], rtol=EVAL_LOSS_RTOL)
+    assert stats["total_images"] == int(g["total_images"][0]) and stats["accuracy"] == 0
+    assert np.array_equal(stats["base_confusion_matrix"], g["base_confusion_matrix"])
+    assert np.array_equal(stats["rle_confusion_matrix"], g["rle_confusion_matrix"])
+    saved = np.loadtxt(os.path.join(out, "RLE_CONFUSION_MATRIX.tsv"), dtype=np.int64)
+    assert np.array_equal(saved, g["rle_confusion_matrix"])

@@ -54,3 +54,19 @@ def test_oracle_batch_independence():
     b = oracle.polish_batch(w, img[2:3])
     assert np.array_equal(a["bases"][2], b["bases"][0])
     assert np.array_equal(a["acc_rle"][2], b["acc_rle"][0])
+
+
+def test_oracle_evaluation_matches_reference():
+    """The evaluation bookkeeping (models/test.py:78-126) on the restatement's logits against the loss
+    sums and confusion matrices torch's CrossEntropyLoss + the reference model produced."""
+    from golden_cases import EVAL_BATCH, EVAL_LOSS_RTOL
+    from helen_amd.options import TrainOptions
+    w, img, g = load_case("eval10")
+    r = oracle.evaluate(w, img, g["label_base"], g["label_rle"], EVAL_BATCH, TrainOptions.CLASS_WEIGHTS)
+    assert r["total_images"] == int(g["total_images"][0]) == 10 * 19
+    np.testing.assert_allclose(r["loss"], g["loss"][0], rtol=EVAL_LOSS_RTOL)
+    np.testing.assert_allclose(r["total_loss_rle"], g["total_loss_rle"][0], rtol=EVAL_LOSS_RTOL)
+    np.testing.assert_allclose(r["chunk_losses"], g["chunk_losses"], rtol=2e-4, atol=1e-6)
+    assert np.array_equal(r["base_confusion_matrix"], g["base_confusion_matrix"])
+    assert np.array_equal(r["rle_confusion_matrix"], g["rle_confusion_matrix"])
+    assert r["base_confusion_matrix"].sum() == 10 * 19 * 100
