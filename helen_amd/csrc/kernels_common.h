@@ -1,0 +1,31 @@
+// kernels_common.h -- types, MFMA wrapper and gate math shared by every kernel
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "layout.h"
+
+namespace helen {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    // D[16x16] += A[16x4] * B[4x16], exact fp32 (k-ordered fmaf chain).
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 splat4(float v) {
+    f32x4 r = {v, v, v, v};
+    return r;
+}
+
+// sigmoid / tanh on the v_exp_f32 + v_rcp_f32 fast paths (each ~1 ulp); saturate correctly at
+// +-inf: exp2(+big) = inf -> rcp = 0.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    // tanh(x) = 1 - 2 / (1 + e^{2x})
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.8853900817779268f));
+}
+
+}  // namespace helen

@@ -1,0 +1,199 @@
+// kernels_gemm.h -- fp32 input projections: gemm_gi_kernel (streaming weights) and gemm_enc_ws_kernel (weight-stationary)
+#pragma once
+#include "kernels_common.h"
+
+namespace helen {
+
+// ------------------------------------------------------------------------------------------------
+// Input projection  gi = A . W_ih^T + bias  for both directions (the non-recurrent half of nn.GRU,
+// TransducerModel.py:70,72).  A is a KB16 operand with MG = K/16 groups per (tile, position).
+//   The 48 column tiles (2 directions x 24) are split over 8 "wave slots": slot v -> direction
+//   v>>2, column tiles 6(v&3) .. +5; a workgroup holds HELEN_GEMM_WAVES slots (grid.z the rest) and
+//   covers 4 positions, so each wave keeps a 4 x 6 block of 16x16 accumulators.
+//   Operands come straight from global memory in a register ping-pong (group m+1 in flight while
+//   group m's 96 MFMAs issue): every load is one contiguous 1 KiB per wave and the packed weights
+//   (<= 786 KB) stay L2-resident; no LDS, no barriers.  Small workgroups (2 waves) measured best:
+//   several independent workgroups per CU overlap each other's prologue/epilogue.
+//   bias[dir][col] = b_ih[col] + (col < 2H ? b_hh[col] : 0)   (b_hn is applied inside r*(...)).
+// Output gi[tile][slot][dir][ntile 24][lane 64] float4 (FRAG layout); slot = pos for direction 0,
+// npos-1-pos for direction 1.
+// ------------------------------------------------------------------------------------------------
+// waves per projection workgroup; 8 / HELEN_GEMM_WAVES workgroups (grid.z) cover the 48 column tiles
+#ifndef HELEN_GEMM_WAVES
+#define HELEN_GEMM_WAVES 2
+#endif
+template <int MG, bool REV_A>
+__global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_kernel(const f32x4* __restrict__ A, long a_tile_stride,
+                                                      const f32x4* __restrict__ Wp,
+                                                      const float* __restrict__ bias,
+                                                      f32x4* __restrict__ gi, long gi_tile_stride,
+                                                      int npos, int ntiles) {
+    // Output slot: direction 0 -> position p, direction 1 -> npos-1-p (time-reversed), so the
+    // recurrence reads both directions in ascending address order.
+    static_assert(MG % 2 == 0, "operand groups are consumed in ping-pong pairs");
+    constexpr int P = 4, N = 6;
+    const int lane = threadIdx.x & 63;
+    // grid.x enumerates (unit, z): unit = (position group, tile), z = which HELEN_GEMM_WAVES wave
+    // slots.  Workgroups are dispatched round-robin over the 8 XCDs (id % 8), so the ZB = 8 /
+    // HELEN_GEMM_WAVES workgroups that share one unit's A operand get ids u, u+8, u+16, ... inside a
+    // block of 8*ZB ids: same XCD, same L2, adjacent in time -> A is fetched from HBM once.
+    constexpr int ZB = 8 / HELEN_GEMM_WAVES;
+    const int bid = blockIdx.x;
+    const int unit = (bid / (8 * ZB)) * 8 + (bid & 7);
+    const int zb = (bid >> 3) % ZB;
+    const int npg = (npos + P - 1) / P;                 // position groups per tile
+    const int tile = unit / npg;
+    const int pos0 = (unit % npg) * P;
+    if (tile >= ntiles) return;                           // grid is padded to a multiple of 8 units
+    const int wave = (threadIdx.x >> 6) + zb * HELEN_GEMM_WAVES;
+    const int dir = wave >> 2;
+    const int nt0 = (wave & 3) * N;
+
+    const f32x4* w_base = Wp + (size_t)((dir * kNTile + nt0) * MG) * 64 + lane;
+    // REV_A: A is a layer output y[tile][slot][fwd | bwd]; the bwd half (groups MG/2..) of
+    // position p sits in slot npos-1-p.
+    const f32x4* a_ptr[P];
+    const f32x4* a_ptr_b[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int pc = min(pos0 + p, npos - 1);
+        a_ptr[p] = A + (size_t)tile * a_tile_stride + (size_t)pc * (MG * 64) + lane;
+        a_ptr_b[p] = A + (size_t)tile * a_tile_stride + (size_t)(npos - 1 - pc) * (MG * 64) + lane;
+    }
+
+    f32x4 acc[P][N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const float b = bias[dir * kG + (nt0 + n) * 16 + (lane & 15)];
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[p][n] = splat4(b);
+    }
+
+    // Register ping-pong: the operands of group m+1 are in flight while group m's 96 MFMAs issue.
+    f32x4 a0[P], b0[N], a1[P], b1[N];
+#define HELEN_LOAD_OPS(a, b, m)                                       \
+    _Pragma("unroll") for (int p = 0; p < P; ++p)                     \
+        a[p] = (REV_A && (m) >= MG / 2) ? a_ptr_b[p][(m) * 64] : a_ptr[p][(m) * 64]; \
+    _Pragma("unroll") for (int n = 0; n < N; ++n) b[n] = w_base[(n * MG + (m)) * 64];
+#define HELEN_MMA_OPS(a, b)                                           \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)                     \
+    _Pragma("unroll") for (int p = 0; p < P; ++p)                     \
+    _Pragma("unroll") for (int n = 0; n < N; ++n) acc[p][n] = mfma4(a[p][e], b[n][e], acc[p][n]);
+
+    HELEN_LOAD_OPS(a0, b0, 0)
+#pragma unroll
+    for (int m = 0; m < MG; m += 2) {
+        HELEN_LOAD_OPS(a1, b1, m + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        HELEN_MMA_OPS(a0, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (m + 2 < MG) { HELEN_LOAD_OPS(a0, b0, m + 2) }
+        __builtin_amdgcn_sched_barrier(0);
+        HELEN_MMA_OPS(a1, b1)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef HELEN_LOAD_OPS
+#undef HELEN_MMA_OPS
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if (pos0 + p < npos) {
+            const int slot = dir ? (npos - 1 - (pos0 + p)) : (pos0 + p);
+            f32x4* o = gi + (size_t)tile * gi_tile_stride +
+                       ((size_t)slot * 2 + dir) * (kNTile * 64) + nt0 * 64 + lane;
+#pragma unroll
+            for (int n = 0; n < N; ++n) o[n * 64] = acc[p][n];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Encoder input projection, weight-stationary (fp32 MFMA): gi = X . W_ih^T + bias for all `npos` positions.
+//   K is only 96, so a wave can hold its whole slice of W_ih in registers: 4 column tiles x 6 groups =
+//   96 registers, loaded once.  Workgroup = 4 waves = one third of the 48 column tiles; grid = 3 column
+//   sets x tiles, enumerated so that the three sets of a tile run on one XCD (its xa stream comes from HBM
+//   once).  Only the activations move: a stage is 4 positions (24 KiB of KB16 fragments) brought in by
+//   LDS-DMA into a 2-deep ring, 384 MFMAs per wave per barrier, and the 16 output stores of a stage stay
+//   in flight across the next barrier.  Two workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemm_enc_ws_kernel(const f32x4* __restrict__ A, long a_tile_stride,
+                                                             const f32x4* __restrict__ Wp,
+                                                             const float* __restrict__ bias,
+                                                             f32x4* __restrict__ gi, long gi_tile_stride,
+                                                             int npos, int ntiles) {
+    constexpr int MG = kFPad / 16;          // 6 operand groups of 16 k
+    constexpr int PB = 4, N = 4;
+    constexpr int ROWS = PB * MG;           // 24 rows of 1 KiB per stage
+    __shared__ f32x4 smem[2 * ROWS * 64];   // 48 KiB
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int local = blockIdx.x >> 3;
+    const int set = local % 3;
+    const int tile = (local / 3) * 8 + (blockIdx.x & 7);
+    if (tile >= ntiles) return;
+    const int gt0 = 16 * set + N * w;       // first of this wave's global column tiles (dir*24 + nt)
+    const int dir = gt0 / kNTile;
+    const int nt0 = gt0 % kNTile;
+    f32x4 B[N][MG];
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int m = 0; m < MG; ++m) B[n][m] = Wp[(size_t)((gt0 + n) * MG + m) * 64 + lane];
+    float bs[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) bs[n] = bias[dir * kG + (nt0 + n) * 16 + (lane & 15)];
+    const f32x4* ap = A + (size_t)tile * a_tile_stride + lane;
+    auto stage = [&](int g, int b) {        // positions 4g..4g+3: row r = p*6 + m, 6 rows per wave
+        f32x4* dst = smem + b * (ROWS * 64);
+#pragma unroll
+        for (int i = 0; i < ROWS / 4; ++i) {
+            const int r = w + 4 * i;
+            const int pc = min(PB * g + r / MG, npos - 1);
+            const f32x4* src = ap + (size_t)pc * (MG * 64) + (r % MG) * 64;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                             (void __attribute__((address_space(3)))*)(dst + r * 64), 16, 0, 0);
+        }
+    };
+    const int ng = (npos + PB - 1) / PB;
+    stage(0, 0);
+    for (int g = 0; g < ng; ++g) {
+        // VMEM queue, oldest first: 6 DMA rows of group g, then the 16 output stores of group g-1
+        if (g == 0)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (g + 1 < ng) stage(g + 1, (g + 1) & 1);
+        const f32x4* L = smem + (g & 1) * (ROWS * 64) + lane;
+        f32x4 acc[PB][N];
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+#pragma unroll
+            for (int n = 0; n < N; ++n) acc[p][n] = splat4(bs[n]);
+#pragma unroll
+        for (int m = 0; m < MG; ++m) {
+            f32x4 a[PB];
+#pragma unroll
+            for (int p = 0; p < PB; ++p) a[p] = L[(p * MG + m) * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int p = 0; p < PB; ++p)
+#pragma unroll
+                    for (int n = 0; n < N; ++n) acc[p][n] = mfma4(a[p][e], B[n][m][e], acc[p][n]);
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            // exactly 16 stores per lane per stage (counted above): positions past the end of the last
+            // stage rewrite the last valid one with identical values
+            const int pos = min(PB * g + p, npos - 1);
+            const int slot = dir ? (npos - 1 - pos) : pos;
+            f32x4* o = gi + (size_t)tile * gi_tile_stride + ((size_t)slot * 2 + dir) * (kNTile * 64) + nt0 * 64 + lane;
+#pragma unroll
+            for (int n = 0; n < N; ++n) o[n * 64] = acc[p][n];
+        }
+    }
+}
+
+}  // namespace helen

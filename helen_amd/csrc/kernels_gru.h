@@ -1,0 +1,197 @@
+// kernels_gru.h -- fp32 GRU recurrence (gru_kernel) and the gate cell
+#pragma once
+#include "kernels_common.h"
+
+namespace helen {
+
+// ------------------------------------------------------------------------------------------------
+// GRU recurrence for one direction of one layer over T dependent steps (nn.GRU cell, see
+// oracle/helen_oracle.c gru_dir for the scalar statement).
+//   grid (tiles, 2 directions), 4 waves per workgroup, TWO workgroups per CU (two waves per SIMD
+//   from independent tiles): while one tile is in its gate math / LDS exchange / barrier, the
+//   other tile's MFMAs keep the matrix pipe busy.  That needs <= 256 registers per lane, so:
+//     - wave w owns hidden units 32w..32w+31 = six 16-column tiles (r, z, n gates x two halves);
+//       the W_hh slices of five of them (160 floats per lane) stay in registers for the whole
+//       launch, the sixth is parked in LDS and streamed as a B operand each step;
+//     - h lives in LDS in KB16 layout (double-buffered, ONE barrier per step) and is the MFMA A
+//       operand of the next step;
+//     - the gate pre-activations gi are DMA'd global->LDS (global_load_lds: no registers) one
+//       step ahead into a per-wave, single-buffered slot that is refilled as soon as it is read.
+//   Each step's h is streamed out as y[tile][slot][dir] (KB16) for the next projection, slot =
+//   step index (t for direction 0, T-1-t for direction 1).
+//   Direction 1 walks t = T-1 .. 0 (the `_reverse` weights); its h_n is the state after t = 0.
+//   gi and y are indexed by SLOT = step order for both directions (the reverse direction is
+//   stored time-reversed) so both directions walk memory upwards: descending DMA/store addresses
+//   cost 1000+ cycles of VMEM issue stall per step on gfx950.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gru_cell(float ar, float az, float an, float gr, float gz, float gn,
+                                          float hp) {
+    const float rg = fast_sigmoid(ar + gr);
+    const float zg = fast_sigmoid(az + gz);
+    const float ng = fast_tanh(gn + rg * an);
+    return ng + zg * (hp - ng);  // (1-z)*n + z*h
+}
+
+constexpr int kGruLdsF4 = 2 * 512 + 4 * 384 + 4 * 512;  // h[2] | gi[4 waves] | W tile 5[4 waves]
+
+__global__ __launch_bounds__(256, 2) void gru_kernel(const f32x4* __restrict__ gi, long gi_tile_stride,
+                                                     int slot0_fwd, int slot0_bwd, int T,
+                                                     const f32x4* __restrict__ Whp,
+                                                     const float* __restrict__ bhn,
+                                                     f32x4* __restrict__ hid, f32x4* __restrict__ y,
+                                                     long y_tile_stride) {
+    __shared__ f32x4 smem[kGruLdsF4];  // 72 KiB, one object (two workgroups fit in 160 KiB)
+    f32x4* const hbuf = smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    f32x4* const gbuf = smem + 1024 + w * 384;         // this wave's gi slot: [6][64]
+    f32x4* const w5buf = smem + 1024 + 1536 + w * 512; // this wave's parked W tile: [8][64]
+    const int j = lane & 15;
+    const int q = lane >> 4;
+    const int tile = blockIdx.x;
+    const int dir = blockIdx.y;
+    const int slot0 = dir ? slot0_bwd : slot0_fwd;
+
+    // W_hh slice: W[n = gate*2 + half][m] holds k = 16m + 4q + e, col = unit(half, j)
+    f32x4 W[5][8];
+    {
+        const f32x4* wp = Whp + (size_t)((dir * 4 + w) * 48) * 64 + lane;
+#pragma unroll
+        for (int n = 0; n < 5; ++n)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) W[n][m] = wp[(n * 8 + m) * 64];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) w5buf[m * 64 + lane] = wp[(5 * 8 + m) * 64];
+    }
+    float bn[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) bn[hh] = bhn[dir * kH + 32 * w + 16 * hh + j];
+
+    // gi fragments of this wave: column tile of (gate g, half hh) is g*8 + 2w + hh
+    const f32x4* gi_p = gi + (size_t)tile * gi_tile_stride + (size_t)dir * (kNTile * 64) +
+                        (2 * w) * 64 + lane;
+    constexpr long kPosStride = 2 * kNTile * 64;  // float4 per slot
+    auto dma_gi = [&](int slot) {
+        const f32x4* p = gi_p + (size_t)slot * kPosStride;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+                __builtin_amdgcn_global_load_lds(
+                    (const void __attribute__((address_space(1)))*)(p + (g * 8 + hh) * 64),
+                    (void __attribute__((address_space(3)))*)(gbuf + (g * 2 + hh) * 64), 16, 0, 0);
+    };
+
+    f32x4* hid_p = hid + ((size_t)tile * 2 + dir) * (kHidDirStride / 4);
+    hbuf[tid] = hid_p[tid];
+    hbuf[tid + 256] = hid_p[tid + 256];
+    dma_gi(slot0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    float hprev[2][4];
+    int hoff[2];  // float offset of (row 4q, unit) inside an h buffer; rows r add 4r
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int u = 32 * w + 16 * hh + j;
+        hoff[hh] = ((u >> 2) * kTile + 4 * q) * 4 + (u & 3);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hprev[hh][r] = ((const float*)hbuf)[hoff[hh] + 4 * r];
+    }
+    f32x4* y_p = y + (size_t)tile * y_tile_stride + (size_t)dir * (kHidDirStride / 4);
+
+#ifdef HELEN_GRU_TIMING
+    long long tk[7] = {0, 0, 0, 0, 0, 0, 0};
+#define HELEN_TICK(i) { __builtin_amdgcn_sched_barrier(0); long long now_ = __builtin_readcyclecounter(); tk[i] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
+    long long tlast = __builtin_readcyclecounter();
+#else
+#define HELEN_TICK(i)
+#endif
+    for (int s = 0; s < T; ++s) {
+        const int cur = s & 1;
+        const f32x4* hb = hbuf + cur * 512 + lane;
+        const f32x4* wb = w5buf + lane;
+
+        f32x4 acc[6];
+        acc[0] = splat4(0.f);
+        acc[1] = splat4(0.f);
+        acc[2] = splat4(0.f);
+        acc[3] = splat4(0.f);
+        acc[4] = splat4(bn[0]);
+        acc[5] = splat4(bn[1]);
+        // LDS operand ping-pong: group m+1's A / parked-W reads are in flight behind group m's 24
+        // MFMAs (pinned with sched_barriers; left alone, hipcc issues the reads right before use
+        // and exposes the LDS latency four times per step).
+#define HELEN_GRU_MMA(a, b5, m)                                                     \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                 \
+        _Pragma("unroll") for (int n = 0; n < 5; ++n) acc[n] = mfma4(a[e], W[n][m][e], acc[n]); \
+        acc[5] = mfma4(a[e], b5[e], acc[5]);                                        \
+    }
+        f32x4 a0 = hb[0], b0 = wb[0], a1, b1;
+#pragma unroll
+        for (int m = 0; m < 8; m += 2) {
+            a1 = hb[(m + 1) * 64];
+            b1 = wb[(m + 1) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            HELEN_GRU_MMA(a0, b0, m)
+            __builtin_amdgcn_sched_barrier(0);
+            if (m + 2 < 8) {
+                a0 = hb[(m + 2) * 64];
+                b0 = wb[(m + 2) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            HELEN_GRU_MMA(a1, b1, m + 1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef HELEN_GRU_MMA
+        HELEN_TICK(0)
+        // gate pre-activations of this step (DMA'd during the previous step), then refill the slot
+        // VMEM queue of this wave, oldest first: 6 gi DMAs (issued last step), 2 y stores (issued
+        // after last step's barrier).  vmcnt(2) = the DMAs have landed; the stores may still fly.
+        // (hipcc does not order these LDS reads behind the DMA by itself.)
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        HELEN_TICK(5)
+        f32x4 G[6];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) G[n] = gbuf[n * 64 + lane];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        HELEN_TICK(6)
+        if (s + 1 < T) dma_gi(slot0 + s + 1);
+        HELEN_TICK(1)
+
+        float* hw = (float*)(hbuf + (cur ^ 1) * 512);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float hn = gru_cell(acc[hh][r], acc[2 + hh][r], acc[4 + hh][r], G[hh][r],
+                                          G[2 + hh][r], G[4 + hh][r], hprev[hh][r]);
+                hprev[hh][r] = hn;
+                hw[hoff[hh] + 4 * r] = hn;
+            }
+        HELEN_TICK(2)
+        // raw barrier: only LDS traffic has to be drained, the gi DMA stays in flight across it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        HELEN_TICK(3)
+        // stream h(t) out as the layer output
+        f32x4* yo = y_p + (size_t)s * (kYStride / 4);  // slot s: t for dir 0, T-1-t for dir 1
+        const f32x4* hn4 = hbuf + (cur ^ 1) * 512;
+        yo[tid] = hn4[tid];
+        yo[tid + 256] = hn4[tid + 256];
+        HELEN_TICK(4)
+    }
+#ifdef HELEN_GRU_TIMING
+    if (tile == 0 && lane == 0) {
+        printf("gru dir %d wave %d: cycles/step  mfma %lld  vmwait %lld  Gread %lld  dma-issue %lld  gates %lld  barrier %lld  ycopy %lld\n",
+               dir, w, tk[0] / T, tk[5] / T, tk[6] / T, tk[1] / T, tk[2] / T, tk[3] / T, tk[4] / T);
+    }
+#endif
+    const f32x4* hl = hbuf + (T & 1) * 512;
+    hid_p[tid] = hl[tid];
+    hid_p[tid + 256] = hl[tid + 256];
+}
+
+}  // namespace helen

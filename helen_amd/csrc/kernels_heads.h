@@ -1,0 +1,255 @@
+// kernels_heads.h -- heads + softmax + accumulate + argmax, and the evaluation variant
+#pragma once
+#include "kernels_common.h"
+
+namespace helen {
+
+// ------------------------------------------------------------------------------------------------
+// Heads + softmax + accumulate + argmax (TransducerModel.py:75-76, predict_gpu.py:137-156).
+//   One 16-column MFMA tile is exactly the 5 base + 11 run-length logits of 16 windows.
+//   grid (tiles, groups of kHeadsSpan positions), 4 waves striding over the positions of the group
+//   (many small workgroups: the kernel is latency/HBM-bound, so it wants waves in flight).
+//   mode 0 (polish): positions 50c+t; the first half of chunk c receives its second (final)
+//     contribution -> add the pending softmax of chunk c-1, argmax, labels; the second half is
+//     parked in `pending` for chunk c+1 (or is final for the last chunk).  A position gets at most
+//     two contributions, and 0 + a + b == a + b in fp32, so this equals the reference's
+//     zero-pad-and-add into a [B,1000,C] accumulator.
+//   mode 1 (logits): write base[B,T,5] / rle[B,T,11] logits (the operator-level boundary).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 16));
+    return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 16);
+    return v;
+}
+// argmax with first-maximum tie-break (torch.max on CPU, predict_gpu.py:155)
+__device__ __forceinline__ int group16_argmax(float v, int idx) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const float ov = __shfl_xor(v, o, 16);
+        const int oi = __shfl_xor(idx, o, 16);
+        if (ov > v || (ov == v && oi < idx)) {
+            v = ov;
+            idx = oi;
+        }
+    }
+    return idx;
+}
+
+constexpr int kHeadsSpan = 10;  // positions per workgroup; divides kJump so a group never straddles halves
+
+__global__ __launch_bounds__(256) void heads_kernel(
+    const f32x4* __restrict__ y2, long y_tile_stride, const f32x4* __restrict__ Whd,
+    const float* __restrict__ bhd, int mode, int chunk, int T, int n_windows,
+    f32x4* __restrict__ pending, uint8_t* __restrict__ bases, uint8_t* __restrict__ rles,
+    float* __restrict__ acc_base, float* __restrict__ acc_rle, float* __restrict__ logit_base,
+    float* __restrict__ logit_rle) {
+    __shared__ uint8_t lab[2][kTile][kHeadsSpan];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int j = lane & 15;
+    const int q = lane >> 4;
+    const int tile = blockIdx.x;
+    const int t0 = blockIdx.y * kHeadsSpan;
+    const int t1 = min(T, t0 + kHeadsSpan);
+    const int half = t0 / kJump;
+    const bool isb = j < kNB;
+
+    f32x4 B[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) B[m] = Whd[m * 64 + lane];
+    const float bias = bhd[j];
+
+    const bool park = (mode == 0) && (half == 1) && (chunk < kChunks - 1);
+    const bool add_prev = (mode == 0) && (half == 0) && (chunk > 0);
+
+    for (int t = t0 + w; t < t1; t += 4) {
+        // y2[tile][slot][fwd | bwd]: the bwd half of position t sits in slot T-1-t
+        const f32x4* a_p = y2 + (size_t)tile * y_tile_stride + (size_t)t * (kYStride / 4) + lane;
+        const f32x4* a_pb = y2 + (size_t)tile * y_tile_stride + (size_t)(T - 1 - t) * (kYStride / 4) + lane;
+        f32x4 acc0 = splat4(bias);
+        f32x4 acc1 = splat4(0.f);
+#pragma unroll
+        for (int m = 0; m < 16; m += 2) {
+            const f32x4 a0 = (m >= 8 ? a_pb : a_p)[m * 64];
+            const f32x4 a1 = (m >= 8 ? a_pb : a_p)[(m + 1) * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = mfma4(a0[e], B[m][e], acc0);
+                acc1 = mfma4(a1[e], B[m + 1][e], acc1);
+            }
+        }
+        const f32x4 logit = acc0 + acc1;  // row 4q+r (window), col j (class)
+
+        if (mode == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int window = tile * kTile + 4 * q + r;
+                if (window < n_windows) {
+                    if (isb)
+                        logit_base[((size_t)window * T + t) * kNB + j] = logit[r];
+                    else
+                        logit_rle[((size_t)window * T + t) * kNR + (j - kNB)] = logit[r];
+                }
+            }
+            continue;
+        }
+
+        f32x4 p;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = logit[r];
+            const float mb = group16_max(isb ? x : -INFINITY);
+            const float mr = group16_max(isb ? -INFINITY : x);
+            const float e = expf(x - (isb ? mb : mr));
+            const float sb = group16_sum(isb ? e : 0.f);
+            const float sr = group16_sum(isb ? 0.f : e);
+            p[r] = e / (isb ? sb : sr);
+        }
+        // `pending` is double-buffered by chunk parity: this launch's second half parks into slot
+        // chunk&1 while its first half still reads what chunk-1 parked in the other slot.
+        if (park) {
+            pending[(((size_t)tile * 2 + (chunk & 1)) * kJump + (t - kJump)) * 64 + lane] = p;
+            continue;
+        }
+        if (add_prev) p += pending[(((size_t)tile * 2 + ((chunk - 1) & 1)) * kJump + t) * 64 + lane];
+        const int pos = chunk * kJump + t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int window = tile * kTile + 4 * q + r;
+            if (window < n_windows) {
+                if (acc_base != nullptr && isb)
+                    acc_base[((size_t)window * kSeq + pos) * kNB + j] = p[r];
+                if (acc_rle != nullptr && !isb)
+                    acc_rle[((size_t)window * kSeq + pos) * kNR + (j - kNB)] = p[r];
+            }
+            const int ib = group16_argmax(isb ? p[r] : -1.f, isb ? j : 99);
+            const int ir = group16_argmax(isb ? -1.f : p[r], isb ? 99 : j);
+            if (j == 0) {
+                lab[0][4 * q + r][t - t0] = (uint8_t)ib;
+                lab[1][4 * q + r][t - t0] = (uint8_t)(ir - kNB);
+            }
+        }
+    }
+    if (mode != 0 || park) return;
+    __syncthreads();
+    const int span = t1 - t0;
+    for (int g = tid; g < 2 * kTile * kHeadsSpan; g += 256) {
+        const int kind = g / (kTile * kHeadsSpan);
+        const int rem = g % (kTile * kHeadsSpan);
+        const int win = rem / kHeadsSpan;
+        const int tl = rem % kHeadsSpan;
+        const int window = tile * kTile + win;
+        if (window < n_windows && tl < span) {
+            uint8_t* out = kind ? rles : bases;
+            out[(size_t)window * kSeq + chunk * kJump + t0 + tl] = lab[kind][win][tl];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Heads + cross-entropy + confusion counts: the per-chunk body of the reference's evaluation loop
+// (models/test.py:104-121) for chunk `chunk` of 16-window tiles.
+//   logits as in heads_kernel; per position: nll_base = logsumexp(base) - base[label_base],
+//   nll_rle likewise (nn.CrossEntropyLoss = log_softmax + nll), predictions = first-maximum argmax of
+//   the LOGITS (torchnet ConfusionMeter: np.argmax), confusion[target][predicted] += 1.
+//   Outputs: stats[window][chunk][group of kHeadsSpan positions][3] = (sum nll_base, sum w[l]*nll_rle,
+//   sum w[l]) summed over the group's positions in position order (deterministic; the host finishes
+//   the per-batch means), and the two confusion matrices accumulated with integer atomics.
+//   Labels outside 0..4 / 0..10 are the caller's error (torch raises); they are clamped here only
+//   to keep the accesses in range.
+// ------------------------------------------------------------------------------------------------
+struct RleClassWeights {
+    float w[kNR];
+};
+
+__global__ __launch_bounds__(256) void heads_eval_kernel(
+    const f32x4* __restrict__ y2, long y_tile_stride, const f32x4* __restrict__ Whd,
+    const float* __restrict__ bhd, int chunk, int T, int n_windows,
+    const uint8_t* __restrict__ label_base, const uint8_t* __restrict__ label_rle, RleClassWeights cw,
+    float* __restrict__ stats, unsigned long long* __restrict__ conf_base,
+    unsigned long long* __restrict__ conf_rle) {
+    __shared__ float vals[3][kTile][kHeadsSpan];
+    __shared__ unsigned hist_b[kNB * kNB], hist_r[kNR * kNR];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int j = lane & 15;
+    const int q = lane >> 4;
+    const int tile = blockIdx.x;
+    const int t0 = blockIdx.y * kHeadsSpan;
+    const int t1 = min(T, t0 + kHeadsSpan);
+    const bool isb = j < kNB;
+    for (int g = tid; g < 3 * kTile * kHeadsSpan; g += 256) (&vals[0][0][0])[g] = 0.f;
+    if (tid < kNB * kNB) hist_b[tid] = 0;
+    if (tid < kNR * kNR) hist_r[tid] = 0;
+    __syncthreads();
+
+    f32x4 B[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) B[m] = Whd[m * 64 + lane];
+    const float bias = bhd[j];
+
+    for (int t = t0 + w; t < t1; t += 4) {
+        const f32x4* a_p = y2 + (size_t)tile * y_tile_stride + (size_t)t * (kYStride / 4) + lane;
+        const f32x4* a_pb = y2 + (size_t)tile * y_tile_stride + (size_t)(T - 1 - t) * (kYStride / 4) + lane;
+        f32x4 acc0 = splat4(bias);
+        f32x4 acc1 = splat4(0.f);
+#pragma unroll
+        for (int m = 0; m < 16; m += 2) {
+            const f32x4 a0 = (m >= 8 ? a_pb : a_p)[m * 64];
+            const f32x4 a1 = (m >= 8 ? a_pb : a_p)[(m + 1) * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = mfma4(a0[e], B[m][e], acc0);
+                acc1 = mfma4(a1[e], B[m + 1][e], acc1);
+            }
+        }
+        const f32x4 logit = acc0 + acc1;  // row 4q+r (window), col j (class)
+        const int pos = chunk * kJump + t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int window = tile * kTile + 4 * q + r;
+            const bool valid = window < n_windows;
+            const int lb = valid ? min((int)label_base[(size_t)window * kSeq + pos], kNB - 1) : 0;
+            const int lr = valid ? min((int)label_rle[(size_t)window * kSeq + pos], kNR - 1) : 0;
+            const float x = logit[r];
+            const float mb = group16_max(isb ? x : -INFINITY);
+            const float mr = group16_max(isb ? -INFINITY : x);
+            const float e = expf(x - (isb ? mb : mr));
+            const float sb = group16_sum(isb ? e : 0.f);
+            const float sr = group16_sum(isb ? 0.f : e);
+            const float xb = group16_sum((isb && j == lb) ? x : 0.f);
+            const float xr = group16_sum((!isb && j - kNB == lr) ? x : 0.f);
+            const int pb = group16_argmax(isb ? x : -INFINITY, isb ? j : 99);
+            const int pr = group16_argmax(isb ? -INFINITY : x, isb ? 99 : j) - kNB;
+            if (j == 0 && valid) {
+                const float wr = cw.w[lr];
+                vals[0][4 * q + r][t - t0] = (mb + logf(sb)) - xb;
+                vals[1][4 * q + r][t - t0] = wr * ((mr + logf(sr)) - xr);
+                vals[2][4 * q + r][t - t0] = wr;
+                atomicAdd(&hist_b[lb * kNB + pb], 1u);
+                atomicAdd(&hist_r[lr * kNR + pr], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 3 * kTile) {
+        const int k = tid / kTile, win = tid % kTile;
+        const int window = tile * kTile + win;
+        if (window < n_windows) {
+            float sum = 0.f;
+            for (int tl = 0; tl < t1 - t0; ++tl) sum += vals[k][win][tl];
+            stats[(((size_t)window * kChunks + chunk) * (kWin / kHeadsSpan) + blockIdx.y) * 3 + k] = sum;
+        }
+    }
+    if (tid < kNB * kNB && hist_b[tid]) atomicAdd(&conf_base[tid], (unsigned long long)hist_b[tid]);
+    if (tid < kNR * kNR && hist_r[tid]) atomicAdd(&conf_rle[tid], (unsigned long long)hist_r[tid]);
+}
+
+}  // namespace helen

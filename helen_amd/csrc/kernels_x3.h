@@ -1,0 +1,459 @@
+// kernels_x3.h -- bf16 matrix-core kernels on split operands: fp32x3 recurrence, weight-stationary projections (three terms or one)
+#pragma once
+#include "kernels_common.h"
+#include "kernels_gru.h"
+#include "kernels_bf16.h"
+
+namespace helen {
+
+// ------------------------------------------------------------------------------------------------
+// fp32x3 recurrence (HELEN_PRECISION_FP32X3, opt-in): fp32-class h . W_hh^T on the bf16 matrix cores.
+//   Every fp32 value is the exact sum of three bf16 terms (3 x 8 significand bits): h = h1 + h2 + h3,
+//   w = w1 + w2 + w3.  Each partial product hi*wj is exact in fp32, and the six leading ones
+//   (i + j <= 4) reproduce h*w to ~2^-26 relative (RNE splits: |h2| <= 2^-9 |h|, |h3| <= 2^-18 |h|; the
+//   dropped h2*w3, h3*w2, h3*w3 are <= 2 * 2^-27) -- a quarter of fp32's own rounding unit -- so
+//       sum_k h_k w_k = sum over the 6 products of (bf16 MFMA, fp32 accumulate)
+//   is an fp32 dot product up to summation order, at 6 x 16.7 cycles per 32 k on
+//   v_mfma_f32_16x16x32_bf16 instead of 8 x 32 cycles on v_mfma_f32_16x16x4_f32.
+//   W_hh's three terms for a wave's columns must stay in registers (3 x the bf16 kernel's), so the
+//   workgroup is 8 waves, wave v owning hidden units 16v..16v+15 (one 16-column tile per gate).
+//   The new h is split once, by the lane that produced it, into three bf16 planes in LDS laid out as
+//   the A fragment of the K = 32 MFMA (unit (k/8, row) of 8 bf16 = 16 bytes; group M of lane (row, q)
+//   is unit 4M + q); an fp32 copy feeds the layer output y and the carried state, which keep the
+//   fp32 path's layouts -- only this kernel changes, the projections stay on fp32 MFMAs.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short bf16_bits(float f) {   // RNE, via the hardware convert
+    const bf16x2_t p = __builtin_convertvector((f32x2){f, 0.f}, bf16x2_t);
+    return (unsigned short)(__builtin_bit_cast(unsigned, p) & 0xffffu);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) {
+    return __builtin_bit_cast(float, (unsigned)b << 16);
+}
+
+template <int NT>
+__global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ gi, long gi_tile_stride,
+                                                     int slot0_fwd, int slot0_bwd, int T,
+                                                     const bf16x8* __restrict__ W3,
+                                                     const float* __restrict__ bhn,
+                                                     f32x4* __restrict__ hid, f32x4* __restrict__ y,
+                                                     long y_tile_stride, f32x4* __restrict__ yplanes,
+                                                     long yp_tile_stride, int ntiles) {
+    // NT window tiles per workgroup share the resident W_hh terms and one barrier per step.  Measured:
+    // NT = 2 is no faster than NT = 1 (0.459 vs 0.449 ms) -- a step is 2 x 1200 cycles of MFMA issue plus
+    // 2 x 940 cycles of gate/split VALU work per SIMD, which do not overlap, not barrier latency -- so
+    // NT = 1 (more workgroups, half the LDS) is what is launched.  A workgroup past the last tile
+    // recomputes the last one (identical stores).
+    // Layer output: fp32 y[tile][slot][dir] (KB16, for the heads) when `y` is given, and/or the three
+    // bf16 planes yplanes[tile][slot][dir][plane][256 units] (for gemm_dec_x3_kernel) when given.
+    // LDS per tile: fp32 h [2][512 f4] | bf16 planes [2 buffers][3 terms][256 units of 16 B] |
+    // gi slots [8 waves][3][64 f4]
+    constexpr int kPerTile = 2 * 512 + 2 * 3 * 256 + 8 * 192;   // 4096 f4 = 64 KiB
+    __shared__ f32x4 smem[NT * kPerTile];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int v = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7: hidden units 16v..16v+15
+    const int j = lane & 15;
+    const int q = lane >> 4;
+    const int dir = blockIdx.y;
+    const int slot0 = dir ? slot0_bwd : slot0_fwd;
+    const int u = 16 * v + j;                                  // this lane's hidden unit
+    int tile[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) tile[n] = min((int)blockIdx.x * NT + n, ntiles - 1);
+
+    // W[g][M][t]: term t of W_hh[row g*128 + u][k = 32M + 8q + e], e = 0..7
+    bf16x8 W[3][4][3];
+    {
+        const bf16x8* wp = W3 + (size_t)((dir * 8 + v) * 36) * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int M = 0; M < 4; ++M)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) W[g][M][t] = wp[((g * 4 + M) * 3 + t) * 64];
+    }
+    const float bn = bhn[dir * kH + u];
+
+    constexpr long kPosStride = 2 * kNTile * 64;
+    auto hbuf = [&](int n) { return smem + n * kPerTile; };
+    auto planes = [&](int n) { return smem + n * kPerTile + 1024; };
+    auto gbuf = [&](int n) { return smem + n * kPerTile + 1024 + 1536 + v * 192; };
+    auto dma_gi = [&](int n, int slot) {
+        const f32x4* p = gi + (size_t)tile[n] * gi_tile_stride + (size_t)dir * (kNTile * 64) + v * 64 + lane +
+                         (size_t)slot * kPosStride;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+            __builtin_amdgcn_global_load_lds(
+                (const void __attribute__((address_space(1)))*)(p + (g * 8) * 64),
+                (void __attribute__((address_space(3)))*)(gbuf(n) + g * 64), 16, 0, 0);
+    };
+    // this lane's 4 values: rows 4q + r of unit u.  fp32 h: float index ((u>>2)*16 + 4q + r)*4 + (u&3);
+    // planes: bf16 index ((u>>3)*16 + 4q + r)*8 + (u&7) inside a 256-unit plane
+    const int hoff = ((u >> 2) * kTile + 4 * q) * 4 + (u & 3);
+    const int poff = ((u >> 3) * kTile + 4 * q) * 8 + (u & 7);
+    auto store_h = [&](int n, int buf, int r, float h) {
+        ((float*)(hbuf(n) + buf * 512))[hoff + 4 * r] = h;
+        unsigned short* pl = (unsigned short*)(planes(n) + buf * 768);
+        const unsigned short t1 = bf16_bits(h);
+        const float r1 = h - bf16_to_f32(t1);
+        const unsigned short t2 = bf16_bits(r1);
+        const float r2 = r1 - bf16_to_f32(t2);
+        const unsigned short t3 = bf16_bits(r2);
+        pl[0 * 2048 + poff + 8 * r] = t1;
+        pl[1 * 2048 + poff + 8 * r] = t2;
+        pl[2 * 2048 + poff + 8 * r] = t3;
+    };
+
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        hbuf(n)[tid] = (hid + ((size_t)tile[n] * 2 + dir) * (kHidDirStride / 4))[tid];
+        dma_gi(n, slot0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float hprev[NT][4];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hprev[n][r] = ((const float*)hbuf(n))[hoff + 4 * r];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) store_h(n, 0, r, hprev[n][r]);   // planes of h0 (fp32 copy rewritten in place)
+    __syncthreads();
+#ifdef HELEN_GRU_TIMING
+    long long tk[7] = {0, 0, 0, 0, 0, 0, 0};
+    long long tlast = __builtin_readcyclecounter();
+#endif
+    for (int s = 0; s < T; ++s) {
+        const int cur = s & 1;
+        f32x4 acc[NT][3];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const bf16x8* pa = (const bf16x8*)(planes(n) + cur * 768) + lane;
+            acc[n][0] = splat4(0.f);
+            acc[n][1] = splat4(0.f);
+            acc[n][2] = splat4(bn);
+#pragma unroll
+            for (int M = 0; M < 4; ++M) {
+                const bf16x8 a1 = pa[0 * 256 + M * 64], a2 = pa[1 * 256 + M * 64], a3 = pa[2 * 256 + M * 64];
+                const bf16x8 at[3] = {a1, a2, a3};
+                constexpr int TA[6] = {0, 2, 1, 0, 1, 0};   // six leading products, smallest first;
+                constexpr int TB[6] = {2, 0, 1, 1, 0, 0};   // product index outermost: 3 accumulators rotate
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        acc[n][g] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[TA[k]], W[g][M][TB[k]], acc[n][g], 0, 0, 0);
+            }
+        }
+        HELEN_TICK(0)
+#ifdef HELEN_GRU_TIMING
+        asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]));
+        HELEN_TICK(1)
+#endif
+        // VMEM queue, oldest first: 3 gi DMAs per tile, then the previous step's output stores (at least
+        // one per tile): the DMAs have landed once no more than NT operations are outstanding
+        if (NT == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        HELEN_TICK(2)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            f32x4 G[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) G[g] = gbuf(n)[g * 64 + lane];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (s + 1 < T) dma_gi(n, slot0 + s + 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float hn = gru_cell(acc[n][0][r], acc[n][1][r], acc[n][2][r], G[0][r], G[1][r], G[2][r],
+                                          hprev[n][r]);
+                hprev[n][r] = hn;
+                store_h(n, cur ^ 1, r, hn);
+            }
+        }
+        HELEN_TICK(3)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        HELEN_TICK(4)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        HELEN_TICK(5)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            if (y != nullptr) {
+                f32x4* yo = y + (size_t)tile[n] * y_tile_stride + (size_t)dir * (kHidDirStride / 4) +
+                            (size_t)s * (kYStride / 4);
+                yo[tid] = (hbuf(n) + (cur ^ 1) * 512)[tid];
+            }
+            if (yplanes != nullptr) {   // 768 units of 16 B per (tile, slot, dir)
+                f32x4* po = yplanes + (size_t)tile[n] * yp_tile_stride + ((size_t)s * 2 + dir) * 768;
+                const f32x4* ps = planes(n) + (cur ^ 1) * 768;
+                po[tid] = ps[tid];
+                if (tid < 256) po[512 + tid] = ps[512 + tid];
+            }
+        }
+    }
+#ifdef HELEN_GRU_TIMING
+    if (blockIdx.x == 0 && lane == 0 && (v == 0 || v == 5))
+        printf("gru_x3 dir %d wave %d: cycles/step  mfma-issue %lld  mfma-drain %lld  vmwait %lld  G+gates+stores %lld  lgkm %lld  barrier %lld  (ycopy in mfma-issue)\n",
+               dir, v, tk[0] / T, tk[1] / T, tk[2] / T, tk[3] / T, tk[4] / T, tk[5] / T);
+#endif
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+        (hid + ((size_t)tile[n] * 2 + dir) * (kHidDirStride / 4))[tid] = (hbuf(n) + (T & 1) * 512)[tid];
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32x3 decoder projection: gi = Y1 . W_ih^T + b with both operands as three bf16 terms (six exact
+// partial products per term pair, fp32 accumulate; see gru_x3_kernel).  Y1 arrives already split
+// (the encoder recurrence wrote the planes), W_ih was split on the host.
+//   With MFMAs this cheap the kernel lives or dies by operand traffic, so it is WEIGHT-STATIONARY:
+//   a workgroup (8 waves) owns 16 of the 48 column tiles (2 per wave) and keeps all three terms of
+//   their W_ih slice -- 2 tiles x 8 groups x 3 terms = 192 registers per lane -- for its whole life,
+//   walking the 100 positions of one window tile two at a time.  Per stage only A moves: 2 positions
+//   x 3 planes x 8 groups = 48 rows of 1 KiB, DMA'd global->LDS into a 2-deep ring while the previous
+//   stage is multiplied (192 MFMAs per wave and stage, one barrier per stage): 32 MFMAs per KiB
+//   staged instead of 8-11 for a block-tiled kernel that also stages the weights.
+//   k < 128 comes from the forward encoder direction at slot p, k >= 128 from the backward one at
+//   slot npos-1-p; output slot order as gemm_gi_kernel.  grid (3 column sets, window tiles).
+//   NP = 3 planes / weight terms (fp32x3: six products) or 1 (HELEN_PRECISION_BF16: Y1 and W_ih rounded to
+//   bf16, one product); PB = positions per stage (NP * PB * 8 rows of 1 KiB).
+// ------------------------------------------------------------------------------------------------
+template <int NP, int PB>
+__global__ __launch_bounds__(512) void gemm_dec_x3_kernel(const f32x4* __restrict__ yplanes,
+                                                          long yp_tile_stride,
+                                                          const f32x4* __restrict__ W3d,
+                                                          const float* __restrict__ bias,
+                                                          f32x4* __restrict__ gi, long gi_tile_stride,
+                                                          int npos, int ntiles) {
+    static_assert(NP == 1 || NP == 3, "one bf16 plane or the three-term split");
+    constexpr int ROWS = PB * NP * 8;       // rows of 1 KiB per stage: (position, plane, group)
+    static_assert(ROWS % 8 == 0 && 2 * ROWS <= 96, "two stages must fit 96 KiB");
+    __shared__ f32x4 smem[2 * ROWS * 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // 1-D grid of 3 * roundup8(ntiles) ids.  Workgroups go round-robin over the 8 XCDs (id % 8): the three
+    // column sets of a tile get consecutive local slots of ONE XCD, so its A stream is fetched from HBM
+    // once and served from that XCD's L2 to the other two.
+    const int local = blockIdx.x >> 3;
+    const int set = local % 3;
+    const int tile = (local / 3) * 8 + (blockIdx.x & 7);
+    if (tile >= ntiles) return;
+    const int gt0 = 16 * set + 2 * w;          // first of this wave's two global column tiles (dir*24 + nt)
+    const int dir = gt0 / kNTile;
+    const int nt = gt0 % kNTile;
+
+    // weight terms -> registers: B[ti][M][t]  (W3d always holds three terms; term 0 = RNE(w))
+    bf16x8 B[2][8][NP];
+    {
+        const bf16x8* wp = (const bf16x8*)W3d + lane;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int M = 0; M < 8; ++M)
+#pragma unroll
+                for (int t = 0; t < NP; ++t) B[ti][M][t] = wp[((size_t)((gt0 + ti) * 8 + M) * 3 + t) * 64];
+    }
+    float bs[2];
+    bs[0] = bias[dir * kG + nt * 16 + (lane & 15)];
+    bs[1] = bias[dir * kG + (nt + 1) * 16 + (lane & 15)];
+
+    const f32x4* yp = yplanes + (size_t)tile * yp_tile_stride + lane;
+    // DMA of position group g into buffer b; row r = (p*NP + plane)*8 + M is copied by wave r % 8
+    auto stage = [&](int g, int b) {
+        f32x4* dst = smem + b * (ROWS * 64);
+#pragma unroll
+        for (int i = 0; i < ROWS / 8; ++i) {
+            const int r = w + 8 * i;
+            const int M = r & 7, plane = (r >> 3) % NP, p = r / (8 * NP);
+            const int part = M >> 2;
+            const int pc = min(PB * g + p, npos - 1);
+            const int slot = part ? (npos - 1 - pc) : pc;
+            const f32x4* src = yp + ((size_t)slot * 2 + part) * (NP * 256) + plane * 256 + (M & 3) * 64;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                             (void __attribute__((address_space(3)))*)(dst + r * 64), 16, 0, 0);
+        }
+    };
+    constexpr int NPROD = NP == 3 ? 6 : 1;
+    constexpr int TA[6] = {NP == 3 ? 0 : 0, 2, 1, 0, 1, 0};   // leading products, smallest first: term of A
+    constexpr int TB[6] = {NP == 3 ? 2 : 0, 0, 1, 1, 0, 0};   //                                   term of B
+    const int ng = (npos + PB - 1) / PB;
+    stage(0, 0);
+    for (int g = 0; g < ng; ++g) {
+        // this wave's rows of group g have landed; after the barrier everybody's have, and the
+        // other buffer (read during group g-1) is free for group g+1.  VMEM queue, oldest first: the
+        // DMA rows of group g, then the 2 * PB output stores of group g-1 -- which may stay in flight.
+        if (g == 0)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PB) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (g + 1 < ng) stage(g + 1, (g + 1) & 1);
+        const bf16x8* L = (const bf16x8*)(smem + (g & 1) * (ROWS * 64)) + lane;
+        f32x4 acc[PB][2];
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            acc[p][0] = splat4(bs[0]);
+            acc[p][1] = splat4(bs[1]);
+        }
+#pragma unroll
+        for (int M = 0; M < 8; ++M) {
+            bf16x8 a[PB][NP];
+#pragma unroll
+            for (int p = 0; p < PB; ++p)
+#pragma unroll
+                for (int t = 0; t < NP; ++t) a[p][t] = L[((p * NP + t) * 8 + M) * 64];
+#pragma unroll
+            for (int k = 0; k < NPROD; ++k)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int p = 0; p < PB; ++p)
+                        acc[p][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p][TA[k]], B[ti][M][TB[k]],
+                                                                            acc[p][ti], 0, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            // exactly 2 * PB stores per lane per stage (counted above): positions past the end of the last
+            // stage rewrite the last valid one with identical values
+            const int pos = min(PB * g + p, npos - 1);
+            const int slot = dir ? (npos - 1 - pos) : pos;
+            f32x4* o = gi + (size_t)tile * gi_tile_stride + ((size_t)slot * 2 + dir) * (kNTile * 64) + nt * 64 + lane;
+            o[0] = acc[p][0];
+            o[64] = acc[p][1];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32x3 encoder projection.  The encoder input is raw pileup counts 0..255 (predict_gpu.py:97): every x
+// is EXACTLY one bf16 term, so x*w = x*w1 + x*w2 + x*w3 with exact partial products -- three bf16 MFMAs
+// per 32 k.  pack_images_x3_kernel writes the counts straight as bf16 A fragments (K padded 90 -> 96 =
+// 3 groups), gemm_enc_x3_kernel is weight-stationary like gemm_dec_x3_kernel: 2 column tiles per
+// wave (72 registers of weight terms), 8 positions per stage (24 KiB of A), and it runs at the speed
+// of its fp32 output stream (3 MB per window).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_images_x3_kernel(const uint8_t* __restrict__ img, int n_windows,
+                                                             int npos, f32x4* __restrict__ xb) {
+    // one 16-byte unit (8 bf16) per thread: unit index within (tile, pos) = M*64 + q*16 + row
+    const int tile = blockIdx.y;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= npos * 192) return;
+    const int row = g & 15;
+    const int o = (g >> 4) % 12;          // octet of k: k = 8*o + e
+    const int pos = g / 192;
+    const int window = tile * kTile + row;
+    unsigned short v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0;
+    if (window < n_windows) {
+        const uint8_t* p = img + ((size_t)window * npos + pos) * kF + o * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (o * 8 + e < kF) v[e] = bf16_bits((float)p[e]);   // exact: integers <= 255
+    }
+    uint4 u;
+    u.x = v[0] | ((unsigned)v[1] << 16);
+    u.y = v[2] | ((unsigned)v[3] << 16);
+    u.z = v[4] | ((unsigned)v[5] << 16);
+    u.w = v[6] | ((unsigned)v[7] << 16);
+    xb[((size_t)tile * npos + pos) * 192 + o * 16 + row] = __builtin_bit_cast(f32x4, u);
+}
+
+//   TERMS = 3 (fp32x3) or 1 (HELEN_PRECISION_BF16: W_ih rounded to bf16, i.e. the first term only).
+template <int TERMS>
+__global__ __launch_bounds__(512) void gemm_enc_x3_kernel(const f32x4* __restrict__ xb, long xb_tile_stride,
+                                                          const f32x4* __restrict__ W3e,
+                                                          const float* __restrict__ bias,
+                                                          f32x4* __restrict__ gi, long gi_tile_stride,
+                                                          int npos, int ntiles) {
+    constexpr int PB = 8, ROWS = PB * 3;    // rows of 1 KiB per stage: (position, group)
+    __shared__ f32x4 smem[2 * ROWS * 64];   // 48 KiB
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // 1-D grid of 3 * roundup8(ntiles) ids.  Workgroups go round-robin over the 8 XCDs (id % 8): the three
+    // column sets of a tile get consecutive local slots of ONE XCD, so its A stream is fetched from HBM
+    // once and served from that XCD's L2 to the other two.
+    const int local = blockIdx.x >> 3;
+    const int set = local % 3;
+    const int tile = (local / 3) * 8 + (blockIdx.x & 7);
+    if (tile >= ntiles) return;
+    const int gt0 = 16 * set + 2 * w;
+    const int dir = gt0 / kNTile;
+    const int nt = gt0 % kNTile;
+    bf16x8 B[2][3][TERMS];
+    {
+        const bf16x8* wp = (const bf16x8*)W3e + lane;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int M = 0; M < 3; ++M)
+#pragma unroll
+                for (int t = 0; t < TERMS; ++t) B[ti][M][t] = wp[((size_t)((gt0 + ti) * 3 + M) * 3 + t) * 64];
+    }
+    float bs[2];
+    bs[0] = bias[dir * kG + nt * 16 + (lane & 15)];
+    bs[1] = bias[dir * kG + (nt + 1) * 16 + (lane & 15)];
+    const f32x4* xp = xb + (size_t)tile * xb_tile_stride + lane;
+    auto stage = [&](int g, int b) {    // positions 8g..8g+7: 24 rows, 3 per wave; row r = p*3 + M
+        f32x4* dst = smem + b * (ROWS * 64);
+#pragma unroll
+        for (int i = 0; i < ROWS / 8; ++i) {
+            const int r = w + 8 * i;
+            const int pc = min(PB * g + r / 3, npos - 1);
+            const f32x4* src = xp + (size_t)pc * 192 + (r % 3) * 64;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                             (void __attribute__((address_space(3)))*)(dst + r * 64), 16, 0, 0);
+        }
+    };
+    const int ng = (npos + PB - 1) / PB;
+    stage(0, 0);
+    for (int g = 0; g < ng; ++g) {
+        // VMEM queue, oldest first: 3 DMA rows of group g, then 16 output stores of group g-1
+        if (g == 0)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (g + 1 < ng) stage(g + 1, (g + 1) & 1);
+        const bf16x8* L = (const bf16x8*)(smem + (g & 1) * (ROWS * 64)) + lane;
+        f32x4 acc[PB][2];
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            acc[p][0] = splat4(bs[0]);
+            acc[p][1] = splat4(bs[1]);
+        }
+#pragma unroll
+        for (int M = 0; M < 3; ++M) {
+            bf16x8 a[PB];
+#pragma unroll
+            for (int p = 0; p < PB; ++p) a[p] = L[(p * 3 + M) * 64];
+#pragma unroll
+            for (int t = TERMS - 1; t >= 0; --t)   // smallest term first
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int p = 0; p < PB; ++p)
+                        acc[p][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p], B[ti][M][t], acc[p][ti], 0, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            // every stage issues exactly 16 stores per lane (counted above): out-of-range positions of the
+            // last stage rewrite the last valid one with identical values
+            const int pos = min(PB * g + p, npos - 1);
+            const int slot = dir ? (npos - 1 - pos) : pos;
+            f32x4* o = gi + (size_t)tile * gi_tile_stride + ((size_t)slot * 2 + dir) * (kNTile * 64) + nt * 64 + lane;
+            o[0] = acc[p][0];
+            o[64] = acc[p][1];
+        }
+    }
+}
+
+}  // namespace helen
