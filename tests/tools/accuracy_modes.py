@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import torch
 
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 sys.path.insert(0, os.path.join(R, "tests"))
 from golden_cases import load_case  # noqa: E402
