@@ -59,12 +59,8 @@ struct HelenModel {
     float* bhn_enc = nullptr;  // [2][128]
     float* bhn_dec = nullptr;
     float* bhd = nullptr;      // [16]
-    // bf16 copies of the gate matrices (HELEN_PRECISION_BF16), 4 x bf16 per lane and group
-    bf16x4* wpb_enc = nullptr;
-    bf16x4* wpb_dec = nullptr;
-    bf16x4* whpb_enc = nullptr;
-    bf16x4* whpb_dec = nullptr;
     // three-term bf16 split of W_hh for the fp32x3 recurrence: [2 dirs][8 waves][3 gates][4 M][3 terms][64]
+    // (HELEN_PRECISION_BF16 uses term 0 = RNE(w) of the same packings)
     bf16x8* w3h_enc = nullptr;
     bf16x8* w3h_dec = nullptr;
     bf16x8* w3i_dec = nullptr;   // decoder W_ih split: [2 dirs][24 tiles][8 M][3 terms][64]
@@ -165,13 +161,6 @@ short to_bf16(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (short)(u >> 16);
 }
-std::vector<bf16x4> round_pack(const std::vector<f32x4>& in) {
-    std::vector<bf16x4> out(in.size());
-    for (size_t i = 0; i < in.size(); ++i)
-        for (int e = 0; e < 4; ++e) out[i][e] = to_bf16(in[i][e]);
-    return out;
-}
-
 float from_bf16(short b) {
     uint32_t u = (uint32_t)(uint16_t)b << 16;
     float f;
@@ -280,10 +269,7 @@ constexpr int kWsMinWorkgroups = 384;   // 1.5 workgroups per CU-slot pair: belo
 
 void launch_enc_gemm(HelenModel* m, hipStream_t s, int tiles, int npos) {
     const dim3 grid(gemm_grid(npos, tiles)), block(HELEN_GEMM_WAVES * 64);
-    if (m->precision == HELEN_PRECISION_BF16)
-        LAUNCH(HELEN_K_GEMM_ENC, (gemm_gi_bf16_kernel<kFPad / 16, false, 4, false>), dim3(gemm_grid(npos, tiles, 4)), block, m->xa,
-               kXaTileStride, m->wpb_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles);
-    else if (3 * tiles >= kWsMinWorkgroups)
+    if (3 * tiles >= kWsMinWorkgroups)
         // enough tiles to fill the chip with one workgroup per (tile, column set): weights stay in
         // registers, same MFMA order per accumulator as gemm_gi_kernel (bit-identical gi)
         LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_ws_kernel, dim3(3 * ((tiles + 7) / 8 * 8)), dim3(256), m->xa,
@@ -304,14 +290,14 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
     const dim3 ggrid(gemm_grid(T, tiles)), gblock(HELEN_GEMM_WAVES * 64);
     // encoder gi holds `enc_npos` positions; the reverse direction is stored time-reversed
     if (m->precision == HELEN_PRECISION_BF16) {
-        // encoder output goes out as one bf16 plane (what the projection would round it to anyway)
-        LAUNCH(HELEN_K_GRU_ENC, gru_bf16_kernel, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride,
-               pos0, enc_npos - pos0 - T, T, m->whpb_enc, m->bhn_enc, m->hid, (f32x4*)nullptr, kYTileStride,
-               m->y1p, kY1bTileStride);
-        LAUNCH(HELEN_K_GEMM_DEC, (gemm_dec_x3_kernel<1, 6>), dim3(3 * ((tiles + 7) / 8 * 8)), dim3(512), m->y1p,
-               kY1bTileStride, (const f32x4*)m->w3i_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
-        LAUNCH(HELEN_K_GRU_DEC, gru_bf16_kernel, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0,
-               0, T, m->whpb_dec, m->bhn_dec, m->hid, m->y2, kYTileStride, (f32x4*)nullptr, kY1bTileStride);
+        // projection fused into the recurrence: no gi at all; the encoder reads the packed pileup counts,
+        // the decoder the encoder's bf16 output plane
+        LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_kernel<3, false>), dim3(tiles, 2), dim3(512), m->xb,
+               (long)kSeq * 192, pos0, T, m->w3i_enc, m->w3h_enc, m->bias_enc, m->bhn_enc, m->hid,
+               (f32x4*)nullptr, kYTileStride, m->y1p, kY1bTileStride);
+        LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_kernel<8, true>), dim3(tiles, 2), dim3(512), m->y1p,
+               kY1bTileStride, 0, T, m->w3i_dec, m->w3h_dec, m->bias_dec, m->bhn_dec, m->hid, m->y2,
+               kYTileStride, (f32x4*)nullptr, kY1bTileStride);
         return;
     }
     if (m->precision == HELEN_PRECISION_FP32X3) {
@@ -337,7 +323,7 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
 void free_model(HelenModel* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    void* ptrs[] = {m->w3i_enc, m->xb, m->w3i_dec, m->y1p, m->w3h_enc, m->w3h_dec, m->wpb_enc, m->wpb_dec, m->whpb_enc, m->whpb_dec, m->wp_enc, m->wp_dec, m->whp_enc, m->whp_dec, m->whd, m->bias_enc, m->bias_dec,
+    void* ptrs[] = {m->w3i_enc, m->xb, m->w3i_dec, m->y1p, m->w3h_enc, m->w3h_dec, m->wp_enc, m->wp_dec, m->whp_enc, m->whp_dec, m->whd, m->bias_enc, m->bias_dec,
                     m->bhn_enc, m->bhn_dec, m->bhd, m->xa, m->gi_enc, m->gi_dec, m->y1, m->y2,
                     m->hid, m->pending, m->dev_in[0], m->dev_in[1], m->dev_out[0], m->dev_out[1]};
     for (void* p : ptrs)
@@ -376,10 +362,12 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
     m->max_tiles = (max_windows + kTile - 1) / kTile;
 
     int rc;
-    if ((rc = upload(m, &m->wp_enc, pack_w_ih(w->enc_w_ih, kF, kFPad / 16)))) return rc;
-    if ((rc = upload(m, &m->wp_dec, pack_w_ih(w->dec_w_ih, 2 * kH, 16)))) return rc;
-    if ((rc = upload(m, &m->whp_enc, pack_w_hh(w->enc_w_hh)))) return rc;
-    if ((rc = upload(m, &m->whp_dec, pack_w_hh(w->dec_w_hh)))) return rc;
+    if (precision != HELEN_PRECISION_BF16) {   // fp32 operand packings (fp32x3 keeps them for the operator entry)
+        if ((rc = upload(m, &m->wp_enc, pack_w_ih(w->enc_w_ih, kF, kFPad / 16)))) return rc;
+        if ((rc = upload(m, &m->wp_dec, pack_w_ih(w->dec_w_ih, 2 * kH, 16)))) return rc;
+        if ((rc = upload(m, &m->whp_enc, pack_w_hh(w->enc_w_hh)))) return rc;
+        if ((rc = upload(m, &m->whp_dec, pack_w_hh(w->dec_w_hh)))) return rc;
+    }
     if (precision == HELEN_PRECISION_FP32X3) {
         if ((rc = upload(m, &m->w3h_enc, pack_w_hh_x3(w->enc_w_hh)))) return rc;
         if ((rc = upload(m, &m->w3h_dec, pack_w_hh_x3(w->dec_w_hh)))) return rc;
@@ -389,11 +377,9 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
         if ((rc = dev_alloc(m, &m->y1p, (size_t)m->max_tiles * kY1pTileStride))) return rc;
     }
     if (precision == HELEN_PRECISION_BF16) {
-        if ((rc = upload(m, &m->wpb_enc, round_pack(pack_w_ih(w->enc_w_ih, kF, kFPad / 16))))) return rc;
-        if ((rc = upload(m, &m->wpb_dec, round_pack(pack_w_ih(w->dec_w_ih, 2 * kH, 16))))) return rc;
-        if ((rc = upload(m, &m->whpb_enc, round_pack(pack_w_hh(w->enc_w_hh))))) return rc;
-        if ((rc = upload(m, &m->whpb_dec, round_pack(pack_w_hh(w->dec_w_hh))))) return rc;
-        // weight-stationary projections read term 0 (= RNE(w)) of the three-term packing
+        // the fused kernels read term 0 (= RNE(w)) of the three-term packings
+        if ((rc = upload(m, &m->w3h_enc, pack_w_hh_x3(w->enc_w_hh)))) return rc;
+        if ((rc = upload(m, &m->w3h_dec, pack_w_hh_x3(w->dec_w_hh)))) return rc;
         if ((rc = upload(m, &m->w3i_dec, pack_w_ih_x3(w->dec_w_ih)))) return rc;
         if ((rc = upload(m, &m->w3i_enc, pack_w_ih_x3(w->enc_w_ih, kF)))) return rc;
         if ((rc = dev_alloc(m, &m->xb, (size_t)m->max_tiles * kSeq * 192))) return rc;
@@ -430,10 +416,13 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
         if ((rc = upload(m, layer ? &m->bhn_dec : &m->bhn_enc, bhn))) return rc;
     }
     const size_t nt = (size_t)m->max_tiles;
-    if ((rc = dev_alloc(m, &m->xa, nt * kXaTileStride))) return rc;
-    if ((rc = dev_alloc(m, &m->gi_enc, nt * kGiEncTileStride))) return rc;
-    if ((rc = dev_alloc(m, &m->gi_dec, nt * kGiDecTileStride))) return rc;
-    if ((rc = dev_alloc(m, &m->y1, nt * kYTileStride))) return rc;
+    if (precision != HELEN_PRECISION_BF16) {   // the fused bf16 kernels have no gi, no fp32 operand tiles, no fp32 y1
+        if ((rc = dev_alloc(m, &m->xa, nt * kXaTileStride))) return rc;
+        if ((rc = dev_alloc(m, &m->gi_enc, nt * kGiEncTileStride))) return rc;
+        if ((rc = dev_alloc(m, &m->gi_dec, nt * kGiDecTileStride))) return rc;
+    }
+    if (precision == HELEN_PRECISION_FP32)
+        if ((rc = dev_alloc(m, &m->y1, nt * kYTileStride))) return rc;
     if ((rc = dev_alloc(m, &m->y2, nt * kYTileStride))) return rc;
     if ((rc = dev_alloc(m, &m->hid, nt * (kHidStride / 4)))) return rc;
     if ((rc = dev_alloc(m, &m->pending, nt * 2 * kJump * 64))) return rc;
@@ -499,9 +488,7 @@ static int launch_front(HelenModel* m, hipStream_t s, const uint8_t* images, int
         if (m->precision == HELEN_PRECISION_FP32X3)
             LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_x3_kernel<3>, egrid, dim3(512), m->xb, (long)kSeq * 192,
                    (const f32x4*)m->w3i_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, kSeq, tiles);
-        else
-            LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_x3_kernel<1>, egrid, dim3(512), m->xb, (long)kSeq * 192,
-                   (const f32x4*)m->w3i_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, kSeq, tiles);
+        // (bf16: the projection is fused into the recurrence, gru_fused_bf16_kernel reads xb directly)
     } else {
         // uint8 -> fp32 operand tiles (predict_gpu.py:97)
         LAUNCH(HELEN_K_PACK, pack_images_kernel, dim3((kSeq * (kXaStride / 4) + 255) / 256, tiles),
@@ -565,10 +552,15 @@ int helen_gru_chunk_forward(HelenModel* m, const float* x, const float* h_in, in
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
     const int tiles = (B + kTile - 1) / kTile;
-    LAUNCH(HELEN_K_PACK, pack_x_f32_kernel, dim3((T * (kXaStride / 4) + 255) / 256, tiles), dim3(256),
-           x, B, T, m->xa, kXaTileStride);
     hipLaunchKernelGGL(pack_hidden_kernel, dim3(tiles), dim3(256), 0, s, h_in, B, (float*)m->hid);
-    launch_enc_gemm(m, s, tiles, T);
+    if (m->precision == HELEN_PRECISION_BF16) {
+        LAUNCH(HELEN_K_PACK, pack_x_bf16_kernel, dim3((T * 192 + 255) / 256, tiles), dim3(256), x, B, T, m->xb,
+               (long)kSeq * 192);
+    } else {
+        LAUNCH(HELEN_K_PACK, pack_x_f32_kernel, dim3((T * (kXaStride / 4) + 255) / 256, tiles), dim3(256),
+               x, B, T, m->xa, kXaTileStride);
+        launch_enc_gemm(m, s, tiles, T);
+    }
     launch_chunk(m, s, tiles, 0, T, T);
     LAUNCH(HELEN_K_HEADS, heads_kernel, dim3(tiles, (T + kHeadsSpan - 1) / kHeadsSpan), dim3(256), m->y2,
            kYTileStride, m->whd, m->bhd, 1, 0, T, B, m->pending, (uint8_t*)nullptr, (uint8_t*)nullptr,

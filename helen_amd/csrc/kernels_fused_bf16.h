@@ -1,0 +1,194 @@
+// kernels_fused_bf16.h -- HELEN_PRECISION_BF16: input projection fused into the recurrence
+#pragma once
+#include "kernels_common.h"
+#include "kernels_gru.h"
+#include "kernels_x3.h"
+
+namespace helen {
+
+// ------------------------------------------------------------------------------------------------
+// One GRU layer direction, projection AND recurrence, for bf16 gate matmuls (fp32 accumulate, fp32
+// state, fp32 gates).  With bf16 operands a direction's W_ih and W_hh both fit the register file
+// (8 waves, wave v owns hidden units 16v..16v+15 = one 16-column tile per gate: W_hh 3 x 4 K32-groups
+// = 48 registers, W_ih 3 x MI groups = 36 (encoder, K = 96) or 96 (decoder, K = 256)), so the gate
+// pre-activations never exist in memory: per step the kernel reads the layer INPUT (3 KiB of packed
+// pileup counts, or 8 KiB of the encoder's bf16 output plane) instead of 24 KiB of fp32 gi, and the
+// separate projection kernels and their 24 MB-per-window gi round trip disappear.
+//   Per step:  A  gh = h . W_hh^T on the bf16 h plane in LDS, added onto the input part computed one
+//                 step earlier (n gate kept apart: n = tanh(gi_n + r * gh_n))
+//              B  gates (fp32), new h -> LDS as fp32 (state / layer output) and as a bf16 plane
+//              C  this wave's input row of step s+1 has landed (counted vmcnt)
+//              D  one barrier
+//              E  DMA the input of step s+2 (3-deep ring), store this step's output
+//              F  input part of step s+1: x . W_ih^T + bias -- independent of h, so it sits between
+//                 the barrier and the next step's recurrent MFMAs
+//   Input rows (1 KiB = one K32 group of 16 windows, the MFMA A fragment):
+//     encoder (MI = 3): xb[tile][pos][3][64 units], pos = pos0 + s (dir 0) or pos0 + T-1-s (dir 1)
+//     decoder (MI = 8): yplane[tile][slot][d][4][64 units]; time t = s (dir 0) or T-1-s (dir 1);
+//                       k < 128 is the forward encoder output of time t (slot t), k >= 128 the backward
+//                       one (stored time-reversed: slot T-1-t)
+//   Output: fp32 y[tile][slot = s][dir] (KB16, for the heads) when DEC, else one bf16 plane
+//   yplane_out[tile][slot = s][dir][256 units] for the decoder.
+//   Weights come from the three-term packings of kernels_x3.h; term 0 is RNE(w).
+// ------------------------------------------------------------------------------------------------
+template <int MI, bool DEC>
+__global__ __launch_bounds__(512) void gru_fused_bf16_kernel(
+    const f32x4* __restrict__ in, long in_tile_stride, int pos0, int T, const bf16x8* __restrict__ Wi3,
+    const bf16x8* __restrict__ Wh3, const float* __restrict__ bias, const float* __restrict__ bhn,
+    f32x4* __restrict__ hid, f32x4* __restrict__ y, long y_tile_stride, f32x4* __restrict__ yplane_out,
+    long yp_tile_stride) {
+    // LDS: fp32 h [2][512 f4] | bf16 h plane [2][256 units] | input ring [3][MI * 64 units]
+    __shared__ f32x4 smem[2 * 512 + 2 * 256 + 3 * MI * 64];
+    f32x4* const hbuf = smem;
+    f32x4* const hplane = smem + 1024;
+    f32x4* const inbuf = smem + 1024 + 512;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15;
+    const int q = lane >> 4;
+    const int tile = blockIdx.x;
+    const int dir = blockIdx.y;
+    const int u = 16 * v + j;
+
+    bf16x8 Wh[3][4], Wi[3][MI];
+    {
+        const bf16x8* wh = Wh3 + (size_t)((dir * 8 + v) * 36) * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+#pragma unroll
+            for (int M = 0; M < 4; ++M) Wh[g][M] = wh[((g * 4 + M) * 3) * 64];
+            const bf16x8* wi = Wi3 + (size_t)((dir * kNTile + g * 8 + v) * MI) * 3 * 64 + lane;
+#pragma unroll
+            for (int M = 0; M < MI; ++M) Wi[g][M] = wi[(M * 3) * 64];
+        }
+    }
+    float bi[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bi[g] = bias[dir * kG + g * kH + u];
+    const float bn = bhn[dir * kH + u];
+
+    const f32x4* in_p = in + (size_t)tile * in_tile_stride + lane;
+    auto dma_in = [&](int s, int b) {      // wave v < MI brings row v of step s into ring buffer b
+        if (v >= MI) return;
+        const f32x4* src;
+        if (DEC) {
+            const int t = dir ? (T - 1 - s) : s;
+            const int part = v >> 2;
+            const int slot = part ? (T - 1 - t) : t;
+            src = in_p + ((size_t)slot * 2 + part) * 256 + (v & 3) * 64;
+        } else {
+            const int pos = pos0 + (dir ? (T - 1 - s) : s);
+            src = in_p + (size_t)pos * (MI * 64) + v * 64;
+        }
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                         (void __attribute__((address_space(3)))*)(inbuf + (b * MI + v) * 64), 16, 0,
+                                         0);
+    };
+    auto input_part = [&](int b, f32x4* acc) {   // x . W_ih^T + bias for this wave's three column tiles
+        const bf16x8* L = (const bf16x8*)(inbuf + b * (MI * 64)) + lane;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = splat4(bi[g]);
+#pragma unroll
+        for (int M = 0; M < MI; ++M) {
+            const bf16x8 a = L[M * 64];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Wi[g][M], acc[g], 0, 0, 0);
+        }
+    };
+    // this lane's 4 values: rows 4q + r of unit u (see gru_x3_kernel)
+    const int hoff = ((u >> 2) * kTile + 4 * q) * 4 + (u & 3);
+    const int poff = ((u >> 3) * kTile + 4 * q) * 8 + (u & 7);
+    auto store_h = [&](int buf, int r, float h) {
+        ((float*)(hbuf + buf * 512))[hoff + 4 * r] = h;
+        ((unsigned short*)(hplane + buf * 256))[poff + 8 * r] = bf16_bits(h);
+    };
+
+    f32x4* hid_p = hid + ((size_t)tile * 2 + dir) * (kHidDirStride / 4);
+    hbuf[tid] = hid_p[tid];
+    dma_in(0, 0);
+    if (T > 1) dma_in(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float hprev[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hprev[r] = ((const float*)hbuf)[hoff + 4 * r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) store_h(0, r, hprev[r]);
+    f32x4 gin[3];
+    input_part(0, gin);
+    __syncthreads();
+
+    int b_next = 1, b_dma = 2;       // ring slots of step s+1 and s+2
+    for (int s = 0; s < T; ++s) {
+        const int cur = s & 1;
+        // A: recurrent part
+        f32x4 ar = gin[0], az = gin[1], ahn = splat4(bn);
+        {
+            const bf16x8* pa = (const bf16x8*)(hplane + cur * 256) + lane;
+#pragma unroll
+            for (int M = 0; M < 4; ++M) {
+                const bf16x8 a = pa[M * 64];
+                ar = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Wh[0][M], ar, 0, 0, 0);
+                az = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Wh[1][M], az, 0, 0, 0);
+                ahn = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Wh[2][M], ahn, 0, 0, 0);
+            }
+        }
+        // B: gates
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float hn = gru_cell(ar[r], az[r], ahn[r], 0.f, 0.f, gin[2][r], hprev[r]);
+            hprev[r] = hn;
+            store_h(cur ^ 1, r, hn);
+        }
+        // C: VMEM queue of a wave that DMAs, oldest first: its row of step s+1, then one output store
+        if (v < MI) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        // D
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // E
+        if (s + 2 < T) dma_in(s + 2, b_dma);
+        if (DEC) {
+            (y + (size_t)tile * y_tile_stride + (size_t)dir * (kHidDirStride / 4) + (size_t)s * (kYStride / 4))[tid] =
+                (hbuf + (cur ^ 1) * 512)[tid];
+        } else if (tid < 256) {
+            (yplane_out + (size_t)tile * yp_tile_stride + ((size_t)s * 2 + dir) * 256)[tid] =
+                (hplane + (cur ^ 1) * 256)[tid];
+        }
+        // F
+        if (s + 1 < T) input_part(b_next, gin);
+        b_next = b_next == 2 ? 0 : b_next + 1;
+        b_dma = b_dma == 2 ? 0 : b_dma + 1;
+    }
+    hid_p[tid] = (hbuf + (T & 1) * 512)[tid];
+}
+
+// float32 x [B, T, F] (operator-level boundary) -> bf16 A fragments xb[tile][pos][3][64 units], RNE.
+__global__ __launch_bounds__(256) void pack_x_bf16_kernel(const float* __restrict__ x, int n_windows, int T,
+                                                          f32x4* __restrict__ xb, long xb_tile_stride) {
+    const int tile = blockIdx.y;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= T * 192) return;
+    const int row = g & 15;
+    const int o = (g >> 4) % 12;
+    const int pos = g / 192;
+    const int window = tile * kTile + row;
+    unsigned short b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b[e] = 0;
+    if (window < n_windows) {
+        const float* p = x + ((size_t)window * T + pos) * kF + o * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (o * 8 + e < kF) b[e] = bf16_bits(p[e]);
+    }
+    uint4 w;
+    w.x = b[0] | ((unsigned)b[1] << 16);
+    w.y = b[2] | ((unsigned)b[3] << 16);
+    w.z = b[4] | ((unsigned)b[5] << 16);
+    w.w = b[6] | ((unsigned)b[7] << 16);
+    xb[(size_t)tile * xb_tile_stride + (size_t)pos * 192 + o * 16 + row] = __builtin_bit_cast(f32x4, w);
+}
+
+}  // namespace helen

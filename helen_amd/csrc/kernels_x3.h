@@ -2,7 +2,6 @@
 #pragma once
 #include "kernels_common.h"
 #include "kernels_gru.h"
-#include "kernels_bf16.h"
 
 namespace helen {
 
@@ -23,8 +22,12 @@ namespace helen {
 //   fp32 path's layouts -- only this kernel changes, the projections stay on fp32 MFMAs.
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ unsigned short bf16_bits(float f) {   // RNE, via the hardware convert
+// fptrunc <2 x float> -> <2 x bfloat> selects v_cvt_pk_bf16_f32 (RNE) on gfx950; unlike an inline-asm cvt
+// the compiler pads the VALU-write -> MFMA-read hazard itself (the asm form produced NaNs)
+__device__ __forceinline__ unsigned short bf16_bits(float f) {
     const bf16x2_t p = __builtin_convertvector((f32x2){f, 0.f}, bf16x2_t);
     return (unsigned short)(__builtin_bit_cast(unsigned, p) & 0xffffu);
 }
@@ -219,8 +222,9 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
 //   staged instead of 8-11 for a block-tiled kernel that also stages the weights.
 //   k < 128 comes from the forward encoder direction at slot p, k >= 128 from the backward one at
 //   slot npos-1-p; output slot order as gemm_gi_kernel.  grid (3 column sets, window tiles).
-//   NP = 3 planes / weight terms (fp32x3: six products) or 1 (HELEN_PRECISION_BF16: Y1 and W_ih rounded to
-//   bf16, one product); PB = positions per stage (NP * PB * 8 rows of 1 KiB).
+//   NP = 3 planes / weight terms (fp32x3: six products); NP = 1 is the plain bf16 projection (one plane, one
+//   product; 0.27 ms per launch as <1, 6>) that HELEN_PRECISION_BF16 used before its projections were fused
+//   into the recurrence (kernels_fused_bf16.h).  PB = positions per stage (NP * PB * 8 rows of 1 KiB).
 // ------------------------------------------------------------------------------------------------
 template <int NP, int PB>
 __global__ __launch_bounds__(512) void gemm_dec_x3_kernel(const f32x4* __restrict__ yplanes,
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(256) void pack_images_x3_kernel(const uint8_t* __re
     xb[((size_t)tile * npos + pos) * 192 + o * 16 + row] = __builtin_bit_cast(f32x4, u);
 }
 
-//   TERMS = 3 (fp32x3) or 1 (HELEN_PRECISION_BF16: W_ih rounded to bf16, i.e. the first term only).
+//   TERMS = 3 (fp32x3); TERMS = 1 is the plain bf16 projection (W_ih rounded to bf16 = the first term).
 template <int TERMS>
 __global__ __launch_bounds__(512) void gemm_enc_x3_kernel(const f32x4* __restrict__ xb, long xb_tile_stride,
                                                           const f32x4* __restrict__ W3e,
