@@ -40,7 +40,10 @@ __device__ __forceinline__ int group16_argmax(float v, int idx) {
     return idx;
 }
 
-constexpr int kHeadsSpan = 10;  // positions per workgroup; divides kJump so a group never straddles halves
+#ifndef HELEN_HEADS_SPAN
+#define HELEN_HEADS_SPAN 10
+#endif
+constexpr int kHeadsSpan = HELEN_HEADS_SPAN;  // positions per workgroup; divides kJump so a group never straddles halves
 
 __global__ __launch_bounds__(256) void heads_kernel(
     const f32x4* __restrict__ y2, long y_tile_stride, const f32x4* __restrict__ Whd,

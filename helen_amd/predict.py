@@ -216,24 +216,11 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     writers = writer_count(num_workers)
     prediction_data_file = DataStore(prediction_file_name(output_filename, rank), mode="w") \
         if writers == 1 else None
-    transducer_model, hidden_size, gru_layers, prev_ite = ModelHandler.load_simple_model(
-        model_path, input_channels=ImageSizeOptions.IMAGE_CHANNELS,
-        image_features=ImageSizeOptions.IMAGE_HEIGHT, seq_len=ImageSizeOptions.SEQ_LENGTH,
-        num_base_classes=ImageSizeOptions.TOTAL_BASE_LABELS,
-        num_rle_classes=ImageSizeOptions.TOTAL_RLE_LABELS)
-    transducer_model.eval()
-    torch.cuda.set_device(device_id)
-    transducer_model.to(device_id)
     group = max(1, DEVICE_CALL_WINDOWS // batch_size)       # loader batches per device call
     cap = group * batch_size
-    transducer_model.set_capacity(min(DEVICE_CALL_WINDOWS, cap))
-    engine = transducer_model.engine
-    if rank == 0:
-        print(prediction_file_name(output_filename, rank))
-        sys.stderr.write("INFO: MI355X HIP PATH, DEVICE " + str(device_id) + ", "
-                         + str(engine.device_bytes >> 20) + " MiB OF DEVICE MEMORY HELD.\n")
-        sys.stderr.write("Loading data\n")
 
+    # Readers and writers first: their processes start (and the first slots fill) while the model is
+    # loaded and the device context is created below.
     test_data = SequenceDataset(image_directory=None, file_list=test_file)
     pairs = test_data.all_images
     batches = [pairs[i:i + batch_size] for i in range(0, len(pairs), batch_size)]   # sequential,
@@ -262,13 +249,8 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     else:
         writer_pool = _WriterPool(output_filename, rank, writers, free_slots, werr)
     feeder.start()
-    stage = None
-    if os.environ.get("HELEN_DEVICE_STAGE", "async") != "sync" and hasattr(engine, "polish") \
-            and torch.cuda.is_available() and calls:
-        try:
-            stage = _DeviceStage(engine, slots, cap, device_id)
-        except Exception as e:      # page-locking refused (ulimit -l, container policy): staged copies
-            sys.stderr.write("INFO: SLOTS NOT PAGE-LOCKED (" + str(e) + "), USING STAGED COPIES.\n")
+
+    stage = engine = None
 
     def to_writer(slot, n):
         if writer_pool is None:
@@ -279,6 +261,27 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     start_time = time.time()
     batch_iterator = 0
     try:
+        transducer_model, hidden_size, gru_layers, prev_ite = ModelHandler.load_simple_model(
+            model_path, input_channels=ImageSizeOptions.IMAGE_CHANNELS,
+            image_features=ImageSizeOptions.IMAGE_HEIGHT, seq_len=ImageSizeOptions.SEQ_LENGTH,
+            num_base_classes=ImageSizeOptions.TOTAL_BASE_LABELS,
+            num_rle_classes=ImageSizeOptions.TOTAL_RLE_LABELS)
+        transducer_model.eval()
+        torch.cuda.set_device(device_id)
+        transducer_model.to(device_id)
+        transducer_model.set_capacity(min(DEVICE_CALL_WINDOWS, cap))
+        engine = transducer_model.engine
+        if rank == 0:
+            print(prediction_file_name(output_filename, rank))
+            sys.stderr.write("INFO: MI355X HIP PATH, DEVICE " + str(device_id) + ", "
+                             + str(engine.device_bytes >> 20) + " MiB OF DEVICE MEMORY HELD.\n")
+            sys.stderr.write("Loading data\n")
+        if os.environ.get("HELEN_DEVICE_STAGE", "async") != "sync" and hasattr(engine, "polish") \
+                and torch.cuda.is_available() and calls:
+            try:
+                stage = _DeviceStage(engine, slots, cap, device_id)
+            except Exception as e:      # page-locking refused (ulimit -l, container policy): staged copies
+                sys.stderr.write("INFO: SLOTS NOT PAGE-LOCKED (" + str(e) + "), USING STAGED COPIES.\n")
         while True:
             t0 = time.time()
             item = ready_q.get()
