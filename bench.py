@@ -47,13 +47,33 @@ def pmc_traffic(windows_per_launch):
         return None, None
 
 
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota (a container
+    that sees 256 CPUs may be limited to 16 CPUs' worth of time)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())        # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(batch, seconds_target=12.0):
     """Time the CPU oracle (port of the reference path) on this box's host cores, bounded."""
     import numpy as np
 
     import oracle
     from helen_amd.weights import make_images, make_weights
-    threads = oracle.max_threads()
+    threads = min(oracle.max_threads(), usable_cpus())
+    oracle.set_threads(threads)
     w = make_weights(input_scale=1.0 / 64.0)
     probe = make_images(((threads + 7) // 8) * 8, seed=1)   # one 8-window block per thread
     t0 = time.time()
@@ -68,7 +88,7 @@ def cpu_baseline(batch, seconds_target=12.0):
     dt = time.time() - t0
     return {"value": round(n / dt, 2), "unit": "windows/s", "cores": threads, "kind": "port",
             "sample": "%d uniform-random windows through oracle/helen_oracle.c (fp32, OpenMP over "
-                      "8-window blocks), %.1f s" % (n, dt)}
+                      "8-window blocks, %d threads = usable CPUs under the cgroup quota), %.1f s" % (n, threads, dt)}
 
 
 def main():

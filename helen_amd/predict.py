@@ -10,8 +10,8 @@ double-buffered copies and labels come back as uint8; reader processes fill shar
 while the previous slot is on the GPU and the one before is being written by a writer thread.
 No process group is created (the reference's gloo group is never used on this path).
 
-The prediction writer is sharded over W processes per rank (W = $HELEN_WRITERS, default one per four
-reader workers, 1..8): creating the three small HDF5 datasets of a window costs ~70 us inside
+The prediction writer is sharded over W processes per rank (W = $HELEN_WRITERS, default one per reader
+worker, 1..8): creating the three small HDF5 datasets of a window costs ~70 us inside
 libhdf5, ~10-14 k windows/s per process, against ~75 k windows/s of device throughput.
 Writer 0 keeps the reference's file name `<output>_<rank>.hdf`, writer k > 0 writes
 `<output>_<rank>_w<k>.hdf`; all chunks of one region go to the same file, and stitch takes every
@@ -117,12 +117,14 @@ class _DeviceStage(object):
 
 
 def writer_count(num_workers):
-    """Writer processes per rank: $HELEN_WRITERS if set, else one per four reader workers (1..8) --
-    `-w 0..7` keeps the reference's single `<output>_<rank>.hdf`."""
+    """Writer processes per rank: $HELEN_WRITERS if set, else as many as reader workers (1..8): storing
+    a window costs libhdf5 about what reading one does (~100 us), so the two pools want the same size
+    (measured under a 16-CPU quota: 8 readers + 8 writers 48 k windows/s, 8 + 4 35 k, 16 + 1 9 k).
+    HELEN_WRITERS=1 (or -w 0/1) keeps the reference's single `<output>_<rank>.hdf`."""
     env = os.environ.get("HELEN_WRITERS")
     if env:
         return max(1, int(env))
-    return min(8, max(1, int(num_workers) // 4))
+    return min(8, max(1, int(num_workers)))
 
 
 class _WriterPool(object):

@@ -82,7 +82,9 @@ def test_cli_polish_with_workers(workdir):
     assert len(pred_dirs) == 1                                          # PolishInterface.py:65-69
     pdir = os.path.join(out, pred_dirs[0])
     files = [os.path.join(pdir, f) for f in sorted(os.listdir(pdir))]
-    assert [os.path.basename(f) for f in files] == ["asm_0.hdf"]          # PolishInterface.py:77-86
+    # -w 2: two reader workers and two writer processes -> <prefix>_<rank>.hdf + <prefix>_<rank>_w1.hdf,
+    # which stitch reads as one set (StitchInterface.py:35-36)
+    assert [os.path.basename(f) for f in files] == ["asm_0.hdf", "asm_0_w1.hdf"]
     _check_prediction_files(files, expected)
     # ... and the stitched FASTA: one record, identical to stitching the same predictions again
     fasta = open(os.path.join(out, "asm.fa")).read().split("\n")

@@ -40,6 +40,7 @@ def test_pipeline_with_stand_in_device(tmp_path, monkeypatch, workers):
     monkeypatch.setattr(T.TransducerGRU, "to", lambda self, d: self)
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
     monkeypatch.setattr(P, "DEVICE_CALL_WINDOWS", 64)       # 4 loader batches per "device call"
+    monkeypatch.setenv("HELEN_WRITERS", "1")                # the reference's single file per rank
     img_dir = str(tmp_path / "img")
     write_image_dir(img_dir, 150, n_files=3, short_every=7)   # 150 = 9 batches of 16 + one of 6
     model = str(tmp_path / "m.pkl")
