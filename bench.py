@@ -75,7 +75,7 @@ def cpu_baseline(batch, seconds_target=12.0):
     threads = min(oracle.max_threads(), usable_cpus())
     oracle.set_threads(threads)
     w = make_weights(input_scale=1.0 / 64.0)
-    probe = make_images(((threads + 7) // 8) * 8, seed=1)   # one 8-window block per thread
+    probe = make_images(threads * 8, seed=1)   # one 8-window block per thread
     t0 = time.time()
     oracle.polish_batch(w, probe)
     dt = time.time() - t0
