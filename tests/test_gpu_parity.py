@@ -337,3 +337,39 @@ def test_evaluation_ragged_batch_vs_oracle():
     # correct fp32 implementations; the matrices must agree up to that
     assert np.abs(cm_b - ref["base_confusion_matrix"]).sum() <= 4
     assert np.abs(cm_r - ref["rle_confusion_matrix"]).sum() <= 4
+
+
+def test_bf16_short_chunk_and_batch_split():
+    """The fused bf16 kernels on the operator entry with T = 37 and a non-zero incoming hidden (ring
+    prologue / epilogue with T not a multiple of anything), against the oracle's bf16 emulation; and
+    batch-split invariance of the polish entry (capacity 16 vs 64 on 40 windows: bit-identical)."""
+    import oracle
+    from helen_amd.engine import HelenEngine
+    w, img, g = load_case("small_input6")
+    oracle.set_precision("bf16")
+    try:
+        eb, er, eh = oracle.gru_chunk_forward(w, g["fwd_x"], g["fwd_h0"])
+    finally:
+        oracle.set_precision("fp32")
+    eng = HelenEngine(w, device=0, max_windows=16, precision="bf16")
+    base, rle, h = eng.chunk_forward(torch.from_numpy(g["fwd_x"]).cuda(), torch.from_numpy(g["fwd_h0"]).cuda())
+    np.testing.assert_allclose(base.cpu().numpy(), eb, atol=BF16_LOGIT_ATOL_VS_EMULATION, rtol=0)
+    np.testing.assert_allclose(rle.cpu().numpy(), er, atol=BF16_LOGIT_ATOL_VS_EMULATION, rtol=0)
+    np.testing.assert_allclose(h.cpu().numpy(), eh, atol=BF16_LOGIT_ATOL_VS_EMULATION, rtol=0)
+    # one-step chunk: the input ring has nothing to prefetch
+    b1, r1, h1 = eng.chunk_forward(torch.from_numpy(g["fwd_x"][:, :1].copy()).cuda(), torch.from_numpy(g["fwd_h0"]).cuda())
+    oracle.set_precision("bf16")
+    try:
+        ob1, or1, oh1 = oracle.gru_chunk_forward(w, g["fwd_x"][:, :1].copy(), g["fwd_h0"])
+    finally:
+        oracle.set_precision("fp32")
+    np.testing.assert_allclose(b1.cpu().numpy(), ob1, atol=BF16_LOGIT_ATOL_VS_EMULATION, rtol=0)
+    np.testing.assert_allclose(h1.cpu().numpy(), oh1, atol=BF16_LOGIT_ATOL_VS_EMULATION, rtol=0)
+    images = torch.from_numpy(make_images(40, seed=5, mode="uniform")).cuda()
+    small = eng.polish(images)
+    eng.close()
+    big_eng = HelenEngine(w, device=0, max_windows=64, precision="bf16")
+    big = big_eng.polish(images)
+    torch.cuda.synchronize()
+    assert torch.equal(small[0], big[0]) and torch.equal(small[1], big[1])
+    big_eng.close()
