@@ -66,6 +66,7 @@ struct HelenModel {
     bf16x8* w3i_dec = nullptr;   // decoder W_ih split: [2 dirs][24 tiles][8 M][3 terms][64]
     bf16x8* w3i_enc = nullptr;   // encoder W_ih split: [2 dirs][24 tiles][3 M][3 terms][64] (K padded to 96)
     f32x4* xb = nullptr;         // pileup counts as bf16 A fragments: [tile][pos][192] x 16 B
+    f32x4* plogit = nullptr;     // bf16 mode: per-direction partial logits [tile][slot][dir][64] x 16 B (no y2)
     f32x4* y1p = nullptr;        // encoder output as bf16 planes: [tile][slot][dir][3 (fp32x3) | 1 (bf16)][256] x 16 B
     // scratch (device)
     f32x4* xa = nullptr;
@@ -100,6 +101,7 @@ constexpr long kGiDecTileStride = (long)kWin * (kGiStride / 4);
 constexpr long kYTileStride = (long)kWin * (kYStride / 4);
 constexpr long kY1pTileStride = (long)kWin * 2 * 768;                // three bf16 planes per (slot, dir)
 constexpr long kY1bTileStride = (long)kWin * 2 * 256;                // one bf16 plane per (slot, dir)
+constexpr long kPlTileStride = (long)kWin * 2 * 64;                  // one 16x16 partial-logit tile per (slot, dir)
 
 template <typename T>
 int dev_alloc(HelenModel* m, T** p, size_t count) {
@@ -293,11 +295,11 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
         // projection fused into the recurrence: no gi at all; the encoder reads the packed pileup counts,
         // the decoder the encoder's bf16 output plane
         LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_kernel<3, false>), dim3(tiles, 2), dim3(512), m->xb,
-               (long)kSeq * 192, pos0, T, m->w3i_enc, m->w3h_enc, m->bias_enc, m->bhn_enc, m->hid,
-               (f32x4*)nullptr, kYTileStride, m->y1p, kY1bTileStride);
+               (long)kSeq * 192, pos0, T, m->w3i_enc, m->w3h_enc, m->bias_enc, m->bhn_enc, m->hid, m->y1p,
+               kY1bTileStride, (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride);
         LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_kernel<8, true>), dim3(tiles, 2), dim3(512), m->y1p,
-               kY1bTileStride, 0, T, m->w3i_dec, m->w3h_dec, m->bias_dec, m->bhn_dec, m->hid, m->y2,
-               kYTileStride, (f32x4*)nullptr, kY1bTileStride);
+               kY1bTileStride, 0, T, m->w3i_dec, m->w3h_dec, m->bias_dec, m->bhn_dec, m->hid, (f32x4*)nullptr,
+               kY1bTileStride, m->whd, m->plogit, kPlTileStride);
         return;
     }
     if (m->precision == HELEN_PRECISION_FP32X3) {
@@ -323,7 +325,7 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
 void free_model(HelenModel* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    void* ptrs[] = {m->w3i_enc, m->xb, m->w3i_dec, m->y1p, m->w3h_enc, m->w3h_dec, m->wp_enc, m->wp_dec, m->whp_enc, m->whp_dec, m->whd, m->bias_enc, m->bias_dec,
+    void* ptrs[] = {m->plogit, m->w3i_enc, m->xb, m->w3i_dec, m->y1p, m->w3h_enc, m->w3h_dec, m->wp_enc, m->wp_dec, m->whp_enc, m->whp_dec, m->whd, m->bias_enc, m->bias_dec,
                     m->bhn_enc, m->bhn_dec, m->bhd, m->xa, m->gi_enc, m->gi_dec, m->y1, m->y2,
                     m->hid, m->pending, m->dev_in[0], m->dev_in[1], m->dev_out[0], m->dev_out[1]};
     for (void* p : ptrs)
@@ -423,7 +425,11 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
     }
     if (precision == HELEN_PRECISION_FP32)
         if ((rc = dev_alloc(m, &m->y1, nt * kYTileStride))) return rc;
-    if ((rc = dev_alloc(m, &m->y2, nt * kYTileStride))) return rc;
+    if (precision == HELEN_PRECISION_BF16) {   // the decoder emits partial logits instead of y2
+        if ((rc = dev_alloc(m, &m->plogit, nt * kPlTileStride))) return rc;
+    } else {
+        if ((rc = dev_alloc(m, &m->y2, nt * kYTileStride))) return rc;
+    }
     if ((rc = dev_alloc(m, &m->hid, nt * (kHidStride / 4)))) return rc;
     if ((rc = dev_alloc(m, &m->pending, nt * 2 * kJump * 64))) return rc;
     return HELEN_OK;
@@ -512,9 +518,14 @@ int helen_polish_batch(HelenModel* m, const uint8_t* images, int n_windows, uint
     if (rc) return rc;
     for (int c = 0; c < kChunks; ++c) {  // predict_gpu.py:114-149
         launch_chunk(m, s, tiles, c * kJump, kWin, kSeq);
-        LAUNCH(HELEN_K_HEADS, heads_kernel, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->y2, kYTileStride, m->whd,
-               m->bhd, 0, c, kWin, n_windows, m->pending, bases, rles, acc_base_opt, acc_rle_opt,
-               (float*)nullptr, (float*)nullptr);
+        if (m->precision == HELEN_PRECISION_BF16)
+            LAUNCH(HELEN_K_HEADS, heads_kernel<true>, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->plogit,
+                   kPlTileStride, m->whd, m->bhd, 0, c, kWin, n_windows, m->pending, bases, rles, acc_base_opt,
+                   acc_rle_opt, (float*)nullptr, (float*)nullptr);
+        else
+            LAUNCH(HELEN_K_HEADS, heads_kernel<false>, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->y2,
+                   kYTileStride, m->whd, m->bhd, 0, c, kWin, n_windows, m->pending, bases, rles, acc_base_opt,
+                   acc_rle_opt, (float*)nullptr, (float*)nullptr);
     }
     return check_launch("helen_polish_batch");
 }
@@ -537,9 +548,14 @@ int helen_evaluate_batch(HelenModel* m, const uint8_t* images, const uint8_t* la
     if (rc) return rc;
     for (int c = 0; c < kChunks; ++c) {  // models/test.py:95-121
         launch_chunk(m, s, tiles, c * kJump, kWin, kSeq);
-        LAUNCH(HELEN_K_HEADS, heads_eval_kernel, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->y2, kYTileStride,
-               m->whd, m->bhd, c, kWin, n_windows, label_base, label_rle, cw, chunk_stats, base_confusion,
-               rle_confusion);
+        if (m->precision == HELEN_PRECISION_BF16)
+            LAUNCH(HELEN_K_HEADS, heads_eval_kernel<true>, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->plogit,
+                   kPlTileStride, m->whd, m->bhd, c, kWin, n_windows, label_base, label_rle, cw, chunk_stats,
+                   base_confusion, rle_confusion);
+        else
+            LAUNCH(HELEN_K_HEADS, heads_eval_kernel<false>, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->y2,
+                   kYTileStride, m->whd, m->bhd, c, kWin, n_windows, label_base, label_rle, cw, chunk_stats,
+                   base_confusion, rle_confusion);
     }
     return check_launch("helen_evaluate_batch");
 }
@@ -562,9 +578,13 @@ int helen_gru_chunk_forward(HelenModel* m, const float* x, const float* h_in, in
         launch_enc_gemm(m, s, tiles, T);
     }
     launch_chunk(m, s, tiles, 0, T, T);
-    LAUNCH(HELEN_K_HEADS, heads_kernel, dim3(tiles, (T + kHeadsSpan - 1) / kHeadsSpan), dim3(256), m->y2,
-           kYTileStride, m->whd, m->bhd, 1, 0, T, B, m->pending, (uint8_t*)nullptr, (uint8_t*)nullptr,
-           (float*)nullptr, (float*)nullptr, base, rle);
+    const dim3 hgrid(tiles, (T + kHeadsSpan - 1) / kHeadsSpan);
+    if (m->precision == HELEN_PRECISION_BF16)
+        LAUNCH(HELEN_K_HEADS, heads_kernel<true>, hgrid, dim3(256), m->plogit, kPlTileStride, m->whd, m->bhd, 1, 0, T,
+               B, m->pending, (uint8_t*)nullptr, (uint8_t*)nullptr, (float*)nullptr, (float*)nullptr, base, rle);
+    else
+        LAUNCH(HELEN_K_HEADS, heads_kernel<false>, hgrid, dim3(256), m->y2, kYTileStride, m->whd, m->bhd, 1, 0, T, B,
+               m->pending, (uint8_t*)nullptr, (uint8_t*)nullptr, (float*)nullptr, (float*)nullptr, base, rle);
     hipLaunchKernelGGL(unpack_hidden_kernel, dim3(tiles), dim3(256), 0, s, (const float*)m->hid, B,
                        h_out);
     return check_launch("helen_gru_chunk_forward");

@@ -17,9 +17,9 @@ namespace helen {
 //   Per step:  A  gh = h . W_hh^T on the bf16 h plane in LDS, added onto the input part computed one
 //                 step earlier (n gate kept apart: n = tanh(gi_n + r * gh_n))
 //              B  gates (fp32), new h -> LDS as fp32 (state / layer output) and as a bf16 plane
-//              C  this wave's input row of step s+1 has landed (counted vmcnt)
+//              C  this wave's input row of step s+1 has landed
 //              D  one barrier
-//              E  DMA the input of step s+2 (3-deep ring), store this step's output
+//              E  store this step's output, DMA the input of step s+2 (3-deep ring)
 //              F  input part of step s+1: x . W_ih^T + bias -- independent of h, so it sits between
 //                 the barrier and the next step's recurrent MFMAs
 //   Input rows (1 KiB = one K32 group of 16 windows, the MFMA A fragment):
@@ -27,21 +27,29 @@ namespace helen {
 //     decoder (MI = 8): yplane[tile][slot][d][4][64 units]; time t = s (dir 0) or T-1-s (dir 1);
 //                       k < 128 is the forward encoder output of time t (slot t), k >= 128 the backward
 //                       one (stored time-reversed: slot T-1-t)
-//   Output: fp32 y[tile][slot = s][dir] (KB16, for the heads) when DEC, else one bf16 plane
-//   yplane_out[tile][slot = s][dir][256 units] for the decoder.
+//   Output: the encoder writes one bf16 plane yplane_out[tile][slot = s][dir][256 units] for the decoder.
+//   The decoder (DEC) writes no layer output at all: the heads are linear in [h_fwd | h_bwd], so each
+//   direction contributes its half of the 16 logits.  Wave v owns exactly the k-slice 16v..16v+15 of
+//   h (one fp32 MFMA A fragment in the LDS copy of h): at step s+1 it multiplies the slice of h(s) by its
+//   slice of the head weights (4 fp32 MFMAs, issued with the recurrent ones) and parks the 16x16 partial
+//   in LDS; after that step's barrier one wave (s mod 8) adds the eight partials in wave order and stores 1 KiB
+//   plogit[tile][slot = s][dir][64 lanes] (FRAG layout) instead of 8 KiB of y2.  The heads kernel then
+//   only adds two partial tiles and the bias.
 //   Weights come from the three-term packings of kernels_x3.h; term 0 is RNE(w).
 // ------------------------------------------------------------------------------------------------
 template <int MI, bool DEC>
 __global__ __launch_bounds__(512) void gru_fused_bf16_kernel(
     const f32x4* __restrict__ in, long in_tile_stride, int pos0, int T, const bf16x8* __restrict__ Wi3,
     const bf16x8* __restrict__ Wh3, const float* __restrict__ bias, const float* __restrict__ bhn,
-    f32x4* __restrict__ hid, f32x4* __restrict__ y, long y_tile_stride, f32x4* __restrict__ yplane_out,
-    long yp_tile_stride) {
-    // LDS: fp32 h [2][512 f4] | bf16 h plane [2][256 units] | input ring [3][MI * 64 units]
-    __shared__ f32x4 smem[2 * 512 + 2 * 256 + 3 * MI * 64];
+    f32x4* __restrict__ hid, f32x4* __restrict__ yplane_out, long yp_tile_stride,
+    const f32x4* __restrict__ Whd, f32x4* __restrict__ plogit, long pl_tile_stride) {
+    // LDS: fp32 h [2][512 f4] | bf16 h plane [2][256 units] | input ring [3][MI * 64 units] |
+    // (DEC) head partials [2][8 waves][64 f4]
+    __shared__ f32x4 smem[2 * 512 + 2 * 256 + 3 * MI * 64 + (DEC ? 2 * 8 * 64 : 0)];
     f32x4* const hbuf = smem;
     f32x4* const hplane = smem + 1024;
     f32x4* const inbuf = smem + 1024 + 512;
+    f32x4* const part = inbuf + 3 * MI * 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,6 +71,8 @@ __global__ __launch_bounds__(512) void gru_fused_bf16_kernel(
             for (int M = 0; M < MI; ++M) Wi[g][M] = wi[(M * 3) * 64];
         }
     }
+    f32x4 Bh = splat4(0.f);   // DEC: head weights for k = dir*128 + 16v + 4q + e, class j
+    if (DEC) Bh = Whd[(dir * 8 + v) * 64 + lane];
     float bi[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) bi[g] = bias[dir * kG + g * kH + u];
@@ -104,6 +114,22 @@ __global__ __launch_bounds__(512) void gru_fused_bf16_kernel(
         ((unsigned short*)(hplane + buf * 256))[poff + 8 * r] = bf16_bits(h);
     };
 
+    auto head_partial = [&](int hb, int pb) {   // h in hbuf[hb]: wave v's k-slice is one fp32 A fragment
+        const f32x4 a = (hbuf + hb * 512)[v * 64 + lane];
+        f32x4 pl = splat4(0.f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pl = mfma4(a[e], Bh[e], pl);
+        (part + (pb * 8 + v) * 64)[lane] = pl;
+    };
+    auto head_store = [&](int slot) {           // one wave adds the eight slices in wave order
+        if (v != (slot & 7)) return;
+        const f32x4* pp = part + (slot & 1) * 8 * 64 + lane;
+        f32x4 sum = pp[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) sum += pp[k * 64];
+        (plogit + (size_t)tile * pl_tile_stride + ((size_t)slot * 2 + dir) * 64)[lane] = sum;
+    };
+
     f32x4* hid_p = hid + ((size_t)tile * 2 + dir) * (kHidDirStride / 4);
     hbuf[tid] = hid_p[tid];
     dma_in(0, 0);
@@ -122,8 +148,10 @@ __global__ __launch_bounds__(512) void gru_fused_bf16_kernel(
     int b_next = 1, b_dma = 2;       // ring slots of step s+1 and s+2
     for (int s = 0; s < T; ++s) {
         const int cur = s & 1;
-        // A: recurrent part
+        // A: recurrent part (+ DEC: this wave's k-slice of the head product for the PREVIOUS step's h,
+        // which sits in hbuf[cur] since the last barrier: its LDS read rides with the plane reads)
         f32x4 ar = gin[0], az = gin[1], ahn = splat4(bn);
+        if (DEC && s > 0) head_partial(cur, (s - 1) & 1);
         {
             const bf16x8* pa = (const bf16x8*)(hplane + cur * 256) + lane;
 #pragma unroll
@@ -141,25 +169,31 @@ __global__ __launch_bounds__(512) void gru_fused_bf16_kernel(
             hprev[r] = hn;
             store_h(cur ^ 1, r, hn);
         }
-        // C: VMEM queue of a wave that DMAs, oldest first: its row of step s+1, then one output store
-        if (v < MI) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        // C: everything this wave has in flight is older than a step except its input row of step s+1
+        // (issued after the previous step's store): wait for all of it
+        if (v < MI) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // D
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        // E
-        if (s + 2 < T) dma_in(s + 2, b_dma);
+        // E: output first (DEC: the partial logits of step s-1, whose eight slices were parked before this
+        // barrier), then the input of step s+2
         if (DEC) {
-            (y + (size_t)tile * y_tile_stride + (size_t)dir * (kHidDirStride / 4) + (size_t)s * (kYStride / 4))[tid] =
-                (hbuf + (cur ^ 1) * 512)[tid];
+            if (s > 0) head_store(s - 1);
         } else if (tid < 256) {
             (yplane_out + (size_t)tile * yp_tile_stride + ((size_t)s * 2 + dir) * 256)[tid] =
                 (hplane + (cur ^ 1) * 256)[tid];
         }
+        if (s + 2 < T) dma_in(s + 2, b_dma);
         // F
         if (s + 1 < T) input_part(b_next, gin);
         b_next = b_next == 2 ? 0 : b_next + 1;
         b_dma = b_dma == 2 ? 0 : b_dma + 1;
+    }
+    if (DEC) {   // the last step's logits
+        head_partial(T & 1, (T - 1) & 1);
+        __syncthreads();
+        head_store(T - 1);
     }
     hid_p[tid] = (hbuf + (T & 1) * 512)[tid];
 }

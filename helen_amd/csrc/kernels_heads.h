@@ -45,6 +45,36 @@ __device__ __forceinline__ int group16_argmax(float v, int idx) {
 #endif
 constexpr int kHeadsSpan = HELEN_HEADS_SPAN;  // positions per workgroup; divides kJump so a group never straddles halves
 
+// The 16 logits of 16 windows at chunk position t.  PARTIALS = false: y2[tile][slot][fwd | bwd] (KB16; the
+// bwd half of position t sits in slot T-1-t) times the head weights, 32 fp32 MFMAs.  PARTIALS = true: the
+// decoder already multiplied each direction's half (plogit[tile][slot][dir][64], kernels_fused_bf16.h):
+// add the two partial tiles and the bias.
+template <bool PARTIALS>
+__device__ __forceinline__ f32x4 head_logits(const f32x4* __restrict__ src, long tile_stride, int tile, int t,
+                                             int T, const f32x4* B, float bias, int lane) {
+    if constexpr (PARTIALS) {
+        const f32x4* p = src + (size_t)tile * tile_stride + lane;
+        return p[((size_t)t * 2) * 64] + p[((size_t)(T - 1 - t) * 2 + 1) * 64] + splat4(bias);
+    } else {
+        const f32x4* a_p = src + (size_t)tile * tile_stride + (size_t)t * (kYStride / 4) + lane;
+        const f32x4* a_pb = src + (size_t)tile * tile_stride + (size_t)(T - 1 - t) * (kYStride / 4) + lane;
+        f32x4 acc0 = splat4(bias);
+        f32x4 acc1 = splat4(0.f);
+#pragma unroll
+        for (int m = 0; m < 16; m += 2) {
+            const f32x4 a0 = (m >= 8 ? a_pb : a_p)[m * 64];
+            const f32x4 a1 = (m >= 8 ? a_pb : a_p)[(m + 1) * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = mfma4(a0[e], B[m][e], acc0);
+                acc1 = mfma4(a1[e], B[m + 1][e], acc1);
+            }
+        }
+        return acc0 + acc1;  // row 4q+r (window), col j (class)
+    }
+}
+
+template <bool PARTIALS>
 __global__ __launch_bounds__(256) void heads_kernel(
     const f32x4* __restrict__ y2, long y_tile_stride, const f32x4* __restrict__ Whd,
     const float* __restrict__ bhd, int mode, int chunk, int T, int n_windows,
@@ -63,31 +93,18 @@ __global__ __launch_bounds__(256) void heads_kernel(
     const int half = t0 / kJump;
     const bool isb = j < kNB;
 
-    f32x4 B[16];
+    f32x4 B[PARTIALS ? 1 : 16];
+    if constexpr (!PARTIALS) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) B[m] = Whd[m * 64 + lane];
+        for (int m = 0; m < 16; ++m) B[m] = Whd[m * 64 + lane];
+    }
     const float bias = bhd[j];
 
     const bool park = (mode == 0) && (half == 1) && (chunk < kChunks - 1);
     const bool add_prev = (mode == 0) && (half == 0) && (chunk > 0);
 
     for (int t = t0 + w; t < t1; t += 4) {
-        // y2[tile][slot][fwd | bwd]: the bwd half of position t sits in slot T-1-t
-        const f32x4* a_p = y2 + (size_t)tile * y_tile_stride + (size_t)t * (kYStride / 4) + lane;
-        const f32x4* a_pb = y2 + (size_t)tile * y_tile_stride + (size_t)(T - 1 - t) * (kYStride / 4) + lane;
-        f32x4 acc0 = splat4(bias);
-        f32x4 acc1 = splat4(0.f);
-#pragma unroll
-        for (int m = 0; m < 16; m += 2) {
-            const f32x4 a0 = (m >= 8 ? a_pb : a_p)[m * 64];
-            const f32x4 a1 = (m >= 8 ? a_pb : a_p)[(m + 1) * 64];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc0 = mfma4(a0[e], B[m][e], acc0);
-                acc1 = mfma4(a1[e], B[m + 1][e], acc1);
-            }
-        }
-        const f32x4 logit = acc0 + acc1;  // row 4q+r (window), col j (class)
+        const f32x4 logit = head_logits<PARTIALS>(y2, y_tile_stride, tile, t, T, B, bias, lane);
 
         if (mode == 1) {
 #pragma unroll
@@ -171,6 +188,7 @@ struct RleClassWeights {
     float w[kNR];
 };
 
+template <bool PARTIALS>
 __global__ __launch_bounds__(256) void heads_eval_kernel(
     const f32x4* __restrict__ y2, long y_tile_stride, const f32x4* __restrict__ Whd,
     const float* __restrict__ bhd, int chunk, int T, int n_windows,
@@ -193,27 +211,15 @@ __global__ __launch_bounds__(256) void heads_eval_kernel(
     if (tid < kNR * kNR) hist_r[tid] = 0;
     __syncthreads();
 
-    f32x4 B[16];
+    f32x4 B[PARTIALS ? 1 : 16];
+    if constexpr (!PARTIALS) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) B[m] = Whd[m * 64 + lane];
+        for (int m = 0; m < 16; ++m) B[m] = Whd[m * 64 + lane];
+    }
     const float bias = bhd[j];
 
     for (int t = t0 + w; t < t1; t += 4) {
-        const f32x4* a_p = y2 + (size_t)tile * y_tile_stride + (size_t)t * (kYStride / 4) + lane;
-        const f32x4* a_pb = y2 + (size_t)tile * y_tile_stride + (size_t)(T - 1 - t) * (kYStride / 4) + lane;
-        f32x4 acc0 = splat4(bias);
-        f32x4 acc1 = splat4(0.f);
-#pragma unroll
-        for (int m = 0; m < 16; m += 2) {
-            const f32x4 a0 = (m >= 8 ? a_pb : a_p)[m * 64];
-            const f32x4 a1 = (m >= 8 ? a_pb : a_p)[(m + 1) * 64];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc0 = mfma4(a0[e], B[m][e], acc0);
-                acc1 = mfma4(a1[e], B[m + 1][e], acc1);
-            }
-        }
-        const f32x4 logit = acc0 + acc1;  // row 4q+r (window), col j (class)
+        const f32x4 logit = head_logits<PARTIALS>(y2, y_tile_stride, tile, t, T, B, bias, lane);
         const int pos = chunk * kJump + t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
