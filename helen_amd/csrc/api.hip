@@ -66,7 +66,7 @@ struct HelenModel {
     bf16x8* w3i_dec = nullptr;   // decoder W_ih split: [2 dirs][24 tiles][8 M][3 terms][64]
     bf16x8* w3i_enc = nullptr;   // encoder W_ih split: [2 dirs][24 tiles][3 M][3 terms][64] (K padded to 96)
     f32x4* xb = nullptr;         // pileup counts as bf16 A fragments: [tile][pos][192] x 16 B
-    f32x4* plogit = nullptr;     // bf16 mode: per-direction partial logits [tile][slot][dir][64] x 16 B (no y2)
+    f32x4* plogit = nullptr;     // bf16 / fp32x3: per-direction partial logits [tile][slot][dir][64] x 16 B (no y2)
     f32x4* y1p = nullptr;        // encoder output as bf16 planes: [tile][slot][dir][3 (fp32x3) | 1 (bf16)][256] x 16 B
     // scratch (device)
     f32x4* xa = nullptr;
@@ -284,10 +284,6 @@ void launch_enc_gemm(HelenModel* m, hipStream_t s, int tiles, int npos) {
 // One TransducerGRU.forward over `tiles` tiles whose encoder pre-activations are already in
 // gi_enc at positions [pos0, pos0+T): encoder recurrence -> decoder projection -> decoder
 // recurrence.  y2 then holds the decoder output, hid the returned hidden state.
-#ifndef HELEN_X3_NT
-#define HELEN_X3_NT 1   // window tiles per workgroup of the fp32x3 recurrence (2: no faster, see kernel)
-#endif
-
 void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int enc_npos) {
     const dim3 ggrid(gemm_grid(T, tiles)), gblock(HELEN_GEMM_WAVES * 64);
     // encoder gi holds `enc_npos` positions; the reverse direction is stored time-reversed
@@ -304,14 +300,13 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
     }
     if (m->precision == HELEN_PRECISION_FP32X3) {
         // encoder output goes out as three bf16 planes only; the projection consumes them directly
-        LAUNCH(HELEN_K_GRU_ENC, gru_x3_kernel<HELEN_X3_NT>, dim3((tiles + HELEN_X3_NT - 1) / HELEN_X3_NT, 2),
-               dim3(512), m->gi_enc, kGiEncTileStride, pos0, enc_npos - pos0 - T, T, m->w3h_enc, m->bhn_enc,
-               m->hid, (f32x4*)nullptr, kYTileStride, m->y1p, kY1pTileStride, tiles);
+        LAUNCH(HELEN_K_GRU_ENC, gru_x3_kernel, dim3(tiles, 2), dim3(512), m->gi_enc, kGiEncTileStride, pos0,
+               enc_npos - pos0 - T, T, m->w3h_enc, m->bhn_enc, m->hid, m->y1p, kY1pTileStride,
+               (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride);
         LAUNCH(HELEN_K_GEMM_DEC, (gemm_dec_x3_kernel<3, 2>), dim3(3 * ((tiles + 7) / 8 * 8)), dim3(512), m->y1p, kY1pTileStride,
                (const f32x4*)m->w3i_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
-        LAUNCH(HELEN_K_GRU_DEC, gru_x3_kernel<HELEN_X3_NT>, dim3((tiles + HELEN_X3_NT - 1) / HELEN_X3_NT, 2),
-               dim3(512), m->gi_dec, kGiDecTileStride, 0, 0, T, m->w3h_dec, m->bhn_dec, m->hid, m->y2,
-               kYTileStride, (f32x4*)nullptr, kY1pTileStride, tiles);
+        LAUNCH(HELEN_K_GRU_DEC, gru_x3_kernel, dim3(tiles, 2), dim3(512), m->gi_dec, kGiDecTileStride, 0, 0, T,
+               m->w3h_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kY1pTileStride, m->whd, m->plogit, kPlTileStride);
         return;
     }
     LAUNCH(HELEN_K_GRU_ENC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
@@ -425,7 +420,7 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
     }
     if (precision == HELEN_PRECISION_FP32)
         if ((rc = dev_alloc(m, &m->y1, nt * kYTileStride))) return rc;
-    if (precision == HELEN_PRECISION_BF16) {   // the decoder emits partial logits instead of y2
+    if (precision != HELEN_PRECISION_FP32) {   // the decoder emits partial logits instead of y2
         if ((rc = dev_alloc(m, &m->plogit, nt * kPlTileStride))) return rc;
     } else {
         if ((rc = dev_alloc(m, &m->y2, nt * kYTileStride))) return rc;
@@ -518,7 +513,7 @@ int helen_polish_batch(HelenModel* m, const uint8_t* images, int n_windows, uint
     if (rc) return rc;
     for (int c = 0; c < kChunks; ++c) {  // predict_gpu.py:114-149
         launch_chunk(m, s, tiles, c * kJump, kWin, kSeq);
-        if (m->precision == HELEN_PRECISION_BF16)
+        if (m->precision != HELEN_PRECISION_FP32)
             LAUNCH(HELEN_K_HEADS, heads_kernel<true>, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->plogit,
                    kPlTileStride, m->whd, m->bhd, 0, c, kWin, n_windows, m->pending, bases, rles, acc_base_opt,
                    acc_rle_opt, (float*)nullptr, (float*)nullptr);
@@ -548,7 +543,7 @@ int helen_evaluate_batch(HelenModel* m, const uint8_t* images, const uint8_t* la
     if (rc) return rc;
     for (int c = 0; c < kChunks; ++c) {  // models/test.py:95-121
         launch_chunk(m, s, tiles, c * kJump, kWin, kSeq);
-        if (m->precision == HELEN_PRECISION_BF16)
+        if (m->precision != HELEN_PRECISION_FP32)
             LAUNCH(HELEN_K_HEADS, heads_eval_kernel<true>, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->plogit,
                    kPlTileStride, m->whd, m->bhd, c, kWin, n_windows, label_base, label_rle, cw, chunk_stats,
                    base_confusion, rle_confusion);
@@ -579,7 +574,7 @@ int helen_gru_chunk_forward(HelenModel* m, const float* x, const float* h_in, in
     }
     launch_chunk(m, s, tiles, 0, T, T);
     const dim3 hgrid(tiles, (T + kHeadsSpan - 1) / kHeadsSpan);
-    if (m->precision == HELEN_PRECISION_BF16)
+    if (m->precision != HELEN_PRECISION_FP32)
         LAUNCH(HELEN_K_HEADS, heads_kernel<true>, hgrid, dim3(256), m->plogit, kPlTileStride, m->whd, m->bhd, 1, 0, T,
                B, m->pending, (uint8_t*)nullptr, (uint8_t*)nullptr, (float*)nullptr, (float*)nullptr, base, rle);
     else

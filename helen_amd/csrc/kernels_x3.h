@@ -18,8 +18,7 @@ namespace helen {
 //   workgroup is 8 waves, wave v owning hidden units 16v..16v+15 (one 16-column tile per gate).
 //   The new h is split once, by the lane that produced it, into three bf16 planes in LDS laid out as
 //   the A fragment of the K = 32 MFMA (unit (k/8, row) of 8 bf16 = 16 bytes; group M of lane (row, q)
-//   is unit 4M + q); an fp32 copy feeds the layer output y and the carried state, which keep the
-//   fp32 path's layouts -- only this kernel changes, the projections stay on fp32 MFMAs.
+//   is unit 4M + q); an fp32 copy feeds the carried state and the decoder's head partials.
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -35,36 +34,40 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short b) {
     return __builtin_bit_cast(float, (unsigned)b << 16);
 }
 
-template <int NT>
 __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ gi, long gi_tile_stride,
                                                      int slot0_fwd, int slot0_bwd, int T,
                                                      const bf16x8* __restrict__ W3,
                                                      const float* __restrict__ bhn,
-                                                     f32x4* __restrict__ hid, f32x4* __restrict__ y,
-                                                     long y_tile_stride, f32x4* __restrict__ yplanes,
-                                                     long yp_tile_stride, int ntiles) {
-    // NT window tiles per workgroup share the resident W_hh terms and one barrier per step.  Measured:
-    // NT = 2 is no faster than NT = 1 (0.459 vs 0.449 ms) -- a step is 2 x 1200 cycles of MFMA issue plus
-    // 2 x 940 cycles of gate/split VALU work per SIMD, which do not overlap, not barrier latency -- so
-    // NT = 1 (more workgroups, half the LDS) is what is launched.  A workgroup past the last tile
-    // recomputes the last one (identical stores).
-    // Layer output: fp32 y[tile][slot][dir] (KB16, for the heads) when `y` is given, and/or the three
-    // bf16 planes yplanes[tile][slot][dir][plane][256 units] (for gemm_dec_x3_kernel) when given.
-    // LDS per tile: fp32 h [2][512 f4] | bf16 planes [2 buffers][3 terms][256 units of 16 B] |
-    // gi slots [8 waves][3][64 f4]
-    constexpr int kPerTile = 2 * 512 + 2 * 3 * 256 + 8 * 192;   // 4096 f4 = 64 KiB
-    __shared__ f32x4 smem[NT * kPerTile];
+                                                     f32x4* __restrict__ hid, f32x4* __restrict__ yplanes,
+                                                     long yp_tile_stride, const f32x4* __restrict__ Whd,
+                                                     f32x4* __restrict__ plogit, long pl_tile_stride) {
+    // Output.  Encoder launch (`yplanes`): the three bf16 planes yplanes[tile][slot][dir][plane][256 units]
+    // for gemm_dec_x3_kernel.  Decoder launch (`plogit`): no layer output at all -- the heads are linear in
+    // [h_fwd | h_bwd], so each direction contributes its half of the 16 logits: wave v owns the k-slice
+    // 16v..16v+15 of h (one fp32 MFMA A fragment in the LDS copy of h); at step s+1 it multiplies the slice
+    // of h(s) by its slice of the head weights (4 fp32 MFMAs) and parks the 16x16 partial in LDS; after that
+    // step's barrier one wave (s mod 8) adds the eight partials in wave order and stores 1 KiB
+    // plogit[tile][slot = s][dir][64 lanes] (FRAG layout) instead of 8 KiB of y2 (heads_kernel<true>).
+    // (Two window tiles per workgroup sharing W_hh and the barrier were measured: no faster, 0.459 vs
+    // 0.449 ms -- a step is 2 x 1200 cycles of MFMA issue plus 2 x 940 cycles of gate/split VALU work per
+    // SIMD, which do not overlap, not barrier latency.)
+    // LDS: fp32 h [2][512 f4] | bf16 planes [2 buffers][3 terms][256 units of 16 B] |
+    // gi slots [8 waves][3][64 f4] | head partials [2][8 waves][64 f4]
+    __shared__ f32x4 smem[2 * 512 + 2 * 3 * 256 + 8 * 192 + 2 * 8 * 64];   // 80 KiB
+    f32x4* const hbuf = smem;
+    f32x4* const planes = smem + 1024;
+    f32x4* const part = smem + 1024 + 1536 + 8 * 192;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int v = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7: hidden units 16v..16v+15
+    f32x4* const gbuf = smem + 1024 + 1536 + v * 192;
     const int j = lane & 15;
     const int q = lane >> 4;
+    const int tile = blockIdx.x;
     const int dir = blockIdx.y;
     const int slot0 = dir ? slot0_bwd : slot0_fwd;
     const int u = 16 * v + j;                                  // this lane's hidden unit
-    int tile[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) tile[n] = min((int)blockIdx.x * NT + n, ntiles - 1);
+    const bool dec = plogit != nullptr;
 
     // W[g][M][t]: term t of W_hh[row g*128 + u][k = 32M + 8q + e], e = 0..7
     bf16x8 W[3][4][3];
@@ -78,27 +81,26 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
                 for (int t = 0; t < 3; ++t) W[g][M][t] = wp[((g * 4 + M) * 3 + t) * 64];
     }
     const float bn = bhn[dir * kH + u];
+    f32x4 Bh = splat4(0.f);   // decoder: head weights for k = dir*128 + 16v + 4q + e, class j
+    if (dec) Bh = Whd[(dir * 8 + v) * 64 + lane];
 
+    const f32x4* gi_p = gi + (size_t)tile * gi_tile_stride + (size_t)dir * (kNTile * 64) + v * 64 + lane;
     constexpr long kPosStride = 2 * kNTile * 64;
-    auto hbuf = [&](int n) { return smem + n * kPerTile; };
-    auto planes = [&](int n) { return smem + n * kPerTile + 1024; };
-    auto gbuf = [&](int n) { return smem + n * kPerTile + 1024 + 1536 + v * 192; };
-    auto dma_gi = [&](int n, int slot) {
-        const f32x4* p = gi + (size_t)tile[n] * gi_tile_stride + (size_t)dir * (kNTile * 64) + v * 64 + lane +
-                         (size_t)slot * kPosStride;
+    auto dma_gi = [&](int slot) {
+        const f32x4* p = gi_p + (size_t)slot * kPosStride;
 #pragma unroll
         for (int g = 0; g < 3; ++g)
             __builtin_amdgcn_global_load_lds(
                 (const void __attribute__((address_space(1)))*)(p + (g * 8) * 64),
-                (void __attribute__((address_space(3)))*)(gbuf(n) + g * 64), 16, 0, 0);
+                (void __attribute__((address_space(3)))*)(gbuf + g * 64), 16, 0, 0);
     };
     // this lane's 4 values: rows 4q + r of unit u.  fp32 h: float index ((u>>2)*16 + 4q + r)*4 + (u&3);
     // planes: bf16 index ((u>>3)*16 + 4q + r)*8 + (u&7) inside a 256-unit plane
     const int hoff = ((u >> 2) * kTile + 4 * q) * 4 + (u & 3);
     const int poff = ((u >> 3) * kTile + 4 * q) * 8 + (u & 7);
-    auto store_h = [&](int n, int buf, int r, float h) {
-        ((float*)(hbuf(n) + buf * 512))[hoff + 4 * r] = h;
-        unsigned short* pl = (unsigned short*)(planes(n) + buf * 768);
+    auto store_h = [&](int buf, int r, float h) {
+        ((float*)(hbuf + buf * 512))[hoff + 4 * r] = h;
+        unsigned short* pl = (unsigned short*)(planes + buf * 768);
         const unsigned short t1 = bf16_bits(h);
         const float r1 = h - bf16_to_f32(t1);
         const unsigned short t2 = bf16_bits(r1);
@@ -108,23 +110,32 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
         pl[1 * 2048 + poff + 8 * r] = t2;
         pl[2 * 2048 + poff + 8 * r] = t3;
     };
-
+    auto head_partial = [&](int hb, int pb) {   // h in hbuf[hb]: wave v's k-slice is one fp32 A fragment
+        const f32x4 a = (hbuf + hb * 512)[v * 64 + lane];
+        f32x4 pl = splat4(0.f);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        hbuf(n)[tid] = (hid + ((size_t)tile[n] * 2 + dir) * (kHidDirStride / 4))[tid];
-        dma_gi(n, slot0);
-    }
+        for (int e = 0; e < 4; ++e) pl = mfma4(a[e], Bh[e], pl);
+        (part + (pb * 8 + v) * 64)[lane] = pl;
+    };
+    auto head_store = [&](int slot) {           // one wave adds the eight slices in wave order
+        if (v != (slot & 7)) return;
+        const f32x4* pp = part + (slot & 1) * 8 * 64 + lane;
+        f32x4 sum = pp[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) sum += pp[k * 64];
+        (plogit + (size_t)tile * pl_tile_stride + ((size_t)slot * 2 + dir) * 64)[lane] = sum;
+    };
+
+    f32x4* hid_p = hid + ((size_t)tile * 2 + dir) * (kHidDirStride / 4);
+    hbuf[tid] = hid_p[tid];
+    dma_gi(slot0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    float hprev[NT][4];
+    float hprev[4];
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+    for (int r = 0; r < 4; ++r) hprev[r] = ((const float*)hbuf)[hoff + 4 * r];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hprev[n][r] = ((const float*)hbuf(n))[hoff + 4 * r];
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) store_h(n, 0, r, hprev[n][r]);   // planes of h0 (fp32 copy rewritten in place)
+    for (int r = 0; r < 4; ++r) store_h(0, r, hprev[r]);     // planes of h0 (fp32 copy rewritten in place)
     __syncthreads();
 #ifdef HELEN_GRU_TIMING
     long long tk[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -132,51 +143,46 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
 #endif
     for (int s = 0; s < T; ++s) {
         const int cur = s & 1;
-        f32x4 acc[NT][3];
+        const bf16x8* pa = (const bf16x8*)(planes + cur * 768) + lane;
+        f32x4 acc[3];
+        acc[0] = splat4(0.f);
+        acc[1] = splat4(0.f);
+        acc[2] = splat4(bn);
+        if (dec && s > 0) head_partial(cur, (s - 1) & 1);    // h(s-1) sits in hbuf[cur] since the last barrier
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const bf16x8* pa = (const bf16x8*)(planes(n) + cur * 768) + lane;
-            acc[n][0] = splat4(0.f);
-            acc[n][1] = splat4(0.f);
-            acc[n][2] = splat4(bn);
+        for (int M = 0; M < 4; ++M) {
+            const bf16x8 a1 = pa[0 * 256 + M * 64], a2 = pa[1 * 256 + M * 64], a3 = pa[2 * 256 + M * 64];
+            const bf16x8 at[3] = {a1, a2, a3};
+            constexpr int TA[6] = {0, 2, 1, 0, 1, 0};   // six leading products, smallest first;
+            constexpr int TB[6] = {2, 0, 1, 1, 0, 0};   // product index outermost: 3 accumulators rotate
 #pragma unroll
-            for (int M = 0; M < 4; ++M) {
-                const bf16x8 a1 = pa[0 * 256 + M * 64], a2 = pa[1 * 256 + M * 64], a3 = pa[2 * 256 + M * 64];
-                const bf16x8 at[3] = {a1, a2, a3};
-                constexpr int TA[6] = {0, 2, 1, 0, 1, 0};   // six leading products, smallest first;
-                constexpr int TB[6] = {2, 0, 1, 1, 0, 0};   // product index outermost: 3 accumulators rotate
+            for (int k = 0; k < 6; ++k)
 #pragma unroll
-                for (int k = 0; k < 6; ++k)
-#pragma unroll
-                    for (int g = 0; g < 3; ++g)
-                        acc[n][g] =
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[TA[k]], W[g][M][TB[k]], acc[n][g], 0, 0, 0);
-            }
+                for (int g = 0; g < 3; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[TA[k]], W[g][M][TB[k]], acc[g], 0, 0, 0);
         }
         HELEN_TICK(0)
 #ifdef HELEN_GRU_TIMING
-        asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]));
+        asm volatile("s_nop 0" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]));
         HELEN_TICK(1)
 #endif
-        // VMEM queue, oldest first: 3 gi DMAs per tile, then the previous step's output stores (at least
-        // one per tile): the DMAs have landed once no more than NT operations are outstanding
-        if (NT == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        // VMEM queue, oldest first: the 3 gi DMAs of this step (issued in the previous one), then that
+        // step's output stores -- encoder: at least one per wave; decoder: one, by wave (s-2) mod 8 only
+        if (!dec || (s >= 2 && v == ((s - 2) & 7)))
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         HELEN_TICK(2)
+        f32x4 G[3];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            f32x4 G[3];
+        for (int g = 0; g < 3; ++g) G[g] = gbuf[g * 64 + lane];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (s + 1 < T) dma_gi(slot0 + s + 1);
 #pragma unroll
-            for (int g = 0; g < 3; ++g) G[g] = gbuf(n)[g * 64 + lane];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (s + 1 < T) dma_gi(n, slot0 + s + 1);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float hn = gru_cell(acc[n][0][r], acc[n][1][r], acc[n][2][r], G[0][r], G[1][r], G[2][r],
-                                          hprev[n][r]);
-                hprev[n][r] = hn;
-                store_h(n, cur ^ 1, r, hn);
-            }
+        for (int r = 0; r < 4; ++r) {
+            const float hn = gru_cell(acc[0][r], acc[1][r], acc[2][r], G[0][r], G[1][r], G[2][r], hprev[r]);
+            hprev[r] = hn;
+            store_h(cur ^ 1, r, hn);
         }
         HELEN_TICK(3)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -184,29 +190,26 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         HELEN_TICK(5)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            if (y != nullptr) {
-                f32x4* yo = y + (size_t)tile[n] * y_tile_stride + (size_t)dir * (kHidDirStride / 4) +
-                            (size_t)s * (kYStride / 4);
-                yo[tid] = (hbuf(n) + (cur ^ 1) * 512)[tid];
-            }
-            if (yplanes != nullptr) {   // 768 units of 16 B per (tile, slot, dir)
-                f32x4* po = yplanes + (size_t)tile[n] * yp_tile_stride + ((size_t)s * 2 + dir) * 768;
-                const f32x4* ps = planes(n) + (cur ^ 1) * 768;
-                po[tid] = ps[tid];
-                if (tid < 256) po[512 + tid] = ps[512 + tid];
-            }
+        if (dec) {
+            if (s > 0) head_store(s - 1);
+        } else {   // 768 units of 16 B per (tile, slot, dir)
+            f32x4* po = yplanes + (size_t)tile * yp_tile_stride + ((size_t)s * 2 + dir) * 768;
+            const f32x4* ps = planes + (cur ^ 1) * 768;
+            po[tid] = ps[tid];
+            if (tid < 256) po[512 + tid] = ps[512 + tid];
         }
     }
 #ifdef HELEN_GRU_TIMING
     if (blockIdx.x == 0 && lane == 0 && (v == 0 || v == 5))
-        printf("gru_x3 dir %d wave %d: cycles/step  mfma-issue %lld  mfma-drain %lld  vmwait %lld  G+gates+stores %lld  lgkm %lld  barrier %lld  (ycopy in mfma-issue)\n",
+        printf("gru_x3 dir %d wave %d: cycles/step  mfma-issue %lld  mfma-drain %lld  vmwait %lld  G+gates+stores %lld  lgkm %lld  barrier %lld  (output in mfma-issue)\n",
                dir, v, tk[0] / T, tk[1] / T, tk[2] / T, tk[3] / T, tk[4] / T, tk[5] / T);
 #endif
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-        (hid + ((size_t)tile[n] * 2 + dir) * (kHidDirStride / 4))[tid] = (hbuf(n) + (T & 1) * 512)[tid];
+    if (dec) {   // the last step's logits
+        head_partial(T & 1, (T - 1) & 1);
+        __syncthreads();
+        head_store(T - 1);
+    }
+    hid_p[tid] = (hbuf + (T & 1) * 512)[tid];
 }
 
 // ------------------------------------------------------------------------------------------------
