@@ -198,13 +198,14 @@ def main():
         avg_ms = gru_ms / max(gru_n, 1)
         win_per_launch = call_windows
         achieved = GRU_FLOP_PER_WINDOW_LAUNCH * win_per_launch / (avg_ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(win_per_launch)
+        traffic, traffic_src = pmc_traffic(win_per_launch) if args.precision == "fp32" else (None, None)
         peak = BF16_MFMA_PEAK if args.precision == "bf16" else FP32_MFMA_PEAK
         bound, unit = "mfma", "TFLOP/s"
-        if args.precision == "bf16" and traffic:
-            # with bf16 MFMAs the recurrence is bound by its fp32 gi/y stream, not by the matrix pipe
-            bound, unit, peak = "hbm", "GB/s", 8000e9
-            achieved = traffic / (avg_ms * 1e-3) / 1e9
+        if args.precision == "bf16":
+            # the fused layer kernels do projection + recurrence (+ the decoder's head partials): count a
+            # layer launch's algorithmic matmul FLOPs, averaged over the encoder and decoder launches
+            flop = 100 * 2 * 384 * 2 * ((90 + 128) + (256 + 128) + 16) / 2.0
+            achieved = flop * win_per_launch / (avg_ms * 1e-3) / 1e12
         out = {
             "metric": "pileup windows/sec (batch 256, 1000-pos)",
             "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps,
@@ -221,7 +222,8 @@ def main():
                        "positions": 1000, "features": 90, "windows_per_gpu": args.steps * call_windows,
                        "resident_windows_per_gpu": n_res, "sharding": "by rank, no collective"},
             "roofline": {"bound": bound, "kernel": {"fp32": "gru_kernel (GRU recurrence, fp32 MFMA)",
-                                    "bf16": "gru_bf16_kernel (GRU recurrence, bf16 MFMA)",
+                                    "bf16": "gru_fused_bf16_kernel (projection + recurrence per layer, bf16 MFMA; "
+                                            "bound in practice by the fp32 gate math, not the matrix pipe)",
                                     "fp32x3": "gru_x3_kernel (GRU recurrence, 6 bf16 MFMAs per fp32 product "
                                               "group; fraction is of the fp32 MFMA peak)"}[args.precision],
                          "achieved": round(achieved, 2),
