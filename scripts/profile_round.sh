@@ -9,6 +9,9 @@ set -u
 R=$(pwd)
 mkdir -p $R/gpurun_out
 python bench.py > $R/gpurun_out/bench.json 2> $R/gpurun_out/bench.err
+for p in fp32x3 bf16; do   # the opt-in arithmetic modes, for the record
+    python bench.py --no-cpu-baseline --precision $p > $R/gpurun_out/bench_$p.json 2>> $R/gpurun_out/bench.err
+done
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o p -- \
     python $R/bench.py --steps 16 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof.log 2>&1
