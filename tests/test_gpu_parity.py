@@ -190,11 +190,12 @@ def test_bf16_variant_against_emulation_and_fp32(case):
 
 
 # ---- full-size properties (BASELINE.json configs[1] scale per call: 4096+ windows) ----
-def test_full_size_properties():
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3", "bf16"])
+def test_full_size_properties(precision):
     """At the benchmark's per-call size the oracle is too slow for every window, so check
     size-independent properties: permutation equivariance (windows never interact), duplicates
     give identical rows, the host-streaming entry equals the device entry, and a random subset
-    matches the oracle bit for bit."""
+    matches the oracle bit for bit (fp32 and fp32x3; bf16: its emulation, up to thin-margin flips)."""
     import oracle
     from helen_amd.engine import HelenEngine
     n = 4096 + 40                       # one full device call plus a ragged tail (2.5 tiles)
@@ -204,7 +205,7 @@ def test_full_size_properties():
     img[17] = img[4000]                 # duplicates in different tiles / different calls
     img[4100] = img[5]
     img[33, 613:] = 0                   # a short window, zero-padded like the reader does
-    eng = HelenEngine(w, device=0, max_windows=4096)
+    eng = HelenEngine(w, device=0, max_windows=4096, precision=precision)
     bases, rles = eng.polish(img)
     assert torch.equal(bases[17], bases[4000]) and torch.equal(rles[17], rles[4000])
     assert torch.equal(bases[4100], bases[5]) and torch.equal(rles[4100], rles[5])
@@ -215,22 +216,31 @@ def test_full_size_properties():
     assert np.array_equal(bh, bases.cpu().numpy()) and np.array_equal(rh, rles.cpu().numpy())
     pick = np.sort(np.random.default_rng(1).choice(n, size=32, replace=False))
     pick[:3] = [17, 33, 4100]
-    o = oracle.polish_batch(w, img[torch.from_numpy(pick).cuda()].cpu().numpy())
+    if precision == "bf16":
+        oracle.set_precision("bf16")
+    try:
+        o = oracle.polish_batch(w, img[torch.from_numpy(pick).cuda()].cpu().numpy())
+    finally:
+        oracle.set_precision("fp32")
     nb, rep = label_mismatch_report(o["acc_base"], o["bases"], bases.cpu().numpy()[pick], "base")
     nr, rep2 = label_mismatch_report(o["acc_rle"], o["rles"], rles.cpu().numpy()[pick], "rle")
-    assert nb == 0 and nr == 0, rep + "\n" + rep2
+    if precision == "bf16":
+        assert nb + nr <= BF16_LABEL_MISMATCH_MAX * 2 * 32 * 1000, rep + "\n" + rep2
+    else:
+        assert nb == 0 and nr == 0, rep + "\n" + rep2
     assert int(bases.max()) <= 4 and int(rles.max()) <= 10
     eng.close()
 
 
-def test_run_to_run_determinism():
-    """No atomics, fixed reduction orders: repeated calls give bit-identical accumulators and labels
-    (also across the fp32 and operator-level entry points' shared kernels)."""
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3", "bf16"])
+def test_run_to_run_determinism(precision):
+    """No floating-point atomics, fixed reduction orders: repeated calls give bit-identical accumulators
+    and labels."""
     from helen_amd.engine import HelenEngine
     w = make_weights(seed=20260928, input_scale=1.0 / 64.0)
     g = torch.Generator(device="cuda").manual_seed(11)
     img = torch.randint(0, 256, (600, 1000, 90), dtype=torch.uint8, device="cuda", generator=g)
-    eng = HelenEngine(w, device=0, max_windows=1024)
+    eng = HelenEngine(w, device=0, max_windows=1024, precision=precision)
     first = eng.polish(img, want_acc=True)
     for _ in range(3):
         again = eng.polish(img, want_acc=True)
