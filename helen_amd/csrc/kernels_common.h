@@ -28,4 +28,11 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.8853900817779268f));
 }
 
+// Pileup rows are 90 bytes, so a position's bytes are only 2-byte aligned: gfx950 takes unaligned wide
+// global loads, and these under-aligned types make hipcc emit them (one dword / qword load instead of
+// 4 / 8 byte loads).
+typedef uint16_t __attribute__((aligned(2))) u16_a2;
+typedef uint32_t __attribute__((aligned(2))) u32_a2;
+typedef uint64_t __attribute__((aligned(2))) u64_a2;
+
 }  // namespace helen

@@ -21,11 +21,12 @@ __global__ __launch_bounds__(256) void pack_images_kernel(const uint8_t* __restr
     const int pos = g / per_pos;
     const int window = tile * kTile + i;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (window < n_windows) {
+    if (window < n_windows && kb * 4 < kF) {
         const uint8_t* p = img + ((size_t)window * npos + pos) * kF + kb * 4;
+        // the last group of a row holds k = 88, 89 only: never read past the row (and the buffer)
+        const uint32_t w = kb * 4 + 4 <= kF ? *(const u32_a2*)p : (uint32_t) * (const u16_a2*)p;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (kb * 4 + e < kF) v[e] = (float)p[e];
+        for (int e = 0; e < 4; ++e) v[e] = (float)((w >> (8 * e)) & 0xffu);
     }
     xa[((size_t)tile * npos + pos) * per_pos + kb * kTile + i] = v;
 }

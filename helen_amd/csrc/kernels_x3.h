@@ -360,9 +360,10 @@ __global__ __launch_bounds__(256) void pack_images_x3_kernel(const uint8_t* __re
     for (int e = 0; e < 8; ++e) v[e] = 0;
     if (window < n_windows) {
         const uint8_t* p = img + ((size_t)window * npos + pos) * kF + o * 8;
+        // the last octet of a row holds k = 88, 89 only: never read past the row (and the buffer)
+        const uint64_t w = o * 8 + 8 <= kF ? *(const u64_a2*)p : (uint64_t) * (const u16_a2*)p;
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (o * 8 + e < kF) v[e] = bf16_bits((float)p[e]);   // exact: integers <= 255
+        for (int e = 0; e < 8; ++e) v[e] = bf16_bits((float)((w >> (8 * e)) & 0xffu));   // exact: integers <= 255
     }
     uint4 u;
     u.x = v[0] | ((unsigned)v[1] << 16);
