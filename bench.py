@@ -27,7 +27,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FLOP_PER_WINDOW = 1772441600.0        # 932,864 FLOP/step x 100 steps x 19 chunks
-GRU_FLOP_PER_WINDOW_LAUNCH = 100 * 2 * 2.0 * 384 * 128   # one recurrence launch, both directions
+# One recurrence launch, both directions: h.W_hh^T (100 steps x 2 x 384 x 128 MACs); the decoder launches
+# also carry the heads' product (8,192 FLOP per timestep).  Averaged over the encoder and
+# decoder launches, which the timing below also averages.
+GRU_FLOP_PER_WINDOW_LAUNCH = 100 * 2 * 2.0 * 384 * 128 + 100 * 8192 / 2.0
 FP32_MFMA_PEAK = 157.3e12             # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 BF16_MFMA_PEAK = 2.5e15               # MI355X_MICROARCH.md: bf16 MFMA, dense
 
@@ -221,7 +224,7 @@ def main():
                        "batch": B, "batches_per_step": G, "windows_per_step": call_windows,
                        "positions": 1000, "features": 90, "windows_per_gpu": args.steps * call_windows,
                        "resident_windows_per_gpu": n_res, "sharding": "by rank, no collective"},
-            "roofline": {"bound": bound, "kernel": {"fp32": "gru_kernel (GRU recurrence, fp32 MFMA)",
+            "roofline": {"bound": bound, "kernel": {"fp32": "gru_kernel (GRU recurrence, fp32 MFMA; decoder launches include the heads' product)",
                                     "bf16": "gru_fused_bf16_kernel (projection + recurrence per layer, bf16 MFMA; "
                                             "bound in practice by the fp32 gate math, not the matrix pipe)",
                                     "fp32x3": "gru_x3_kernel (GRU recurrence, 6 bf16 MFMAs per fp32 product "

@@ -66,14 +66,13 @@ struct HelenModel {
     bf16x8* w3i_dec = nullptr;   // decoder W_ih split: [2 dirs][24 tiles][8 M][3 terms][64]
     bf16x8* w3i_enc = nullptr;   // encoder W_ih split: [2 dirs][24 tiles][3 M][3 terms][64] (K padded to 96)
     f32x4* xb = nullptr;         // pileup counts as bf16 A fragments: [tile][pos][192] x 16 B
-    f32x4* plogit = nullptr;     // bf16 / fp32x3: per-direction partial logits [tile][slot][dir][64] x 16 B (no y2)
+    f32x4* plogit = nullptr;     // decoder output: per-direction partial logits [tile][slot][dir][64] x 16 B (no y2)
     f32x4* y1p = nullptr;        // encoder output as bf16 planes: [tile][slot][dir][3 (fp32x3) | 1 (bf16)][256] x 16 B
     // scratch (device)
     f32x4* xa = nullptr;
     f32x4* gi_enc = nullptr;
     f32x4* gi_dec = nullptr;
     f32x4* y1 = nullptr;
-    f32x4* y2 = nullptr;
     f32x4* hid = nullptr;
     f32x4* pending = nullptr;
     // host-streaming path (helen_polish_host)
@@ -259,7 +258,7 @@ int check_launch(const char* what) {
 
 // One TransducerGRU.forward over `tiles` tiles whose encoder pre-activations are already in
 // gi_enc at positions [pos0, pos0+T): encoder recurrence -> decoder projection -> decoder
-// recurrence.  y2 then holds the decoder output, hid the returned hidden state.
+// recurrence.  plogit then holds the decoder's partial logits, hid the returned hidden state.
 // 1-D grid of the projection kernels: units = tiles x position groups, padded to a multiple of 8
 // (the XCD count), times 8 / HELEN_GEMM_WAVES column-group workgroups per unit.
 unsigned gemm_grid(int npos, int tiles, int positions_per_wave = 4) {
@@ -283,7 +282,7 @@ void launch_enc_gemm(HelenModel* m, hipStream_t s, int tiles, int npos) {
 
 // One TransducerGRU.forward over `tiles` tiles whose encoder pre-activations are already in
 // gi_enc at positions [pos0, pos0+T): encoder recurrence -> decoder projection -> decoder
-// recurrence.  y2 then holds the decoder output, hid the returned hidden state.
+// recurrence.  plogit then holds the decoder's partial logits, hid the returned hidden state.
 void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int enc_npos) {
     const dim3 ggrid(gemm_grid(T, tiles)), gblock(HELEN_GEMM_WAVES * 64);
     // encoder gi holds `enc_npos` positions; the reverse direction is stored time-reversed
@@ -309,19 +308,20 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
                m->w3h_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kY1pTileStride, m->whd, m->plogit, kPlTileStride);
         return;
     }
-    LAUNCH(HELEN_K_GRU_ENC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
-           enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride);
+    LAUNCH(HELEN_K_GRU_ENC, gru_kernel<false>, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
+           enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride, (const f32x4*)nullptr,
+           (f32x4*)nullptr, kPlTileStride);
     LAUNCH(HELEN_K_GEMM_DEC, (gemm_gi_kernel<16, true>), ggrid, gblock, m->y1, kYTileStride, m->wp_dec,
            m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
-    LAUNCH(HELEN_K_GRU_DEC, gru_kernel, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, 0, T,
-           m->whp_dec, m->bhn_dec, m->hid, m->y2, kYTileStride);
+    LAUNCH(HELEN_K_GRU_DEC, gru_kernel<true>, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, 0, T,
+           m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd, m->plogit, kPlTileStride);
 }
 
 void free_model(HelenModel* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     void* ptrs[] = {m->plogit, m->w3i_enc, m->xb, m->w3i_dec, m->y1p, m->w3h_enc, m->w3h_dec, m->wp_enc, m->wp_dec, m->whp_enc, m->whp_dec, m->whd, m->bias_enc, m->bias_dec,
-                    m->bhn_enc, m->bhn_dec, m->bhd, m->xa, m->gi_enc, m->gi_dec, m->y1, m->y2,
+                    m->bhn_enc, m->bhn_dec, m->bhd, m->xa, m->gi_enc, m->gi_dec, m->y1,
                     m->hid, m->pending, m->dev_in[0], m->dev_in[1], m->dev_out[0], m->dev_out[1]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -420,11 +420,7 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
     }
     if (precision == HELEN_PRECISION_FP32)
         if ((rc = dev_alloc(m, &m->y1, nt * kYTileStride))) return rc;
-    if (precision != HELEN_PRECISION_FP32) {   // the decoder emits partial logits instead of y2
-        if ((rc = dev_alloc(m, &m->plogit, nt * kPlTileStride))) return rc;
-    } else {
-        if ((rc = dev_alloc(m, &m->y2, nt * kYTileStride))) return rc;
-    }
+    if ((rc = dev_alloc(m, &m->plogit, nt * kPlTileStride))) return rc;   // the decoder emits partial logits, no y2
     if ((rc = dev_alloc(m, &m->hid, nt * (kHidStride / 4)))) return rc;
     if ((rc = dev_alloc(m, &m->pending, nt * 2 * kJump * 64))) return rc;
     return HELEN_OK;
@@ -513,14 +509,9 @@ int helen_polish_batch(HelenModel* m, const uint8_t* images, int n_windows, uint
     if (rc) return rc;
     for (int c = 0; c < kChunks; ++c) {  // predict_gpu.py:114-149
         launch_chunk(m, s, tiles, c * kJump, kWin, kSeq);
-        if (m->precision != HELEN_PRECISION_FP32)
-            LAUNCH(HELEN_K_HEADS, heads_kernel<true>, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->plogit,
-                   kPlTileStride, m->whd, m->bhd, 0, c, kWin, n_windows, m->pending, bases, rles, acc_base_opt,
-                   acc_rle_opt, (float*)nullptr, (float*)nullptr);
-        else
-            LAUNCH(HELEN_K_HEADS, heads_kernel<false>, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->y2,
-                   kYTileStride, m->whd, m->bhd, 0, c, kWin, n_windows, m->pending, bases, rles, acc_base_opt,
-                   acc_rle_opt, (float*)nullptr, (float*)nullptr);
+        LAUNCH(HELEN_K_HEADS, heads_kernel, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->plogit, kPlTileStride,
+               m->bhd, 0, c, kWin, n_windows, m->pending, bases, rles, acc_base_opt, acc_rle_opt,
+               (float*)nullptr, (float*)nullptr);
     }
     return check_launch("helen_polish_batch");
 }
@@ -543,14 +534,8 @@ int helen_evaluate_batch(HelenModel* m, const uint8_t* images, const uint8_t* la
     if (rc) return rc;
     for (int c = 0; c < kChunks; ++c) {  // models/test.py:95-121
         launch_chunk(m, s, tiles, c * kJump, kWin, kSeq);
-        if (m->precision != HELEN_PRECISION_FP32)
-            LAUNCH(HELEN_K_HEADS, heads_eval_kernel<true>, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->plogit,
-                   kPlTileStride, m->whd, m->bhd, c, kWin, n_windows, label_base, label_rle, cw, chunk_stats,
-                   base_confusion, rle_confusion);
-        else
-            LAUNCH(HELEN_K_HEADS, heads_eval_kernel<false>, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->y2,
-                   kYTileStride, m->whd, m->bhd, c, kWin, n_windows, label_base, label_rle, cw, chunk_stats,
-                   base_confusion, rle_confusion);
+        LAUNCH(HELEN_K_HEADS, heads_eval_kernel, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->plogit, kPlTileStride,
+               m->bhd, c, kWin, n_windows, label_base, label_rle, cw, chunk_stats, base_confusion, rle_confusion);
     }
     return check_launch("helen_evaluate_batch");
 }
@@ -574,12 +559,8 @@ int helen_gru_chunk_forward(HelenModel* m, const float* x, const float* h_in, in
     }
     launch_chunk(m, s, tiles, 0, T, T);
     const dim3 hgrid(tiles, (T + kHeadsSpan - 1) / kHeadsSpan);
-    if (m->precision != HELEN_PRECISION_FP32)
-        LAUNCH(HELEN_K_HEADS, heads_kernel<true>, hgrid, dim3(256), m->plogit, kPlTileStride, m->whd, m->bhd, 1, 0, T,
-               B, m->pending, (uint8_t*)nullptr, (uint8_t*)nullptr, (float*)nullptr, (float*)nullptr, base, rle);
-    else
-        LAUNCH(HELEN_K_HEADS, heads_kernel<false>, hgrid, dim3(256), m->y2, kYTileStride, m->whd, m->bhd, 1, 0, T, B,
-               m->pending, (uint8_t*)nullptr, (uint8_t*)nullptr, (float*)nullptr, (float*)nullptr, base, rle);
+    LAUNCH(HELEN_K_HEADS, heads_kernel, hgrid, dim3(256), m->plogit, kPlTileStride, m->bhd, 1, 0, T, B, m->pending,
+           (uint8_t*)nullptr, (uint8_t*)nullptr, (float*)nullptr, (float*)nullptr, base, rle);
     hipLaunchKernelGGL(unpack_hidden_kernel, dim3(tiles), dim3(256), 0, s, (const float*)m->hid, B,
                        h_out);
     return check_launch("helen_gru_chunk_forward");

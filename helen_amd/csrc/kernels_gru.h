@@ -17,8 +17,15 @@ namespace helen {
 //       operand of the next step;
 //     - the gate pre-activations gi are DMA'd global->LDS (global_load_lds: no registers) one
 //       step ahead into a per-wave, single-buffered slot that is refilled as soon as it is read.
-//   Each step's h is streamed out as y[tile][slot][dir] (KB16) for the next projection, slot =
-//   step index (t for direction 0, T-1-t for direction 1).
+//   Encoder launch (DEC = false): each step's h is streamed out as y[tile][slot][dir] (KB16) for the
+//   decoder projection, slot = step index (t for direction 0, T-1-t for direction 1).
+//   Decoder launch (DEC = true): no layer output.  The heads are linear in [h_fwd | h_bwd], so each
+//   direction's workgroup contributes its half of the 16 logits: wave w owns the k-slice 32w..32w+31
+//   of h (two KB16 groups = two fp32 MFMA A fragments in the LDS copy of h); at step s+1 it multiplies
+//   the slice of h(s) by its slice of the head weights (8 MFMAs beside the 192 recurrent ones), parks
+//   the 16x16 partial in LDS, and after that step's barrier wave s mod 4 adds the four partials in
+//   wave order and stores 1 KiB plogit[tile][slot = s][dir][64 lanes] (FRAG layout) instead of 8 KiB of
+//   y2: the heads kernel shrinks from 0.12 to 0.035 ms per launch for +0.03 ms here.
 //   Direction 1 walks t = T-1 .. 0 (the `_reverse` weights); its h_n is the state after t = 0.
 //   gi and y are indexed by SLOT = step order for both directions (the reverse direction is
 //   stored time-reversed) so both directions walk memory upwards: descending DMA/store addresses
@@ -34,14 +41,19 @@ __device__ __forceinline__ float gru_cell(float ar, float az, float an, float gr
 
 constexpr int kGruLdsF4 = 2 * 512 + 4 * 384 + 4 * 512;  // h[2] | gi[4 waves] | W tile 5[4 waves]
 
+template <bool DEC>
 __global__ __launch_bounds__(256, 2) void gru_kernel(const f32x4* __restrict__ gi, long gi_tile_stride,
                                                      int slot0_fwd, int slot0_bwd, int T,
                                                      const f32x4* __restrict__ Whp,
                                                      const float* __restrict__ bhn,
                                                      f32x4* __restrict__ hid, f32x4* __restrict__ y,
-                                                     long y_tile_stride) {
-    __shared__ f32x4 smem[kGruLdsF4];  // 72 KiB, one object (two workgroups fit in 160 KiB)
+                                                     long y_tile_stride, const f32x4* __restrict__ Whd,
+                                                     f32x4* __restrict__ plogit, long pl_tile_stride) {
+    // DEC (decoder launch): no layer output; each direction emits its half of the 16 logits as fp32
+    // partials (see gru_x3_kernel): wave w owns the k-slice 32w..32w+31 of h = two KB16 groups.
+    __shared__ f32x4 smem[kGruLdsF4 + (DEC ? 2 * 4 * 64 : 0)];  // 72 (+8) KiB: two workgroups fit in 160 KiB
     f32x4* const hbuf = smem;
+    f32x4* const part = smem + kGruLdsF4;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -64,6 +76,27 @@ __global__ __launch_bounds__(256, 2) void gru_kernel(const f32x4* __restrict__ g
 #pragma unroll
         for (int m = 0; m < 8; ++m) w5buf[m * 64 + lane] = wp[(5 * 8 + m) * 64];
     }
+    f32x4 Bh[2] = {splat4(0.f), splat4(0.f)};   // DEC: head weights of k = dir*128 + 32w + 16g + 4q + e, class j
+    if (DEC) {
+        Bh[0] = Whd[(dir * 8 + 2 * w) * 64 + lane];
+        Bh[1] = Whd[(dir * 8 + 2 * w + 1) * 64 + lane];
+    }
+    auto head_partial = [&](int hb_, int pb) {   // this wave's two k-groups of h in hbuf[hb_]
+        const f32x4 a0 = (hbuf + hb_ * 512)[(2 * w) * 64 + lane], a1 = (hbuf + hb_ * 512)[(2 * w + 1) * 64 + lane];
+        f32x4 p0 = splat4(0.f), p1 = splat4(0.f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            p0 = mfma4(a0[e], Bh[0][e], p0);
+            p1 = mfma4(a1[e], Bh[1][e], p1);
+        }
+        (part + (pb * 4 + w) * 64)[lane] = p0 + p1;
+    };
+    auto head_store = [&](int slot) {             // one wave adds the four slices in wave order
+        if (w != (slot & 3)) return;
+        const f32x4* pp = part + (slot & 1) * 4 * 64 + lane;
+        const f32x4 sum = ((pp[0] + pp[64]) + pp[128]) + pp[192];
+        (plogit + (size_t)tile * pl_tile_stride + ((size_t)slot * 2 + dir) * 64)[lane] = sum;
+    };
     float bn[2];
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) bn[hh] = bhn[dir * kH + 32 * w + 16 * hh + j];
@@ -120,6 +153,7 @@ __global__ __launch_bounds__(256, 2) void gru_kernel(const f32x4* __restrict__ g
         acc[3] = splat4(0.f);
         acc[4] = splat4(bn[0]);
         acc[5] = splat4(bn[1]);
+        if (DEC && s > 0) head_partial(cur, (s - 1) & 1);   // h(s-1) sits in hbuf[cur] since the last barrier
         // LDS operand ping-pong: group m+1's A / parked-W reads are in flight behind group m's 24
         // MFMAs (pinned with sched_barriers; left alone, hipcc issues the reads right before use
         // and exposes the LDS latency four times per step).
@@ -150,7 +184,13 @@ __global__ __launch_bounds__(256, 2) void gru_kernel(const f32x4* __restrict__ g
         // VMEM queue of this wave, oldest first: 6 gi DMAs (issued last step), 2 y stores (issued
         // after last step's barrier).  vmcnt(2) = the DMAs have landed; the stores may still fly.
         // (hipcc does not order these LDS reads behind the DMA by itself.)
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        // DEC: the only store of the previous step is the partial-logit tile, by wave (s-2) mod 4.
+        if (!DEC)
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (s >= 2 && w == ((s - 2) & 3))
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         HELEN_TICK(5)
         f32x4 G[6];
 #pragma unroll
@@ -176,12 +216,21 @@ __global__ __launch_bounds__(256, 2) void gru_kernel(const f32x4* __restrict__ g
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         HELEN_TICK(3)
-        // stream h(t) out as the layer output
-        f32x4* yo = y_p + (size_t)s * (kYStride / 4);  // slot s: t for dir 0, T-1-t for dir 1
-        const f32x4* hn4 = hbuf + (cur ^ 1) * 512;
-        yo[tid] = hn4[tid];
-        yo[tid + 256] = hn4[tid + 256];
+        if (DEC) {
+            if (s > 0) head_store(s - 1);
+        } else {
+            // stream h(t) out as the layer output
+            f32x4* yo = y_p + (size_t)s * (kYStride / 4);  // slot s: t for dir 0, T-1-t for dir 1
+            const f32x4* hn4 = hbuf + (cur ^ 1) * 512;
+            yo[tid] = hn4[tid];
+            yo[tid + 256] = hn4[tid + 256];
+        }
         HELEN_TICK(4)
+    }
+    if (DEC) {   // the last step's logits
+        head_partial(T & 1, (T - 1) & 1);
+        __syncthreads();
+        head_store(T - 1);
     }
 #ifdef HELEN_GRU_TIMING
     if (tile == 0 && lane == 0) {

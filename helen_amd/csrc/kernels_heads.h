@@ -6,9 +6,10 @@ namespace helen {
 
 // ------------------------------------------------------------------------------------------------
 // Heads + softmax + accumulate + argmax (TransducerModel.py:75-76, predict_gpu.py:137-156).
-//   One 16-column MFMA tile is exactly the 5 base + 11 run-length logits of 16 windows.
-//   grid (tiles, groups of kHeadsSpan positions), 4 waves striding over the positions of the group
-//   (many small workgroups: the kernel is latency/HBM-bound, so it wants waves in flight).
+//   One 16-column MFMA tile is exactly the 5 base + 11 run-length logits of 16 windows; the matrix product
+//   itself happens inside the decoder recurrences (each direction's half, see gru_kernel<true>), this
+//   kernel adds the two partial tiles and does everything after the logits.
+//   grid (tiles, groups of kHeadsSpan positions), 4 waves striding over the positions of the group.
 //   mode 0 (polish): positions 50c+t; the first half of chunk c receives its second (final)
 //     contribution -> add the pending softmax of chunk c-1, argmax, labels; the second half is
 //     parked in `pending` for chunk c+1 (or is final for the last chunk).  A position gets at most
@@ -45,38 +46,18 @@ __device__ __forceinline__ int group16_argmax(float v, int idx) {
 #endif
 constexpr int kHeadsSpan = HELEN_HEADS_SPAN;  // positions per workgroup; divides kJump so a group never straddles halves
 
-// The 16 logits of 16 windows at chunk position t.  PARTIALS = false: y2[tile][slot][fwd | bwd] (KB16; the
-// bwd half of position t sits in slot T-1-t) times the head weights, 32 fp32 MFMAs.  PARTIALS = true: the
-// decoder already multiplied each direction's half (plogit[tile][slot][dir][64], kernels_fused_bf16.h):
-// add the two partial tiles and the bias.
-template <bool PARTIALS>
-__device__ __forceinline__ f32x4 head_logits(const f32x4* __restrict__ src, long tile_stride, int tile, int t,
-                                             int T, const f32x4* B, float bias, int lane) {
-    if constexpr (PARTIALS) {
-        const f32x4* p = src + (size_t)tile * tile_stride + lane;
-        return p[((size_t)t * 2) * 64] + p[((size_t)(T - 1 - t) * 2 + 1) * 64] + splat4(bias);
-    } else {
-        const f32x4* a_p = src + (size_t)tile * tile_stride + (size_t)t * (kYStride / 4) + lane;
-        const f32x4* a_pb = src + (size_t)tile * tile_stride + (size_t)(T - 1 - t) * (kYStride / 4) + lane;
-        f32x4 acc0 = splat4(bias);
-        f32x4 acc1 = splat4(0.f);
-#pragma unroll
-        for (int m = 0; m < 16; m += 2) {
-            const f32x4 a0 = (m >= 8 ? a_pb : a_p)[m * 64];
-            const f32x4 a1 = (m >= 8 ? a_pb : a_p)[(m + 1) * 64];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc0 = mfma4(a0[e], B[m][e], acc0);
-                acc1 = mfma4(a1[e], B[m + 1][e], acc1);
-            }
-        }
-        return acc0 + acc1;  // row 4q+r (window), col j (class)
-    }
+// The 16 logits of 16 windows at chunk position t: the decoder recurrences already multiplied each
+// direction's half of [h_fwd | h_bwd] by the head weights (plogit[tile][slot][dir][64 lanes], FRAG layout;
+// the backward direction is stored time-reversed: position t sits in slot T-1-t) -- add the two tiles
+// and the bias.
+__device__ __forceinline__ f32x4 head_logits(const f32x4* __restrict__ plogit, long tile_stride, int tile, int t,
+                                             int T, float bias, int lane) {
+    const f32x4* p = plogit + (size_t)tile * tile_stride + lane;
+    return p[((size_t)t * 2) * 64] + p[((size_t)(T - 1 - t) * 2 + 1) * 64] + splat4(bias);
 }
 
-template <bool PARTIALS>
 __global__ __launch_bounds__(256) void heads_kernel(
-    const f32x4* __restrict__ y2, long y_tile_stride, const f32x4* __restrict__ Whd,
+    const f32x4* __restrict__ plogit, long pl_tile_stride,
     const float* __restrict__ bhd, int mode, int chunk, int T, int n_windows,
     f32x4* __restrict__ pending, uint8_t* __restrict__ bases, uint8_t* __restrict__ rles,
     float* __restrict__ acc_base, float* __restrict__ acc_rle, float* __restrict__ logit_base,
@@ -93,18 +74,13 @@ __global__ __launch_bounds__(256) void heads_kernel(
     const int half = t0 / kJump;
     const bool isb = j < kNB;
 
-    f32x4 B[PARTIALS ? 1 : 16];
-    if constexpr (!PARTIALS) {
-#pragma unroll
-        for (int m = 0; m < 16; ++m) B[m] = Whd[m * 64 + lane];
-    }
     const float bias = bhd[j];
 
     const bool park = (mode == 0) && (half == 1) && (chunk < kChunks - 1);
     const bool add_prev = (mode == 0) && (half == 0) && (chunk > 0);
 
     for (int t = t0 + w; t < t1; t += 4) {
-        const f32x4 logit = head_logits<PARTIALS>(y2, y_tile_stride, tile, t, T, B, bias, lane);
+        const f32x4 logit = head_logits(plogit, pl_tile_stride, tile, t, T, bias, lane);   // row 4q+r (window), col j (class)
 
         if (mode == 1) {
 #pragma unroll
@@ -175,7 +151,7 @@ __global__ __launch_bounds__(256) void heads_kernel(
 // ------------------------------------------------------------------------------------------------
 // Heads + cross-entropy + confusion counts: the per-chunk body of the reference's evaluation loop
 // (models/test.py:104-121) for chunk `chunk` of 16-window tiles.
-//   logits as in heads_kernel; per position: nll_base = logsumexp(base) - base[label_base],
+//   logits as in heads_kernel (from the decoder's partial tiles); per position: nll_base = logsumexp(base) - base[label_base],
 //   nll_rle likewise (nn.CrossEntropyLoss = log_softmax + nll), predictions = first-maximum argmax of
 //   the LOGITS (torchnet ConfusionMeter: np.argmax), confusion[target][predicted] += 1.
 //   Outputs: stats[window][chunk][group of kHeadsSpan positions][3] = (sum nll_base, sum w[l]*nll_rle,
@@ -188,9 +164,8 @@ struct RleClassWeights {
     float w[kNR];
 };
 
-template <bool PARTIALS>
 __global__ __launch_bounds__(256) void heads_eval_kernel(
-    const f32x4* __restrict__ y2, long y_tile_stride, const f32x4* __restrict__ Whd,
+    const f32x4* __restrict__ plogit, long pl_tile_stride,
     const float* __restrict__ bhd, int chunk, int T, int n_windows,
     const uint8_t* __restrict__ label_base, const uint8_t* __restrict__ label_rle, RleClassWeights cw,
     float* __restrict__ stats, unsigned long long* __restrict__ conf_base,
@@ -211,15 +186,10 @@ __global__ __launch_bounds__(256) void heads_eval_kernel(
     if (tid < kNR * kNR) hist_r[tid] = 0;
     __syncthreads();
 
-    f32x4 B[PARTIALS ? 1 : 16];
-    if constexpr (!PARTIALS) {
-#pragma unroll
-        for (int m = 0; m < 16; ++m) B[m] = Whd[m * 64 + lane];
-    }
     const float bias = bhd[j];
 
     for (int t = t0 + w; t < t1; t += 4) {
-        const f32x4 logit = head_logits<PARTIALS>(y2, y_tile_stride, tile, t, T, B, bias, lane);
+        const f32x4 logit = head_logits(plogit, pl_tile_stride, tile, t, T, bias, lane);   // row 4q+r (window), col j (class)
         const int pos = chunk * kJump + t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
