@@ -44,8 +44,11 @@ def pmc_traffic(windows_per_launch):
     if not files:
         return None, None
     try:
-        k = json.load(open(files[-1]))["kernels"]["helen::gru_kernel"]
-        return int(k["hbm_bytes_per_launch"] * windows_per_launch / 4096.0), os.path.basename(files[-1])
+        # encoder and decoder launches of the recurrence (gru_kernel<false> / <true>), launch-weighted
+        ks = [v for k, v in json.load(open(files[-1]))["kernels"].items() if k.startswith("helen::gru_kernel")]
+        n = sum(k["launches_profiled"] for k in ks)
+        per_launch = sum(k["hbm_bytes_per_launch"] * k["launches_profiled"] for k in ks) / n
+        return int(per_launch * windows_per_launch / 4096.0), os.path.basename(files[-1])
     except Exception:
         return None, None
 
