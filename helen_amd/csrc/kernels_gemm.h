@@ -22,6 +22,9 @@ namespace helen {
 #ifndef HELEN_GEMM_WAVES
 #define HELEN_GEMM_WAVES 2
 #endif
+#ifndef HELEN_GEMM_DEPTH
+#define HELEN_GEMM_DEPTH 2   // operand groups in flight, including the one being multiplied
+#endif
 template <int MG, bool REV_A>
 __global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_kernel(const f32x4* __restrict__ A, long a_tile_stride,
                                                       const f32x4* __restrict__ Wp,
@@ -30,7 +33,6 @@ __global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_kernel(const f3
                                                       int npos, int ntiles) {
     // Output slot: direction 0 -> position p, direction 1 -> npos-1-p (time-reversed), so the
     // recurrence reads both directions in ascending address order.
-    static_assert(MG % 2 == 0, "operand groups are consumed in ping-pong pairs");
     constexpr int P = 4, N = 6;
     const int lane = threadIdx.x & 63;
     // grid.x enumerates (unit, z): unit = (position group, tile), z = which HELEN_GEMM_WAVES wave
@@ -69,8 +71,11 @@ __global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_kernel(const f3
         for (int p = 0; p < P; ++p) acc[p][n] = splat4(b);
     }
 
-    // Register ping-pong: the operands of group m+1 are in flight while group m's 96 MFMAs issue.
-    f32x4 a0[P], b0[N], a1[P], b1[N];
+    // Register pipeline, HELEN_GEMM_DEPTH groups deep: the operands of groups m+1 .. m+DEPTH-1 are in
+    // flight while group m's 96 MFMAs issue (the kernel runs at one wave per SIMD with the accumulators in
+    // AGPRs, so its own prefetch distance is all the latency hiding there is).
+    constexpr int D = HELEN_GEMM_DEPTH;
+    f32x4 a[D][P], b[D][N];
 #define HELEN_LOAD_OPS(a, b, m)                                       \
     _Pragma("unroll") for (int p = 0; p < P; ++p)                     \
         a[p] = (REV_A && (m) >= MG / 2) ? a_ptr_b[p][(m) * 64] : a_ptr[p][(m) * 64]; \
@@ -80,16 +85,13 @@ __global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_kernel(const f3
     _Pragma("unroll") for (int p = 0; p < P; ++p)                     \
     _Pragma("unroll") for (int n = 0; n < N; ++n) acc[p][n] = mfma4(a[p][e], b[n][e], acc[p][n]);
 
-    HELEN_LOAD_OPS(a0, b0, 0)
 #pragma unroll
-    for (int m = 0; m < MG; m += 2) {
-        HELEN_LOAD_OPS(a1, b1, m + 1)
+    for (int m = 0; m < D - 1; ++m) { HELEN_LOAD_OPS(a[m], b[m], m) }
+#pragma unroll
+    for (int m = 0; m < MG; ++m) {
+        if (m + D - 1 < MG) { HELEN_LOAD_OPS(a[(m + D - 1) % D], b[(m + D - 1) % D], m + D - 1) }
         __builtin_amdgcn_sched_barrier(0);
-        HELEN_MMA_OPS(a0, b0)
-        __builtin_amdgcn_sched_barrier(0);
-        if (m + 2 < MG) { HELEN_LOAD_OPS(a0, b0, m + 2) }
-        __builtin_amdgcn_sched_barrier(0);
-        HELEN_MMA_OPS(a1, b1)
+        HELEN_MMA_OPS(a[m % D], b[m % D])
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef HELEN_LOAD_OPS
