@@ -383,3 +383,30 @@ def test_bf16_short_chunk_and_batch_split():
     torch.cuda.synchronize()
     assert torch.equal(small[0], big[0]) and torch.equal(small[1], big[1])
     big_eng.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3", "bf16"])
+def test_operator_entry_odd_shapes(precision):
+    """helen_gru_chunk_forward on the corners of its domain -- T in {1, 2, 3, 99, 100}, B in {1, 17}
+    (one partly filled tile, two tiles) with a non-zero hidden -- against the CPU restatement."""
+    import oracle
+    from helen_amd.engine import HelenEngine
+    w = make_weights(seed=5, head_scale=4.0, input_scale=1.0 / 64.0)
+    eng = HelenEngine(w, device=0, max_windows=32, precision=precision)
+    rng = np.random.default_rng(17)
+    atol = BF16_LOGIT_ATOL_VS_EMULATION if precision == "bf16" else LOGIT_ATOL
+    if precision == "bf16":
+        oracle.set_precision("bf16")
+    try:
+        for B in (1, 17):
+            for T in (1, 2, 3, 99, 100):
+                x = rng.integers(0, 256, size=(B, T, 90)).astype(np.float32)
+                h0 = rng.uniform(-1, 1, size=(B, 2, 128)).astype(np.float32)
+                eb, er, eh = oracle.gru_chunk_forward(w, x, h0)
+                base, rle, h = eng.chunk_forward(torch.from_numpy(x).cuda(), torch.from_numpy(h0).cuda())
+                np.testing.assert_allclose(base.cpu().numpy(), eb, atol=atol, rtol=LOGIT_RTOL, err_msg="B %d T %d" % (B, T))
+                np.testing.assert_allclose(rle.cpu().numpy(), er, atol=atol, rtol=LOGIT_RTOL, err_msg="B %d T %d" % (B, T))
+                np.testing.assert_allclose(h.cpu().numpy(), eh, atol=max(atol, HIDDEN_ATOL), rtol=0, err_msg="B %d T %d" % (B, T))
+    finally:
+        oracle.set_precision("fp32")
+    eng.close()
