@@ -261,7 +261,7 @@ int check_launch(const char* what) {
 // recurrence.  plogit then holds the decoder's partial logits, hid the returned hidden state.
 // 1-D grid of the projection kernels: units = tiles x position groups, padded to a multiple of 8
 // (the XCD count), times 8 / HELEN_GEMM_WAVES column-group workgroups per unit.
-unsigned gemm_grid(int npos, int tiles, int positions_per_wave = 4) {
+unsigned gemm_grid(int npos, int tiles, int positions_per_wave = HELEN_GEMM_P) {
     const int units = tiles * ((npos + positions_per_wave - 1) / positions_per_wave);
     return (unsigned)((units + 7) / 8 * 8) * (8 / HELEN_GEMM_WAVES);
 }

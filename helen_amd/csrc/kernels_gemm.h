@@ -9,11 +9,14 @@ namespace helen {
 // TransducerModel.py:70,72).  A is a KB16 operand with MG = K/16 groups per (tile, position).
 //   The 48 column tiles (2 directions x 24) are split over 8 "wave slots": slot v -> direction
 //   v>>2, column tiles 6(v&3) .. +5; a workgroup holds HELEN_GEMM_WAVES slots (grid.z the rest) and
-//   covers 4 positions, so each wave keeps a 4 x 6 block of 16x16 accumulators.
+//   covers P = 10 positions, so each wave keeps a 10 x 6 block of 16x16 accumulators (240 AGPRs).  The
+//   kernel runs at ONE wave per SIMD (the compiler spends the whole 512-register budget; constraining it
+//   to two waves per SIMD is 65 % slower), so nothing hides a workgroup's first loads and its output
+//   stores but its own length: 10 positions per wave instead of 4 is +2.5 %, and W_ih is re-read 2.5x
+//   less often.
 //   Operands come straight from global memory in a register ping-pong (group m+1 in flight while
-//   group m's 96 MFMAs issue): every load is one contiguous 1 KiB per wave and the packed weights
-//   (<= 786 KB) stay L2-resident; no LDS, no barriers.  Small workgroups (2 waves) measured best:
-//   several independent workgroups per CU overlap each other's prologue/epilogue.
+//   group m's 240 MFMAs issue): every load is one contiguous 1 KiB per wave and the packed weights
+//   (<= 786 KB) stay L2-resident; no LDS, no barriers.  Small workgroups (2 waves) measured best.
 //   bias[dir][col] = b_ih[col] + (col < 2H ? b_hh[col] : 0)   (b_hn is applied inside r*(...)).
 // Output gi[tile][slot][dir][ntile 24][lane 64] float4 (FRAG layout); slot = pos for direction 0,
 // npos-1-pos for direction 1.
@@ -21,6 +24,9 @@ namespace helen {
 // waves per projection workgroup; 8 / HELEN_GEMM_WAVES workgroups (grid.z) cover the 48 column tiles
 #ifndef HELEN_GEMM_WAVES
 #define HELEN_GEMM_WAVES 2
+#endif
+#ifndef HELEN_GEMM_P
+#define HELEN_GEMM_P 10  // positions per wave of the streaming-weights projection (4: 1.21 ms, 5: 1.19, 10: 1.18 per decoder launch)
 #endif
 #ifndef HELEN_GEMM_DEPTH
 #define HELEN_GEMM_DEPTH 2   // operand groups in flight, including the one being multiplied
@@ -33,7 +39,7 @@ __global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_kernel(const f3
                                                       int npos, int ntiles) {
     // Output slot: direction 0 -> position p, direction 1 -> npos-1-p (time-reversed), so the
     // recurrence reads both directions in ascending address order.
-    constexpr int P = 4, N = 6;
+    constexpr int P = HELEN_GEMM_P, N = 6;
     const int lane = threadIdx.x & 63;
     // grid.x enumerates (unit, z): unit = (position group, tile), z = which HELEN_GEMM_WAVES wave
     // slots.  Workgroups are dispatched round-robin over the 8 XCDs (id % 8), so the ZB = 8 /
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_kernel(const f3
     }
 
     // Register pipeline, HELEN_GEMM_DEPTH groups deep: the operands of groups m+1 .. m+DEPTH-1 are in
-    // flight while group m's 96 MFMAs issue (the kernel runs at one wave per SIMD with the accumulators in
+    // flight while group m's MFMAs issue (the kernel runs at one wave per SIMD with the accumulators in
     // AGPRs, so its own prefetch distance is all the latency hiding there is).
     constexpr int D = HELEN_GEMM_DEPTH;
     f32x4 a[D][P], b[D][N];
