@@ -16,14 +16,14 @@ namespace helen {
 //   less often.
 //   Operands come straight from global memory in a register ping-pong (group m+1 in flight while
 //   group m's 240 MFMAs issue): every load is one contiguous 1 KiB per wave and the packed weights
-//   (<= 786 KB) stay L2-resident; no LDS, no barriers.  Small workgroups (2 waves) measured best.
+//   (<= 786 KB) stay L2-resident; no LDS, no barriers.  Single-wave workgroups measured best.
 //   bias[dir][col] = b_ih[col] + (col < 2H ? b_hh[col] : 0)   (b_hn is applied inside r*(...)).
 // Output gi[tile][slot][dir][ntile 24][lane 64] float4 (FRAG layout); slot = pos for direction 0,
 // npos-1-pos for direction 1.
 // ------------------------------------------------------------------------------------------------
 // waves per projection workgroup; 8 / HELEN_GEMM_WAVES workgroups (grid.z) cover the 48 column tiles
 #ifndef HELEN_GEMM_WAVES
-#define HELEN_GEMM_WAVES 2
+#define HELEN_GEMM_WAVES 1   // measured at 10 positions per wave: 1 -> 1.164 ms, 2 -> 1.180, 4 -> 1.215 per decoder launch
 #endif
 #ifndef HELEN_GEMM_P
 #define HELEN_GEMM_P 10  // positions per wave of the streaming-weights projection (4: 1.21 ms, 5: 1.19, 10: 1.18 per decoder launch)
