@@ -123,13 +123,16 @@ __global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_kernel(const f3
 //   LDS-DMA into a 2-deep ring, 384 MFMAs per wave per barrier, and the 16 output stores of a stage stay
 //   in flight across the next barrier.  Two workgroups per CU.
 // ------------------------------------------------------------------------------------------------
+#ifndef HELEN_WS_PB
+#define HELEN_WS_PB 4
+#endif
 __global__ __launch_bounds__(256, 2) void gemm_enc_ws_kernel(const f32x4* __restrict__ A, long a_tile_stride,
                                                              const f32x4* __restrict__ Wp,
                                                              const float* __restrict__ bias,
                                                              f32x4* __restrict__ gi, long gi_tile_stride,
                                                              int npos, int ntiles) {
     constexpr int MG = kFPad / 16;          // 6 operand groups of 16 k
-    constexpr int PB = 4, N = 4;
+    constexpr int PB = HELEN_WS_PB, N = 4;
     constexpr int ROWS = PB * MG;           // 24 rows of 1 KiB per stage
     __shared__ f32x4 smem[2 * ROWS * 64];   // 48 KiB
     const int tid = threadIdx.x;
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void gemm_enc_ws_kernel(const f32x4* __rest
         if (g == 0)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else
-            asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PB * N) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (g + 1 < ng) stage(g + 1, (g + 1) & 1);
