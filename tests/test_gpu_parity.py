@@ -410,3 +410,27 @@ def test_operator_entry_odd_shapes(precision):
     finally:
         oracle.set_precision("fp32")
     eng.close()
+
+
+def test_evaluation_bf16_vs_emulation():
+    """The evaluation entry in bf16 mode against the CPU restatement's bf16 emulation: same logits up to
+    rounding flips, so losses agree to a few 1e-3 and the confusion matrices up to thin-margin flips."""
+    import oracle
+    from golden_cases import EVAL_BATCH
+    from helen_amd.engine import HelenEngine
+    from helen_amd.options import TrainOptions
+    w, img, g = load_case("eval10")
+    oracle.set_precision("bf16")
+    try:
+        ref = oracle.evaluate(w, img, g["label_base"], g["label_rle"], EVAL_BATCH, TrainOptions.CLASS_WEIGHTS)
+    finally:
+        oracle.set_precision("fp32")
+    eng = HelenEngine(w, device=0, max_windows=16, precision="bf16")
+    loss_b, loss_r, cm_b, cm_r = _eval_on_gpu(eng, img, g["label_base"], g["label_rle"], [EVAL_BATCH, EVAL_BATCH, 2])
+    eng.close()
+    np.testing.assert_allclose(float((loss_b + loss_r).sum()), ref["total_loss"], rtol=5e-3)
+    np.testing.assert_allclose(float(loss_r.sum()), ref["total_loss_rle"], rtol=5e-3)
+    total = 10 * 19 * 100
+    assert cm_b.sum() == cm_r.sum() == total
+    assert np.abs(cm_b - ref["base_confusion_matrix"]).sum() <= BF16_LABEL_MISMATCH_MAX * 2 * total
+    assert np.abs(cm_r - ref["rle_confusion_matrix"]).sum() <= BF16_LABEL_MISMATCH_MAX * 2 * total
