@@ -128,3 +128,25 @@ def test_reader_error_surfaces(tmp_path, monkeypatch):
     ModelHandler.save_model(make_weights(), None, 128, 1, 0, model)
     with pytest.raises(ValueError, match="IMAGE SIZE ERROR"):
         P.predict([bad], str(tmp_path / "out"), model, 4, 0, 0, 0)
+
+
+def test_writer_count_and_region_sharding(monkeypatch):
+    """Writer pool sizing (one writer per reader worker, 1..8, $HELEN_WRITERS overrides) and the region ->
+    writer map: every chunk of a region, and a repeat of the same image, lands on the same writer."""
+    import helen_amd.predict as P
+    from helen_amd.prediction_writer import prediction_file_name, writer_of_region
+    monkeypatch.delenv("HELEN_WRITERS", raising=False)
+    assert [P.writer_count(w) for w in (0, 1, 2, 8, 40)] == [1, 1, 2, 8, 8]
+    monkeypatch.setenv("HELEN_WRITERS", "3")
+    assert P.writer_count(0) == 3 and P.writer_count(40) == 3
+    assert prediction_file_name("/o/p", 2) == "/o/p_2.hdf" and prediction_file_name("/o/p", 2, 5) == "/o/p_2_w5.hdf"
+    meta = np.zeros((600, 3), np.int64)
+    meta[:, 0] = np.repeat(np.arange(200) * 800, 3)      # 200 regions x 3 chunk ids
+    meta[:, 1] = meta[:, 0] + 1000
+    meta[:, 2] = np.tile(np.arange(3), 200)
+    for writers in (1, 2, 5, 8):
+        k = writer_of_region(meta, writers)
+        assert k.min() >= 0 and k.max() < writers
+        assert np.array_equal(k[0::3], k[1::3]) and np.array_equal(k[0::3], k[2::3])
+        if writers > 1:
+            assert len(np.unique(k)) == writers            # 200 regions spread over every writer
