@@ -263,7 +263,7 @@ int check_launch(const char* what) {
 // (the XCD count), times 8 / HELEN_GEMM_WAVES column-group workgroups per unit.
 unsigned gemm_grid(int npos, int tiles, int positions_per_wave = HELEN_GEMM_P) {
     const int units = tiles * ((npos + positions_per_wave - 1) / positions_per_wave);
-    return (unsigned)((units + 7) / 8 * 8) * (8 / HELEN_GEMM_WAVES);
+    return (unsigned)((units + 7) / 8 * 8) * ((2 * kNTile / HELEN_GEMM_N) / HELEN_GEMM_WAVES);
 }
 
 constexpr int kWsMinWorkgroups = 384;   // 1.5 workgroups per CU-slot pair: below this the position-parallel kernel wins

@@ -28,6 +28,9 @@ namespace helen {
 #ifndef HELEN_GEMM_P
 #define HELEN_GEMM_P 10  // positions per wave of the streaming-weights projection (4: 1.21 ms, 5: 1.19, 10: 1.18 per decoder launch)
 #endif
+#ifndef HELEN_GEMM_N
+#define HELEN_GEMM_N 6   // column tiles per wave (48 / N wave slots per position group)
+#endif
 #ifndef HELEN_GEMM_DEPTH
 #define HELEN_GEMM_DEPTH 2   // operand groups in flight, including the one being multiplied
 #endif
@@ -39,13 +42,14 @@ __global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_kernel(const f3
                                                       int npos, int ntiles) {
     // Output slot: direction 0 -> position p, direction 1 -> npos-1-p (time-reversed), so the
     // recurrence reads both directions in ascending address order.
-    constexpr int P = HELEN_GEMM_P, N = 6;
+    constexpr int P = HELEN_GEMM_P, N = HELEN_GEMM_N;
+    constexpr int SLOTS = 2 * kNTile / N;   // wave slots covering the 48 column tiles
     const int lane = threadIdx.x & 63;
     // grid.x enumerates (unit, z): unit = (position group, tile), z = which HELEN_GEMM_WAVES wave
     // slots.  Workgroups are dispatched round-robin over the 8 XCDs (id % 8), so the ZB = 8 /
     // HELEN_GEMM_WAVES workgroups that share one unit's A operand get ids u, u+8, u+16, ... inside a
     // block of 8*ZB ids: same XCD, same L2, adjacent in time -> A is fetched from HBM once.
-    constexpr int ZB = 8 / HELEN_GEMM_WAVES;
+    constexpr int ZB = SLOTS / HELEN_GEMM_WAVES;
     const int bid = blockIdx.x;
     const int unit = (bid / (8 * ZB)) * 8 + (bid & 7);
     const int zb = (bid >> 3) % ZB;
@@ -54,8 +58,8 @@ __global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_kernel(const f3
     const int pos0 = (unit % npg) * P;
     if (tile >= ntiles) return;                           // grid is padded to a multiple of 8 units
     const int wave = (threadIdx.x >> 6) + zb * HELEN_GEMM_WAVES;
-    const int dir = wave >> 2;
-    const int nt0 = (wave & 3) * N;
+    const int dir = wave / (SLOTS / 2);
+    const int nt0 = (wave % (SLOTS / 2)) * N;
 
     const f32x4* w_base = Wp + (size_t)((dir * kNTile + nt0) * MG) * 64 + lane;
     // REV_A: A is a layer output y[tile][slot][fwd | bwd]; the bwd half (groups MG/2..) of
