@@ -1,0 +1,108 @@
+"""Schema check of a MarginPolish image directory.
+
+The input schema is only known from the reference's reader (models/dataloader_predict.py:64-70; labeled
+files add label_base / label_run_length, models/dataloader.py:59-61).  This reports, per file, what is
+actually stored -- dataset presence, type class / width, shape, layout, filters -- and flags whatever the
+path cannot take, so a real file can be vetted before a run:
+
+    python -m helen_amd check_images -i <image_dir> [--images-per-file 8]
+"""
+import sys
+
+from . import hdf5
+from .file_manager import get_file_paths_from_directory
+from .options import ImageSizeOptions
+
+REQUIRED = ("contig", "contig_start", "contig_end", "feature_chunk_idx", "image", "position")
+LABELS = ("label_base", "label_run_length")
+FILTER_NAMES = {1: "deflate", 2: "shuffle", 3: "fletcher32", 4: "szip", 5: "nbit", 6: "scaleoffset",
+                32000: "lzf", 32001: "blosc", 32004: "lz4", 32015: "zstd"}
+
+
+def check_image(f, name):
+    """-> (facts dict per dataset, list of problems) for image group `name` of open file `f`."""
+    facts, problems = {}, []
+    L, H = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT
+    base = "images/" + name + "/"
+    for ds in REQUIRED + LABELS:
+        if (base + ds) not in f:
+            if ds in REQUIRED:
+                problems.append("missing dataset '%s'" % ds)
+            continue
+        i = facts[ds] = f.info(base + ds)
+        if not i["filters_available"]:
+            problems.append("%s: filter(s) %s not available in this libhdf5" % (
+                ds, [FILTER_NAMES.get(x, x) for x in i["filters"]]))
+    im, po = facts.get("image"), facts.get("position")
+    if im is not None:
+        if im["class"] != "int" or len(im["shape"]) != 2 or im["shape"][1] != H:
+            problems.append("image is %s %s, expected integers [l <= %d, %d]" % (im["class"], im["shape"], L, H))
+        elif im["shape"][0] > L:
+            problems.append("image has %d positions (> SEQ_LENGTH %d)" % (im["shape"][0], L))
+        elif im["size"] != 1:
+            problems.append("image elements are %d bytes wide (read as uint8: values > 255 would wrap)" % im["size"])
+    if po is not None:
+        if po["class"] != "int" or len(po["shape"]) != 2 or po["shape"][1] != 3:
+            problems.append("position is %s %s, expected integers [l, 3]" % (po["class"], po["shape"]))
+        elif im is not None and len(im["shape"]) == 2 and po["shape"][0] != im["shape"][0]:
+            problems.append("position has %d rows, image %d" % (po["shape"][0], im["shape"][0]))
+    for ds in ("contig_start", "contig_end", "feature_chunk_idx"):
+        i = facts.get(ds)
+        if i is not None and (i["class"] != "int" or int(_count(i["shape"])) < 1):
+            problems.append("%s is %s %s, expected at least one integer" % (ds, i["class"], i["shape"]))
+    if "contig" in facts and facts["contig"]["class"] != "string":
+        problems.append("contig is %s, expected a string" % facts["contig"]["class"])
+    for ds in LABELS:
+        i = facts.get(ds)
+        if i is not None and im is not None and (i["class"] != "int" or i["shape"] != im["shape"][:1]):
+            problems.append("%s is %s %s, expected integers [%d]" % (ds, i["class"], i["shape"], im["shape"][0]))
+    return facts, problems
+
+
+def _count(shape):
+    n = 1
+    for d in shape:
+        n *= d
+    return n
+
+
+def _describe(i):
+    s = "%s%d%s %s %s" % (i["class"], 8 * i["size"], "" if i["signed"] in (None, True) else "u", list(i["shape"]),
+                          i["layout"])
+    if i["chunk"]:
+        s += " chunk %s" % list(i["chunk"])
+    if i["filters"]:
+        s += " filters %s" % [FILTER_NAMES.get(x, x) for x in i["filters"]]
+    if i["variable_string"]:
+        s += " (variable-length)"
+    return s
+
+
+def check_image_directory(image_dir, images_per_file=8, out=sys.stdout):
+    """Vet every file of `image_dir`; prints a report, returns the number of problems found."""
+    n_problems = 0
+    files = get_file_paths_from_directory(image_dir)
+    if not files:
+        out.write("NO .h5 / .hdf5 FILES IN " + str(image_dir) + "\n")
+        return 1
+    for path in files:
+        with hdf5.File(path, "r") as f:
+            if "images" not in f:
+                out.write("%s: no 'images' group (the reader warns and skips the file)\n" % path)
+                continue
+            names = f.keys("images")
+            out.write("%s: %d images\n" % (path, len(names)))
+            step = max(1, len(names) // max(1, images_per_file))
+            shown = False
+            for name in names[::step][:images_per_file]:
+                facts, problems = check_image(f, name)
+                if not shown:
+                    for ds in REQUIRED + LABELS:
+                        if ds in facts:
+                            out.write("    %-18s %s\n" % (ds, _describe(facts[ds])))
+                    shown = True
+                for p in problems:
+                    out.write("  PROBLEM %s: %s\n" % (name, p))
+                n_problems += len(problems)
+    out.write("%d problem(s)\n" % n_problems)
+    return n_problems

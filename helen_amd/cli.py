@@ -63,6 +63,9 @@ def build_parser():
     add_polish_arguments(sub.add_parser("call_consensus", help="generate the prediction HDF5 files"), 16)
     add_stitch_arguments(sub.add_parser("stitch", help="prediction HDF5 files -> polished FASTA"))
     add_test_arguments(sub.add_parser("test", help="evaluate a model on labeled images (helen_train test)"))
+    chk = sub.add_parser("check_images", help="vet the HDF5 schema of a MarginPolish image directory")
+    chk.add_argument("-i", "--image_dir", type=str, required=True, help="directory of MarginPolish .h5 images")
+    chk.add_argument("--images-per-file", type=int, default=8, help="images sampled per file")
     sub.add_parser("version", help="show the version")
     sub.add_parser("torch_stat", help="show torch / device configuration")
     return parser
@@ -89,6 +92,9 @@ def main(argv=None):
         sys.stderr.write("INFO: TEST MODULE SELECTED\n")
         test_interface(flags.test_image_dir, flags.batch_size, flags.gpu_mode, flags.num_workers,
                        flags.model_path, flags.output_dir, flags.print_details)
+    elif flags.sub_command == "check_images":
+        from .check_images import check_image_directory
+        return 1 if check_image_directory(flags.image_dir, flags.images_per_file) else 0
     elif flags.sub_command == "version":
         print("HELEN-MI355X VERSION: " + __version__)
     elif flags.sub_command == "torch_stat":

@@ -86,6 +86,12 @@ def _load():
         "H5Tset_size": (I, [H, ctypes.c_size_t]),
         "H5Pcreate": (H, [H]), "H5Pclose": (I, [H]),
         "H5Pset_create_intermediate_group": (I, [H, ctypes.c_uint]),
+        "H5Dget_create_plist": (H, [H]), "H5Pget_layout": (I, [H]), "H5Pget_nfilters": (I, [H]),
+        "H5Pget_filter2": (I, [H, ctypes.c_uint, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_size_t),
+                               P, ctypes.c_size_t, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint)]),
+        "H5Pget_chunk": (I, [H, I, ctypes.POINTER(_hsize)]),
+        "H5Pset_chunk": (I, [H, I, ctypes.POINTER(_hsize)]), "H5Pset_deflate": (I, [H, ctypes.c_uint]),
+        "H5Zfilter_avail": (I, [I]),
     }
     for name, (res, args) in sigs.items():
         f = getattr(lib, name)
@@ -259,9 +265,49 @@ class File(object):
         return np.array(vals, dtype=object).reshape(shape)
 
     # ---- writing ----
-    def write(self, path, value, dtype=None):
+    def info(self, path):
+        """Storage facts of dataset `path`: shape, type class / size / signedness, layout (compact,
+        contiguous, chunked), chunk shape and filter ids (1 = deflate, 2 = shuffle, 32000 = lzf, ...)."""
+        L = self._lib
+        did = L.H5Dopen2(self._fid, path.encode(), 0)
+        if did < 0:
+            raise Hdf5Error("%s: no dataset '%s'" % (self.path, path))
+        sid, tid, pid = L.H5Dget_space(did), L.H5Dget_type(did), L.H5Dget_create_plist(did)
+        try:
+            nd = L.H5Sget_simple_extent_ndims(sid)
+            dims = (_hsize * max(nd, 1))()
+            if nd > 0:
+                L.H5Sget_simple_extent_dims(sid, dims, None)
+            cls = L.H5Tget_class(tid)
+            layout = {0: "compact", 1: "contiguous", 2: "chunked"}.get(L.H5Pget_layout(pid), "other")
+            chunk = None
+            if layout == "chunked" and nd > 0:
+                c = (_hsize * nd)()
+                L.H5Pget_chunk(pid, nd, c)
+                chunk = tuple(int(c[i]) for i in range(nd))
+            filters = []
+            for i in range(max(0, L.H5Pget_nfilters(pid))):
+                flags, nelem, cfg = ctypes.c_uint(0), ctypes.c_size_t(0), ctypes.c_uint(0)
+                fid = L.H5Pget_filter2(pid, i, ctypes.byref(flags), ctypes.byref(nelem), None, 0, None,
+                                       ctypes.byref(cfg))
+                filters.append(int(fid))
+            return {"shape": tuple(int(dims[i]) for i in range(nd)),
+                    "class": {H5T_INTEGER: "int", H5T_FLOAT: "float", H5T_STRING: "string"}.get(cls, "other"),
+                    "size": int(L.H5Tget_size(tid)),
+                    "signed": bool(L.H5Tget_sign(tid) == 1) if cls == H5T_INTEGER else None,
+                    "variable_string": bool(L.H5Tis_variable_str(tid) > 0) if cls == H5T_STRING else None,
+                    "layout": layout, "chunk": chunk, "filters": filters,
+                    "filters_available": all(L.H5Zfilter_avail(f) > 0 for f in filters)}
+        finally:
+            L.H5Pclose(pid)
+            L.H5Tclose(tid)
+            L.H5Sclose(sid)
+            L.H5Dclose(did)
+
+    def write(self, path, value, dtype=None, chunks=None, gzip=None):
         """Create dataset `path` (intermediate groups are created) from a Python int (scalar
-        int64 dataset, what `h5py_file[path] = int` makes) or an ndarray."""
+        int64 dataset, what `h5py_file[path] = int` makes) or an ndarray.  `chunks` (a shape) makes it
+        chunked, `gzip` (1..9) adds the deflate filter (as h5py's compression="gzip" does)."""
         if self.mode != "w":
             raise Hdf5Error("file not opened for writing")
         L = self._lib
@@ -279,7 +325,16 @@ class File(object):
         else:
             dims = (_hsize * arr.ndim)(*arr.shape)
             sid = L.H5Screate_simple(arr.ndim, dims, None)
-        did = L.H5Dcreate2(self._fid, path.encode(), _gid(_STD[dt]), sid, self._lcpl, 0, 0)
+        dcpl = 0
+        if (chunks is not None or gzip) and arr.ndim > 0 and arr.size:
+            dcpl = L.H5Pcreate(_gid("H5P_CLS_DATASET_CREATE_ID_g"))
+            ch = tuple(chunks) if chunks is not None else arr.shape
+            L.H5Pset_chunk(dcpl, arr.ndim, (_hsize * arr.ndim)(*[max(1, min(int(c), int(d))) for c, d in zip(ch, arr.shape)]))
+            if gzip:
+                L.H5Pset_deflate(dcpl, int(gzip))
+        did = L.H5Dcreate2(self._fid, path.encode(), _gid(_STD[dt]), sid, self._lcpl, dcpl, 0)
+        if dcpl:
+            L.H5Pclose(dcpl)
         if did < 0:
             L.H5Sclose(sid)
             raise Hdf5Error("%s: cannot create dataset '%s' (already exists?)" % (self.path, path))

@@ -14,11 +14,12 @@ from .weights import make_images
 
 
 def write_image_file(path, images, contig="chr20_synth", first_window=0, lengths=None,
-                     chunks_per_region=1, labels=None):
+                     chunks_per_region=1, labels=None, gzip=None):
     """Write `images` (uint8 [n, 1000, 90]) as n images of one file.  Window k covers
     contig_start = 800*k .. +1000 (SEQ_OVERLAP 200, Options.py:17); `lengths[i] < 1000` stores a
     short image (the reader pads it).  labels = (label_base, label_run_length) uint8 [n, 1000] makes
-    it a labeled file as the evaluation loader reads it (models/dataloader.py:59-61)."""
+    it a labeled file as the evaluation loader reads it (models/dataloader.py:59-61); gzip = 1..9 stores
+    image and position chunked + deflated (as an h5py writer with compression="gzip" would)."""
     n = images.shape[0]
     with hdf5.File(path, "w") as f:
         for i in range(n):
@@ -33,10 +34,10 @@ def write_image_file(path, images, contig="chr20_synth", first_window=0, lengths
             f.write(base + "contig_start", np.array([start], np.int64))
             f.write(base + "contig_end", np.array([start + 1000], np.int64))
             f.write(base + "feature_chunk_idx", np.array([chunk], np.int64))
-            f.write(base + "image", images[i, :L], np.uint8)
+            f.write(base + "image", images[i, :L], np.uint8, chunks=(256, 90) if gzip else None, gzip=gzip)
             pos = np.zeros((L, 3), np.int64)
             pos[:, 0] = start + np.arange(L)
-            f.write(base + "position", pos, np.int64)
+            f.write(base + "position", pos, np.int64, chunks=(L, 3) if gzip else None, gzip=gzip)
             if labels is not None:
                 f.write(base + "label_base", labels[0][i, :L], np.uint8)
                 f.write(base + "label_run_length", labels[1][i, :L], np.uint8)

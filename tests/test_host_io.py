@@ -220,3 +220,45 @@ def test_labeled_dataset_and_batch_losses(tmp_path):
     s64 = stats.astype(np.float64).sum(axis=2)
     np.testing.assert_allclose(loss_b[0], s64[:3, :, 0].sum(0) / 300)
     np.testing.assert_allclose(loss_r[1], s64[3:, :, 1].sum(0) / s64[3:, :, 2].sum(0))
+
+
+def test_compressed_images_and_schema_check(tmp_path):
+    """Chunked + deflated image / position datasets (what an h5py writer with compression='gzip' makes)
+    read the same through both readers; check_images reports the storage facts and flags files the path
+    cannot take."""
+    import io
+
+    from helen_amd.check_images import check_image_directory
+    img = make_images(6, seed=9)
+    good = tmp_path / "good"
+    good.mkdir()
+    write_image_file(str(good / "z.h5"), img, first_window=100, lengths=np.array([1000, 1000, 613, 1000, 1000, 1000]),
+                     gzip=4)
+    with hdf5.File(str(good / "z.h5")) as f:
+        name = f.keys("images")[0]
+        i = f.info("images/" + name + "/image")
+        assert i["layout"] == "chunked" and i["filters"] == [1] and i["chunk"] == (256, 90) and i["class"] == "int"
+    ds = SequenceDataset(str(good))
+    assert len(ds) == 6
+    from helen_amd.sequence_dataset import _load_batch
+    batch = _load_batch(ds.all_images)                    # native reader when libhelen_io.so is built
+    assert np.array_equal(batch.images[0], img[0]) and np.array_equal(batch.images[2][:613], img[2][:613])
+    assert not batch.images[2][613:].any() and (batch.positions[2][613:] == -1).all()
+    item = ds[3]                                          # ctypes reader
+    assert np.array_equal(item[4], img[3])
+    rep = io.StringIO()
+    assert check_image_directory(str(good), out=rep) == 0
+    assert "deflate" in rep.getvalue() and "6 images" in rep.getvalue()
+    bad = tmp_path / "bad"
+    bad.mkdir()
+    with hdf5.File(str(bad / "b.h5"), "w") as f:
+        base = "images/x-0-1000-0/"
+        f.write(base + "contig", "x")
+        for k in ("contig_start", "contig_end"):
+            f.write(base + k, np.array([0], np.int64))
+        f.write(base + "image", np.zeros((1000, 10), np.uint8))       # wrong width, no feature_chunk_idx
+        f.write(base + "position", np.zeros((900, 3), np.int64))      # row count differs
+    rep = io.StringIO()
+    n = check_image_directory(str(bad), out=rep)
+    text = rep.getvalue()
+    assert n >= 2 and "missing dataset 'feature_chunk_idx'" in text and "expected integers [l <= 1000, 90]" in text
