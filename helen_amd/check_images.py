@@ -67,8 +67,15 @@ def _count(shape):
 
 
 def _describe(i):
-    s = "%s%d%s %s %s" % (i["class"], 8 * i["size"], "" if i["signed"] in (None, True) else "u", list(i["shape"]),
-                          i["layout"])
+    if i["class"] == "int":
+        t = "%sint%d" % ("" if i["signed"] else "u", 8 * i["size"])
+    elif i["class"] == "float":
+        t = "float%d" % (8 * i["size"])
+    elif i["class"] == "string":
+        t = "string" if i["variable_string"] else "string[%d]" % i["size"]
+    else:
+        t = i["class"]
+    s = "%s %s %s" % (t, list(i["shape"]), i["layout"])
     if i["chunk"]:
         s += " chunk %s" % list(i["chunk"])
     if i["filters"]:
@@ -80,7 +87,11 @@ def _describe(i):
 
 def check_image_directory(image_dir, images_per_file=8, out=sys.stdout):
     """Vet every file of `image_dir`; prints a report, returns the number of problems found."""
+    import os
     n_problems = 0
+    if not os.path.isdir(image_dir):
+        out.write("NOT A DIRECTORY: " + str(image_dir) + "\n")
+        return 1
     files = get_file_paths_from_directory(image_dir)
     if not files:
         out.write("NO .h5 / .hdf5 FILES IN " + str(image_dir) + "\n")
