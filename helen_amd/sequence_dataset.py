@@ -128,7 +128,13 @@ class SharedSlot(object):
                        self.cap * native_io.NAME_BYTES, self.cap * L, self.cap * L)
         total = sum(self._sizes)
         if create:
-            d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+            # RAM-backed when /dev/shm has room for it (a container's default 64 MB tmpfs does not, and
+            # writing past a tmpfs' size is a SIGBUS, not an error code); otherwise the temp directory
+            d = None
+            if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK):
+                st = os.statvfs("/dev/shm")
+                if st.f_bavail * st.f_frsize > 2 * total:
+                    d = "/dev/shm"
             fd, path = tempfile.mkstemp(prefix="helen_slot_", dir=d)
             os.ftruncate(fd, total)
             os.close(fd)
