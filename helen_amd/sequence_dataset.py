@@ -138,6 +138,8 @@ class SharedSlot(object):
             fd, path = tempfile.mkstemp(prefix="helen_slot_", dir=d)
             os.ftruncate(fd, total)
             os.close(fd)
+            import atexit
+            atexit.register(_unlink_quietly, path)      # also when the run dies with an exception
         self.path = path
         self.owner = create
         self._mm = np.memmap(path, dtype=np.uint8, mode="r+", shape=(total,))
@@ -160,6 +162,14 @@ class SharedSlot(object):
         self._mm = None
         if self.owner and self.path and os.path.exists(self.path):
             os.unlink(self.path)
+
+
+def _unlink_quietly(path):
+    import os
+    try:
+        os.unlink(path)
+    except OSError:
+        pass
 
 
 _attached = {}
