@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -280,6 +281,24 @@ void launch_enc_gemm(HelenModel* m, hipStream_t s, int tiles, int npos) {
                kXaTileStride, m->wp_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles);
 }
 
+// Which fp32 recurrence kernel: gru_kernel puts one tile per workgroup, two workgroups per CU; gru_pair_kernel
+// two tiles per workgroup, one workgroup per CU (same results bit for bit).  A launch of either lasts as long
+// as its longest CU queue: `rounds` x the time of one resident set.  (HELEN_GRU_PAIR=0/1 forces one: A/B probes.)
+bool use_pair_recurrence(int tiles) {
+    static const char* force = getenv("HELEN_GRU_PAIR");
+    if (force && *force) return *force == '1';
+    const int cus = 256;
+    const int wg_single = 2 * tiles, wg_pair = 2 * ((tiles + 1) / 2);
+    // measured per resident set at 100 steps: one workgroup per CU alone 0.36 ms, two per CU 0.64 ms, a pair
+    // workgroup 0.59 ms
+    auto t_single = [&](int wgs) {
+        const int full = wgs / (2 * cus), rest = wgs % (2 * cus);
+        return full * 0.64 + (rest == 0 ? 0.0 : rest <= cus ? 0.36 : 0.64);
+    };
+    const double t_pair = ((wg_pair + cus - 1) / cus) * 0.59;
+    return t_pair < t_single(wg_single);
+}
+
 // One TransducerGRU.forward over `tiles` tiles whose encoder pre-activations are already in
 // gi_enc at positions [pos0, pos0+T): encoder recurrence -> decoder projection -> decoder
 // recurrence.  plogit then holds the decoder's partial logits, hid the returned hidden state.
@@ -308,13 +327,24 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
                m->w3h_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kY1pTileStride, m->whd, m->plogit, kPlTileStride);
         return;
     }
-    LAUNCH(HELEN_K_GRU_ENC, gru_kernel<false>, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
-           enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride, (const f32x4*)nullptr,
-           (f32x4*)nullptr, kPlTileStride);
+    const bool pair = use_pair_recurrence(tiles);
+    if (pair)
+        LAUNCH(HELEN_K_GRU_ENC, gru_pair_kernel<false>, dim3((tiles + 1) / 2, 2), dim3(256), m->gi_enc,
+               kGiEncTileStride, pos0, enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride,
+               (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride, tiles);
+    else
+        LAUNCH(HELEN_K_GRU_ENC, gru_kernel<false>, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
+               enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride, (const f32x4*)nullptr,
+               (f32x4*)nullptr, kPlTileStride);
     LAUNCH(HELEN_K_GEMM_DEC, (gemm_gi_kernel<16, true>), ggrid, gblock, m->y1, kYTileStride, m->wp_dec,
            m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
-    LAUNCH(HELEN_K_GRU_DEC, gru_kernel<true>, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, 0, T,
-           m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd, m->plogit, kPlTileStride);
+    if (pair)
+        LAUNCH(HELEN_K_GRU_DEC, gru_pair_kernel<true>, dim3((tiles + 1) / 2, 2), dim3(256), m->gi_dec,
+               kGiDecTileStride, 0, 0, T, m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd,
+               m->plogit, kPlTileStride, tiles);
+    else
+        LAUNCH(HELEN_K_GRU_DEC, gru_kernel<true>, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, 0, T,
+               m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd, m->plogit, kPlTileStride);
 }
 
 void free_model(HelenModel* m) {

@@ -39,6 +39,33 @@ __device__ __forceinline__ float gru_cell(float ar, float az, float an, float gr
     return ng + zg * (hp - ng);  // (1-z)*n + z*h
 }
 
+// Gate math of four cells at once, as two packed pairs: measured alone on a gfx950 SIMD a v_pk_{add,mul,fma}_f32
+// costs 5.2 cycles against 4.8 for ONE scalar add / mul / fma (v_exp_f32 / v_rcp_f32: 8.6 each, no packed form),
+// and none of it overlaps with the fp32 MFMAs (scripts/ubench/f32_mfma_valu_overlap.hip).  Per component this is
+// exactly:  r = sigmoid(ar + gr), z = sigmoid(az + gz), n = tanh(fma(r, an, gn)), h' = fma(z, h - n, n)
+// with sigmoid(x) = rcp(1 + exp2(-log2e x)), tanh(x) = fma(-2, rcp(1 + exp2(2 log2e x)), 1).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 exp2_pair(f32x2 v) {
+    return f32x2{__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)};
+}
+__device__ __forceinline__ f32x2 rcp_pair(f32x2 v) {
+    return f32x2{__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y)};
+}
+__device__ __forceinline__ f32x2 gru_cell2(f32x2 ar, f32x2 az, f32x2 an, f32x2 gr, f32x2 gz, f32x2 gn, f32x2 hp) {
+    const f32x2 one = {1.0f, 1.0f}, m2 = {-2.0f, -2.0f};
+    const f32x2 rg = rcp_pair(one + exp2_pair((ar + gr) * -1.4426950408889634f));
+    const f32x2 zg = rcp_pair(one + exp2_pair((az + gz) * -1.4426950408889634f));
+    const f32x2 pre = __builtin_elementwise_fma(rg, an, gn);
+    const f32x2 ng = __builtin_elementwise_fma(m2, rcp_pair(one + exp2_pair(pre * 2.8853900817779268f)), one);
+    return __builtin_elementwise_fma(zg, hp - ng, ng);  // (1-z)*n + z*h
+}
+__device__ __forceinline__ f32x4 gru_cell4(f32x4 ar, f32x4 az, f32x4 an, f32x4 gr, f32x4 gz, f32x4 gn,
+                                           const float (&hp)[4]) {
+    const f32x2 lo = gru_cell2(ar.xy, az.xy, an.xy, gr.xy, gz.xy, gn.xy, f32x2{hp[0], hp[1]});
+    const f32x2 hi = gru_cell2(ar.zw, az.zw, an.zw, gr.zw, gz.zw, gn.zw, f32x2{hp[2], hp[3]});
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+
 constexpr int kGruLdsF4 = 2 * 512 + 4 * 384 + 4 * 512;  // h[2] | gi[4 waves] | W tile 5[4 waves]
 
 template <bool DEC>
@@ -202,14 +229,14 @@ __global__ __launch_bounds__(256, 2) void gru_kernel(const f32x4* __restrict__ g
 
         float* hw = (float*)(hbuf + (cur ^ 1) * 512);
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
+        for (int hh = 0; hh < 2; ++hh) {
+            const f32x4 hn = gru_cell4(acc[hh], acc[2 + hh], acc[4 + hh], G[hh], G[2 + hh], G[4 + hh], hprev[hh]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float hn = gru_cell(acc[hh][r], acc[2 + hh][r], acc[4 + hh][r], G[hh][r],
-                                          G[2 + hh][r], G[4 + hh][r], hprev[hh][r]);
-                hprev[hh][r] = hn;
-                hw[hoff[hh] + 4 * r] = hn;
+                hprev[hh][r] = hn[r];
+                hw[hoff[hh] + 4 * r] = hn[r];
             }
+        }
         HELEN_TICK(2)
         // raw barrier: only LDS traffic has to be drained, the gi DMA stays in flight across it
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
