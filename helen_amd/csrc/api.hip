@@ -329,7 +329,7 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
     }
     const bool pair = use_pair_recurrence(tiles);
     if (pair)
-        LAUNCH(HELEN_K_GRU_ENC, gru_pair_kernel<false>, dim3((tiles + 1) / 2, 2), dim3(256), m->gi_enc,
+        LAUNCH(HELEN_K_GRU_ENC, gru_pair_kernel<false>, dim3((tiles + 1) / 2, 2), dim3(512), m->gi_enc,
                kGiEncTileStride, pos0, enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride,
                (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride, tiles);
     else
@@ -339,7 +339,7 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
     LAUNCH(HELEN_K_GEMM_DEC, (gemm_gi_kernel<16, true>), ggrid, gblock, m->y1, kYTileStride, m->wp_dec,
            m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
     if (pair)
-        LAUNCH(HELEN_K_GRU_DEC, gru_pair_kernel<true>, dim3((tiles + 1) / 2, 2), dim3(256), m->gi_dec,
+        LAUNCH(HELEN_K_GRU_DEC, gru_pair_kernel<true>, dim3((tiles + 1) / 2, 2), dim3(512), m->gi_dec,
                kGiDecTileStride, 0, 0, T, m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd,
                m->plogit, kPlTileStride, tiles);
     else
