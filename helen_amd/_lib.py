@@ -22,7 +22,8 @@ KERNEL_CLASSES = ("pack", "gemm_enc", "gru_enc", "gemm_dec", "gru_dec", "heads")
 EXPORTS = (
     "helen_abi_version", "helen_last_error", "helen_model_create", "helen_model_destroy",
     "helen_model_device_bytes", "helen_polish_batch", "helen_polish_host",
-    "helen_gru_chunk_forward", "helen_evaluate_batch", "helen_set_profiling", "helen_reset_kernel_stats",
+    "helen_gru_chunk_forward", "helen_evaluate_batch", "helen_debug_inject_failure", "helen_set_profiling",
+    "helen_reset_kernel_stats",
     "helen_get_kernel_stats",
 )
 
@@ -99,6 +100,8 @@ def load():
     lib.helen_gru_chunk_forward.argtypes = [vp, vp, vp, ci, ci, vp, vp, vp, vp]
     lib.helen_evaluate_batch.restype = ci
     lib.helen_evaluate_batch.argtypes = [vp, vp, vp, vp, ci, _f32p, vp, vp, vp, vp]
+    lib.helen_debug_inject_failure.restype = ci
+    lib.helen_debug_inject_failure.argtypes = [vp, ci]
     lib.helen_set_profiling.restype = ci
     lib.helen_set_profiling.argtypes = [vp, ctypes.c_uint]
     lib.helen_reset_kernel_stats.restype = ci

@@ -5,6 +5,7 @@
 // models/TransducerModel.py:60-79).  No torch, no exceptions across the ABI.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -83,17 +84,34 @@ struct HelenModel {
     uint8_t* dev_out[2] = {nullptr, nullptr};
     hipStream_t h2d_stream = nullptr;
     hipStream_t d2h_stream = nullptr;
+    bool ring_ready = false;   // set only when every piece of the staging ring exists
+    int fail_at_sub = -1;      // helen_debug_inject_failure: sub-batch of the next helen_polish_host that fails
+    std::atomic<bool> busy{false};   // a handle serves one host thread at a time (include/helen_hip.h): enforced
     hipEvent_t ev_in[2] = {nullptr, nullptr};
     hipEvent_t ev_done[2] = {nullptr, nullptr};
     hipEvent_t ev_out[2] = {nullptr, nullptr};
     // profiling
     unsigned prof_mask = 0;
+    std::vector<EventPair> prof_pool;   // recycled event pairs: none is created in steady state
     std::vector<EventPair> prof[HELEN_K_COUNT];
     double prof_ms[HELEN_K_COUNT] = {0};
     long long prof_n[HELEN_K_COUNT] = {0};
 };
 
 namespace {
+
+// One host thread per handle at a time: a second concurrent entry is refused instead of corrupting the scratch.
+struct BusyGuard {
+    HelenModel* m;
+    bool ok;
+    explicit BusyGuard(HelenModel* model) : m(model), ok(!model->busy.exchange(true)) {}
+    ~BusyGuard() {
+        if (ok) m->busy.store(false);
+    }
+};
+#define HELEN_ENTER(m)                                                                             \
+    BusyGuard guard_(m);                                                                           \
+    if (!guard_.ok) return fail(HELEN_EINVAL, "handle is in use by another thread (one thread per handle)")
 
 constexpr long kXaTileStride = (long)kSeq * (kXaStride / 4);        // float4
 constexpr long kGiEncTileStride = (long)kSeq * (kGiStride / 4);
@@ -230,7 +248,14 @@ std::vector<bf16x8> pack_w_ih_x3(const float* const w[2], int K = 2 * kH) {
 void record_begin(HelenModel* m, int cls, hipStream_t s, EventPair* ev, bool* on) {
     *on = (m->prof_mask >> cls) & 1u;
     if (!*on) return;
-    if (hipEventCreate(&ev->a) != hipSuccess || hipEventCreate(&ev->b) != hipSuccess) {
+    if (!m->prof_pool.empty()) {   // steady state: a pair that drain_stats() has read and recycled
+        *ev = m->prof_pool.back();
+        m->prof_pool.pop_back();
+    } else if (hipEventCreate(&ev->a) != hipSuccess) {
+        *on = false;
+        return;
+    } else if (hipEventCreate(&ev->b) != hipSuccess) {
+        (void)hipEventDestroy(ev->a);
         *on = false;
         return;
     }
@@ -299,6 +324,17 @@ bool use_pair_recurrence(int tiles) {
     return t_pair < t_single(wg_single);
 }
 
+// Which decoder projection: gemm_dec_ws_kernel has one long workgroup per (tile, direction) and one workgroup per
+// CU, so it wants whole rounds of 256; gemm_gi_kernel is fine-grained (same gi bit for bit).
+// (HELEN_DEC_WS=0/1 forces one: A/B probes.)
+bool use_ws_dec_projection(int tiles) {
+    static const char* force = getenv("HELEN_DEC_WS");
+    if (force && *force) return *force == '1';
+    const int wgs = 2 * tiles, cus = 256;
+    const int rounds = (wgs + cus - 1) / cus;
+    return wgs >= cus && rounds * cus - wgs <= cus / 8;   // at most an eighth of the last round idle
+}
+
 // One TransducerGRU.forward over `tiles` tiles whose encoder pre-activations are already in
 // gi_enc at positions [pos0, pos0+T): encoder recurrence -> decoder projection -> decoder
 // recurrence.  plogit then holds the decoder's partial logits, hid the returned hidden state.
@@ -336,8 +372,12 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
         LAUNCH(HELEN_K_GRU_ENC, gru_kernel<false>, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
                enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride, (const f32x4*)nullptr,
                (f32x4*)nullptr, kPlTileStride);
-    LAUNCH(HELEN_K_GEMM_DEC, (gemm_gi_kernel<16, true>), ggrid, gblock, m->y1, kYTileStride, m->wp_dec,
-           m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
+    if (use_ws_dec_projection(tiles))
+        LAUNCH(HELEN_K_GEMM_DEC, gemm_dec_ws_kernel, dim3(2 * ((tiles + 7) / 8 * 8)), dim3(512), m->y1, kYTileStride,
+               m->wp_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
+    else
+        LAUNCH(HELEN_K_GEMM_DEC, (gemm_gi_kernel<16, true>), ggrid, gblock, m->y1, kYTileStride, m->wp_dec,
+               m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
     if (pair)
         LAUNCH(HELEN_K_GRU_DEC, gru_pair_kernel<true>, dim3((tiles + 1) / 2, 2), dim3(512), m->gi_dec,
                kGiDecTileStride, 0, 0, T, m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd,
@@ -347,28 +387,41 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
                m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd, m->plogit, kPlTileStride);
 }
 
-void free_model(HelenModel* m) {
-    if (!m) return;
-    (void)hipSetDevice(m->device);
-    void* ptrs[] = {m->plogit, m->w3i_enc, m->xb, m->w3i_dec, m->y1p, m->w3h_enc, m->w3h_dec, m->wp_enc, m->wp_dec, m->whp_enc, m->whp_dec, m->whd, m->bias_enc, m->bias_dec,
-                    m->bhn_enc, m->bhn_dec, m->bhd, m->xa, m->gi_enc, m->gi_dec, m->y1,
-                    m->hid, m->pending, m->dev_in[0], m->dev_in[1], m->dev_out[0], m->dev_out[1]};
-    for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+// The staging ring of helen_polish_host: two slots of device input / output buffers, pinned host mirrors (used
+// only for pageable caller memory), two copy streams and the events that chain them.
+void free_ring(HelenModel* m) {
     for (int i = 0; i < 2; ++i) {
+        if (m->dev_in[i]) { (void)hipFree(m->dev_in[i]); m->device_bytes -= (size_t)m->max_windows * kSeq * kF; }
+        if (m->dev_out[i]) { (void)hipFree(m->dev_out[i]); m->device_bytes -= (size_t)m->max_windows * 2 * kSeq; }
         if (m->pin_in[i]) (void)hipHostFree(m->pin_in[i]);
         if (m->pin_out[i]) (void)hipHostFree(m->pin_out[i]);
         if (m->ev_in[i]) (void)hipEventDestroy(m->ev_in[i]);
         if (m->ev_done[i]) (void)hipEventDestroy(m->ev_done[i]);
         if (m->ev_out[i]) (void)hipEventDestroy(m->ev_out[i]);
+        m->dev_in[i] = m->dev_out[i] = m->pin_in[i] = m->pin_out[i] = nullptr;
+        m->ev_in[i] = m->ev_done[i] = m->ev_out[i] = nullptr;
     }
     if (m->h2d_stream) (void)hipStreamDestroy(m->h2d_stream);
     if (m->d2h_stream) (void)hipStreamDestroy(m->d2h_stream);
+    m->h2d_stream = m->d2h_stream = nullptr;
+    m->ring_ready = false;
+}
+
+void free_model(HelenModel* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    free_ring(m);
+    void* ptrs[] = {m->plogit, m->w3i_enc, m->xb, m->w3i_dec, m->y1p, m->w3h_enc, m->w3h_dec, m->wp_enc, m->wp_dec, m->whp_enc, m->whp_dec, m->whd, m->bias_enc, m->bias_dec,
+                    m->bhn_enc, m->bhn_dec, m->bhd, m->xa, m->gi_enc, m->gi_dec, m->y1,
+                    m->hid, m->pending};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
     for (int c = 0; c < HELEN_K_COUNT; ++c)
-        for (auto& e : m->prof[c]) {
-            (void)hipEventDestroy(e.a);
-            (void)hipEventDestroy(e.b);
-        }
+        for (auto& e : m->prof[c]) m->prof_pool.push_back(e);
+    for (auto& e : m->prof_pool) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
     delete m;
 }
 
@@ -527,8 +580,8 @@ static int launch_front(HelenModel* m, hipStream_t s, const uint8_t* images, int
     return HELEN_OK;
 }
 
-int helen_polish_batch(HelenModel* m, const uint8_t* images, int n_windows, uint8_t* bases,
-                       uint8_t* rles, float* acc_base_opt, float* acc_rle_opt, void* stream) {
+static int polish_batch_impl(HelenModel* m, const uint8_t* images, int n_windows, uint8_t* bases,
+                             uint8_t* rles, float* acc_base_opt, float* acc_rle_opt, void* stream) {
     if (!m || !images || !bases || !rles) return fail(HELEN_EINVAL, "null argument");
     if (n_windows <= 0 || n_windows > m->max_windows)
         return fail(HELEN_EINVAL, "n_windows %d outside 1..%d", n_windows, m->max_windows);
@@ -546,6 +599,13 @@ int helen_polish_batch(HelenModel* m, const uint8_t* images, int n_windows, uint
     return check_launch("helen_polish_batch");
 }
 
+int helen_polish_batch(HelenModel* m, const uint8_t* images, int n_windows, uint8_t* bases,
+                       uint8_t* rles, float* acc_base_opt, float* acc_rle_opt, void* stream) {
+    if (!m) return fail(HELEN_EINVAL, "null argument");
+    HELEN_ENTER(m);
+    return polish_batch_impl(m, images, n_windows, bases, rles, acc_base_opt, acc_rle_opt, stream);
+}
+
 int helen_evaluate_batch(HelenModel* m, const uint8_t* images, const uint8_t* label_base,
                          const uint8_t* label_rle, int n_windows, const float* rle_class_weights,
                          float* chunk_stats, unsigned long long* base_confusion,
@@ -555,6 +615,7 @@ int helen_evaluate_batch(HelenModel* m, const uint8_t* images, const uint8_t* la
         return fail(HELEN_EINVAL, "null argument");
     if (n_windows <= 0 || n_windows > m->max_windows)
         return fail(HELEN_EINVAL, "n_windows %d outside 1..%d", n_windows, m->max_windows);
+    HELEN_ENTER(m);
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
     const int tiles = (n_windows + kTile - 1) / kTile;
@@ -575,6 +636,7 @@ int helen_gru_chunk_forward(HelenModel* m, const float* x, const float* h_in, in
     if (!m || !x || !h_in || !base || !rle || !h_out) return fail(HELEN_EINVAL, "null argument");
     if (B <= 0 || B > m->max_windows) return fail(HELEN_EINVAL, "B %d outside 1..%d", B, m->max_windows);
     if (T <= 0 || T > kWin) return fail(HELEN_EINVAL, "T %d outside 1..%d (TRAIN_WINDOW)", T, kWin);
+    HELEN_ENTER(m);
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
     const int tiles = (B + kTile - 1) / kTile;
@@ -596,20 +658,13 @@ int helen_gru_chunk_forward(HelenModel* m, const float* x, const float* h_in, in
     return check_launch("helen_gru_chunk_forward");
 }
 
-int helen_polish_host(HelenModel* m, const uint8_t* images, int n_windows, uint8_t* bases,
-                      uint8_t* rles, void* stream) {
-    if (!m || !images || !bases || !rles) return fail(HELEN_EINVAL, "null argument");
-    if (n_windows <= 0) return fail(HELEN_EINVAL, "n_windows must be > 0");
-    HIP_TRY(hipSetDevice(m->device));
-    hipStream_t s = (hipStream_t)stream;
-    const int sub = m->max_windows;
-    const size_t img_bytes = (size_t)kSeq * kF, lab_bytes = (size_t)kSeq;
-    if (!m->h2d_stream) {  // lazily build the two-slot pinned staging ring
+// Build the staging ring; on any failure everything built so far is released again (a later call retries cleanly).
+static int build_ring(HelenModel* m) {
+    const size_t sub = (size_t)m->max_windows, img_bytes = (size_t)kSeq * kF, lab_bytes = (size_t)kSeq;
+    auto build = [&]() -> int {
         HIP_TRY(hipStreamCreateWithFlags(&m->h2d_stream, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&m->d2h_stream, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) {
-            HIP_TRY(hipHostMalloc((void**)&m->pin_in[i], sub * img_bytes, hipHostMallocDefault));
-            HIP_TRY(hipHostMalloc((void**)&m->pin_out[i], sub * 2 * lab_bytes, hipHostMallocDefault));
             int rc;
             if ((rc = dev_alloc(m, &m->dev_in[i], sub * img_bytes))) return rc;
             if ((rc = dev_alloc(m, &m->dev_out[i], sub * 2 * lab_bytes))) return rc;
@@ -617,41 +672,126 @@ int helen_polish_host(HelenModel* m, const uint8_t* images, int n_windows, uint8
             HIP_TRY(hipEventCreateWithFlags(&m->ev_done[i], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&m->ev_out[i], hipEventDisableTiming));
         }
+        return HELEN_OK;
+    };
+    const int rc = build();
+    if (rc != HELEN_OK) {
+        free_ring(m);
+        return rc;
+    }
+    m->ring_ready = true;
+    return HELEN_OK;
+}
+
+// Is [p, p + bytes) page-locked host memory the copy engines can address directly (hipHostMalloc or
+// hipHostRegister'd)?  Pageable memory makes the attribute query fail or report an unregistered pointer.
+static bool host_range_is_pinned(const void* p, size_t bytes) {
+    hipPointerAttribute_t a0, a1;
+    if (hipPointerGetAttributes(&a0, p) != hipSuccess || a0.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (hipPointerGetAttributes(&a1, (const char*)p + bytes - 1) != hipSuccess || a1.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return true;
+}
+
+int helen_polish_host(HelenModel* m, const uint8_t* images, int n_windows, uint8_t* bases,
+                      uint8_t* rles, void* stream) {
+    if (!m || !images || !bases || !rles) return fail(HELEN_EINVAL, "null argument");
+    if (n_windows <= 0) return fail(HELEN_EINVAL, "n_windows must be > 0");
+    HELEN_ENTER(m);
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int sub = m->max_windows;
+    const int fail_at = m->fail_at_sub;
+    m->fail_at_sub = -1;
+    const size_t img_bytes = (size_t)kSeq * kF, lab_bytes = (size_t)kSeq;
+    int rc;
+    if (!m->ring_ready && (rc = build_ring(m))) return rc;
+    // Page-locked caller memory (hipHostMalloc / hipHostRegister: torch pinned tensors, the shared-memory slots of
+    // helen_amd.predict) is the source / destination of the DMA itself; pageable memory goes through pinned mirrors.
+    const bool in_pinned = host_range_is_pinned(images, (size_t)n_windows * img_bytes);
+    const bool out_pinned = host_range_is_pinned(bases, (size_t)n_windows * lab_bytes) &&
+                            host_range_is_pinned(rles, (size_t)n_windows * lab_bytes);
+    for (int i = 0; i < 2; ++i) {
+        if (!in_pinned && !m->pin_in[i]) HIP_TRY(hipHostMalloc((void**)&m->pin_in[i], sub * img_bytes, hipHostMallocDefault));
+        if (!out_pinned && !m->pin_out[i]) HIP_TRY(hipHostMalloc((void**)&m->pin_out[i], sub * 2 * lab_bytes, hipHostMallocDefault));
     }
     const int nsub = (n_windows + sub - 1) / sub;
     auto count = [&](int k) { return (k == nsub - 1) ? n_windows - k * sub : sub; };
-    auto drain = [&](int k) -> int {  // labels of sub-batch k: pinned slot -> caller's arrays
+    int issued = 0;   // sub-batches whose D2H has been enqueued
+    int drained = 0;  // sub-batches whose labels are in the caller's arrays
+    auto drain = [&](int k) -> int {   // labels of sub-batch k are in host memory (and, staged, in the caller's arrays)
         const int b = k & 1;
         HIP_TRY(hipEventSynchronize(m->ev_out[b]));
-        memcpy(bases + (size_t)k * sub * lab_bytes, m->pin_out[b], count(k) * lab_bytes);
-        memcpy(rles + (size_t)k * sub * lab_bytes, m->pin_out[b] + (size_t)sub * lab_bytes,
-               count(k) * lab_bytes);
+        if (!out_pinned) {
+            memcpy(bases + (size_t)k * sub * lab_bytes, m->pin_out[b], count(k) * lab_bytes);
+            memcpy(rles + (size_t)k * sub * lab_bytes, m->pin_out[b] + (size_t)sub * lab_bytes, count(k) * lab_bytes);
+        }
+        drained = k + 1;
         return HELEN_OK;
     };
-    // Slot b = k & 1.  H2D of sub-batch k+1 (h2d stream) overlaps the kernels of sub-batch k
-    // (caller's stream) and the D2H of sub-batch k-1 (d2h stream).
-    for (int k = 0; k < nsub; ++k) {
-        const int b = k & 1;
-        int rc;
-        if (k >= 2 && (rc = drain(k - 2))) return rc;  // slot b is free again after this
-        memcpy(m->pin_in[b], images + (size_t)k * sub * img_bytes, count(k) * img_bytes);
-        HIP_TRY(hipMemcpyAsync(m->dev_in[b], m->pin_in[b], count(k) * img_bytes,
-                               hipMemcpyHostToDevice, m->h2d_stream));
-        HIP_TRY(hipEventRecord(m->ev_in[b], m->h2d_stream));
-        HIP_TRY(hipStreamWaitEvent(s, m->ev_in[b], 0));
-        rc = helen_polish_batch(m, m->dev_in[b], count(k), m->dev_out[b],
-                                m->dev_out[b] + (size_t)sub * lab_bytes, nullptr, nullptr, s);
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord(m->ev_done[b], s));
-        HIP_TRY(hipStreamWaitEvent(m->d2h_stream, m->ev_done[b], 0));
-        HIP_TRY(hipMemcpyAsync(m->pin_out[b], m->dev_out[b], (size_t)sub * 2 * lab_bytes,
-                               hipMemcpyDeviceToHost, m->d2h_stream));
-        HIP_TRY(hipEventRecord(m->ev_out[b], m->d2h_stream));
+    // Slot b = k & 1.  H2D of sub-batch k+1 (h2d stream) overlaps the kernels of sub-batch k (caller's stream) and
+    // the D2H of sub-batch k-1 (d2h stream).
+    auto run = [&]() -> int {
+        for (int k = 0; k < nsub; ++k) {
+            const int b = k & 1;
+            int r;
+            if (k >= 2 && (r = drain(k - 2))) return r;   // slot b (device buffers, mirrors) is free again after this
+            const uint8_t* src = images + (size_t)k * sub * img_bytes;
+            if (!in_pinned) {
+                memcpy(m->pin_in[b], src, count(k) * img_bytes);
+                src = m->pin_in[b];
+            }
+            HIP_TRY(hipMemcpyAsync(m->dev_in[b], src, count(k) * img_bytes, hipMemcpyHostToDevice, m->h2d_stream));
+            HIP_TRY(hipEventRecord(m->ev_in[b], m->h2d_stream));
+            HIP_TRY(hipStreamWaitEvent(s, m->ev_in[b], 0));
+            r = polish_batch_impl(m, m->dev_in[b], count(k), m->dev_out[b], m->dev_out[b] + (size_t)sub * lab_bytes,
+                                  nullptr, nullptr, s);
+            if (r) return r;
+            if (k == fail_at) return fail(HELEN_EHIP, "injected failure after sub-batch %d (helen_debug_inject_failure)", k);
+            HIP_TRY(hipEventRecord(m->ev_done[b], s));
+            HIP_TRY(hipStreamWaitEvent(m->d2h_stream, m->ev_done[b], 0));
+            if (out_pinned) {
+                HIP_TRY(hipMemcpyAsync(bases + (size_t)k * sub * lab_bytes, m->dev_out[b], count(k) * lab_bytes,
+                                       hipMemcpyDeviceToHost, m->d2h_stream));
+                HIP_TRY(hipMemcpyAsync(rles + (size_t)k * sub * lab_bytes, m->dev_out[b] + (size_t)sub * lab_bytes,
+                                       count(k) * lab_bytes, hipMemcpyDeviceToHost, m->d2h_stream));
+            } else {
+                HIP_TRY(hipMemcpyAsync(m->pin_out[b], m->dev_out[b], (size_t)sub * 2 * lab_bytes, hipMemcpyDeviceToHost,
+                                       m->d2h_stream));
+            }
+            HIP_TRY(hipEventRecord(m->ev_out[b], m->d2h_stream));
+            issued = k + 1;
+        }
+        for (int k = drained; k < nsub; ++k) {
+            const int r = drain(k);
+            if (r) return r;
+        }
+        return HELEN_OK;
+    };
+    rc = run();
+    if (rc != HELEN_OK) {
+        // Nothing may stay in flight on the caller's buffers or on the ring after a failure: wait for whatever was
+        // enqueued (the error text of the first failure is kept).
+        char keep[sizeof(g_err)];
+        memcpy(keep, g_err, sizeof(keep));
+        (void)hipStreamSynchronize(m->h2d_stream);
+        (void)hipStreamSynchronize(s);
+        (void)hipStreamSynchronize(m->d2h_stream);
+        (void)hipGetLastError();
+        memcpy(g_err, keep, sizeof(keep));
+        (void)issued;
     }
-    for (int k = (nsub >= 2 ? nsub - 2 : 0); k < nsub; ++k) {
-        int rc = drain(k);
-        if (rc) return rc;
-    }
+    return rc;
+}
+
+int helen_debug_inject_failure(HelenModel* m, int sub_batch) {
+    if (!m) return fail(HELEN_EINVAL, "null argument");
+    m->fail_at_sub = sub_batch;
     return HELEN_OK;
 }
 
@@ -669,8 +809,7 @@ static int drain_stats(HelenModel* m) {
             HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
             m->prof_ms[c] += ms;
             m->prof_n[c] += 1;
-            (void)hipEventDestroy(e.a);
-            (void)hipEventDestroy(e.b);
+            m->prof_pool.push_back(e);
         }
         m->prof[c].clear();
     }

@@ -211,4 +211,99 @@ __global__ __launch_bounds__(256, 2) void gemm_enc_ws_kernel(const f32x4* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Decoder input projection, weight-stationary (fp32 MFMA): gi = Y1 . W_ih^T + bias, K = 256.
+//   One workgroup = one (tile, direction): 8 waves x 3 column tiles = the direction's 24 column tiles, and a
+//   wave's whole slice of W_ih (3 tiles x 16 k-groups = 192 registers) is loaded once and stays.  Only the
+//   activations move: a stage is PB positions (16 KiB each: the forward half of slot p and the backward half of
+//   slot npos-1-p of the encoder output) brought in by LDS-DMA into a 2-deep ring; a position is three chains of
+//   64 MFMAs against 16 LDS reads, its three output stores left in flight.  Two waves per SIMD: one wave's
+//   LDS-DMA issue (~90 cycles a piece), barrier and stores hide behind its partner's MFMAs.
+//   No per-(position group) prologue / epilogue as in gemm_gi_kernel, whose 20,480 single-wave workgroups each pay
+//   ~10 k cycles of first loads, VALU address arithmetic between MFMAs and an exposed store tail on 123 k of MFMAs.
+//   Same MFMA order per accumulator as gemm_gi_kernel<16, true> (m ascending, e ascending): bit-identical gi.
+//   Grid: the two directions of a tile sit on one XCD (ids b, b + 8) so that y1 comes from HBM once.
+// ------------------------------------------------------------------------------------------------
+#ifndef HELEN_DWS_PB
+#define HELEN_DWS_PB 4
+#endif
+__global__ __launch_bounds__(512, 1) void gemm_dec_ws_kernel(const f32x4* __restrict__ A, long a_tile_stride,
+                                                             const f32x4* __restrict__ Wp,
+                                                             const float* __restrict__ bias,
+                                                             f32x4* __restrict__ gi, long gi_tile_stride,
+                                                             int npos, int ntiles) {
+    constexpr int MG = 16, PB = HELEN_DWS_PB, N = 3;
+    constexpr int ROWS = PB * MG;            // 1 KiB rows per stage
+    constexpr int RPP = ROWS / 8 / PB;       // rows a wave brings in per position (2)
+    __shared__ f32x4 smem[2 * ROWS * 64];    // 2 x PB x 16 KiB
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int local = blockIdx.x >> 3;
+    const int dir = local & 1;
+    const int tile = (local >> 1) * 8 + (blockIdx.x & 7);
+    if (tile >= ntiles) return;
+    const int nt0 = N * v;
+    f32x4 B[N][MG];
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int m = 0; m < MG; ++m) B[n][m] = Wp[(size_t)((dir * kNTile + nt0 + n) * MG + m) * 64 + lane];
+    f32x4 bsv[N];   // bias: the C operand of a chain's first MFMA
+#pragma unroll
+    for (int n = 0; n < N; ++n) bsv[n] = splat4(bias[dir * kG + (nt0 + n) * 16 + (lane & 15)]);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(char*)smem;
+    const char* a_tile = (const char*)(A + (size_t)tile * a_tile_stride);                     // uniform
+    char* o_tile = (char*)(gi + (size_t)tile * gi_tile_stride + (size_t)dir * (kNTile * 64) + nt0 * 64);
+    // Row r = p*16 + m of stage g (positions PB g .. PB g + PB-1); wave v brings in rows v, v+8, ...: RPP per position.
+    auto stage_rows = [&](int g, int b, int i0, int i1) {
+#pragma unroll
+        for (int i = i0; i < i1; ++i) {
+            const int r = v + 8 * i;
+            const int pc = min(PB * g + r / MG, npos - 1);
+            const int m = r % MG;
+            const int slot = m < MG / 2 ? pc : npos - 1 - pc;   // forward half of slot p | backward half of slot npos-1-p
+            dma_row_to_lds(lds0 + (unsigned)((b * ROWS + r) * 1024), a_tile + ((size_t)slot * MG + m) * 1024, lane16);
+        }
+    };
+    const int ng = (npos + PB - 1) / PB;
+    stage_rows(0, 0, 0, ROWS / 8);
+    for (int g = 0; g < ng; ++g) {
+        // VMEM queue, oldest first: ... the last DMA rows of stage g, then the N output stores of the last position
+        // of stage g-1 (the next stage's rows are issued RPP per position, BEFORE that position's MFMAs: a wave that
+        // issues LDS-DMA -- ~90 cycles a piece -- leaves the matrix pipe to its partner meanwhile)
+        if (g == 0)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const f32x4* L = smem + (g & 1) * (ROWS * 64) + lane;
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {       // one position at a time: three chains of 64 MFMAs
+            if (g + 1 < ng) stage_rows(g + 1, (g + 1) & 1, p * RPP, (p + 1) * RPP);
+            f32x4 acc[N], a[2];
+            a[0] = L[(p * MG) * 64];
+#pragma unroll
+            for (int m = 0; m < MG; ++m) {   // A fragment m+1 is in flight behind fragment m's 12 MFMAs
+                if (m + 1 < MG) a[(m + 1) & 1] = L[(p * MG + m + 1) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int n = 0; n < N; ++n) acc[n] = mfma4(a[m & 1][e], B[n][m][e], (m | e) ? acc[n] : bsv[n]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // exactly N stores per lane per position (counted above): positions past the end of the last stage
+            // rewrite the last valid one with identical values
+            const int pos = min(PB * g + p, npos - 1);
+            const int slot = dir ? (npos - 1 - pos) : pos;
+            char* o = o_tile + (size_t)slot * (2 * kNTile * 64 * 16) + in_block(lane16);
+#pragma unroll
+            for (int n = 0; n < N; ++n) *(f32x4*)(o + n * 1024) = acc[n];
+        }
+    }
+}
+
 }  // namespace helen

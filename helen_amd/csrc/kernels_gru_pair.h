@@ -38,13 +38,6 @@ namespace helen {
 constexpr int kPairHF4 = 2 * 2 * 512;        // h[tile x][buffer][512]
 constexpr int kPairPF4 = 2 * 2 * 8 * 64;     // head partials [tile x][parity][wave][64]
 
-// A lane offset the optimiser cannot hoist out of the block: keeps `uniform base + zext(offset)` visible to
-// instruction selection, which then uses the SGPR-base address form instead of a 64-bit VALU add per access.
-__device__ __forceinline__ unsigned in_block(unsigned v) {
-    asm volatile("" : "+v"(v));
-    return v;
-}
-
 template <bool DEC>
 __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restrict__ gi, long gi_tile_stride,
                                                           int slot0_fwd, int slot0_bwd, int T,
@@ -78,7 +71,7 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
     }
     f32x4 Bh = splat4(0.f);   // DEC: head weights of k = dir*128 + 16v + 4q + e, class j
     if (DEC) Bh = Whd[(dir * 8 + v) * 64 + lane];
-    const float bn = bhn[dir * kH + 16 * v + j];
+    const f32x4 bnv = splat4(bhn[dir * kH + 16 * v + j]);   // b_hn: initial value of the n-gate accumulator
 
     // Uniform running byte pointers per tile -- next gi slot to fetch, next layer-output / partial-logit slot to
     // store -- advanced by SALU adds; everything per-lane is a constant 32-bit byte offset.
@@ -135,9 +128,6 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
         const f32x4* hx = hbuf + (x * 2 + cur) * 512;            // h_x(s-1): A operand of this phase
         const f32x4* hb = hx + lane;
         f32x4 acc[3], a[2], yv = splat4(0.f), hd = splat4(0.f), hp = splat4(0.f);
-        acc[0] = splat4(0.f);
-        acc[1] = splat4(0.f);
-        acc[2] = splat4(bn);
         a[0] = a_pref;
         a[1] = hb[1 * 64];
         if (so + 1 < T) load_gi(o);                              // tile o's registers were consumed in G(o, so)
@@ -149,7 +139,8 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int g = 0; g < 3; ++g) acc[g] = mfma4(a[m & 1][e], W[g][m][e], acc[g]);
+                for (int g = 0; g < 3; ++g)   // the first MFMA of a chain takes its initial value as the C operand
+                    acc[g] = mfma4(a[m & 1][e], W[g][m][e], (m | e) ? acc[g] : g < 2 ? splat4(0.f) : bnv);
             __builtin_amdgcn_sched_barrier(0);
             if (m + 2 < 8) a[m & 1] = hb[(m + 2) * 64];
             if (m == 1 && DEC && s > 0) {

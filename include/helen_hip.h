@@ -10,7 +10,8 @@
  *   - every function returns HELEN_OK (0) or a negative HELEN_E* code and never throws;
  *     helen_last_error() returns a thread-local, NUL-terminated description of the last failure.
  *   - a HelenModel is bound to one device (one process per GPU, `models/predict_gpu.py:223`);
- *     calls on one handle must be serialised by the caller (one host thread / one stream at a time).
+ *     calls on one handle must be serialised by the caller (one host thread / one stream at a time):
+ *     a second thread entering a busy handle gets HELEN_EINVAL.
  *   - "window" = one MarginPolish pileup image, SEQ_LENGTH(1000) positions x features(90) uint8
  *     (`Options.py:13-21`); "chunk" = TRAIN_WINDOW(100) consecutive positions, stride
  *     WINDOW_JUMP(50), 19 per window (`Options.py:24-29`, `models/predict_gpu.py:114-117`).
@@ -135,14 +136,24 @@ int helen_polish_batch(HelenModel* model, const uint8_t* images, int n_windows, 
                        uint8_t* rles, float* acc_base_opt, float* acc_rle_opt, void* stream);
 
 /*
- * Same, from HOST memory: `images` is a host pointer (pinned or pageable); the library streams
- * sub-batches through two pinned staging buffers with hipMemcpyAsync on a copy stream,
- * overlapped with compute, and writes labels back to host `bases`/`rles`.  Synchronous: returns
- * when the labels are in host memory.  Replaces the DataLoader -> `.to(device_id)` ->
- * `.cpu()` hand-offs of `models/predict_gpu.py:94-159`.
+ * Same, from HOST memory: sub-batches of `max_windows` windows go up with hipMemcpyAsync on a copy
+ * stream, overlapped with the kernels of the previous sub-batch and the label download of the one
+ * before.  Page-locked caller memory (hipHostMalloc / hipHostRegister, e.g. a torch pinned tensor) is
+ * the source and destination of the DMA itself; pageable memory goes through two pinned mirrors.
+ * Synchronous: returns when the labels are in host memory; on an error nothing is left in flight.
+ * Hand it MANY sub-batches per call: the first upload and the last download are the only exposed
+ * copies.  Replaces the DataLoader -> `.to(device_id)` -> `.cpu()` hand-offs of
+ * `models/predict_gpu.py:94-159`.
  */
 int helen_polish_host(HelenModel* model, const uint8_t* images, int n_windows, uint8_t* bases,
                       uint8_t* rles, void* stream);
+
+/*
+ * Test hook for the error path of helen_polish_host: the NEXT call fails with HELEN_EHIP right after it has
+ * enqueued sub-batch `sub_batch` (copies and kernels of that and earlier sub-batches are in flight at that
+ * moment).  The call must still return with nothing in flight and the handle usable.  -1 disarms.
+ */
+int helen_debug_inject_failure(HelenModel* model, int sub_batch);
 
 /*
  * One TransducerGRU.forward call (`models/TransducerModel.py:60-79`), the operator-level
