@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- pileup windows / second of the `helen polish` inference path on MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N > 1 under torch.distributed.run, one
-rank per GPU).  A "step" is one pass of the hot path -- one helen_polish_batch call -- over
+Contract: `python bench.py --gpus N --steps K --warmup W`, one rank per GPU.  N > 1 either arrives
+under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or, started plainly,
+re-executes itself under `python -m torch.distributed.run --nproc-per-node N` on 127.0.0.1 -- and
+refuses when fewer than N GPUs are visible.  A "step" is one pass of the hot path -- one helen_polish_batch call -- over
 `--coalesce` (16) loader batches of 256 synthetic pileup windows (1000 positions x 90 features,
 uint8, already resident in HBM): uint8->f32, 19 overlapping chunks of the 2-layer bidirectional GRU
 with carried hidden state, heads, softmax-accumulate and argmax labels (reference:
@@ -11,10 +13,13 @@ the device 16 loader batches at once gives the same labels as 16 separate calls
 (tests/test_gpu_parity.py::test_batch_split_invariance); 4096 windows = 256 tiles is what fills
 256 CUs x 2 workgroups.  `value` is windows per second over all ranks.
 
-Prints ONE JSON line (rank 0) with the whole-job windows/s, the MFMA-roofline figures of the
-dominant kernel (the GRU recurrence, timed with HIP events on the launch stream inside the timed
-region) and a CPU baseline (the repo's oracle, a port of the reference algorithm, on the host
-cores of this box).
+Prints ONE JSON line (rank 0) with the whole-job windows/s (`value`: inputs resident in HBM when the
+timed region starts), the MFMA-roofline figures of the dominant kernel (the GRU recurrence, timed
+with recycled HIP events on the launch stream inside the timed region), `host_path` -- the same
+windows from page-locked HOST memory to labels in HOST memory through helen_polish_host (PCIe
+included, SURVEY.md 8d's "images in host memory -> labels in host memory"; reported beside `value`,
+never as it) -- per-rank rates, and a CPU baseline (the repo's oracle, a port of the reference
+algorithm, on the host cores of this box).
 """
 import argparse
 import json
@@ -45,7 +50,8 @@ def pmc_traffic(windows_per_launch):
         return None, None
     try:
         # encoder and decoder launches of the recurrence (gru_kernel<false> / <true>), launch-weighted
-        ks = [v for k, v in json.load(open(files[-1]))["kernels"].items() if k.startswith("helen::gru_kernel")]
+        ks = [v for k, v in json.load(open(files[-1]))["kernels"].items()
+              if k.startswith(("helen::gru_kernel", "helen::gru_pair_kernel"))]
         n = sum(k["launches_profiled"] for k in ks)
         per_launch = sum(k["hbm_bytes_per_launch"] * k["launches_profiled"] for k in ks) / n
         return int(per_launch * windows_per_launch / 4096.0), os.path.basename(files[-1])
@@ -97,6 +103,37 @@ def cpu_baseline(batch, seconds_target=12.0):
                       "8-window blocks, %d threads = usable CPUs under the cgroup quota), %.1f s" % (n, threads, dt)}
 
 
+def precision_check(eng, precision, images, dev):
+    """BASELINE.json configs[3] asks for the reduced-precision mode's own check: argmax parity and logits
+    tolerance against the fp32 path on the same inputs.  Labels: one device call of each engine over the first
+    windows of the shard.  Logits: the reference's 19-chunk operator loop (predict_gpu.py:114-129, hidden
+    carried) on 512 of them, both engines, max |logit difference| over all chunks."""
+    import torch
+
+    from helen_amd.engine import HelenEngine
+    from helen_amd.weights import make_weights
+    n = min(images.shape[0], 4096)
+    ref = HelenEngine(make_weights(input_scale=1.0 / 64.0), device=dev.index, max_windows=n, precision="fp32")
+    b0, r0 = ref.polish(images[:n])
+    b1, r1 = eng.polish(images[:n])
+    same = float((b0 == b1).float().mean().item() + (r0 == r1).float().mean().item()) / 2
+    m = min(n, 512)
+    x = images[:m].float()
+    h0 = torch.zeros((m, 2, 128), device=dev)
+    h1 = h0.clone()
+    worst, biggest = 0.0, 0.0
+    for c in range(19):
+        xc = x[:, 50 * c:50 * c + 100].contiguous()
+        ob0, or0, h0 = ref.chunk_forward(xc, h0)
+        ob1, or1, h1 = eng.chunk_forward(xc, h1)
+        worst = max(worst, float((ob0 - ob1).abs().max().item()), float((or0 - or1).abs().max().item()))
+        biggest = max(biggest, float(ob0.abs().max().item()), float(or0.abs().max().item()))
+    ref.close()
+    return {"against": "the fp32 path of this library on the same windows", "windows_labels": n,
+            "label_identity": round(same, 6), "windows_logits": m, "max_abs_logit_diff": round(worst, 5),
+            "max_abs_logit": round(biggest, 3), "precision": precision}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +143,7 @@ def main():
     ap.add_argument("--coalesce", type=int, default=16, help="loader batches per device call")
     ap.add_argument("--mode", default="uniform", choices=["uniform", "pileup"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the host-memory -> host-memory leg")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp32x3"],
                     help="gate-matmul arithmetic; fp32 (true fp32 MFMA) is BASELINE.json configs[1], the "
                          "headline; fp32x3 = fp32-class via three-term bf16 splits (opt-in experiment)")
@@ -115,19 +153,46 @@ def main():
                     help="testing aid: every rank uses cuda:0 (exercise the N>1 code path on one GPU)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly with --gpus N: become N ranks, one per GPU (predict_gpu.py:207-226 spawns one process
+        # per device the same way)
+        import socket
+        import subprocess
+
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus and not args.single_device:
+            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (args.gpus, have))
+            sys.exit(2)
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d\n" % (args.gpus, world))
+        sys.exit(2)
     if args.single_device:
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        sys.stderr.write("bench.py: rank %d wants cuda:%d but %d GPU(s) are visible\n"
+                         % (rank, local_rank, torch.cuda.device_count()))
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # under torch.distributed.run (any world size) the process group is used for the barrier and the
     # max-over-ranks time; a plain `python bench.py` needs none
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         import torch.distributed as dist
+        if args.single_device:
+            args.dist_backend = "gloo"      # RCCL refuses two ranks on one device
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -178,23 +243,57 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if args.warmup > 0:
-        run(args.warmup)
+    # HIP events around the dominant kernel only; the pairs are created during the warm-up (topped up to the
+    # number of timed steps) and recycled afterwards: no event is created or destroyed inside the timed region
+    eng.set_profiling(["gru_enc", "gru_dec"])
+    run(args.warmup)
+    if args.warmup < args.steps:   # untimed: as many event pairs as the timed steps will need
+        run(args.steps - args.warmup)
     barrier()
-    eng.set_profiling(["gru_enc", "gru_dec"])   # HIP events around the dominant kernel only
     eng.reset_kernel_stats()
+    barrier()
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     stats = eng.kernel_stats()
     eng.set_profiling([])
+    my_elapsed = elapsed
 
+    # host path: the same number of windows from page-locked host memory to labels in host memory, ONE
+    # helen_polish_host call (it pipelines sub-batches of `call_windows`: upload k+1 | kernels k | download k-1)
+    host_elapsed, hn = None, n_res
+    if not args.no_host_path:
+        # the resident shard (at most 8 device calls' worth), copied to page-locked host memory
+        himg = torch.empty((hn, 1000, 90), dtype=torch.uint8).pin_memory()
+        himg.copy_(images)
+        hb = torch.empty((hn, 1000), dtype=torch.uint8).pin_memory()
+        hr = torch.empty((hn, 1000), dtype=torch.uint8).pin_memory()
+        eng.polish_host(himg[:call_windows], out=(hb.numpy()[:call_windows], hr.numpy()[:call_windows]))   # warm-up
+        barrier()
+        t0 = time.perf_counter()
+        eng.polish_host(himg, out=(hb.numpy(), hr.numpy()))
+        barrier()
+        host_elapsed = time.perf_counter() - t0
+        # the host path must give the labels of the device path (which has walked the whole resident shard
+        # when steps >= its length in calls)
+        k = min(args.steps, n_calls_res) * call_windows
+        if not (torch.equal(hb[:k], bases[:k].cpu()) and torch.equal(hr[:k], rles[:k].cpu())):
+            sys.stderr.write("bench.py: host-path labels differ from the device-path labels\n")
+            sys.exit(3)
+        del himg, hb, hr
+
+    per_rank = [my_elapsed]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device=dev if args.dist_backend == "nccl" else "cpu")
+        cdev = dev if args.dist_backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed, host_elapsed or 0.0], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank = [float(e[0].item()) for e in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        if host_elapsed is not None:
+            host_elapsed = float(t[1].item())
 
     if rank == 0:
         total_windows = world * args.steps * call_windows
@@ -214,7 +313,10 @@ def main():
             achieved = flop * win_per_launch / (avg_ms * 1e-3) / 1e12
         out = {
             "metric": "pileup windows/sec (batch 256, 1000-pos)",
-            "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "ranks_seen": len(per_rank),
+            "per_rank_windows_per_s": [round(args.steps * call_windows / t, 1) for t in per_rank],
+            "devices": "cuda:0 for every rank (--single-device)" if args.single_device else "cuda:LOCAL_RANK",
+            "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16 operands, f32 accumulate/state",
                       "fp32x3": "f32 emulated as 3-term bf16 splits (6 exact partial products), f32 "
@@ -227,7 +329,8 @@ def main():
                        "batch": B, "batches_per_step": G, "windows_per_step": call_windows,
                        "positions": 1000, "features": 90, "windows_per_gpu": args.steps * call_windows,
                        "resident_windows_per_gpu": n_res, "sharding": "by rank, no collective"},
-            "roofline": {"bound": bound, "kernel": {"fp32": "gru_kernel (GRU recurrence, fp32 MFMA; decoder launches include the heads' product)",
+            "roofline": {"bound": bound, "kernel": {"fp32": "gru_pair_kernel (GRU recurrence of two window tiles per 8-wave workgroup, fp32 MFMA; "
+                                            "decoder launches include the heads' product)",
                                     "bf16": "gru_fused_bf16_kernel (projection + recurrence per layer, bf16 MFMA; "
                                             "bound in practice by the fp32 gate math, not the matrix pipe)",
                                     "fp32x3": "gru_x3_kernel (GRU recurrence, 6 bf16 MFMAs per fp32 product "
@@ -239,6 +342,16 @@ def main():
                          "path_frac": round(value / world * FLOP_PER_WINDOW /
                                             (BF16_MFMA_PEAK if args.precision == "bf16" else FP32_MFMA_PEAK), 4)},
         }
+        if args.precision != "fp32":
+            out["precision_check"] = precision_check(eng, args.precision, images, dev)
+        if host_elapsed is not None:
+            hv = world * hn / host_elapsed
+            out["host_path"] = {
+                "value": round(hv, 1), "unit": "windows/s", "vs_device_resident": round(hv / value, 4),
+                "what": "page-locked host uint8 images -> labels in page-locked host memory, one helen_polish_host "
+                        "call per rank over %d windows (sub-batches of %d: upload k+1 | kernels k | download k-1); "
+                        "PCIe included; labels checked equal to the device path" % (hn, call_windows),
+                "h2d_GBps": round(hv / world * 90000 / 1e9, 2)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B)
         print(json.dumps(out))

@@ -27,6 +27,25 @@ def plan_devices(device_ids, visible_devices):
     return devs, len(devs)
 
 
+def vet_image_directory(image_dir, images_per_file=4):
+    """Schema check of a few images of every file before any process is started (helen_amd.check_images,
+    SURVEY.md 8f-2): the report goes to stderr only when something is off, and an image the reader would refuse
+    raises its error right here (`IMAGE SIZE ERROR`, dataloader_predict.py:85-86) instead of from a worker
+    process minutes into the run.  Returns the number of (non-fatal) findings."""
+    import io
+
+    from .check_images import check_image_directory
+    report, size_errors = io.StringIO(), []
+    n = check_image_directory(image_dir, images_per_file=images_per_file, out=report, size_errors=size_errors)
+    if n:
+        sys.stderr.write("WARN: IMAGE DIRECTORY CHECK (python -m helen_amd check_images -i %s):\n%s"
+                         % (image_dir, report.getvalue()))
+    if size_errors:
+        path, shape = size_errors[0]
+        raise ValueError("IMAGE SIZE ERROR: " + str(path) + " " + str(tuple(shape)))
+    return n
+
+
 def call_consensus(image_dir, model_path, batch_size, num_workers, threads, output_dir,
                    output_prefix, gpu_mode, device_ids, callers):
     if not os.path.isfile(model_path):
@@ -65,6 +84,8 @@ def call_consensus(image_dir, model_path, batch_size, num_workers, threads, outp
     sys.stderr.write("INFO: AVAILABLE GPU DEVICES: " + str(device_ids) + "\n")
 
     input_files = file_manager.get_file_paths_from_directory(image_dir)
+    if input_files and os.environ.get("HELEN_SKIP_IMAGE_CHECK", "") != "1":
+        vet_image_directory(image_dir)
     file_chunks = file_manager.shard_round_robin(input_files, callers)
     callers = len(file_chunks)
     if callers == 0:

@@ -21,7 +21,7 @@ FILTER_NAMES = {1: "deflate", 2: "shuffle", 3: "fletcher32", 4: "szip", 5: "nbit
 
 def check_image(f, name):
     """-> (facts dict per dataset, list of problems) for image group `name` of open file `f`."""
-    facts, problems = {}, []
+    facts, problems, size_errors = {}, [], []
     L, H = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT
     base = "images/" + name + "/"
     for ds in REQUIRED + LABELS:
@@ -35,17 +35,20 @@ def check_image(f, name):
                 ds, [FILTER_NAMES.get(x, x) for x in i["filters"]]))
     im, po = facts.get("image"), facts.get("position")
     if im is not None:
-        if im["class"] != "int" or len(im["shape"]) != 2 or im["shape"][1] != H:
+        # the reader does np.array(image, dtype=np.uint8) (dataloader_predict.py:69): integers of any width and
+        # floats are all taken (values outside 0..255 wrap there as they do here)
+        if im["class"] not in ("int", "float") or len(im["shape"]) != 2 or im["shape"][1] != H:
             problems.append("image is %s %s, expected integers [l <= %d, %d]" % (im["class"], im["shape"], L, H))
+            size_errors.append(tuple(im["shape"]))
         elif im["shape"][0] > L:
             problems.append("image has %d positions (> SEQ_LENGTH %d)" % (im["shape"][0], L))
-        elif im["size"] != 1:
-            problems.append("image elements are %d bytes wide (read as uint8: values > 255 would wrap)" % im["size"])
+            size_errors.append(tuple(im["shape"]))
     if po is not None:
         if po["class"] != "int" or len(po["shape"]) != 2 or po["shape"][1] != 3:
             problems.append("position is %s %s, expected integers [l, 3]" % (po["class"], po["shape"]))
         elif im is not None and len(im["shape"]) == 2 and po["shape"][0] != im["shape"][0]:
             problems.append("position has %d rows, image %d" % (po["shape"][0], im["shape"][0]))
+            size_errors.append(tuple(im["shape"]))
     for ds in ("contig_start", "contig_end", "feature_chunk_idx"):
         i = facts.get(ds)
         if i is not None and (i["class"] != "int" or int(_count(i["shape"])) < 1):
@@ -56,6 +59,7 @@ def check_image(f, name):
         i = facts.get(ds)
         if i is not None and im is not None and (i["class"] != "int" or i["shape"] != im["shape"][:1]):
             problems.append("%s is %s %s, expected integers [%d]" % (ds, i["class"], i["shape"], im["shape"][0]))
+    facts["_size_errors"] = size_errors     # shapes the reader raises IMAGE SIZE ERROR on (dataloader_predict.py:85-86)
     return facts, problems
 
 
@@ -85,8 +89,9 @@ def _describe(i):
     return s
 
 
-def check_image_directory(image_dir, images_per_file=8, out=sys.stdout):
-    """Vet every file of `image_dir`; prints a report, returns the number of problems found."""
+def check_image_directory(image_dir, images_per_file=8, out=sys.stdout, size_errors=None):
+    """Vet every file of `image_dir`; prints a report, returns the number of problems found.  `size_errors`
+    (a list) collects (file, shape) of images the reader would refuse with IMAGE SIZE ERROR."""
     import os
     n_problems = 0
     if not os.path.isdir(image_dir):
@@ -107,6 +112,10 @@ def check_image_directory(image_dir, images_per_file=8, out=sys.stdout):
             shown = False
             for name in names[::step][:images_per_file]:
                 facts, problems = check_image(f, name)
+                if size_errors is not None:
+                    size_errors.extend((path, shape) for shape in facts.pop("_size_errors"))
+                else:
+                    facts.pop("_size_errors")
                 if not shown:
                     for ds in REQUIRED + LABELS:
                         if ds in facts:

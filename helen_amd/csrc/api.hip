@@ -296,7 +296,17 @@ constexpr int kWsMinWorkgroups = 384;   // 1.5 workgroups per CU-slot pair: belo
 
 void launch_enc_gemm(HelenModel* m, hipStream_t s, int tiles, int npos) {
     const dim3 grid(gemm_grid(npos, tiles)), block(HELEN_GEMM_WAVES * 64);
-    if (3 * tiles >= kWsMinWorkgroups)
+    // All three give the same gi bit for bit (same MFMA order per accumulator); HELEN_ENC_WS8=0/1 forces the
+    // one-workgroup-per-tile kernel off / on (A/B probes).
+    static const char* force8 = getenv("HELEN_ENC_WS8");
+    const int cus = 256, rounds = (tiles + cus - 1) / cus;
+    const bool ws8 = (force8 && *force8) ? *force8 == '1'
+                                         : (tiles > cus / 2 && rounds * cus - tiles <= cus / 8) || (rounds == 1 && tiles > 170);
+    if (ws8)
+        // one long workgroup per tile, one per CU: wants whole rounds of 256 tiles
+        LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_ws8_kernel, dim3(tiles), dim3(512), m->xa, kXaTileStride, m->wp_enc,
+               m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles);
+    else if (3 * tiles >= kWsMinWorkgroups)
         // enough tiles to fill the chip with one workgroup per (tile, column set): weights stay in
         // registers, same MFMA order per accumulator as gemm_gi_kernel (bit-identical gi)
         LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_ws_kernel, dim3(3 * ((tiles + 7) / 8 * 8)), dim3(256), m->xa,

@@ -32,7 +32,7 @@ int fail(const char* fmt, ...) {
 
 constexpr int kSeq = 1000;   // ImageSizeOptions.SEQ_LENGTH  (Options.py:16)
 constexpr int kFeat = 90;    // ImageSizeOptions.IMAGE_HEIGHT (Options.py:14)
-constexpr int kName = 128;   // bytes reserved per contig name in the batch arrays
+constexpr int kName = 256;   // bytes reserved per contig name in the batch arrays (a longer name is an error, never cut)
 
 struct Quiet {
     Quiet() { H5Eset_auto2(H5E_DEFAULT, nullptr, nullptr); }
@@ -77,7 +77,8 @@ int read_i64_first(hid_t loc, const char* name, int64_t* out) {
     return rc;
 }
 
-// first element of a string dataset (fixed- or variable-length), NUL-terminated into out[cap]
+// first element of a string dataset (fixed- or variable-length), NUL-terminated into out[cap];
+// -1: missing / not a string, -2: does not fit into cap bytes (two names must never merge by truncation)
 int read_str_first(hid_t loc, const char* name, char* out, size_t cap) {
     hid_t d = H5Dopen2(loc, name, H5P_DEFAULT);
     if (d < 0) return -1;
@@ -92,9 +93,12 @@ int read_str_first(hid_t loc, const char* name, char* out, size_t cap) {
             H5Tset_size(mt, H5T_VARIABLE);
             std::vector<char*> ptrs((size_t)n, nullptr);
             if (H5Dread(d, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, ptrs.data()) >= 0) {
-                if (ptrs[0]) snprintf(out, cap, "%s", ptrs[0]);
-                H5Dvlen_reclaim(mt, s, H5P_DEFAULT, ptrs.data());
                 rc = 0;
+                if (ptrs[0]) {
+                    if (strlen(ptrs[0]) >= cap) rc = -2;
+                    snprintf(out, cap, "%s", ptrs[0]);
+                }
+                H5Dvlen_reclaim(mt, s, H5P_DEFAULT, ptrs.data());
             }
             H5Tclose(mt);
         } else {
@@ -106,7 +110,7 @@ int read_str_first(hid_t loc, const char* name, char* out, size_t cap) {
                 const size_t c = len < cap - 1 ? len : cap - 1;
                 memcpy(out, buf.data(), c);
                 out[c] = 0;
-                rc = 0;
+                rc = len > cap - 1 ? -2 : 0;
             }
             H5Tclose(mt);
         }
@@ -210,7 +214,7 @@ int helen_io_list_images(const char* path, char* out, size_t cap, long long* n_o
  * is the reader's "IMAGE SIZE ERROR".
  *   images    [n, 1000, 90] uint8      positions [n, 1000, 3] int64
  *   meta      [n, 3] int64 = contig_start, contig_end, feature_chunk_idx
- *   contigs   [n, 128] char, NUL-terminated */
+ *   contigs   [n, 256] char, NUL-terminated */
 int helen_io_read_images(const char* path, const char* names, int n, uint8_t* images, int64_t* positions,
                          int64_t* meta, char* contigs) {
     hid_t f = get_file(path);
@@ -227,6 +231,10 @@ int helen_io_read_images(const char* path, const char* names, int n, uint8_t* im
         int64_t* pos = positions + (size_t)i * kSeq * 3;
         int rows = 0, prow = 0;
         int rc = read_str_first(g, "contig", contigs + (size_t)i * kName, kName);
+        if (rc == -2) {
+            H5Gclose(g);
+            return fail("%s: image '%s': contig name longer than %d bytes", path, name.c_str(), kName - 1);
+        }
         rc |= read_i64_first(g, "contig_start", meta + (size_t)i * 3 + 0);
         rc |= read_i64_first(g, "contig_end", meta + (size_t)i * 3 + 1);
         rc |= read_i64_first(g, "feature_chunk_idx", meta + (size_t)i * 3 + 2);

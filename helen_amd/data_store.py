@@ -40,7 +40,7 @@ class DataStore(object):
             self.file_handler.close()
 
     def write_batch(self, contigs, meta, positions, bases, rles, sel=None):
-        """write_prediction for a whole batch: contigs = list of str or packed u8 [n,128], meta i64
+        """write_prediction for a whole batch: contigs = list of str or packed u8 [n,256], meta i64
         [n,3] = (contig_start, contig_end, chunk_id), positions i64 [n,1000,3], labels u8 [n,1000];
         `sel` = optional row indices (in order) to write instead of all rows."""
         if self._native is not None:

@@ -185,6 +185,10 @@ class HelenEngine(object):
             h_out.data_ptr(), self._stream()))
         return base, rle, h_out
 
+    def inject_failure(self, sub_batch):
+        """Test hook: the next polish_host fails right after enqueuing sub-batch `sub_batch` (-1 disarms)."""
+        _lib.check(self._lib.helen_debug_inject_failure(self._handle, int(sub_batch)))
+
     # ---- per-kernel-class timing (HIP events inside the library) ----
     def set_profiling(self, classes):
         mask = 0

@@ -91,6 +91,7 @@ def _load():
                                P, ctypes.c_size_t, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint)]),
         "H5Pget_chunk": (I, [H, I, ctypes.POINTER(_hsize)]),
         "H5Pset_chunk": (I, [H, I, ctypes.POINTER(_hsize)]), "H5Pset_deflate": (I, [H, ctypes.c_uint]),
+        "H5Pset_shuffle": (I, [H]),
         "H5Zfilter_avail": (I, [I]),
     }
     for name, (res, args) in sigs.items():
@@ -304,17 +305,20 @@ class File(object):
             L.H5Sclose(sid)
             L.H5Dclose(did)
 
-    def write(self, path, value, dtype=None, chunks=None, gzip=None):
+    def write(self, path, value, dtype=None, chunks=None, gzip=None, shuffle=False, string="fixed"):
         """Create dataset `path` (intermediate groups are created) from a Python int (scalar
-        int64 dataset, what `h5py_file[path] = int` makes) or an ndarray.  `chunks` (a shape) makes it
-        chunked, `gzip` (1..9) adds the deflate filter (as h5py's compression="gzip" does)."""
+        int64 dataset, what `h5py_file[path] = int` makes), a str / bytes (see `string`) or an ndarray
+        (a 0-d array makes a scalar dataset).  `chunks` (a shape) makes it chunked, `gzip` (1..9) adds the
+        deflate filter (as h5py's compression="gzip" does), `shuffle` the byte-shuffle filter before it.
+        string = "fixed" (one-element array of a fixed-length string: numpy 'S'), "vlen" (one-element array of a
+        variable-length string: h5py's str), "scalar" / "vlen_scalar" (the same as scalar datasets)."""
         if self.mode != "w":
             raise Hdf5Error("file not opened for writing")
         L = self._lib
         if isinstance(value, (int, np.integer)) and dtype is None:
             arr = np.array(int(value), dtype=np.int64)
         elif isinstance(value, (str, bytes)):
-            return self._write_string(path, value)
+            return self._write_string(path, value, string)
         else:
             arr = np.ascontiguousarray(value, dtype=dtype)
         dt = arr.dtype
@@ -326,10 +330,12 @@ class File(object):
             dims = (_hsize * arr.ndim)(*arr.shape)
             sid = L.H5Screate_simple(arr.ndim, dims, None)
         dcpl = 0
-        if (chunks is not None or gzip) and arr.ndim > 0 and arr.size:
+        if (chunks is not None or gzip or shuffle) and arr.ndim > 0 and arr.size:
             dcpl = L.H5Pcreate(_gid("H5P_CLS_DATASET_CREATE_ID_g"))
             ch = tuple(chunks) if chunks is not None else arr.shape
             L.H5Pset_chunk(dcpl, arr.ndim, (_hsize * arr.ndim)(*[max(1, min(int(c), int(d))) for c, d in zip(ch, arr.shape)]))
+            if shuffle:
+                L.H5Pset_shuffle(dcpl)
             if gzip:
                 L.H5Pset_deflate(dcpl, int(gzip))
         did = L.H5Dcreate2(self._fid, path.encode(), _gid(_STD[dt]), sid, self._lcpl, dcpl, 0)
@@ -344,19 +350,28 @@ class File(object):
         if rc < 0:
             raise Hdf5Error("%s: writing '%s' failed" % (self.path, path))
 
-    def _write_string(self, path, value):
-        """Fixed-length string array of one element (how the synthetic image files store `contig`)."""
+    def _write_string(self, path, value, kind="fixed"):
+        """A string dataset of one element: fixed-length (how numpy 'S' arrays and the synthetic image files
+        store `contig`) or variable-length (how h5py stores Python str), as a [1] array or a scalar."""
         L = self._lib
         data = value.encode() if isinstance(value, str) else value
+        vlen = kind.startswith("vlen")
         size = max(len(data), 1)
         tid = L.H5Tcopy(_gid("H5T_C_S1_g"))
-        L.H5Tset_size(tid, size)
-        dims = (_hsize * 1)(1)
-        sid = L.H5Screate_simple(1, dims, None)
+        L.H5Tset_size(tid, ctypes.c_size_t(-1).value if vlen else size)
+        if kind in ("scalar", "vlen_scalar"):
+            sid = L.H5Screate(H5S_SCALAR)
+        else:
+            dims = (_hsize * 1)(1)
+            sid = L.H5Screate_simple(1, dims, None)
         did = L.H5Dcreate2(self._fid, path.encode(), tid, sid, self._lcpl, 0, 0)
         if did < 0:
             raise Hdf5Error("%s: cannot create dataset '%s'" % (self.path, path))
-        buf = ctypes.create_string_buffer(data, size)
+        if vlen:
+            keep = ctypes.create_string_buffer(data)
+            buf = (ctypes.c_char_p * 1)(ctypes.cast(keep, ctypes.c_char_p))
+        else:
+            buf = ctypes.create_string_buffer(data, size)
         rc = L.H5Dwrite(did, tid, 0, 0, 0, buf)
         L.H5Dclose(did)
         L.H5Sclose(sid)

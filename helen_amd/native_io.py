@@ -9,7 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libhelen_io.so")
-NAME_BYTES = 128
+NAME_BYTES = 256
 _lib = None
 _tried = False
 
@@ -84,7 +84,7 @@ def list_images(path):
 
 
 def read_images(path, names, images, positions, meta, contigs):
-    """Fill images u8 [n,1000,90], positions i64 [n,1000,3], meta i64 [n,3], contigs u8 [n,128]
+    """Fill images u8 [n,1000,90], positions i64 [n,1000,3], meta i64 [n,3], contigs u8 [n,256]
     (all C-contiguous views, e.g. into shared memory) with the `names` of one file."""
     lib = load()
     n = len(names)
@@ -93,13 +93,13 @@ def read_images(path, names, images, positions, meta, contigs):
                                   contigs.ctypes.data)
     if rc != 0:
         msg = _err(lib)
-        if msg.startswith("IMAGE SIZE ERROR"):
+        if msg.startswith("IMAGE SIZE ERROR") or "contig name longer than" in msg:
             raise ValueError(msg)
         raise IOError(msg)
 
 
 def contig_names(contigs):
-    """u8 [n,128] NUL-terminated -> list of str."""
+    """u8 [n,NAME_BYTES] NUL-terminated -> list of str."""
     return [bytes(row).split(b"\0", 1)[0].decode() for row in np.asarray(contigs)]
 
 
@@ -107,7 +107,9 @@ def pack_contigs(names, out=None):
     arr = out if out is not None else np.zeros((len(names), NAME_BYTES), np.uint8)
     arr[:] = 0
     for i, s in enumerate(names):
-        b = s.encode()[:NAME_BYTES - 1]
+        b = s.encode()
+        if len(b) > NAME_BYTES - 1:      # never cut: two contigs sharing a prefix would merge into one group
+            raise ValueError("contig name longer than %d bytes: %r" % (NAME_BYTES - 1, s))
         arr[i, :len(b)] = np.frombuffer(b, np.uint8)
     return arr
 

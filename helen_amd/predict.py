@@ -189,7 +189,7 @@ def _feeder_loop(calls, free_slots, ready_q, pool, cap, err, num_workers=0):
     try:
         for batches in calls:
             slot = free_slots.get()
-            if slot is None:
+            if slot is None:        # a writer failed: the main loop must not wait for more slots
                 return
             pairs = [p for b in batches for p in b]
             futures = []
@@ -200,10 +200,21 @@ def _feeder_loop(calls, free_slots, ready_q, pool, cap, err, num_workers=0):
             else:
                 fill_shared(slot.path, cap, 0, pairs)
             ready_q.put((slot, len(pairs), futures, len(batches)))
-        ready_q.put(None)
     except Exception as e:
         err.append(e)
-        ready_q.put(None)
+    finally:
+        ready_q.put(None)           # whatever happened, the consumer gets its end-of-stream
+
+
+def _get_or_error(q, *error_lists):
+    """q.get() that gives up (returns None, like the end-of-stream sentinel) as soon as a pipeline stage has
+    reported an error: a failed writer must fail the run, not leave it waiting for a slot that never comes."""
+    while True:
+        try:
+            return q.get(timeout=0.5)
+        except queue.Empty:
+            if any(error_lists):
+                return None
 
 
 def predict(test_file, output_filename, model_path, batch_size, num_workers, rank, device_id):
@@ -286,7 +297,7 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
                 sys.stderr.write("INFO: SLOTS NOT PAGE-LOCKED (" + str(e) + "), USING STAGED COPIES.\n")
         while True:
             t0 = time.time()
-            item = ready_q.get()
+            item = _get_or_error(ready_q, werr, ferr)
             if item is None:
                 break
             slot, n, futures, nb = item

@@ -22,9 +22,12 @@ def prediction_file_name(output_filename, rank, writer=0):
 
 
 def writer_process(k, writers, filename, task_q, done_q):
-    """Writer process k of `writers`: for every device call, store the windows of its regions."""
+    """Writer process k of `writers`: for every device call, store the windows of its regions.  The file is
+    created when the first window arrives: a writer no region hashes to leaves NO file behind (an HDF5 file
+    without a `predictions` group makes stitch -- this one and the reference's, StitchInterface.py:50-60 --
+    raise)."""
+    store = None
     try:
-        store = DataStore(filename, mode="w")
         while True:
             task = task_q.get()
             if task is None:
@@ -33,10 +36,13 @@ def writer_process(k, writers, filename, task_q, done_q):
             slot = attach_slot(path, cap)
             sel = np.nonzero(writer_of_region(slot.meta[:n], writers) == k)[0].astype(np.int32)
             if sel.size:
+                if store is None:
+                    store = DataStore(filename, mode="w")
                 store.write_batch(slot.contigs[:n], slot.meta[:n], slot.positions[:n], slot.bases[:n],
                                   slot.rles[:n], sel=sel)
             done_q.put((path, None))
-        store.close()
+        if store is not None:
+            store.close()
         done_q.put((None, None))
     except Exception as e:
         done_q.put((None, "writer %d: %r" % (k, e)))

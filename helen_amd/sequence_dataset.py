@@ -128,15 +128,25 @@ class SharedSlot(object):
                        self.cap * native_io.NAME_BYTES, self.cap * L, self.cap * L)
         total = sum(self._sizes)
         if create:
-            # RAM-backed when /dev/shm has room for it (a container's default 64 MB tmpfs does not, and
-            # writing past a tmpfs' size is a SIGBUS, not an error code); otherwise the temp directory
-            d = None
+            # RAM-backed when /dev/shm really has the pages (a container's default tmpfs is 64 MB, and touching a
+            # page past a tmpfs' size is a SIGBUS, not an error code): the pages are RESERVED here with
+            # posix_fallocate -- a sparse ftruncate would let every slot of every rank pass the same free-space
+            # check -- and a refusal (ENOSPC) sends this slot to the temp directory instead.
+            fd = path = None
             if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK):
-                st = os.statvfs("/dev/shm")
-                if st.f_bavail * st.f_frsize > 2 * total:
-                    d = "/dev/shm"
-            fd, path = tempfile.mkstemp(prefix="helen_slot_", dir=d)
-            os.ftruncate(fd, total)
+                fd, path = tempfile.mkstemp(prefix="helen_slot_", dir="/dev/shm")
+                try:
+                    os.posix_fallocate(fd, 0, total)
+                except OSError:
+                    os.close(fd)
+                    _unlink_quietly(path)
+                    fd = path = None
+            if fd is None:
+                fd, path = tempfile.mkstemp(prefix="helen_slot_", dir=None)
+                try:
+                    os.posix_fallocate(fd, 0, total)
+                except OSError:      # a file system without fallocate: plain (sparse) truncate
+                    os.ftruncate(fd, total)
             os.close(fd)
             import atexit
             atexit.register(_unlink_quietly, path)      # also when the run dies with an exception

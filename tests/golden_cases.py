@@ -48,12 +48,14 @@ def load_case(case):
 
 # Stated fp32 tolerance of the path (BASELINE.json north_star: "pre-argmax logits within a stated
 # fp32 tolerance"): two correct fp32 implementations of the 1,900-step recurrence differ by ~5e-7
-# on logits; we allow 2e-4 absolute + 2e-4 relative on logits and hidden state and
-# 1e-4 absolute on the accumulated softmax (values in [0, 2]).
-LOGIT_ATOL = 2e-4
-LOGIT_RTOL = 2e-4
-ACC_ATOL = 1e-4
-HIDDEN_ATOL = 1e-4
+# on logits at the first chunk and by up to ~2e-5 after 19 chunks of carried state (|logit| <= 12.5;
+# measured HIP vs reference: logits 2.1e-5, hidden 2.2e-6, accumulated softmax 9e-6 -- the reference's
+# own fp32 result is 1.7e-5 from a float64 evaluation).  Stated: 5e-5 absolute + 2e-5 relative on
+# logits, 1e-5 absolute on the hidden state, 3e-5 absolute on the accumulated softmax (values in [0, 2]).
+LOGIT_ATOL = 5e-5
+LOGIT_RTOL = 2e-5
+ACC_ATOL = 3e-5
+HIDDEN_ATOL = 1e-5
 
 
 def label_mismatch_report(acc_ref, lab_ref, lab_got, name):

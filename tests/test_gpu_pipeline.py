@@ -92,6 +92,18 @@ def test_cli_polish_with_workers(workdir):
     from helen_amd.stitch import perform_stitch
     again = perform_stitch(pdir, str(d / "restitch"), "again", 2)
     assert open(again).read().split("\n")[1] == fasta[1]
+    # ... and equal to what the ORACLE's labels give when a naive, independent statement of the reference's
+    # stitch procedure (tests/naive_stitch.py; alignments from the reference's own SSW when built) joins them
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import naive_stitch
+    from helen_amd.data_store import DataStore
+    odir = d / "oracle_predictions"
+    odir.mkdir()
+    with DataStore(str(odir / "oracle_0.hdf"), "w") as store:
+        for (cs, chunk), (eb, er, pos) in expected.items():
+            store.write_prediction("chr20_synth", cs, cs + 1000, chunk, pos, eb, er)
+    want = naive_stitch.stitch_directory(str(odir), threads=1)    # polish ran with -t 1 (helen.py default)
+    assert list(want) == ["chr20_synth"] and want["chr20_synth"] == fasta[1]
 
 
 def test_drop_in_model_object(workdir):

@@ -262,3 +262,83 @@ def test_compressed_images_and_schema_check(tmp_path):
     n = check_image_directory(str(bad), out=rep)
     text = rep.getvalue()
     assert n >= 2 and "missing dataset 'feature_chunk_idx'" in text and "expected integers [l <= 1000, 90]" in text
+
+
+def test_reader_takes_every_plausible_schema_variant(tmp_path):
+    """SURVEY.md 8f-2 without real data: whatever h5py or MarginPolish could plausibly have written for the six
+    datasets the reference reader touches (dataloader_predict.py:64-70) must read the same through the native
+    batch reader and the per-item reader: `contig` as a fixed-length, variable-length or scalar string; the three
+    integers in any width, signed or not, as [1] arrays or scalars; `image` as uint8, a wider integer or a
+    float; `position` as int32 / int64 / uint32 / uint64 (the reader casts it to int); chunked + shuffle +
+    deflate storage; label datasets present in an inference directory."""
+    from helen_amd.sequence_dataset import _load_batch
+    img = make_images(8, seed=33)
+    rng = np.random.default_rng(3)
+    variants = [
+        dict(contig="fixed", ints=np.int64, scalar=False, image=np.uint8, position=np.int64, store={}),
+        dict(contig="vlen", ints=np.int32, scalar=False, image=np.uint8, position=np.int32, store={}),
+        dict(contig="scalar", ints=np.uint32, scalar=True, image=np.uint16, position=np.uint32, store={}),
+        dict(contig="vlen_scalar", ints=np.int16, scalar=True, image=np.int32, position=np.uint64,
+             store=dict(gzip=6, shuffle=True)),
+        dict(contig="fixed", ints=np.uint64, scalar=False, image=np.int64, position=np.int64,
+             store=dict(gzip=1)),
+        dict(contig="vlen", ints=np.uint8, scalar=True, image=np.float32, position=np.int64,
+             store=dict(shuffle=True)),
+        dict(contig="fixed", ints=np.int8, scalar=False, image=np.uint8, position=np.int16, store={}, labels=True),
+        dict(contig="scalar", ints=np.uint16, scalar=False, image=np.float64, position=np.int32,
+             store=dict(gzip=9, shuffle=True), labels=True),
+    ]
+    path = str(tmp_path / "variants.h5")
+    lengths = [1000, 1000, 613, 1000, 1, 999, 1000, 500]
+    with hdf5.File(path, "w") as f:
+        for i, v in enumerate(variants):
+            L = lengths[i]
+            small = np.dtype(v["ints"]).itemsize == 1            # one-byte integers cannot hold 800
+            start, chunk = (100 if small else 800 * i), (i % 3)
+            base = "images/w%02d/" % i
+            f.write(base + "contig", "chr%d_variant" % i, string=v["contig"])
+            for name, val in (("contig_start", start), ("contig_end", start + (27 if small else 1000)),
+                              ("feature_chunk_idx", chunk)):
+                f.write(base + name, np.array(val if v["scalar"] else [val], v["ints"]))
+            f.write(base + "image", img[i, :L].astype(v["image"]), v["image"],
+                    chunks=(min(L, 256), 90) if v["store"] else None, **v["store"])
+            pos = np.stack([5000 + np.arange(L), rng.integers(0, 3, L), rng.integers(0, 2, L)], 1)
+            f.write(base + "position", pos.astype(v["position"]), v["position"],
+                    chunks=(L, 3) if v["store"] else None, **v["store"])
+            if v.get("labels"):
+                f.write(base + "label_base", np.zeros(L, np.uint8))
+                f.write(base + "label_run_length", np.zeros(L, np.uint8))
+            v["want"] = ("chr%d_variant" % i, start, start + (27 if small else 1000), chunk, L, pos)
+    ds = SequenceDataset(None, file_list=[path])
+    assert len(ds) == 8
+    batch = _load_batch(ds.all_images)                            # native reader when libhelen_io.so is built
+    for i, v in enumerate(variants):
+        contig, start, end, chunk, L, pos = v["want"]
+        item = ds[i]                                              # per-item (ctypes) reader
+        for got in ((batch.contig[i], batch.contig_start[i], batch.contig_end[i], batch.chunk_id[i],
+                     batch.images[i], batch.positions[i]), item[:6]):
+            assert (got[0], int(got[1]), int(got[2]), int(got[3])) == (contig, start, end, chunk), (i, got[:4])
+            assert got[4].dtype == np.uint8 and np.array_equal(got[4][:L], img[i, :L]) and not got[4][L:].any()
+            assert np.array_equal(got[5][:L], pos) and (got[5][L:] == -1).all()
+
+
+def test_call_consensus_vets_the_image_directory_first(tmp_path, capsys):
+    """A directory with a malformed image is refused before any process is started, with the reference reader's
+    IMAGE SIZE ERROR text (dataloader_predict.py:85-86)."""
+    from helen_amd.call_consensus import vet_image_directory
+    from helen_amd.synthetic import write_image_dir
+    good = str(tmp_path / "good")
+    write_image_dir(good, 12, n_files=2, short_every=5)
+    assert vet_image_directory(good) == 0
+    bad = tmp_path / "bad"
+    bad.mkdir()
+    with hdf5.File(str(bad / "b.h5"), "w") as f:
+        base = "images/x-0-1000-0/"
+        f.write(base + "contig", "x")
+        for k in ("contig_start", "contig_end", "feature_chunk_idx"):
+            f.write(base + k, np.array([0], np.int64))
+        f.write(base + "image", np.zeros((1000, 10), np.uint8))       # F = 10 is not this model's 90
+        f.write(base + "position", np.zeros((1000, 3), np.int64))
+    with pytest.raises(ValueError, match="IMAGE SIZE ERROR"):
+        vet_image_directory(str(bad))
+    assert "expected integers" in capsys.readouterr().err

@@ -150,3 +150,94 @@ def test_writer_count_and_region_sharding(monkeypatch):
         assert np.array_equal(k[0::3], k[1::3]) and np.array_equal(k[0::3], k[2::3])
         if writers > 1:
             assert len(np.unique(k)) == writers            # 200 regions spread over every writer
+
+
+def _stand_in(monkeypatch):
+    import torch
+
+    import helen_amd.predict as P
+    import helen_amd.transducer as T
+    monkeypatch.setattr(T.TransducerGRU, "engine", property(lambda self: _StandInEngine()))
+    monkeypatch.setattr(T.TransducerGRU, "to", lambda self, d: self)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    return P
+
+
+def test_fewer_regions_than_writers_leaves_no_empty_file(tmp_path, monkeypatch):
+    """6 windows with the CLI default of 8 writers: a writer no region hashes to must not leave an HDF5 file
+    without a `predictions` group behind (stitch -- this one and the reference's -- raises on such a file)."""
+    from helen_amd.model_handler import ModelHandler
+    from helen_amd.stitch import perform_stitch
+    from helen_amd.synthetic import write_image_dir
+    from helen_amd.weights import make_weights
+    P = _stand_in(monkeypatch)
+    monkeypatch.setenv("HELEN_WRITERS", "8")
+    img_dir = str(tmp_path / "img")
+    write_image_dir(img_dir, 6, n_files=1)
+    model = str(tmp_path / "m.pkl")
+    ModelHandler.save_model(make_weights(), None, 128, 1, 0, model)
+    out_dir = tmp_path / "pred"
+    out_dir.mkdir()
+    P.predict(sorted(glob.glob(os.path.join(img_dir, "*.h5"))), str(out_dir / "p"), model, 512, 8, 0, 0)
+    outs = sorted(glob.glob(str(out_dir / "*.hdf")))
+    assert 1 <= len(outs) <= 6
+    total = 0
+    for o in outs:
+        with hdf5.File(o) as f:
+            assert "predictions" in f, o
+            for contig in f.keys("predictions"):
+                total += len(f.keys("predictions/" + contig))
+    assert total == 6                                   # every region in exactly one file
+    perform_stitch(str(out_dir), str(tmp_path / "fasta"), "s", 2)
+    fasta = open(glob.glob(str(tmp_path / "fasta" / "*.fa"))[0]).read()
+    assert fasta.startswith(">") and len(fasta) > 1000
+
+
+def test_writer_failure_fails_the_run_instead_of_hanging(tmp_path, monkeypatch):
+    """The writer is the slow stage and then fails: every slot sits in its queue, the feeder waits for a free
+    slot, the main loop for a filled one.  The run must end with the writer's error."""
+    import time
+
+    from helen_amd.data_store import DataStore
+    from helen_amd.model_handler import ModelHandler
+    from helen_amd.synthetic import write_image_dir
+    from helen_amd.weights import make_weights
+    P = _stand_in(monkeypatch)
+    monkeypatch.setattr(P, "DEVICE_CALL_WINDOWS", 16)   # 10 device calls, 5 slots
+    monkeypatch.setenv("HELEN_WRITERS", "1")
+
+    def slow_then_broken(self, *a, **k):
+        time.sleep(1.5)
+        raise IOError("disk full (injected)")
+    monkeypatch.setattr(DataStore, "write_batch", slow_then_broken)
+    img_dir = str(tmp_path / "img")
+    write_image_dir(img_dir, 160, n_files=2)
+    model = str(tmp_path / "m.pkl")
+    ModelHandler.save_model(make_weights(), None, 128, 1, 0, model)
+    t0 = time.time()
+    with pytest.raises(IOError, match="disk full"):
+        P.predict(sorted(glob.glob(os.path.join(img_dir, "*.h5"))), str(tmp_path / "out"), model, 16, 0, 0, 0)
+    assert time.time() - t0 < 60
+
+
+def test_long_contig_names_are_refused_not_cut(tmp_path):
+    """Two contigs sharing a 255-byte prefix must never merge into one prediction group by truncation."""
+    from helen_amd import native_io
+    from helen_amd.sequence_dataset import SequenceDataset
+    ok = "c" * 255
+    arr = native_io.pack_contigs([ok])
+    assert native_io.contig_names(arr) == [ok]
+    with pytest.raises(ValueError, match="longer than"):
+        native_io.pack_contigs(["c" * 256])
+    bad = str(tmp_path / "long.h5")
+    with hdf5.File(bad, "w") as f:
+        base = "images/x-0-1000-0/"
+        f.write(base + "contig", "d" * 300)
+        for k in ("contig_start", "contig_end", "feature_chunk_idx"):
+            f.write(base + k, np.array([0], np.int64))
+        f.write(base + "image", np.zeros((1000, 90), np.uint8))
+        f.write(base + "position", np.zeros((1000, 3), np.int64))
+    ds = SequenceDataset(None, file_list=[bad])
+    assert ds[0][0] == "d" * 300                        # the per-item reader has no limit ...
+    with pytest.raises(ValueError, match="longer than"):
+        list(ds.iter_batches(1))                        # ... the batch arrays refuse what they cannot hold
