@@ -130,7 +130,7 @@ def precision_check(eng, precision, images, dev):
         biggest = max(biggest, float(ob0.abs().max().item()), float(or0.abs().max().item()))
     ref.close()
     return {"against": "the fp32 path of this library on the same windows", "windows_labels": n,
-            "label_identity": round(same, 6), "windows_logits": m, "max_abs_logit_diff": round(worst, 5),
+            "label_identity": round(same, 6), "windows_logits": m, "max_abs_logit_diff": float("%.3g" % worst),
             "max_abs_logit": round(biggest, 3), "precision": precision}
 
 

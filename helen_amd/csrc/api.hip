@@ -324,13 +324,13 @@ bool use_pair_recurrence(int tiles) {
     if (force && *force) return *force == '1';
     const int cus = 256;
     const int wg_single = 2 * tiles, wg_pair = 2 * ((tiles + 1) / 2);
-    // measured per resident set at 100 steps: one workgroup per CU alone 0.36 ms, two per CU 0.64 ms, a pair
-    // workgroup 0.59 ms
+    // measured per resident set at 100 steps: one workgroup per CU alone 0.36 ms, two per CU 0.635 ms, a pair
+    // workgroup 0.617 ms
     auto t_single = [&](int wgs) {
         const int full = wgs / (2 * cus), rest = wgs % (2 * cus);
-        return full * 0.64 + (rest == 0 ? 0.0 : rest <= cus ? 0.36 : 0.64);
+        return full * 0.635 + (rest == 0 ? 0.0 : rest <= cus ? 0.36 : 0.635);
     };
-    const double t_pair = ((wg_pair + cus - 1) / cus) * 0.59;
+    const double t_pair = ((wg_pair + cus - 1) / cus) * 0.617;
     return t_pair < t_single(wg_single);
 }
 

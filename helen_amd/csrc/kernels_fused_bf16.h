@@ -163,11 +163,13 @@ __global__ __launch_bounds__(512) void gru_fused_bf16_kernel(
             }
         }
         // B: gates
+        {   // four cells as two packed pairs (gru_cell4): the gate math is what bounds this kernel
+            const f32x4 hn4 = gru_cell4(ar, az, ahn, splat4(0.f), splat4(0.f), gin[2], hprev);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float hn = gru_cell(ar[r], az[r], ahn[r], 0.f, 0.f, gin[2][r], hprev[r]);
-            hprev[r] = hn;
-            store_h(cur ^ 1, r, hn);
+            for (int r = 0; r < 4; ++r) {
+                hprev[r] = hn4[r];
+                store_h(cur ^ 1, r, hn4[r]);
+            }
         }
         // C: everything this wave has in flight is older than a step except its input row of step s+1
         // (issued after the previous step's store): wait for all of it

@@ -31,7 +31,9 @@ namespace helen {
 //     while its partner's MFMAs keep the pipe busy, and both do their gate math together;
 //   - gi fragments go from global memory straight into registers (each wave reads only its own: there is
 //     nothing to share through LDS), loaded at the start of the other tile's M phase, a full half-step ahead;
-//   - the layer output (encoder) / the head partial products (decoder) of step s-1 leave during M(x,s).
+//   - the layer output (encoder) / the head partial products (decoder) of step s-1 leave during M(x,s); the
+//     decoder's eight partial tiles of step s-2 are added up by one of the OLDER waves of a SIMD right before the
+//     barrier, where it would otherwise only wait for its partner.
 // grid (ceil(tiles / 2), 2 directions).  An odd tile count makes the last workgroup do its one tile twice
 // (identical values are written twice).
 // ------------------------------------------------------------------------------------------------
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
 
     // this wave's gi fragments (gate g = column tile 8g + v) of each tile's next step, in registers
     f32x4 G[2][3];
-    auto load_gi = [&](int x) {
+    auto load_gi = [&](int x) __attribute__((always_inline)) {
         const unsigned l16 = in_block(lane16);
 #pragma unroll
         for (int g = 0; g < 3; ++g) G[x][g] = *(const f32x4*)(gi_next[x] + (l16 + (unsigned)g * 8192u));
@@ -102,6 +104,9 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
 #pragma unroll
     for (int x = 0; x < 2; ++x) hbuf[x * 1024 + tid] = *(const f32x4*)(hid_s[x] + tid16);
     load_gi(0);
+#ifdef HELEN_PAIR_NOLOAD   // timing probe: both tiles' first gi, never reloaded
+    load_gi(1);
+#endif
     __syncthreads();
 
     float hprev[2][4];
@@ -114,92 +119,123 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
     f32x4 a_pref = hbuf[lane];   // group 0 of h_0(-1): the A fragment the first MFMA phase starts with
 
     // the eight k-slices' partial logits of (tile x, parity pb) added in the order gru_kernel adds them
-    auto sum_partials = [&](int x, int pb) {
+    auto sum_partials = [&](int x, int pb) __attribute__((always_inline)) {
         const f32x4* ps = part + (x * 2 + pb) * 512 + lane;
         return (((ps[0] + ps[64]) + (ps[128] + ps[192])) + (ps[256] + ps[320])) + (ps[384] + ps[448]);
     };
 
     // One half-step: MFMA phase and gate math of tile X at step s (CUR = s & 1 at compile time so that every LDS
-    // address is a lane offset + immediate).  `so` = newest step of the OTHER tile o.
-    auto half_step = [&](auto X, auto CUR, int s) {
+    // address is a lane offset + immediate).  `so` = newest step of the OTHER tile o.  STEADY = the caller
+    // guarantees 2 <= s and s + 2 <= T - 1... i.e. every "is there a previous / next step" question is a
+    // compile-time yes (a uniform bool that lives across the phase ends up in a VGPR, and every VALU instruction
+    // between MFMAs costs matrix-pipe time).
+    auto half_step = [&](auto X, auto CUR, auto STEADY, int s) __attribute__((always_inline)) {
         constexpr int x = decltype(X)::value, o = 1 - x, cur = decltype(CUR)::value;
+        constexpr bool steady = decltype(STEADY)::value;
         constexpr int ocur = x ? (cur ^ 1) : cur;                // buffer of h_o(so): (so + 1) & 1
         const int so = x ? s : s - 1;
+        const bool has_next_o = steady || so + 1 < T;            // tile o still has a step so+1 to feed
+        const bool has_prev = steady || s > 0;                   // h_x(s-1) is a step's output (not the initial state)
+        const bool has_prev2 = steady || s > 1;
         const f32x4* hx = hbuf + (x * 2 + cur) * 512;            // h_x(s-1): A operand of this phase
         const f32x4* hb = hx + lane;
-        f32x4 acc[3], a[2], yv = splat4(0.f), hd = splat4(0.f), hp = splat4(0.f);
+        f32x4 acc[3], a[3], yv = splat4(0.f), hd = splat4(0.f), hp = splat4(0.f);
         a[0] = a_pref;
         a[1] = hb[1 * 64];
-        if (so + 1 < T) load_gi(o);                              // tile o's registers were consumed in G(o, so)
-        if (!DEC && s > 0) yv = hx[tid];                         // h_x(s-1) is the layer output of slot s-1
-        if (DEC && s > 0) hd = hb[v * 64];                       // ... or feeds the heads: this wave's k-slice
+#ifndef HELEN_PAIR_NOLOAD   // (timing probe: no gi traffic, results are garbage)
+        if (has_next_o) load_gi(o);                              // tile o's registers were consumed in G(o, so)
+#endif
+        if (!DEC && has_prev) yv = hx[tid];                      // h_x(s-1) is the layer output of slot s-1
+        if (DEC && has_prev) hd = hb[v * 64];                    // ... or feeds the heads: this wave's k-slice
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
+            // A fragment m+2 goes into the register fragment m-1 used, half a group after its last MFMA (straight
+            // after it, hipcc pads the MFMA-read / LDS-write hazard with s_nop 6)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 2; ++e)
 #pragma unroll
                 for (int g = 0; g < 3; ++g)   // the first MFMA of a chain takes its initial value as the C operand
-                    acc[g] = mfma4(a[m & 1][e], W[g][m][e], (m | e) ? acc[g] : g < 2 ? splat4(0.f) : bnv);
+                    acc[g] = mfma4(a[m % 3][e], W[g][m][e], (m | e) ? acc[g] : g < 2 ? splat4(0.f) : bnv);
             __builtin_amdgcn_sched_barrier(0);
-            if (m + 2 < 8) a[m & 1] = hb[(m + 2) * 64];
-            if (m == 1 && DEC && s > 0) {
+            if (m + 2 < 8) a[(m + 2) % 3] = hb[(m + 2) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 2; e < 4; ++e)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g] = mfma4(a[m % 3][e], W[g][m][e], acc[g]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (m == 1 && DEC && has_prev) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) hp = mfma4(hd[e], Bh[e], hp);
             }
-            if (m == 2 && !DEC && s > 0) {
+            if (m == 2 && !DEC && has_prev) {
+#ifndef HELEN_PAIR_NOSTORE   // (timing probe)
                 *(f32x4*)(y_next[x] + in_block(tid16)) = yv;
+#endif
                 y_next[x] += kYStride * 4;
             }
+        }
+        // DEC: tile x's partials of slot s-2 were written in G(x,s-1) and published by the barrier since.  One of
+        // the OLDER waves of a SIMD (v < 4) adds them up here: it is through its MFMAs long before its partner and
+        // would only wait at the barrier.
+        if (DEC && has_prev2) {
+            if (v == ((s - 2) & 3)) *(f32x4*)(pl_next[x] + in_block(lane16)) = sum_partials(x, s & 1);
+            pl_next[x] += 128 * 16;
         }
         // every wave is through M(x,s); the h_o(so) written in the previous half-step's G becomes visible
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         a_pref = hbuf[(o * 2 + ocur) * 512 + lane];              // next phase: M(o, so+1) starts on h_o(so)
-        // DEC: tile o's partials of slot so-1 (written in the previous half-step) are complete: wave (so-1) & 7
-        // adds them up
-        f32x4 lsum = splat4(0.f);
-        const bool have_o = DEC && (x ? s > 0 : s > 1);          // so >= 1
-        const bool sum_o = have_o && ((v - so + 1) & 7) == 0;
-        if (sum_o) lsum = sum_partials(o, (so - 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef HELEN_PAIR_NOGATES   // timing probe: MFMA phase + barrier only (results are garbage)
+        const f32x4 hn = acc[0] + acc[1] + acc[2] + G[x][0] + G[x][1] + G[x][2];
+#else
         const f32x4 hn = gru_cell4(acc[0], acc[1], acc[2], G[x][0], G[x][1], G[x][2], hprev[x]);
+#endif
         float* hw = (float*)(hbuf + (x * 2 + (cur ^ 1)) * 512);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             hprev[x][r] = hn[r];
             hw[hoff + 4 * r] = hn[r];
         }
-        if (DEC && s > 0) (part + ((x * 2 + ((s - 1) & 1)) * 8 + v) * 64)[lane] = hp;
-        if (sum_o) *(f32x4*)(pl_next[o] + in_block(lane16)) = lsum;
-        if (have_o) pl_next[o] += 128 * 16;
+        if (DEC && has_prev) (part + ((x * 2 + ((s - 1) & 1)) * 8 + v) * 64)[lane] = hp;
         __builtin_amdgcn_sched_barrier(0);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
+    using No = std::false_type;
+    using Yes = std::true_type;
+    auto step = [&](auto STEADY, int s_) __attribute__((always_inline)) {   // both tiles; buffer parity = s & 1
+        if (s_ & 1) {
+            half_step(I0{}, I1{}, STEADY, s_);
+            half_step(I1{}, I1{}, STEADY, s_);
+        } else {
+            half_step(I0{}, I0{}, STEADY, s_);
+            half_step(I1{}, I0{}, STEADY, s_);
+        }
+    };
     int s = 0;
-    for (; s + 1 < T; s += 2) {
-        half_step(I0{}, I0{}, s);
-        half_step(I1{}, I0{}, s);
-        half_step(I0{}, I1{}, s + 1);
-        half_step(I1{}, I1{}, s + 1);
+    for (; s < T && s < 2; ++s) step(No{}, s);            // the first two steps: no step s-1 / s-2 yet
+    for (; s + 2 < T; s += 2) {                           // steady state: steps 2 .. T-2, two per trip
+        half_step(I0{}, I0{}, Yes{}, s);
+        half_step(I1{}, I0{}, Yes{}, s);
+        half_step(I0{}, I1{}, Yes{}, s + 1);
+        half_step(I1{}, I1{}, Yes{}, s + 1);
     }
-    if (s < T) {   // odd T: its last step runs on buffer parity 0
-        half_step(I0{}, I0{}, s);
-        half_step(I1{}, I0{}, s);
-    }
+    for (; s < T; ++s) step(No{}, s);                     // the last one or two steps: no step s+1 to feed
     __syncthreads();
     const int last = T & 1;   // buffer of h(T-1)
     if (DEC) {
-        // H(x, s) turns h_x(s-1) into partials and adds up tile o's slot so-1: after the loop tile 1's slot T-2
-        // is still to be added up, and slot T-1 of both tiles has no partials yet.
-        if (T >= 2) {
-            if (v == ((T - 2) & 7)) *(f32x4*)(pl_next[1] + lane16) = sum_partials(1, (T - 2) & 1);
-            pl_next[1] += 128 * 16;   // both tiles' pointers are at slot T-1 now
-        }
+        // H(x, s) turns h_x(s-1) into partials and adds up tile x's slot s-2: after the loop slot T-2 of both tiles
+        // is still to be added up, and slot T-1 has no partials yet.
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
+            if (T >= 2) {
+                if (v == ((T - 2) & 3)) *(f32x4*)(pl_next[x] + lane16) = sum_partials(x, (T - 2) & 1);
+                pl_next[x] += 128 * 16;   // at slot T-1 now
+            }
             const f32x4 hd = hbuf[(x * 2 + last) * 512 + v * 64 + lane];
             f32x4 hp = splat4(0.f);
 #pragma unroll
@@ -207,7 +243,7 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
             (part + ((x * 2 + ((T - 1) & 1)) * 8 + v) * 64)[lane] = hp;
         }
         __syncthreads();
-        if (v == ((T - 1) & 7)) {
+        if (v == ((T - 1) & 3)) {
 #pragma unroll
             for (int x = 0; x < 2; ++x) *(f32x4*)(pl_next[x] + lane16) = sum_partials(x, (T - 1) & 1);
         }

@@ -178,11 +178,13 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
         for (int g = 0; g < 3; ++g) G[g] = gbuf[g * 64 + lane];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (s + 1 < T) dma_gi(slot0 + s + 1);
+        {   // four cells as two packed pairs (gru_cell4)
+            const f32x4 hn4 = gru_cell4(acc[0], acc[1], acc[2], G[0], G[1], G[2], hprev);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float hn = gru_cell(acc[0][r], acc[1][r], acc[2][r], G[0][r], G[1][r], G[2][r], hprev[r]);
-            hprev[r] = hn;
-            store_h(cur ^ 1, r, hn);
+            for (int r = 0; r < 4; ++r) {
+                hprev[r] = hn4[r];
+                store_h(cur ^ 1, r, hn4[r]);
+            }
         }
         HELEN_TICK(3)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -24,14 +24,16 @@ def agg(path):
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
         d[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("End_Timestamp"):
+            d[name]["_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     return d
 
 
 fetch = agg(os.path.join(src, "pmc_FETCH_SIZE", "p_counter_collection.csv"))
 write = agg(os.path.join(src, "pmc_WRITE_SIZE", "p_counter_collection.csv"))
 sq = agg(os.path.join(src, "pmc_sq", "p_counter_collection.csv"))
-out = {"command": "rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 16 --warmup 0 "
-                  "--no-cpu-baseline   (one helen_polish_batch call of 4096 windows)",
+out = {"command": "rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 1 --warmup 0 "
+                  "--no-cpu-baseline --no-host-path   (helen_polish_batch calls of 4096 windows)",
        "notes": "FETCH_SIZE doubled (gfx950 wide-read correction); sizes in bytes per launch",
        "kernels": {}}
 for k in sorted(sq):
@@ -42,7 +44,11 @@ for k in sorted(sq):
     gui = mean(sq, "GRBM_GUI_ACTIVE")
     mf = mean(sq, "SQ_VALU_MFMA_BUSY_CYCLES")
     wave = mean(sq, "SQ_WAVE_CYCLES")
+    ns = mean(sq, "_ns")
     out["kernels"][k] = {
+        # the chip clocks to its power budget: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / kernel duration
+        "effective_clock_GHz": round(gui / 8 / ns, 3) if gui and ns else None,
+        "duration_ms_in_this_pass": round(ns / 1e6, 4) if ns else None,
         "launches_profiled": len(sq[k]["GRBM_GUI_ACTIVE"]),
         "hbm_read_bytes_per_launch": None if f is None else int(2 * f * 1024),
         "hbm_write_bytes_per_launch": None if w is None else int(w * 1024),

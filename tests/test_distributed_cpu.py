@@ -55,3 +55,17 @@ def test_two_rank_sharding_and_timing_rule(tmp_path):
     r = json.loads(line)
     assert r["max_time"] == 2.0 and r["total"] == 7.0
     assert r["shard0"] == ["img_00.h5", "img_02.h5", "img_04.h5", "img_06.h5"]
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` launches N ranks itself -- and says so loudly, with a non-zero exit code, when
+    fewer than N GPUs are visible (none in the build container) instead of quietly running one rank."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2
+    assert "--gpus 2 but only 0 GPU(s) visible" in out.stderr
+    # a rank count that disagrees with the launcher's WORLD_SIZE is refused as well
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 2 and "WORLD_SIZE is 4" in out.stderr
