@@ -14,10 +14,7 @@ def add_polish_arguments(parser, threads_default):
     parser.add_argument("-b", "--batch_size", type=int, required=False, default=512,
                         help="Batch size for testing, default is 512.")
     parser.add_argument("-w", "--num_workers", type=int, required=False, default=8,
-                        help="Number of workers to assign to the dataloader. Default is 8.  With 2 or more, a rank "
-                             "also runs as many prediction-writer processes (at most 8; $HELEN_WRITERS overrides) and "
-                             "writes <prefix>_<rank>.hdf plus <prefix>_<rank>_w<k>.hdf instead of the reference's single "
-                             "file per rank; stitch reads every *.hdf of the directory.  HELEN_WRITERS=1 keeps one file.")
+                        help="Number of workers to assign to the dataloader. Default is 8.")
     parser.add_argument("-t", "--threads", type=int, required=False, default=threads_default,
                         help="Number of PyTorch threads to use, default is %d." % threads_default)
     parser.add_argument("-o", "--output_dir", type=str, required=False, default="./output/",

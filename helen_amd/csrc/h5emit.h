@@ -1,0 +1,237 @@
+// h5emit.h -- a minimal HDF5 *emitter* for the prediction file of `helen call_consensus`.
+//
+// libhdf5 spends ~100-120 us creating the group and three small datasets of one window
+// (DataStore.py:123-133) whatever the caller does -- 8 k windows/s per process against 81 k windows/s of
+// device throughput -- which is why round 1 sharded the writer over processes and files.  The layout of
+// a prediction file is fixed and append-only, so this writes the bytes itself: the datasets' raw data
+// and object headers as the windows arrive (one sequential stream through a large buffer), the group
+// structures at close, when every name is known.  Only the oldest, checksum-free structures of the
+// HDF5 File Format Specification (version 1.x: superblock version 0, version 1 object headers, "old
+// style" groups = local heap + version 1 B-tree + symbol table nodes, contiguous / compact layouts) are
+// produced; any libhdf5 >= 1.6 and h5py read them, and so does helen's stitch.
+//
+//   file     := superblock | objects ... | group structures ...
+//   dataset  := raw data (8-aligned) + object header {dataspace v1, datatype v1 fixed-point,
+//               fill value v2, layout v3 contiguous (compact for the scalars)}
+//   group    := local heap (names) + symbol table nodes (8 sorted entries each) + B-tree nodes
+//               (32 children each, key = heap offset of the largest name of the child to its left)
+//               + object header {symbol table message}
+#pragma once
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace h5emit {
+
+constexpr uint64_t kUndef = ~0ull;
+constexpr int kLeafK = 4;       // symbol table node: up to 2 * kLeafK symbols   (libhdf5's defaults,
+constexpr int kInternalK = 16;  // B-tree node: up to 2 * kInternalK children     recorded in the superblock)
+constexpr size_t kSnodBytes = 8 + 2 * kLeafK * 40;
+constexpr size_t kTreeBytes = 24 + 2 * kInternalK * 8 + (2 * kInternalK + 1) * 8;
+
+struct Child {
+    std::string name;
+    uint64_t header;   // address of the child's object header
+};
+
+class File {
+   public:
+    ~File() {
+        if (fd_ >= 0) ::close(fd_);
+    }
+    bool open(const char* path) {
+        fd_ = ::open(path, O_CREAT | O_TRUNC | O_WRONLY, 0644);
+        if (fd_ < 0) return false;
+        buf_.reserve(kFlush + (1 << 20));
+        // room for the superblock (96 bytes), written last
+        buf_.assign(kDataStart, 0);
+        base_ = 0;
+        return true;
+    }
+    bool ok() const { return fd_ >= 0 && !failed_; }
+
+    // ---- datasets ----
+    // integer dataset of `rank` dims with contiguous layout; returns the object header address
+    uint64_t dataset(const void* data, size_t bytes, int elem_size, bool is_signed, int rank, const uint64_t* dims) {
+        align8();
+        const uint64_t addr = tell();
+        put(data, bytes);
+        align8();
+        const uint64_t hdr = tell();
+        const size_t msgs = (8 + 8 + 8 * rank) + (8 + 16) + (8 + 8) + (8 + 24);
+        header_prefix(4, msgs);
+        msg_dataspace(rank, dims);
+        msg_datatype(elem_size, is_signed);
+        msg_fill(/*alloc late*/ 2);
+        msg_head(0x0008, 24);   // layout v3, contiguous
+        put8(3); put8(1); put64(addr); put64(bytes); pad(6);
+        return hdr;
+    }
+    // scalar int64 dataset with compact layout (the value lives in the object header)
+    uint64_t scalar_i64(int64_t v) {
+        align8();
+        const uint64_t hdr = tell();
+        const size_t msgs = (8 + 8) + (8 + 16) + (8 + 8) + (8 + 16);
+        header_prefix(4, msgs);
+        msg_dataspace(0, nullptr);
+        msg_datatype(8, true);
+        msg_fill(/*alloc early: required for compact*/ 1);
+        msg_head(0x0008, 16);   // layout v3, compact: size u16 + data
+        put8(3); put8(0); put16(8); put64((uint64_t)v); pad(4);
+        return hdr;
+    }
+
+    // ---- groups ----
+    // old-style group over `kids` (any order; sorted here by name, bytewise like strcmp); returns the object
+    // header address, and the B-tree / heap addresses for the root entry of the superblock
+    uint64_t group(std::vector<Child>& kids, uint64_t* btree_out = nullptr, uint64_t* heap_out = nullptr) {
+        std::sort(kids.begin(), kids.end(), [](const Child& a, const Child& b) { return a.name < b.name; });
+        // local heap: "" at offset 0, then the names, each NUL-terminated and padded to 8
+        std::vector<uint64_t> off(kids.size());
+        std::vector<uint8_t> heap(8, 0);
+        for (size_t i = 0; i < kids.size(); ++i) {
+            off[i] = heap.size();
+            const size_t n = kids[i].name.size() + 1;
+            heap.insert(heap.end(), kids[i].name.begin(), kids[i].name.end());
+            heap.resize(heap.size() + 1 + ((8 - (n & 7)) & 7), 0);
+        }
+        align8();
+        const uint64_t heap_addr = tell();
+        put("HEAP", 4); put8(0); pad(3);
+        put64(heap.size());        // data segment size
+        put64(1);                  // free list head: H5HL_FREE_NULL (no free block)
+        put64(heap_addr + 32);     // data segment address: right behind this prefix
+        put(heap.data(), heap.size());
+        // symbol table nodes
+        struct Node { uint64_t addr, max_key; };
+        std::vector<Node> level;
+        for (size_t i = 0; i < kids.size(); i += 2 * kLeafK) {
+            const size_t n = std::min<size_t>(2 * kLeafK, kids.size() - i);
+            const uint64_t a = tell();
+            put("SNOD", 4); put8(1); put8(0); put16((uint16_t)n);
+            for (size_t k = 0; k < n; ++k) {
+                put64(off[i + k]); put64(kids[i + k].header); put32(0); put32(0); pad(16);
+            }
+            pad((2 * kLeafK - n) * 40);
+            level.push_back({a, off[i + n - 1]});
+        }
+        // B-tree levels, bottom up; an empty group is one empty leaf-level node
+        int depth = 0;
+        uint64_t root;
+        for (;;) {
+            std::vector<Node> up;
+            const size_t per = 2 * kInternalK;
+            const size_t nodes = std::max<size_t>(1, (level.size() + per - 1) / per);
+            const uint64_t first = tell();
+            for (size_t j = 0; j < nodes; ++j) {
+                const size_t lo = j * per, n = level.empty() ? 0 : std::min(per, level.size() - lo);
+                const uint64_t a = first + j * kTreeBytes;
+                put("TREE", 4); put8(0); put8((uint8_t)depth); put16((uint16_t)n);
+                put64(j ? a - kTreeBytes : kUndef);
+                put64(j + 1 < nodes ? a + kTreeBytes : kUndef);
+                put64(lo ? level[lo - 1].max_key : 0);   // left key: the largest name of everything to the left ("" at the far left)
+                for (size_t k = 0; k < n; ++k) {
+                    put64(level[lo + k].addr);
+                    put64(level[lo + k].max_key);
+                }
+                pad((per - n) * 16);
+                up.push_back({a, n ? level[lo + n - 1].max_key : 0});
+            }
+            level.swap(up);
+            ++depth;
+            if (level.size() == 1) {
+                root = level[0].addr;
+                break;
+            }
+        }
+        const uint64_t hdr = tell();
+        header_prefix(1, 8 + 16);
+        msg_head(0x0011, 16);   // symbol table message
+        put64(root); put64(heap_addr);
+        if (btree_out) *btree_out = root;
+        if (heap_out) *heap_out = heap_addr;
+        return hdr;
+    }
+
+    // superblock with `root` (from group()) as the root group, flush, close
+    bool finish(uint64_t root_header, uint64_t root_btree, uint64_t root_heap) {
+        align8();
+        const uint64_t eof = tell();
+        flush();
+        uint8_t sb[96];
+        size_t o = 0;
+        auto w8 = [&](uint8_t v) { sb[o++] = v; };
+        auto w16 = [&](uint16_t v) { memcpy(sb + o, &v, 2); o += 2; };
+        auto w32 = [&](uint32_t v) { memcpy(sb + o, &v, 4); o += 4; };
+        auto w64 = [&](uint64_t v) { memcpy(sb + o, &v, 8); o += 8; };
+        const uint8_t sig[8] = {0x89, 'H', 'D', 'F', '\r', '\n', 0x1a, '\n'};
+        memcpy(sb, sig, 8); o = 8;
+        w8(0); w8(0); w8(0); w8(0); w8(0); w8(8); w8(8); w8(0);
+        w16(kLeafK); w16(kInternalK); w32(0);
+        w64(0); w64(kUndef); w64(eof); w64(kUndef);
+        w64(0); w64(root_header); w32(1); w32(0); w64(root_btree); w64(root_heap);
+        bool good = !failed_ && ::pwrite(fd_, sb, sizeof(sb), 0) == (ssize_t)sizeof(sb);
+        good = (::close(fd_) == 0) && good;
+        fd_ = -1;
+        return good;
+    }
+
+   private:
+    static constexpr size_t kFlush = 8 << 20;
+    static constexpr size_t kDataStart = 2048;
+    int fd_ = -1;
+    bool failed_ = false;
+    std::vector<uint8_t> buf_;
+    uint64_t base_ = 0;   // file offset of buf_[0]
+
+    uint64_t tell() const { return base_ + buf_.size(); }
+    void flush() {
+        size_t done = 0;
+        while (done < buf_.size() && !failed_) {
+            const ssize_t n = ::write(fd_, buf_.data() + done, buf_.size() - done);
+            if (n <= 0) failed_ = true;
+            else done += (size_t)n;
+        }
+        base_ += buf_.size();
+        buf_.clear();
+    }
+    void put(const void* p, size_t n) {
+        const uint8_t* b = (const uint8_t*)p;
+        buf_.insert(buf_.end(), b, b + n);
+        if (buf_.size() >= kFlush) flush();
+    }
+    void pad(size_t n) { buf_.resize(buf_.size() + n, 0); }
+    void align8() { pad((8 - (tell() & 7)) & 7); }
+    void put8(uint8_t v) { buf_.push_back(v); }
+    void put16(uint16_t v) { put(&v, 2); }
+    void put32(uint32_t v) { put(&v, 4); }
+    void put64(uint64_t v) { put(&v, 8); }
+
+    void header_prefix(int nmsgs, size_t msg_bytes) {   // version 1 object header prefix, 16 bytes
+        put8(1); put8(0); put16((uint16_t)nmsgs); put32(1); put32((uint32_t)msg_bytes); pad(4);
+    }
+    void msg_head(uint16_t type, uint16_t size) { put16(type); put16(size); put8(0); pad(3); }
+    void msg_dataspace(int rank, const uint64_t* dims) {
+        msg_head(0x0001, (uint16_t)(8 + 8 * rank));
+        put8(1); put8((uint8_t)rank); put8(0); put8(0); put32(0);
+        for (int i = 0; i < rank; ++i) put64(dims[i]);
+    }
+    void msg_datatype(int size, bool is_signed) {   // class 0 (fixed point), version 1, little endian
+        msg_head(0x0003, 16);
+        put8(0x10); put8(is_signed ? 0x08 : 0x00); put8(0); put8(0);
+        put32((uint32_t)size); put16(0); put16((uint16_t)(8 * size)); pad(4);
+    }
+    void msg_fill(int alloc_time) {   // version 2: allocation time, write time "if set", default value
+        msg_head(0x0005, 8);
+        put8(2); put8((uint8_t)alloc_time); put8(2); put8(1); put32(0);
+    }
+};
+
+}  // namespace h5emit

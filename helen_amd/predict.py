@@ -10,12 +10,13 @@ double-buffered copies and labels come back as uint8; reader processes fill shar
 while the previous slot is on the GPU and the one before is being written by a writer thread.
 No process group is created (the reference's gloo group is never used on this path).
 
-The prediction writer is sharded over W processes per rank (W = $HELEN_WRITERS, default one per reader
-worker, 1..8): creating the three small HDF5 datasets of a window costs ~70 us inside
-libhdf5, ~10-14 k windows/s per process, against ~75 k windows/s of device throughput.
-Writer 0 keeps the reference's file name `<output>_<rank>.hdf`, writer k > 0 writes
-`<output>_<rank>_w<k>.hdf`; all chunks of one region go to the same file, and stitch takes every
-`*.hdf` of the directory (StitchInterface.py:35-36), so the result is the same.
+The prediction file is the reference's single `<output>_<rank>.hdf` per rank, written by one thread through the
+direct HDF5 emitter of libhelen_io.so (helen_amd/csrc/h5emit.h): libhdf5 itself spends ~100 us creating the
+group and three small datasets of a window (8-14 k windows/s per process against ~81 k windows/s of device
+throughput), the emitter writes the same objects at ~100 k windows/s.  $HELEN_WRITERS=W > 1 opts into the
+round-1 pool of W writer processes: writer 0 keeps `<output>_<rank>.hdf`, writer k > 0 writes
+`<output>_<rank>_w<k>.hdf`, all chunks of one region go to the same file, a writer without regions leaves no
+file, and stitch takes every `*.hdf` of the directory (StitchInterface.py:35-36).
 """
 import collections
 import multiprocessing as mp
@@ -117,14 +118,15 @@ class _DeviceStage(object):
 
 
 def writer_count(num_workers):
-    """Writer processes per rank: $HELEN_WRITERS if set, else as many as reader workers (1..8): storing
-    a window costs libhdf5 about what reading one does (~100 us), so the two pools want the same size
-    (measured under a 16-CPU quota: 8 readers + 8 writers 48 k windows/s, 8 + 4 35 k, 16 + 1 9 k).
-    HELEN_WRITERS=1 (or -w 0/1) keeps the reference's single `<output>_<rank>.hdf`."""
+    """Writer processes per rank: ONE by default -- the reference's single `<output>_<rank>.hdf`
+    (predict_gpu.py:55), written by a thread of this process through the direct HDF5 emitter
+    (helen_amd/csrc/h5emit.h: ~100 k windows/s, above the device's 81 k).  $HELEN_WRITERS=N > 1 opts into the
+    round-1 pool of N writer processes and `<output>_<rank>_w<k>.hdf` shards (useful only with
+    HELEN_IO_WRITER=libhdf5, whose ~8 k windows/s per process were the reason for the pool)."""
     env = os.environ.get("HELEN_WRITERS")
     if env:
         return max(1, int(env))
-    return min(8, max(1, int(num_workers)))
+    return 1
 
 
 class _WriterPool(object):

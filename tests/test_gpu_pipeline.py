@@ -82,9 +82,8 @@ def test_cli_polish_with_workers(workdir):
     assert len(pred_dirs) == 1                                          # PolishInterface.py:65-69
     pdir = os.path.join(out, pred_dirs[0])
     files = [os.path.join(pdir, f) for f in sorted(os.listdir(pdir))]
-    # -w 2: two reader workers and two writer processes -> <prefix>_<rank>.hdf + <prefix>_<rank>_w1.hdf,
-    # which stitch reads as one set (StitchInterface.py:35-36)
-    assert [os.path.basename(f) for f in files] == ["asm_0.hdf", "asm_0_w1.hdf"]
+    # -w 2: two reader workers; ONE prediction file per rank, as the reference writes it (predict_gpu.py:55)
+    assert [os.path.basename(f) for f in files] == ["asm_0.hdf"]
     _check_prediction_files(files, expected)
     # ... and the stitched FASTA: one record, identical to stitching the same predictions again
     fasta = open(os.path.join(out, "asm.fa")).read().split("\n")

@@ -131,12 +131,12 @@ def test_reader_error_surfaces(tmp_path, monkeypatch):
 
 
 def test_writer_count_and_region_sharding(monkeypatch):
-    """Writer pool sizing (one writer per reader worker, 1..8, $HELEN_WRITERS overrides) and the region ->
-    writer map: every chunk of a region, and a repeat of the same image, lands on the same writer."""
+    """Writer count (ONE file per rank unless $HELEN_WRITERS opts into the pool) and the region -> writer map of
+    the pool: every chunk of a region, and a repeat of the same image, lands on the same writer."""
     import helen_amd.predict as P
     from helen_amd.prediction_writer import prediction_file_name, writer_of_region
     monkeypatch.delenv("HELEN_WRITERS", raising=False)
-    assert [P.writer_count(w) for w in (0, 1, 2, 8, 40)] == [1, 1, 2, 8, 8]
+    assert [P.writer_count(w) for w in (0, 1, 2, 8, 40)] == [1, 1, 1, 1, 1]
     monkeypatch.setenv("HELEN_WRITERS", "3")
     assert P.writer_count(0) == 3 and P.writer_count(40) == 3
     assert prediction_file_name("/o/p", 2) == "/o/p_2.hdf" and prediction_file_name("/o/p", 2, 5) == "/o/p_2_w5.hdf"
