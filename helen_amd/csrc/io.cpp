@@ -9,6 +9,7 @@
 #include <hdf5.h>
 
 #include "h5emit.h"
+#include "h5scan.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -16,8 +17,10 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <set>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -145,6 +148,145 @@ int read_2d(hid_t loc, const char* name, hid_t memtype, int cols, int max_rows, 
     return rc;
 }
 
+// ---- reader side, fast path: the file's own structures walked in a read-only mapping (h5scan.h) ----------
+// One entry per image file: the scanner and the object header of its `images` group; `usable` is false for a
+// file the scanner does not take (libhdf5 reads it instead).  $HELEN_IO_READER=libhdf5 turns the fast path off.
+long long g_fast_windows = 0, g_library_windows = 0;   // images read by the scanner / by libhdf5 in this process
+struct Scanned {
+    h5scan::File file;
+    bool usable = false;
+    bool has_images = false;
+    uint64_t images = 0;
+};
+std::map<std::string, std::unique_ptr<Scanned>>& scanned_files() {
+    static std::map<std::string, std::unique_ptr<Scanned>> m;
+    return m;
+}
+Scanned* scan_file(const char* path) {
+    static const bool off = [] {
+        const char* e = getenv("HELEN_IO_READER");
+        return e && strcmp(e, "libhdf5") == 0;
+    }();
+    if (off) return nullptr;
+    auto& m = scanned_files();
+    auto it = m.find(path);
+    if (it != m.end()) return it->second->usable ? it->second.get() : nullptr;
+    if (m.size() >= 64) m.clear();
+    std::unique_ptr<Scanned> sc(new Scanned());
+    if (sc->file.open(path)) {
+        std::vector<std::pair<std::string, uint64_t>> top;
+        if (sc->file.children(sc->file.root(), &top)) {
+            sc->usable = true;
+            for (auto& kv : top)
+                if (kv.first == "images") {
+                    sc->has_images = true;
+                    sc->images = kv.second;
+                }
+        }
+    }
+    if (!sc->usable) sc->file.close();
+    Scanned* raw = sc.get();
+    m[path] = std::move(sc);
+    return raw->usable ? raw : nullptr;
+}
+
+// element 0 of an integer dataset as int64 (any width, signed or not); false: not a plain integer dataset
+bool scan_i64_first(const h5scan::File& f, uint64_t group, const char* name, int64_t* out) {
+    uint64_t h;
+    h5scan::Dataset d;
+    if (!f.lookup(group, name, &h) || !f.dataset(h, &d) || d.cls != 0 || !d.data || d.count() < 1) return false;
+    switch (d.size * 2 + (d.is_signed ? 1 : 0)) {
+        case 2: *out = *(const uint8_t*)d.data; break;
+        case 3: *out = *(const int8_t*)d.data; break;
+        case 4: { uint16_t v; memcpy(&v, d.data, 2); *out = v; break; }
+        case 5: { int16_t v; memcpy(&v, d.data, 2); *out = v; break; }
+        case 8: { uint32_t v; memcpy(&v, d.data, 4); *out = v; break; }
+        case 9: { int32_t v; memcpy(&v, d.data, 4); *out = v; break; }
+        case 16: { uint64_t v; memcpy(&v, d.data, 8); *out = (int64_t)v; break; }
+        case 17: { int64_t v; memcpy(&v, d.data, 8); *out = v; break; }
+        default: return false;
+    }
+    return true;
+}
+
+// a [rows, cols] dataset converted like np.array(x, dtype=T) does: T = uint8_t (image) or int64_t (position)
+template <typename T>
+bool scan_2d(const h5scan::Dataset& d, T* dst) {
+    const uint64_t n = d.count();
+    const uint8_t* p = d.data;
+    if (n && !p) return false;
+#define HELEN_CONVERT(S) { for (uint64_t i = 0; i < n; ++i) { S v; memcpy(&v, p + i * sizeof(S), sizeof(S)); dst[i] = (T)v; } return true; }
+    if (d.cls == 0) {
+        if (d.size == (int)sizeof(T) && (sizeof(T) == 1 || d.is_signed == std::is_signed<T>::value)) {
+            memcpy(dst, p, n * sizeof(T));
+            return true;
+        }
+        switch (d.size * 2 + (d.is_signed ? 1 : 0)) {
+            case 2: HELEN_CONVERT(uint8_t)
+            case 3: HELEN_CONVERT(int8_t)
+            case 4: HELEN_CONVERT(uint16_t)
+            case 5: HELEN_CONVERT(int16_t)
+            case 8: HELEN_CONVERT(uint32_t)
+            case 9: HELEN_CONVERT(int32_t)
+            case 16: HELEN_CONVERT(uint64_t)
+            case 17: HELEN_CONVERT(int64_t)
+            default: return false;
+        }
+    }
+    if (d.cls == 1) {
+        if (d.size == 4) { for (uint64_t i = 0; i < n; ++i) { float v; memcpy(&v, p + 4 * i, 4); dst[i] = (T)(int64_t)v; } return true; }
+        if (d.size == 8) { for (uint64_t i = 0; i < n; ++i) { double v; memcpy(&v, p + 8 * i, 8); dst[i] = (T)(int64_t)v; } return true; }
+    }
+#undef HELEN_CONVERT
+    return false;
+}
+
+// helen_io_read_images through the scanner.  0: done; -1: the reader's error (message set); 1: something this
+// scanner does not take -- the caller reads the batch through libhdf5 instead.
+int fast_read_images(Scanned* sc, const char* path, const char* names, int n, uint8_t* images, int64_t* positions,
+                     int64_t* meta, char* contigs) {
+    const h5scan::File& f = sc->file;
+    if (!sc->has_images) return 1;
+    const char* p = names;
+    std::string contig;
+    for (int i = 0; i < n; ++i) {
+        const char* e = strchr(p, '\n');
+        const std::string name = e ? std::string(p, e - p) : std::string(p);
+        p = e ? e + 1 : p + name.size();
+        uint64_t g, h;
+        if (!f.lookup(sc->images, name.c_str(), &g)) return 1;
+        h5scan::Dataset dc, di, dp;
+        if (!f.lookup(g, "contig", &h) || !f.dataset(h, &dc) || !f.first_string(dc, &contig)) return 1;
+        if (!scan_i64_first(f, g, "contig_start", meta + (size_t)i * 3 + 0) ||
+            !scan_i64_first(f, g, "contig_end", meta + (size_t)i * 3 + 1) ||
+            !scan_i64_first(f, g, "feature_chunk_idx", meta + (size_t)i * 3 + 2))
+            return 1;
+        if (!f.lookup(g, "image", &h) || !f.dataset(h, &di)) return 1;
+        if (!f.lookup(g, "position", &h) || !f.dataset(h, &dp)) return 1;
+        if (di.cls > 1 || dp.cls != 0) return 1;
+        const int rows = di.rank == 2 ? (int)di.dims[0] : -1;
+        if (di.rank != 2 || (int)di.dims[1] != kFeat || di.dims[0] > (uint64_t)kSeq || dp.rank != 2 || dp.dims[1] != 3 ||
+            dp.dims[0] != di.dims[0])
+            return fail("IMAGE SIZE ERROR: %s (%d, %d)", path, rows, kFeat);   // dataloader_predict.py:85-86
+        uint8_t* img = images + (size_t)i * kSeq * kFeat;
+        int64_t* pos = positions + (size_t)i * kSeq * 3;
+        if (!scan_2d<uint8_t>(di, img) || !scan_2d<int64_t>(dp, pos)) return 1;
+        if (rows < kSeq) {                                                        // :74-82
+            memset(img + (size_t)rows * kFeat, 0, (size_t)(kSeq - rows) * kFeat);
+            for (int k = rows * 3; k < kSeq * 3; ++k) pos[k] = -1;
+        }
+        // np.array2string(...).replace("'", "") of the reader: strip quotes
+        std::string clean;
+        for (char c : contig)
+            if (c != '\'') clean.push_back(c);
+        if (clean.size() > (size_t)kName - 1)
+            return fail("%s: image '%s': contig name longer than %d bytes", path, name.c_str(), kName - 1);
+        char* c = contigs + (size_t)i * kName;
+        memcpy(c, clean.c_str(), clean.size() + 1);
+    }
+    return 0;
+}
+
 // ---- writer side ------------------------------------------------------------------------------
 struct Region {                      // predictions/<contig>/<contig-start-end>
     std::vector<h5emit::Child> kids; // contig_start, contig_end, then one group per chunk id
@@ -182,6 +324,27 @@ int helen_io_abi_version(void) { return 1; }
  * return 1 if the file has no `images` group (the reader warns and skips, :47-49).
  * Returns -1 on error, -2 if `cap` is too small (*n_out then holds the bytes needed). */
 int helen_io_list_images(const char* path, char* out, size_t cap, long long* n_out) {
+    if (Scanned* sc = scan_file(path)) {
+        *n_out = 0;
+        if (!sc->has_images) return 1;
+        std::vector<std::pair<std::string, uint64_t>> kids;
+        if (sc->file.children(sc->images, &kids)) {      // B-tree order = name order = what h5py's .keys() yields
+            size_t used = 0;
+            for (auto& kv : kids) {
+                if (used + kv.first.size() + 1 <= cap) {
+                    memcpy(out + used, kv.first.data(), kv.first.size());
+                    out[used + kv.first.size()] = '\n';
+                }
+                used += kv.first.size() + 1;
+            }
+            if (used > cap) {
+                *n_out = (long long)used;
+                return -2;
+            }
+            *n_out = (long long)kids.size();
+            return 0;
+        }
+    }
     hid_t f = get_file(path);
     if (f < 0) return fail("cannot open '%s'", path);
     *n_out = 0;
@@ -225,6 +388,12 @@ int helen_io_list_images(const char* path, char* out, size_t cap, long long* n_o
  *   contigs   [n, 256] char, NUL-terminated */
 int helen_io_read_images(const char* path, const char* names, int n, uint8_t* images, int64_t* positions,
                          int64_t* meta, char* contigs) {
+    if (Scanned* sc = scan_file(path)) {
+        const int rc = fast_read_images(sc, path, names, n, images, positions, meta, contigs);
+        if (rc == 0) g_fast_windows += n;
+        if (rc <= 0) return rc;       // done, or the reader's own error; 1 = not for the scanner: libhdf5 below
+    }
+    g_library_windows += n;
     hid_t f = get_file(path);
     if (f < 0) return fail("cannot open '%s'", path);
     const char* p = names;
@@ -270,10 +439,17 @@ int helen_io_read_images(const char* path, const char* names, int n, uint8_t* im
     return 0;
 }
 
+/* Images this process has read through the direct scanner (out[0]) and through libhdf5 (out[1]). */
+void helen_io_reader_counts(long long* out) {
+    out[0] = g_fast_windows;
+    out[1] = g_library_windows;
+}
+
 /* Drop every cached read handle of this process. */
 void helen_io_close_readers(void) {
     for (auto& kv : open_files()) H5Fclose(kv.second);
     open_files().clear();
+    scanned_files().clear();
 }
 
 /* Prediction file writer (DataStore(filename, 'w'), predict_gpu.py:55). */

@@ -36,6 +36,8 @@ def load():
     lib.helen_io_list_images.restype = ctypes.c_int
     lib.helen_io_list_images.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t,
                                          ctypes.POINTER(ctypes.c_longlong)]
+    lib.helen_io_reader_counts.restype = None
+    lib.helen_io_reader_counts.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
     lib.helen_io_read_images.restype = ctypes.c_int
     lib.helen_io_read_images.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, vp, vp, vp, vp]
     lib.helen_io_writer_open.restype = vp
@@ -81,6 +83,13 @@ def list_images(path):
         if rc != 0:
             raise IOError(_err(lib))
         return buf.raw.split(b"\0", 1)[0].decode().split("\n")[:n.value] if n.value else []
+
+
+def reader_counts():
+    """(images read by the direct scanner, images read through libhdf5) in this process."""
+    out = (ctypes.c_longlong * 2)()
+    load().helen_io_reader_counts(out)
+    return int(out[0]), int(out[1])
 
 
 def read_images(path, names, images, positions, meta, contigs):
