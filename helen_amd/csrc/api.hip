@@ -723,9 +723,33 @@ int helen_polish_host(HelenModel* m, const uint8_t* images, int n_windows, uint8
     if (!m->ring_ready && (rc = build_ring(m))) return rc;
     // Page-locked caller memory (hipHostMalloc / hipHostRegister: torch pinned tensors, the shared-memory slots of
     // helen_amd.predict) is the source / destination of the DMA itself; pageable memory goes through pinned mirrors.
-    const bool in_pinned = host_range_is_pinned(images, (size_t)n_windows * img_bytes);
-    const bool out_pinned = host_range_is_pinned(bases, (size_t)n_windows * lab_bytes) &&
-                            host_range_is_pinned(rles, (size_t)n_windows * lab_bytes);
+    bool in_pinned = host_range_is_pinned(images, (size_t)n_windows * img_bytes);
+    bool out_pinned = host_range_is_pinned(bases, (size_t)n_windows * lab_bytes) &&
+                      host_range_is_pinned(rles, (size_t)n_windows * lab_bytes);
+    // Pageable caller memory is page-locked for the duration of the call (hipHostRegister: under a millisecond per
+    // GB here) and unlocked before returning; where that is refused (ulimit -l, a range that overlaps a registration)
+    // the pinned mirrors take over.
+    struct Registered {
+        void* p[3] = {nullptr, nullptr, nullptr};
+        int n = 0;
+        bool add(const void* q, size_t bytes) {
+            if (hipHostRegister((void*)q, bytes, hipHostRegisterDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
+            p[n++] = (void*)q;
+            return true;
+        }
+        ~Registered() {
+            for (int i = 0; i < n; ++i) (void)hipHostUnregister(p[i]);
+        }
+    } registered;
+    if (!in_pinned) in_pinned = registered.add(images, (size_t)n_windows * img_bytes);
+    if (!out_pinned) {
+        if (registered.add(bases, (size_t)n_windows * lab_bytes)) {
+            if (registered.add(rles, (size_t)n_windows * lab_bytes)) out_pinned = true;
+        }
+    }
     for (int i = 0; i < 2; ++i) {
         if (!in_pinned && !m->pin_in[i]) HIP_TRY(hipHostMalloc((void**)&m->pin_in[i], sub * img_bytes, hipHostMallocDefault));
         if (!out_pinned && !m->pin_out[i]) HIP_TRY(hipHostMalloc((void**)&m->pin_out[i], sub * 2 * lab_bytes, hipHostMallocDefault));

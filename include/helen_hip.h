@@ -139,7 +139,8 @@ int helen_polish_batch(HelenModel* model, const uint8_t* images, int n_windows, 
  * Same, from HOST memory: sub-batches of `max_windows` windows go up with hipMemcpyAsync on a copy
  * stream, overlapped with the kernels of the previous sub-batch and the label download of the one
  * before.  Page-locked caller memory (hipHostMalloc / hipHostRegister, e.g. a torch pinned tensor) is
- * the source and destination of the DMA itself; pageable memory goes through two pinned mirrors.
+ * the source and destination of the DMA itself; pageable memory is page-locked for the duration of
+ * the call (two pinned mirrors take over where that is refused).
  * Synchronous: returns when the labels are in host memory; on an error nothing is left in flight.
  * Hand it MANY sub-batches per call: the first upload and the last download are the only exposed
  * copies.  Replaces the DataLoader -> `.to(device_id)` -> `.cpu()` hand-offs of
