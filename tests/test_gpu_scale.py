@@ -98,7 +98,13 @@ def test_every_fp32_kernel_choice_gives_the_same_bits(scale_case):
     for u, v_ in zip(big.chunk_forward(x, h), (torch.cat(t) for t in zip(small.chunk_forward(x[:1024], h[:1024]),
                                                                           small.chunk_forward(x[1024:], h[1024:])))):
         assert torch.equal(u, v_)
-    for e in (big, small, mid):
+    # an ODD tile count in the pair recurrence (255 tiles: the last workgroup walks its one tile twice)
+    odd = HelenEngine(w, device=0, max_windows=4080)
+    d = odd.polish(dev[:4080], want_acc=True)
+    torch.cuda.synchronize()
+    for name, x, y in zip(("bases", "rles", "acc_base", "acc_rle"), a, d):
+        assert torch.equal(x[:4080], y), name + ": 255-tile call differs"
+    for e in (big, small, mid, odd):
         e.close()
 
 
