@@ -136,8 +136,11 @@ def test_host_path_survives_an_injected_failure():
         assert np.array_equal(ob.numpy(), want_b) and np.array_equal(orr.numpy(), want_r)
     assert eng.device_bytes == held
     assert free0 - torch.cuda.mem_get_info()[0] < (8 << 20)     # nothing accumulates on the device
-    b2, r2 = eng.polish_host(img.numpy().copy())               # pageable caller memory: staged copies
+    b2, r2 = eng.polish_host(img.numpy().copy())               # pageable caller memory: page-locked for the call
     assert np.array_equal(b2, want_b) and np.array_equal(r2, want_r)
+    both = np.zeros((2, n, 1000), np.uint8)                     # two outputs sharing a page: the second cannot be
+    eng.polish_host(img.numpy().copy(), out=(both[0], both[1]))  # registered on its own -> pinned mirrors
+    assert np.array_equal(both[0], want_b) and np.array_equal(both[1], want_r)
     eng.close()
 
 
