@@ -155,9 +155,11 @@ class Writer(object):
             raise IOError(_err(self._lib))
 
     def close(self):
+        """The group structures and the superblock are written here: a failure (disk full) must not pass silently."""
         if self._h:
-            self._lib.helen_io_writer_close(self._h)
-            self._h = None
+            h, self._h = self._h, None
+            if self._lib.helen_io_writer_close(h) != 0:
+                raise IOError(_err(self._lib))
 
 
 def region_sequence(path, contig, region):

@@ -121,3 +121,16 @@ def test_large_groups_and_every_name_length(tmp_path):
     if os.path.exists(H5LS):
         r = subprocess.run([H5LS, path + "/mid/many"], capture_output=True, text=True)
         assert r.returncode == 0 and len(r.stdout.splitlines()) == n
+
+
+@pytest.mark.skipif(not os.path.exists("/dev/full"), reason="no /dev/full")
+def test_a_full_disk_is_an_error_not_a_short_file(monkeypatch):
+    """The emitter buffers 8 MiB and writes the group structures at close: a write that fails must surface as an
+    IOError from write() or close(), never pass silently."""
+    monkeypatch.delenv("HELEN_IO_WRITER", raising=False)
+    rng = np.random.default_rng(0)
+    names, meta, pos, b, r = _batch(8, rng)
+    with pytest.raises(IOError):
+        w = native_io.Writer("/dev/full")
+        w.write(native_io.pack_contigs(names), meta, pos, b, r)
+        w.close()
