@@ -274,6 +274,7 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
             writer_pool.submit(slot, n)
 
     start_time = time.time()
+    t_setup = t_loop_end = start_time
     batch_iterator = 0
     try:
         transducer_model, hidden_size, gru_layers, prev_ite = ModelHandler.load_simple_model(
@@ -297,6 +298,7 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
                 stage = _DeviceStage(engine, slots, cap, device_id)
             except Exception as e:      # page-locking refused (ulimit -l, container policy): staged copies
                 sys.stderr.write("INFO: SLOTS NOT PAGE-LOCKED (" + str(e) + "), USING STAGED COPIES.\n")
+        t_setup = time.time()
         while True:
             t0 = time.time()
             item = _get_or_error(ready_q, werr, ferr)
@@ -326,6 +328,7 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         while stage is not None and stage.inflight and not werr:
             to_writer(*stage.pop())
         STAGE_SECONDS["device"] += time.time() - t1
+        t_loop_end = time.time()
     finally:
         if writer_pool is None:
             wq.put(None)
@@ -346,9 +349,11 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         prediction_data_file.close()
     engine.close()
     if rank == 0:
-        sys.stderr.write("INFO: %d WINDOWS IN %.1f SECS (WAITING FOR READERS %.1f, DEVICE %.1f, WRITER BUSY %.1f).\n"
+        sys.stderr.write("INFO: %d WINDOWS IN %.1f SECS (WAITING FOR READERS %.1f, DEVICE %.1f, WRITER BUSY %.1f; "
+                         "MODEL + ENGINE SET-UP %.1f, FLUSH + CLOSE %.1f).\n"
                          % (len(pairs), time.time() - start_time, STAGE_SECONDS["read_wait"],
-                            STAGE_SECONDS["device"], STAGE_SECONDS["write"]))
+                            STAGE_SECONDS["device"], STAGE_SECONDS["write"], t_setup - start_time,
+                            time.time() - t_loop_end))
 
 
 def _setup(rank, total_callers, args, all_input_files, all_devices):
