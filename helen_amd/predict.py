@@ -274,6 +274,7 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
             writer_pool.submit(slot, n)
 
     start_time = time.time()
+    through_library = 0
     t_setup = t_loop_end = start_time
     batch_iterator = 0
     try:
@@ -305,8 +306,8 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
             if item is None:
                 break
             slot, n, futures, nb = item
-            for f in futures:
-                f.result()                       # raises the reader's exception, if any
+            for f in futures:                    # raises the reader's exception, if any
+                through_library += getattr(f.result(), "through_library", 0)
             t1 = time.time()
             if stage is not None:
                 stage.submit(slot, n)
@@ -354,6 +355,10 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
                          % (len(pairs), time.time() - start_time, STAGE_SECONDS["read_wait"],
                             STAGE_SECONDS["device"], STAGE_SECONDS["write"], t_setup - start_time,
                             time.time() - t_loop_end))
+        if through_library:
+            sys.stderr.write("INFO: %d OF THEM WERE READ THROUGH LIBHDF5: THE DIRECT IMAGE SCANNER DOES NOT TAKE THEIR "
+                             "STORAGE (CHUNKED / FILTERED / NEW-STYLE FILE); SEE python -m helen_amd check_images.\n"
+                             % through_library)
 
 
 def _setup(rank, total_callers, args, all_input_files, all_devices):

@@ -197,13 +197,21 @@ def attach_slot(path, cap):
     return slot
 
 
+class Filled(int):
+    """len(pairs), plus how many of them libhdf5 had to read because the direct scanner declined the file."""
+    through_library = 0
+
+
 def fill_shared(path, cap, offset, pairs):
-    """Worker entry: read `pairs` into slot `path` at window `offset`.  Returns len(pairs)."""
+    """Worker entry: read `pairs` into slot `path` at window `offset`.  Returns len(pairs) (a `Filled`)."""
     slot = attach_slot(path, cap)
     n = len(pairs)
+    before = native_io.reader_counts()[1] if native_io.available() else 0
     fill_batch(pairs, slot.images[offset:offset + n], slot.positions[offset:offset + n],
                slot.meta[offset:offset + n], slot.contigs[offset:offset + n])
-    return n
+    out = Filled(n)
+    out.through_library = (native_io.reader_counts()[1] - before) if native_io.available() else n
+    return out
 
 
 class SequenceDataset(object):

@@ -241,3 +241,30 @@ def test_long_contig_names_are_refused_not_cut(tmp_path):
     assert ds[0][0] == "d" * 300                        # the per-item reader has no limit ...
     with pytest.raises(ValueError, match="longer than"):
         list(ds.iter_batches(1))                        # ... the batch arrays refuse what they cannot hold
+
+
+def test_fallback_reads_are_reported(tmp_path, monkeypatch, capfd):
+    """Files the direct scanner declines (here: chunked + deflated datasets) are read by libhdf5 -- same labels --
+    and the run says how many windows went that way."""
+    from helen_amd.model_handler import ModelHandler
+    from helen_amd.synthetic import write_image_file
+    from helen_amd.weights import make_images, make_weights
+    if not __import__("helen_amd.native_io", fromlist=["x"]).available():
+        pytest.skip("libhelen_io.so not built")
+    P = _stand_in(monkeypatch)
+    monkeypatch.setattr(P, "DEVICE_CALL_WINDOWS", 32)
+    img_dir = tmp_path / "img"
+    img_dir.mkdir()
+    img = make_images(40, seed=3)
+    write_image_file(str(img_dir / "a_plain.h5"), img[:24], first_window=0)
+    write_image_file(str(img_dir / "b_packed.h5"), img[24:], first_window=24, gzip=4)
+    model = str(tmp_path / "m.pkl")
+    ModelHandler.save_model(make_weights(), None, 128, 1, 0, model)
+    P.predict(sorted(glob.glob(str(img_dir / "*.h5"))), str(tmp_path / "out"), model, 8, 2, 0, 0)
+    err = capfd.readouterr().err
+    assert "16 OF THEM WERE READ THROUGH LIBHDF5" in err
+    with hdf5.File(str(tmp_path / "out_0.hdf")) as f:
+        assert len(f.keys("predictions/chr20_synth")) >= 1
+        total = sum(len([k for k in f.keys("predictions/chr20_synth/" + r) if k not in ("contig_start", "contig_end")])
+                    for r in f.keys("predictions/chr20_synth"))
+        assert total == 40
