@@ -134,6 +134,50 @@ def precision_check(eng, precision, images, dev):
             "max_abs_logit": round(biggest, 3), "precision": precision}
 
 
+def end_to_end(n_windows, workers, batch, weights):
+    """Opt-in leg (--e2e N): the whole `call_consensus` of the product -- synthetic MarginPolish image directory (HDF5,
+    16 files) -> reader processes -> device -> ONE prediction HDF5 -- wall-clocked from the call to its return, start-up,
+    model load and the final close included (SURVEY.md 8d "end-to-end").  Inputs are written by the direct emitter of
+    libhelen_io.so into a RAM-backed directory when /dev/shm has room, the temp directory otherwise."""
+    import shutil
+    import tempfile
+
+    from helen_amd import hdf5
+    from helen_amd import predict as P
+    from helen_amd.call_consensus import call_consensus
+    from helen_amd.model_handler import ModelHandler
+    from helen_amd.synthetic import write_image_dir
+    need = n_windows * 120000 * 2
+    base = None
+    if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK):
+        st = os.statvfs("/dev/shm")
+        if st.f_bavail * st.f_frsize > need:
+            base = "/dev/shm"
+    d = tempfile.mkdtemp(prefix="helen_e2e_", dir=base)
+    try:
+        model = os.path.join(d, "model.pkl")
+        ModelHandler.save_model(weights, None, 128, 1, 0, model)
+        t0 = time.time()
+        write_image_dir(os.path.join(d, "img"), n_windows, n_files=16, direct=True)
+        t_write = time.time() - t0
+        out = os.path.join(d, "out")
+        import contextlib
+        t0 = time.time()
+        with contextlib.redirect_stdout(sys.stderr):     # the CLI prints the output file name: keep stdout to the JSON line
+            call_consensus(os.path.join(d, "img"), model, batch, workers, 1, out, "p", True, "0", 1)
+        dt = time.time() - t0
+        files = sorted(os.listdir(out))
+        with hdf5.File(os.path.join(out, files[0])) as f:
+            stored = sum(len(f.keys("predictions/" + c)) for c in f.keys("predictions"))
+        return {"value": round(n_windows / dt, 1), "unit": "windows/s", "windows": n_windows, "seconds": round(dt, 3),
+                "reader_workers": workers, "output_files": files, "regions_stored": stored,
+                "stage_seconds": {k: round(v, 3) for k, v in P.STAGE_SECONDS.items()},
+                "what": "call_consensus(image_dir -> prediction HDF5) incl. process start-up, model load and close; "
+                        "synthetic inputs written in %.1f s to %s" % (t_write, base or tempfile.gettempdir())}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +188,10 @@ def main():
     ap.add_argument("--mode", default="uniform", choices=["uniform", "pileup"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-memory -> host-memory leg")
+    ap.add_argument("--e2e", type=int, default=0, metavar="WINDOWS",
+                    help="also run the product's call_consensus over a synthetic HDF5 image directory of this many "
+                         "windows (e.g. 300000 = chr20 scale; needs ~120 KB of /dev/shm or temp space per window)")
+    ap.add_argument("--e2e-workers", type=int, default=8, help="reader processes of the --e2e leg")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp32x3"],
                     help="gate-matmul arithmetic; fp32 (true fp32 MFMA) is BASELINE.json configs[1], the "
                          "headline; fp32x3 = fp32-class via three-term bf16 splits (opt-in experiment)")
@@ -362,6 +410,9 @@ def main():
                 "h2d_GBps": round(hv / world * 90000 / 1e9, 2)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B)
+        if args.e2e > 0 and world == 1:
+            eng.close()        # call_consensus builds its own engine (15.9 GB of scratch)
+            out["end_to_end"] = end_to_end(args.e2e, args.e2e_workers, B, make_weights(input_scale=1.0 / 64.0))
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -74,6 +74,24 @@ class File {
         put8(3); put8(1); put64(addr); put64(bytes); pad(6);
         return hdr;
     }
+    // one-element array of a fixed-length string (how the image files store `contig`), compact layout
+    uint64_t string1(const std::string& v) {
+        align8();
+        const uint64_t hdr = tell();
+        const size_t len = v.size() ? v.size() : 1, data = (len + 7) & ~(size_t)7;
+        const size_t lay = (4 + data + 7) & ~(size_t)7;
+        const uint64_t dims[1] = {1};
+        header_prefix(4, (8 + 16) + (8 + 8) + (8 + 8) + (8 + lay));
+        msg_dataspace(1, dims);
+        msg_head(0x0003, 8);    // datatype: class 3 (string), version 1, null-terminated ASCII, `len` bytes
+        put8(0x13); put8(0); put8(0); put8(0); put32((uint32_t)len);
+        msg_fill(1);
+        msg_head(0x0008, (uint16_t)lay);
+        put8(3); put8(0); put16((uint16_t)len);
+        put(v.data(), v.size());
+        pad(lay - 4 - v.size());
+        return hdr;
+    }
     // scalar int64 dataset with compact layout (the value lives in the object header)
     uint64_t scalar_i64(int64_t v) {
         align8();

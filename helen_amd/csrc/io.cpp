@@ -439,6 +439,43 @@ int helen_io_read_images(const char* path, const char* names, int n, uint8_t* im
     return 0;
 }
 
+/* Synthetic MarginPolish image file through the direct emitter (helen_amd.synthetic: benchmark inputs; the files the
+ * reader TESTS use are written by libhdf5): `n` windows named <contig>-<start>-<end>-<chunk> under `images/`, each with
+ * the six datasets of dataloader_predict.py:64-70 -- contig (fixed string [1]), contig_start / contig_end /
+ * feature_chunk_idx (int64 [1]), image uint8 [L, 90], position int64 [L, 3] = (start + k, 0, 0).
+ *   starts, chunks  int64 [n];  lengths int32 [n] (rows stored, <= 1000);  images uint8 [n, 1000, 90] */
+int helen_io_emit_images(const char* path, int n, const char* contig, const int64_t* starts, const int64_t* chunks,
+                         const int32_t* lengths, const uint8_t* images) {
+    h5emit::File f;
+    if (!f.open(path)) return fail("cannot create '%s'", path);
+    std::vector<h5emit::Child> all;
+    std::vector<int64_t> pos((size_t)kSeq * 3);
+    char name[512];
+    for (int i = 0; i < n; ++i) {
+        const int L = lengths[i];
+        if (L < 0 || L > kSeq) return fail("bad length %d", L);
+        for (int k = 0; k < L; ++k) {
+            pos[3 * k] = starts[i] + k;
+            pos[3 * k + 1] = pos[3 * k + 2] = 0;
+        }
+        const uint64_t one[1] = {1}, di[2] = {(uint64_t)L, (uint64_t)kFeat}, dp[2] = {(uint64_t)L, 3};
+        const int64_t cs = starts[i], ce = starts[i] + 1000, ch = chunks[i];
+        std::vector<h5emit::Child> kids(6);
+        kids[0] = {"contig", f.string1(contig)};
+        kids[1] = {"contig_start", f.dataset(&cs, 8, 8, true, 1, one)};
+        kids[2] = {"contig_end", f.dataset(&ce, 8, 8, true, 1, one)};
+        kids[3] = {"feature_chunk_idx", f.dataset(&ch, 8, 8, true, 1, one)};
+        kids[4] = {"image", f.dataset(images + (size_t)i * kSeq * kFeat, (size_t)L * kFeat, 1, false, 2, di)};
+        kids[5] = {"position", f.dataset(pos.data(), (size_t)L * 24, 8, true, 2, dp)};
+        snprintf(name, sizeof(name), "%s-%lld-%lld-%lld", contig, (long long)cs, (long long)ce, (long long)ch);
+        all.push_back({name, f.group(kids)});
+    }
+    std::vector<h5emit::Child> top{{"images", f.group(all)}};
+    uint64_t bt = 0, hp = 0;
+    const uint64_t root = f.group(top, &bt, &hp);
+    return f.finish(root, bt, hp) ? 0 : fail("writing '%s' failed", path);
+}
+
 /* Images this process has read through the direct scanner (out[0]) and through libhdf5 (out[1]). */
 void helen_io_reader_counts(long long* out) {
     out[0] = g_fast_windows;

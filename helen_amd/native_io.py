@@ -36,6 +36,8 @@ def load():
     lib.helen_io_list_images.restype = ctypes.c_int
     lib.helen_io_list_images.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t,
                                          ctypes.POINTER(ctypes.c_longlong)]
+    lib.helen_io_emit_images.restype = ctypes.c_int
+    lib.helen_io_emit_images.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, vp, vp, vp, vp]
     lib.helen_io_reader_counts.restype = None
     lib.helen_io_reader_counts.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
     lib.helen_io_read_images.restype = ctypes.c_int
@@ -83,6 +85,19 @@ def list_images(path):
         if rc != 0:
             raise IOError(_err(lib))
         return buf.raw.split(b"\0", 1)[0].decode().split("\n")[:n.value] if n.value else []
+
+
+def emit_images(path, contig, starts, chunks, lengths, images):
+    """A synthetic image file through the direct emitter (benchmark inputs; see helen_amd.synthetic)."""
+    lib = load()
+    starts = np.ascontiguousarray(starts, np.int64)
+    chunks = np.ascontiguousarray(chunks, np.int64)
+    lengths = np.ascontiguousarray(lengths, np.int32)
+    images = np.ascontiguousarray(images, np.uint8)
+    rc = lib.helen_io_emit_images(os.fsencode(path), int(starts.shape[0]), contig.encode(), starts.ctypes.data,
+                                  chunks.ctypes.data, lengths.ctypes.data, images.ctypes.data)
+    if rc != 0:
+        raise IOError(_err(lib))
 
 
 def reader_counts():

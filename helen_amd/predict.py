@@ -112,6 +112,8 @@ class _DeviceStage(object):
         return slot, n
 
     def close(self):
+        if self.registered:
+            self.torch.cuda.synchronize(self.dev)      # nothing may still be copying from / into the slots
         for ptr in self.registered:
             self.rt.cudaHostUnregister(ptr)
         self.registered = []
@@ -331,24 +333,41 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         STAGE_SECONDS["device"] += time.time() - t1
         t_loop_end = time.time()
     finally:
+        # Tear-down in parallel with the writer's last slots and the file's close (the group structures of the
+        # prediction file are written there): the reader pool, the page-locks, the 16 GB of device scratch and the
+        # shared-memory slots each take 0.1-0.3 s to let go of.
+        def release_device():
+            if stage is not None:
+                stage.close()
+            if engine is not None:
+                engine.close()
+        side = [threading.Thread(target=release_device, daemon=True)]
+        if pool is not None:
+            side.append(threading.Thread(target=lambda: pool.shutdown(wait=True, cancel_futures=True), daemon=True))
         if writer_pool is None:
             wq.put(None)
+        for t in side:
+            t.start()
+        if writer_pool is None:
             writer.join()
         else:
             writer_pool.close()
-        if stage is not None:
-            stage.close()
-        if pool is not None:
-            pool.shutdown(wait=True, cancel_futures=True)
+        close_error = None
+        if prediction_data_file is not None and not (ferr or werr):
+            try:
+                prediction_data_file.close()
+            except Exception as e:      # surfaced below, after the tear-down
+                close_error = e
+        for t in side:
+            t.join()
         for sl in slots:
             sl.close()
     if ferr:
         raise ferr[0]
     if werr:
         raise werr[0]
-    if prediction_data_file is not None:
-        prediction_data_file.close()
-    engine.close()
+    if close_error is not None:
+        raise close_error
     if rank == 0:
         sys.stderr.write("INFO: %d WINDOWS IN %.1f SECS (WAITING FOR READERS %.1f, DEVICE %.1f, WRITER BUSY %.1f; "
                          "MODEL + ENGINE SET-UP %.1f, FLUSH + CLOSE %.1f).\n"

@@ -59,7 +59,7 @@ def e2e_probe(w, args):
         model = os.path.join(d, "m.pkl")
         ModelHandler.save_model(w, None, 128, 1, 0, model)
         t0 = time.time()
-        write_image_dir(os.path.join(d, "img"), args.h5_windows, n_files=16)
+        write_image_dir(os.path.join(d, "img"), args.h5_windows, n_files=16, direct=True)
         print("wrote %d windows of synthetic HDF5 in %.1f s" % (args.h5_windows, time.time() - t0))
         for workers in [int(x) for x in args.workers.split(",")]:
             for writers in [int(x) for x in args.writers.split(",")]:

@@ -103,3 +103,19 @@ def test_damaged_files_are_libhdf5s_business(tmp_path):
         for i, (_, name) in enumerate(ds.all_images):
             j = [n for _, n in SequenceDataset(None, file_list=files).all_images].index(name)
             assert np.array_equal(got.images[i], ok.images[j])
+
+
+def test_directly_emitted_image_files_equal_libhdf5_written_ones(tmp_path):
+    """helen_amd.synthetic.write_image_dir(direct=True) (benchmark inputs, through h5emit.h) stores what the libhdf5
+    path stores: h5diff finds no difference, and both readers return the same batch from either."""
+    import shutil
+    from helen_amd.synthetic import write_image_dir
+    a = write_image_dir(str(tmp_path / "lib"), 300, n_files=2, short_every=7)
+    b = write_image_dir(str(tmp_path / "direct"), 300, n_files=2, short_every=7, direct=True)
+    h5diff = shutil.which("h5diff") or "/opt/conda/bin/h5diff"
+    if os.path.exists(h5diff):
+        for x, y in zip(a, b):
+            r = subprocess.run([h5diff, x, y], capture_output=True, text=True)
+            assert r.returncode == 0, r.stdout + r.stderr
+    for reader in (None, "libhdf5"):
+        _same(_read(a, str(tmp_path / "a.npz"), reader), _read(b, str(tmp_path / "b.npz"), reader))
