@@ -76,9 +76,10 @@ def test_labels_match_oracle_at_scale(scale_case, precision):
 
 
 def test_every_fp32_kernel_choice_gives_the_same_bits(scale_case):
-    """A 4096-window call takes gru_pair_kernel, gemm_dec_ws_kernel and gemm_enc_ws_kernel; 1024-window calls
+    """A 4096-window call takes gru_pair_kernel, gemm_dec_ws_kernel and gemm_enc_ws8_kernel; 1024-window calls
     take gru_kernel, gemm_gi_kernel<16, true> and gemm_gi_kernel<6, false>; 3000 windows (188 tiles) take the
-    pair recurrence with the streaming decoder projection.  Accumulators and labels must be EQUAL."""
+    pair recurrence with the streaming decoder projection; 2400 windows (150 tiles) gemm_enc_ws_kernel.
+    Accumulators and labels must be EQUAL."""
     from helen_amd.engine import HelenEngine
     w, img, _ = scale_case
     dev = torch.from_numpy(img[6144:6144 + 4096]).cuda()        # uniform and pileup windows
@@ -98,6 +99,13 @@ def test_every_fp32_kernel_choice_gives_the_same_bits(scale_case):
     for u, v_ in zip(big.chunk_forward(x, h), (torch.cat(t) for t in zip(small.chunk_forward(x[:1024], h[:1024]),
                                                                           small.chunk_forward(x[1024:], h[1024:])))):
         assert torch.equal(u, v_)
+    # 150 tiles per call: gemm_enc_ws_kernel (three column-set workgroups per tile) with the pair recurrence
+    sets = HelenEngine(w, device=0, max_windows=2400)
+    e3 = sets.polish(dev, want_acc=True)
+    torch.cuda.synchronize()
+    for name, x, y in zip(("bases", "rles", "acc_base", "acc_rle"), a, e3):
+        assert torch.equal(x, y), name + ": 2400 + 1696 differs"
+    sets.close()
     # an ODD tile count in the pair recurrence (255 tiles: the last workgroup walks its one tile twice)
     odd = HelenEngine(w, device=0, max_windows=4080)
     d = odd.polish(dev[:4080], want_acc=True)
