@@ -32,10 +32,16 @@ struct Dataset {
     uint64_t dims[4] = {0, 0, 0, 0};
     const uint8_t* data = nullptr;   // in the mapping: raw data (contiguous or compact)
     uint64_t bytes = 0;
-    uint64_t count() const {
-        uint64_t n = 1;
-        for (int i = 0; i < rank; ++i) n *= dims[i];
-        return n;
+    uint64_t count() const {   // saturates: a damaged dataspace must not wrap around to a small count
+        unsigned __int128 n = 1;
+        for (int i = 0; i < rank; ++i) {
+            n *= dims[i];
+            if (n > ~0ull) return ~0ull;
+        }
+        return (uint64_t)n;
+    }
+    bool holds(uint64_t per_element) const {   // bytes >= count() * per_element, without overflow
+        return (unsigned __int128)count() * per_element <= bytes;
     }
 };
 
@@ -66,6 +72,7 @@ class File {
         size_t o = 16 + 4 + 4;                                        // K values, consistency flags
         if (ver == 1) o += 4;                                         // indexed storage K + reserved
         if (u64(o) != 0) return false;                                // base address
+        if (u64(o + 16) > size_) return false;                        // end-of-file address: a truncated file
         o += 32;                                                      // base, free space, end of file, driver info
         // root group symbol table entry
         root_header_ = u64(o + 8);
@@ -79,7 +86,8 @@ class File {
         uint64_t btree, heap;
         if (!symbol_table(header, &btree, &heap)) return false;
         const Names names = heap_data(heap);
-        return names.p && walk(btree, names, out, 0);
+        uint64_t budget = size_ / 8 + 16;    // no well-formed file has more nodes than that: loops end here
+        return names.p && walk(btree, names, out, 0, &budget);
     }
     // one member by name (descends the B-tree by key comparison); false if absent or not an old-style group
     bool lookup(uint64_t header, const char* name, uint64_t* child) const {
@@ -197,11 +205,9 @@ class File {
             }
         };
         if (!messages(header, visit) || bad || !have_space || !have_type || !have_layout) return false;
-        if (d->cls == 0 || d->cls == 1 || d->cls == 3) {
-            if (d->data && d->bytes < d->count() * (uint64_t)d->size) return false;
-        } else if (d->cls == 9) {
-            if (d->data && d->bytes < d->count() * 16) return false;
-        }
+        if (d->size <= 0) return false;
+        if (d->cls == 9 && d->size != 16) return false;       // {length u32, collection address u64, index u32}
+        if (d->data && !d->holds((uint64_t)d->size)) return false;
         return true;
     }
 
@@ -227,7 +233,7 @@ class File {
             const uint16_t idx = u16(o);
             const uint64_t sz = u64(o + 8);
             if (idx == 0) break;                          // the free-space object ends the list
-            if (o + 16 + sz > col + csize) return false;
+            if (sz > col + csize - (o + 16)) return false;
             if (idx == index) {
                 const size_t n = len <= sz ? len : (size_t)sz;
                 out->assign((const char*)map_ + o + 16, strnlen((const char*)map_ + o + 16, n));
@@ -302,8 +308,10 @@ class File {
         }
         return n;
     }
-    bool walk(uint64_t node, const Names& names, std::vector<std::pair<std::string, uint64_t>>* out, int depth) const {
-        if (depth > 16 || !ok(node, 24)) return false;
+    bool walk(uint64_t node, const Names& names, std::vector<std::pair<std::string, uint64_t>>* out, int depth,
+              uint64_t* budget) const {
+        if (depth > 16 || !ok(node, 24) || *budget == 0) return false;
+        --*budget;
         const uint8_t* p = map_ + node;
         if (memcmp(p, "SNOD", 4) == 0) {
             const int n = u16(node + 6);
@@ -320,7 +328,7 @@ class File {
         const int n = u16(node + 6);
         if (!ok(node, 24 + 8 + (size_t)n * 16)) return false;
         for (int k = 0; k < n; ++k)
-            if (!walk(u64(node + 24 + 8 + 16 * (size_t)k), names, out, depth + 1)) return false;
+            if (!walk(u64(node + 24 + 8 + 16 * (size_t)k), names, out, depth + 1, budget)) return false;
         return true;
     }
 };

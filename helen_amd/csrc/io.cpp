@@ -150,7 +150,9 @@ int read_2d(hid_t loc, const char* name, hid_t memtype, int cols, int max_rows, 
 
 // ---- reader side, fast path: the file's own structures walked in a read-only mapping (h5scan.h) ----------
 // One entry per image file: the scanner and the object header of its `images` group; `usable` is false for a
-// file the scanner does not take (libhdf5 reads it instead).  $HELEN_IO_READER=libhdf5 turns the fast path off.
+// file the scanner does not take (libhdf5 reads it instead).  $HELEN_IO_READER=libhdf5 turns the fast path off;
+// =direct turns the FALLBACK off (what the scanner declines is an error: the fuzz tests' way of exercising the
+// scanner alone on damaged files).
 long long g_fast_windows = 0, g_library_windows = 0;   // images read by the scanner / by libhdf5 in this process
 struct Scanned {
     h5scan::File file;
@@ -162,11 +164,12 @@ std::map<std::string, std::unique_ptr<Scanned>>& scanned_files() {
     static std::map<std::string, std::unique_ptr<Scanned>> m;
     return m;
 }
+bool reader_mode_is(const char* what) {
+    const char* e = getenv("HELEN_IO_READER");
+    return e && strcmp(e, what) == 0;
+}
 Scanned* scan_file(const char* path) {
-    static const bool off = [] {
-        const char* e = getenv("HELEN_IO_READER");
-        return e && strcmp(e, "libhdf5") == 0;
-    }();
+    static const bool off = reader_mode_is("libhdf5");
     if (off) return nullptr;
     auto& m = scanned_files();
     auto it = m.find(path);
@@ -264,8 +267,8 @@ int fast_read_images(Scanned* sc, const char* path, const char* names, int n, ui
         if (!f.lookup(g, "image", &h) || !f.dataset(h, &di)) return 1;
         if (!f.lookup(g, "position", &h) || !f.dataset(h, &dp)) return 1;
         if (di.cls > 1 || dp.cls != 0) return 1;
-        const int rows = di.rank == 2 ? (int)di.dims[0] : -1;
-        if (di.rank != 2 || (int)di.dims[1] != kFeat || di.dims[0] > (uint64_t)kSeq || dp.rank != 2 || dp.dims[1] != 3 ||
+        const int rows = di.rank == 2 && di.dims[0] <= (uint64_t)kSeq ? (int)di.dims[0] : -1;
+        if (di.rank != 2 || di.dims[1] != (uint64_t)kFeat || di.dims[0] > (uint64_t)kSeq || dp.rank != 2 || dp.dims[1] != 3 ||
             dp.dims[0] != di.dims[0])
             return fail("IMAGE SIZE ERROR: %s (%d, %d)", path, rows, kFeat);   // dataloader_predict.py:85-86
         uint8_t* img = images + (size_t)i * kSeq * kFeat;
@@ -345,6 +348,8 @@ int helen_io_list_images(const char* path, char* out, size_t cap, long long* n_o
             return 0;
         }
     }
+    static const bool direct_only = reader_mode_is("direct");
+    if (direct_only) return fail("%s: not a file the direct scanner takes", path);
     hid_t f = get_file(path);
     if (f < 0) return fail("cannot open '%s'", path);
     *n_out = 0;
@@ -393,6 +398,8 @@ int helen_io_read_images(const char* path, const char* names, int n, uint8_t* im
         if (rc == 0) g_fast_windows += n;
         if (rc <= 0) return rc;       // done, or the reader's own error; 1 = not for the scanner: libhdf5 below
     }
+    static const bool direct_only = reader_mode_is("direct");
+    if (direct_only) return fail("%s: not a file the direct scanner takes", path);
     g_library_windows += n;
     hid_t f = get_file(path);
     if (f < 0) return fail("cannot open '%s'", path);

@@ -91,6 +91,15 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
         hid_s[x] = (char*)(hid + ((size_t)tile_of[x] * 2 + dir) * (kHidDirStride / 4));
     }
     const unsigned lane16 = (unsigned)lane * 16u, tid16 = (unsigned)tid * 16u;
+    // h in LDS is the KB16 operand layout with the 16 window entries of row (m, q) XOR-ed with q: a lane's four
+    // gate results (windows 4q..4q+3 of one unit) then go to 64 different banks per ds_write_b32 instead of 16
+    // (unswizzled, the four lanes j, j+4, j+8, j+12 of a 16-lane group hit the same bank: 4-way conflicts on every
+    // write, 9.9 M conflict cycles per launch).  Readers fetch whole 16-byte entries: they only pick another one.
+#ifdef HELEN_PAIR_NOSWZ
+    const int slane = lane, stid = tid;
+#else
+    const int slane = (lane & 48) | (j ^ q), stid = (tid & ~15) | ((tid & 15) ^ ((tid >> 4) & 3));
+#endif
 
     // this wave's gi fragments (gate g = column tile 8g + v) of each tile's next step, in registers
     f32x4 G[2][3];
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
     };
     // initial hidden state of both tiles -> buffer 0; tile 0's first gi (tile 1's is fetched during M(0,0))
 #pragma unroll
-    for (int x = 0; x < 2; ++x) hbuf[x * 1024 + tid] = *(const f32x4*)(hid_s[x] + tid16);
+    for (int x = 0; x < 2; ++x) hbuf[x * 1024 + stid] = *(const f32x4*)(hid_s[x] + tid16);
     load_gi(0);
 #ifdef HELEN_PAIR_NOLOAD   // timing probe: both tiles' first gi, never reloaded
     load_gi(1);
@@ -111,12 +120,20 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
 
     float hprev[2][4];
     const int u = 16 * v + j;
-    const int hoff = ((u >> 2) * kTile + 4 * q) * 4 + (u & 3);  // float offset of (row 4q, unit u) in an h buffer
+    int hoff[4];   // float offset of (window 4q + r, unit u) in an h buffer
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#ifdef HELEN_PAIR_NOSWZ
+        hoff[r] = ((u >> 2) * kTile + 4 * q + r) * 4 + (u & 3);
+#else
+        hoff[r] = ((u >> 2) * kTile + 4 * q + (r ^ (j >> 2))) * 4 + (u & 3);
+#endif
+    }
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hprev[x][r] = ((const float*)(hbuf + x * 1024))[hoff + 4 * r];
-    f32x4 a_pref = hbuf[lane];   // group 0 of h_0(-1): the A fragment the first MFMA phase starts with
+        for (int r = 0; r < 4; ++r) hprev[x][r] = ((const float*)(hbuf + x * 1024))[hoff[r]];
+    f32x4 a_pref = hbuf[slane];   // group 0 of h_0(-1): the A fragment the first MFMA phase starts with
 
     // the eight k-slices' partial logits of (tile x, parity pb) added in the order gru_kernel adds them
     auto sum_partials = [&](int x, int pb) __attribute__((always_inline)) {
@@ -138,14 +155,14 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
         const bool has_prev = steady || s > 0;                   // h_x(s-1) is a step's output (not the initial state)
         const bool has_prev2 = steady || s > 1;
         const f32x4* hx = hbuf + (x * 2 + cur) * 512;            // h_x(s-1): A operand of this phase
-        const f32x4* hb = hx + lane;
+        const f32x4* hb = hx + slane;
         f32x4 acc[3], a[3], yv = splat4(0.f), hd = splat4(0.f), hp = splat4(0.f);
         a[0] = a_pref;
         a[1] = hb[1 * 64];
 #ifndef HELEN_PAIR_NOLOAD   // (timing probe: no gi traffic, results are garbage)
         if (has_next_o) load_gi(o);                              // tile o's registers were consumed in G(o, so)
 #endif
-        if (!DEC && has_prev) yv = hx[tid];                      // h_x(s-1) is the layer output of slot s-1
+        if (!DEC && has_prev) yv = hx[stid];                      // h_x(s-1) is the layer output of slot s-1
         if (DEC && has_prev) hd = hb[v * 64];                    // ... or feeds the heads: this wave's k-slice
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
@@ -187,7 +204,7 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        a_pref = hbuf[(o * 2 + ocur) * 512 + lane];              // next phase: M(o, so+1) starts on h_o(so)
+        a_pref = hbuf[(o * 2 + ocur) * 512 + slane];              // next phase: M(o, so+1) starts on h_o(so)
         __builtin_amdgcn_sched_barrier(0);
 #ifdef HELEN_PAIR_NOGATES   // timing probe: MFMA phase + barrier only (results are garbage)
         const f32x4 hn = acc[0] + acc[1] + acc[2] + G[x][0] + G[x][1] + G[x][2];
@@ -198,7 +215,7 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             hprev[x][r] = hn[r];
-            hw[hoff + 4 * r] = hn[r];
+            hw[hoff[r]] = hn[r];
         }
         if (DEC && has_prev) (part + ((x * 2 + ((s - 1) & 1)) * 8 + v) * 64)[lane] = hp;
         __builtin_amdgcn_sched_barrier(0);
@@ -236,7 +253,7 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
                 if (v == ((T - 2) & 3)) *(f32x4*)(pl_next[x] + lane16) = sum_partials(x, (T - 2) & 1);
                 pl_next[x] += 128 * 16;   // at slot T-1 now
             }
-            const f32x4 hd = hbuf[(x * 2 + last) * 512 + v * 64 + lane];
+            const f32x4 hd = hbuf[(x * 2 + last) * 512 + v * 64 + slane];
             f32x4 hp = splat4(0.f);
 #pragma unroll
             for (int e = 0; e < 4; ++e) hp = mfma4(hd[e], Bh[e], hp);
@@ -249,10 +266,10 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
         }
     } else {   // the last layer outputs
 #pragma unroll
-        for (int x = 0; x < 2; ++x) *(f32x4*)(y_next[x] + tid16) = hbuf[(x * 2 + last) * 512 + tid];
+        for (int x = 0; x < 2; ++x) *(f32x4*)(y_next[x] + tid16) = hbuf[(x * 2 + last) * 512 + stid];
     }
 #pragma unroll
-    for (int x = 0; x < 2; ++x) *(f32x4*)(hid_s[x] + tid16) = hbuf[(x * 2 + last) * 512 + tid];
+    for (int x = 0; x < 2; ++x) *(f32x4*)(hid_s[x] + tid16) = hbuf[(x * 2 + last) * 512 + stid];
 }
 
 }  // namespace helen

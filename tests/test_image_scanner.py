@@ -119,3 +119,119 @@ def test_directly_emitted_image_files_equal_libhdf5_written_ones(tmp_path):
             assert r.returncode == 0, r.stdout + r.stderr
     for reader in (None, "libhdf5"):
         _same(_read(a, str(tmp_path / "a.npz"), reader), _read(b, str(tmp_path / "b.npz"), reader))
+
+
+FUZZ_CHILD = r'''
+import hashlib, os, sys, numpy as np
+sys.path.insert(0, %(root)r)
+from helen_amd import native_io
+paths = %(paths)r
+for k in range(%(first)d, len(paths)):
+    try:
+        names = native_io.list_images(paths[k])
+        if names is None:
+            print(k, "noimages", flush=True)
+            continue
+        n = len(names)
+        images = np.zeros((n, 1000, 90), np.uint8); positions = np.zeros((n, 1000, 3), np.int64)
+        meta = np.zeros((n, 3), np.int64); contigs = np.zeros((n, native_io.NAME_BYTES), np.uint8)
+        if n:
+            native_io.read_images(paths[k], names, images, positions, meta, contigs)
+        h = hashlib.sha1()
+        for a in (images, positions, meta, contigs):
+            h.update(a.tobytes())
+        h.update("\n".join(names).encode())
+        print(k, "ok", h.hexdigest(), flush=True)
+    except (IOError, OSError, ValueError) as e:
+        print(k, "error", flush=True)
+'''
+
+
+def _fuzz_run(paths, reader, tolerate_crashes):
+    """{index: (status, digest)} of reading every file with one reader mode; a crashing reader is restarted behind
+    the file that killed it when `tolerate_crashes` (libhdf5 1.10 on damaged files), else it fails the test."""
+    env = dict(os.environ, HELEN_IO_READER=reader)
+    out, first = {}, 0
+    while first < len(paths):
+        r = subprocess.run([sys.executable, "-c", FUZZ_CHILD % {"root": ROOT, "paths": list(paths), "first": first}],
+                           env=env, capture_output=True, text=True, timeout=900)
+        for line in r.stdout.splitlines():
+            parts = line.split()
+            out[int(parts[0])] = (parts[1], parts[2] if len(parts) > 2 else "")
+        if r.returncode == 0:
+            break
+        assert tolerate_crashes, "reader '%s' died (rc %d) on %s\n%s" % (
+            reader, r.returncode, paths[max(out) + 1 if out else first], r.stderr[-1500:])
+        dead = max(out) + 1 if out else first
+        out[dead] = ("crash", "")
+        first = dead + 1
+    return out
+
+
+def test_scanner_survives_damaged_metadata(tmp_path):
+    """~900 mutants of two small image files (one written by libhdf5, one by the emitter): bytes flipped, 64-bit
+    fields replaced by 0 / ~0 / huge / random values, 16-bit counts maxed out, files truncated.  The scanner alone
+    (HELEN_IO_READER=direct: no fallback) must never crash or hang; and whenever it returns a batch for a file
+    libhdf5 also reads, the two batches are byte-identical."""
+    rng = np.random.default_rng(77)
+    img = make_images(8, seed=3)
+    bases = []
+    for kind in ("lib", "direct"):
+        path = str(tmp_path / (kind + ".h5"))
+        lengths = [5, 12, 3, 9, 1, 7, 12, 4]
+        if kind == "lib":
+            with hdf5.File(path, "w") as f:
+                for i, L in enumerate(lengths):
+                    b = "images/img_%02d/" % i
+                    f.write(b + "contig", "chrF", string="vlen" if i % 2 else "fixed")
+                    f.write(b + "contig_start", np.array([100 * i], np.int64))
+                    f.write(b + "contig_end", np.array([100 * i + L], np.int32))
+                    f.write(b + "feature_chunk_idx", np.array([i % 2], np.uint8))
+                    f.write(b + "image", img[i, :L], np.uint8)
+                    f.write(b + "position", np.stack([np.arange(L), np.zeros(L), np.zeros(L)], 1).astype(np.int64), np.int64)
+        else:
+            native_io.emit_images(path, "chrF", np.arange(8) * 100, np.arange(8) % 2, np.array(lengths, np.int32),
+                                  img)
+        bases.append(open(path, "rb").read())
+    paths = []
+    for b, raw in enumerate(bases):
+        size = len(raw)
+        for k in range(450):
+            m = bytearray(raw)
+            how = k % 5
+            if how == 0:                                   # a few flipped bytes
+                for _ in range(int(rng.integers(1, 5))):
+                    m[int(rng.integers(0, size))] ^= int(rng.integers(1, 256))
+            elif how == 1:                                 # an aligned 64-bit field: 0, ~0, just past the end, random
+                o = int(rng.integers(0, size // 8)) * 8
+                v = [0, 2 ** 64 - 1, size + int(rng.integers(0, 64)), int(rng.integers(0, 2 ** 63))][int(rng.integers(0, 4))]
+                m[o:o + 8] = int(v).to_bytes(8, "little")
+            elif how == 2:                                 # a 16-bit field maxed out / zeroed (entry and message counts)
+                o = int(rng.integers(0, size // 2)) * 2
+                m[o:o + 2] = b"\xff\xff" if rng.integers(0, 2) else b"\0\0"
+            elif how == 3:                                 # truncated
+                m = m[:int(rng.integers(100, size))]
+            else:                                          # a pointer redirected to another structure of the file
+                o = int(rng.integers(0, size // 8)) * 8
+                m[o:o + 8] = (int(rng.integers(0, size // 8)) * 8).to_bytes(8, "little")
+            p = str(tmp_path / ("m%d_%03d.h5" % (b, k)))
+            open(p, "wb").write(bytes(m))
+            paths.append(p)
+    direct = _fuzz_run(paths, "direct", tolerate_crashes=False)
+    assert len(direct) == len(paths)
+    lib = _fuzz_run(paths, "libhdf5", tolerate_crashes=True)
+    both = differ = 0
+    lenient = []
+    for k in range(len(paths)):
+        if direct[k][0] == "ok" and lib.get(k, ("crash", ""))[0] == "ok":
+            both += 1
+            if direct[k][1] != lib[k][1]:
+                differ += 1
+                print("DIFFERENT:", paths[k])
+        elif direct[k][0] == "ok":
+            lenient.append(os.path.basename(paths[k]))
+    stats = {s: sum(1 for v in direct.values() if v[0] == s) for s in ("ok", "error", "noimages")}
+    print("scanner:", stats, " libhdf5 crashes:", sum(1 for v in lib.values() if v[0] == "crash"), " both ok:", both,
+          " scanner only:", lenient)
+    assert differ == 0
+    assert both > 100 and stats["error"] > 100      # the mutants did hit structures that matter, and data that do not
