@@ -293,6 +293,8 @@ int fast_read_images(Scanned* sc, const char* path, const char* names, int n, ui
 // ---- writer side ------------------------------------------------------------------------------
 struct Region {                      // predictions/<contig>/<contig-start-end>
     std::vector<h5emit::Child> kids; // contig_start, contig_end, then one group per chunk id
+    uint64_t header = 0;             // its group as last emitted ...
+    bool dirty = true;               // ... which lacks members added since
 };
 struct Writer {
     hid_t file = -1;
@@ -304,7 +306,18 @@ struct Writer {
     // direct emitter (h5emit.h): the default; $HELEN_IO_WRITER=libhdf5 selects the library path above
     h5emit::File* fast = nullptr;
     std::map<std::string, std::map<std::string, Region>> tree;   // contig -> region name -> members
+    Region* open_region = nullptr;   // the region of the newest window: its group is emitted when the next begins
 };
+// A region's group goes out as soon as the stream moves on to another region (windows arrive file by file, a
+// region's chunk ids together), so that close only has the contig groups left to write -- not 300 k region
+// groups.  A region that does come back later is simply emitted again at close with all its members: the earlier
+// copy of its group structure is then unreferenced space in the file.
+void settle_region(Writer* w, Region* r) {
+    if (r && r->dirty) {
+        r->header = w->fast->group(r->kids);
+        r->dirty = false;
+    }
+}
 
 int write_ds(Writer* w, hid_t loc, const std::string& path, hid_t ftype, hid_t mtype, hid_t space, const void* buf) {
     hid_t d = H5Dcreate2(loc, path.c_str(), ftype, space, w->lcpl, w->dcpl, H5P_DEFAULT);
@@ -555,9 +568,14 @@ int helen_io_write_predictions_sel(void* handle, int n_sel, const int32_t* sel, 
         if (w->fast) {
             // the same bookkeeping (DataStore.py:115-124), the bytes written directly: datasets now, groups at close
             Region& reg = w->tree[contig][prefix];
+            if (&reg != w->open_region) {
+                settle_region(w, w->open_region);
+                w->open_region = &reg;
+            }
             if (w->regions.insert(prefix).second) {
                 reg.kids.push_back({"contig_start", w->fast->scalar_i64(cs)});
                 reg.kids.push_back({"contig_end", w->fast->scalar_i64(ce)});
+                reg.dirty = true;
             }
             if (w->images.insert(contig + prefix + suffix).second) {
                 const int64_t* p = positions + (size_t)i * kSeq * 3;
@@ -568,6 +586,7 @@ int helen_io_write_predictions_sel(void* handle, int n_sel, const int32_t* sel, 
                 kids[1] = {"bases", w->fast->dataset(bases + (size_t)i * kSeq, kSeq, 1, false, 1, dl)};
                 kids[2] = {"rles", w->fast->dataset(rles + (size_t)i * kSeq, kSeq, 1, false, 1, dl)};
                 reg.kids.push_back({suffix, w->fast->group(kids)});
+                reg.dirty = true;
             }
             if (!w->fast->ok()) return fail("write failed (disk full?)");
             continue;
@@ -707,7 +726,10 @@ int helen_io_writer_close(void* handle) {
         std::vector<h5emit::Child> contigs;
         for (auto& c : w->tree) {
             std::vector<h5emit::Child> regions;
-            for (auto& r : c.second) regions.push_back({r.first, w->fast->group(r.second.kids)});
+            for (auto& r : c.second) {
+                settle_region(w, &r.second);
+                regions.push_back({r.first, r.second.header});
+            }
             contigs.push_back({c.first, w->fast->group(regions)});
         }
         std::vector<h5emit::Child> top;

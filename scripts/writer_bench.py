@@ -19,16 +19,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--windows", type=int, default=20000)
     ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--per-region", type=int, default=3, help="chunk ids (images) per region")
     ap.add_argument("--out", default="/dev/shm/helen_writer_bench.hdf")
     a = ap.parse_args()
     n = a.windows
     rng = np.random.default_rng(0)
     names = ["contig_%d" % (i // 5000) for i in range(n)]
     meta = np.zeros((n, 3), dtype=np.int64)
-    region = np.arange(n) // 3                       # three chunk ids per region
+    region = np.arange(n) // a.per_region
     meta[:, 0] = region * 2400
     meta[:, 1] = region * 2400 + 2400
-    meta[:, 2] = np.arange(n) % 3
+    meta[:, 2] = np.arange(n) % a.per_region
     positions = np.zeros((a.batch, 1000, 3), dtype=np.int64)
     positions[:, :, 0] = np.arange(1000)[None, :]
     bases = rng.integers(0, 5, (a.batch, 1000), dtype=np.uint8)
