@@ -334,6 +334,15 @@ bool use_pair_recurrence(int tiles) {
     return t_pair < t_single(wg_single);
 }
 
+// bf16 mode: gru_fused_bf16_kernel (one tile per workgroup, one workgroup per CU) or gru_fused_bf16_pair_kernel
+// (two tiles per workgroup; same results bit for bit).  The pair needs more than one round of single workgroups to
+// pay: below that every tile has a CU of its own anyway.  (HELEN_BF16_PAIR=0/1 forces one: A/B probes.)
+bool use_bf16_pair(int tiles) {
+    static const char* force = getenv("HELEN_BF16_PAIR");
+    if (force && *force) return *force == '1';
+    return 2 * tiles > 256;
+}
+
 // Which decoder projection: gemm_dec_ws_kernel has one long workgroup per (tile, direction) and one workgroup per
 // CU, so it wants whole rounds of 256; gemm_gi_kernel is fine-grained (same gi bit for bit).
 // (HELEN_DEC_WS=0/1 forces one: A/B probes.)
@@ -354,6 +363,15 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
     if (m->precision == HELEN_PRECISION_BF16) {
         // projection fused into the recurrence: no gi at all; the encoder reads the packed pileup counts,
         // the decoder the encoder's bf16 output plane
+        if (use_bf16_pair(tiles)) {
+            LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_pair_kernel<3, false>), dim3((tiles + 1) / 2, 2), dim3(512), m->xb,
+                   (long)kSeq * 192, pos0, T, m->w3i_enc, m->w3h_enc, m->bias_enc, m->bhn_enc, m->hid, m->y1p,
+                   kY1bTileStride, (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride, tiles);
+            LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_pair_kernel<8, true>), dim3((tiles + 1) / 2, 2), dim3(512), m->y1p,
+                   kY1bTileStride, 0, T, m->w3i_dec, m->w3h_dec, m->bias_dec, m->bhn_dec, m->hid, (f32x4*)nullptr,
+                   kY1bTileStride, m->whd, m->plogit, kPlTileStride, tiles);
+            return;
+        }
         LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_kernel<3, false>), dim3(tiles, 2), dim3(512), m->xb,
                (long)kSeq * 192, pos0, T, m->w3i_enc, m->w3h_enc, m->bias_enc, m->bhn_enc, m->hid, m->y1p,
                kY1bTileStride, (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride);

@@ -12,4 +12,5 @@
 #include "kernels_gru_pair.h"
 #include "kernels_x3.h"
 #include "kernels_fused_bf16.h"
+#include "kernels_fused_bf16_pair.h"
 #include "kernels_heads.h"

@@ -141,6 +141,13 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
         return (((ps[0] + ps[64]) + (ps[128] + ps[192])) + (ps[256] + ps[320])) + (ps[384] + ps[448]);
     };
 
+#ifdef HELEN_PAIR_TIMING   // developer probe: where a wave's cycles go
+    long long tk[3] = {0, 0, 0};
+#define HELEN_PAIR_TICK(i) { __builtin_amdgcn_sched_barrier(0); long long now_ = __builtin_readcyclecounter(); tk[i] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
+    long long tlast = __builtin_readcyclecounter();
+#else
+#define HELEN_PAIR_TICK(i)
+#endif
     // One half-step: MFMA phase and gate math of tile X at step s (CUR = s & 1 at compile time so that every LDS
     // address is a lane offset + immediate).  `so` = newest step of the OTHER tile o.  STEADY = the caller
     // guarantees 2 <= s and s + 2 <= T - 1... i.e. every "is there a previous / next step" question is a
@@ -200,10 +207,12 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
             if (v == ((s - 2) & 3)) *(f32x4*)(pl_next[x] + in_block(lane16)) = sum_partials(x, s & 1);
             pl_next[x] += 128 * 16;
         }
+        HELEN_PAIR_TICK(0)
         // every wave is through M(x,s); the h_o(so) written in the previous half-step's G becomes visible
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        HELEN_PAIR_TICK(1)
         a_pref = hbuf[(o * 2 + ocur) * 512 + slane];              // next phase: M(o, so+1) starts on h_o(so)
         __builtin_amdgcn_sched_barrier(0);
 #ifdef HELEN_PAIR_NOGATES   // timing probe: MFMA phase + barrier only (results are garbage)
@@ -219,6 +228,7 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
         }
         if (DEC && has_prev) (part + ((x * 2 + ((s - 1) & 1)) * 8 + v) * 64)[lane] = hp;
         __builtin_amdgcn_sched_barrier(0);
+        HELEN_PAIR_TICK(2)
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -242,6 +252,11 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
         half_step(I1{}, I1{}, Yes{}, s + 1);
     }
     for (; s < T; ++s) step(No{}, s);                     // the last one or two steps: no step s+1 to feed
+#ifdef HELEN_PAIR_TIMING
+    if (blockIdx.x == 0 && lane == 0)
+        printf("pair %s dir %d wave %d: cycles per half-step  mfma phase %lld  barrier %lld  gates %lld\n", DEC ? "dec" : "enc",
+               dir, v, tk[0] / (2 * T), tk[1] / (2 * T), tk[2] / (2 * T));
+#endif
     __syncthreads();
     const int last = T & 1;   // buffer of h(T-1)
     if (DEC) {

@@ -348,16 +348,19 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
             wq.put(None)
         for t in side:
             t.start()
+        t_side = time.time()
         if writer_pool is None:
             writer.join()
         else:
             writer_pool.close()
+        t_drained = time.time()
         close_error = None
         if prediction_data_file is not None and not (ferr or werr):
             try:
                 prediction_data_file.close()
             except Exception as e:      # surfaced below, after the tear-down
                 close_error = e
+        t_closed = time.time()
         for t in side:
             t.join()
         for sl in slots:
@@ -370,10 +373,12 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         raise close_error
     if rank == 0:
         sys.stderr.write("INFO: %d WINDOWS IN %.1f SECS (WAITING FOR READERS %.1f, DEVICE %.1f, WRITER BUSY %.1f; "
-                         "MODEL + ENGINE SET-UP %.1f, FLUSH + CLOSE %.1f).\n"
+                         "MODEL + ENGINE SET-UP %.1f, FLUSH + CLOSE %.1f = LAST SLOTS %.2f + FILE CLOSE %.2f + "
+                         "RELEASE %.2f).\n"
                          % (len(pairs), time.time() - start_time, STAGE_SECONDS["read_wait"],
                             STAGE_SECONDS["device"], STAGE_SECONDS["write"], t_setup - start_time,
-                            time.time() - t_loop_end))
+                            time.time() - t_loop_end, t_drained - t_side, t_closed - t_drained,
+                            time.time() - t_closed))
         if through_library:
             sys.stderr.write("INFO: %d OF THEM WERE READ THROUGH LIBHDF5: THE DIRECT IMAGE SCANNER DOES NOT TAKE THEIR "
                              "STORAGE (CHUNKED / FILTERED / NEW-STYLE FILE); SEE python -m helen_amd check_images.\n"

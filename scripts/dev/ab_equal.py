@@ -1,6 +1,7 @@
 """Developer probe: polish the same seeded windows and either save (labels + accumulators) or compare with a
 saved run bit for bit -- for A/B runs of kernel variants selected by environment / HELEN_HIP_LIB.
-    python scripts/dev/ab_equal.py save /tmp/a.pt [n] ; HELEN_GRU_PAIR=1 python scripts/dev/ab_equal.py cmp /tmp/a.pt [n]"""
+    python scripts/dev/ab_equal.py save /tmp/a.pt [n] ; HELEN_GRU_PAIR=1 python scripts/dev/ab_equal.py cmp /tmp/a.pt [n]
+HELEN_AB_PRECISION=bf16 / fp32x3 selects the engine's precision mode."""
 import os
 import sys
 
@@ -15,7 +16,8 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 cap = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
 g = torch.Generator(device="cuda").manual_seed(11)
 img = torch.randint(0, 256, (n, 1000, 90), dtype=torch.uint8, device="cuda", generator=g)
-eng = HelenEngine(make_weights(seed=20260928, head_scale=8.0, input_scale=1 / 64.0), device=0, max_windows=cap)
+eng = HelenEngine(make_weights(seed=20260928, head_scale=8.0, input_scale=1 / 64.0), device=0, max_windows=cap,
+                  precision=os.environ.get("HELEN_AB_PRECISION", "fp32"))
 out = [t.cpu() for t in eng.polish(img, want_acc=True)]
 x = torch.rand((min(n, 64), 100, 90), device="cuda", generator=g)
 h = torch.rand((min(n, 64), 2, 128), device="cuda", generator=g) - 0.5
