@@ -159,6 +159,7 @@ struct Scanned {
     bool usable = false;
     bool has_images = false;
     uint64_t images = 0;
+    uint64_t last_used = 0;
 };
 std::map<std::string, std::unique_ptr<Scanned>>& scanned_files() {
     static std::map<std::string, std::unique_ptr<Scanned>> m;
@@ -171,10 +172,22 @@ bool reader_mode_is(const char* what) {
 Scanned* scan_file(const char* path) {
     static const bool off = reader_mode_is("libhdf5");
     if (off) return nullptr;
+    // A reader walks its files one after the other: only the newest few stay mapped.  (A process that had read
+    // a 27 GB directory through eight mappings took up to 2 s to exit -- the kernel unmaps page by page -- and
+    // predict waits for its readers; dropped when the reader moves on, that cost runs beside the device instead.)
+    static uint64_t tick = 0;
     auto& m = scanned_files();
     auto it = m.find(path);
-    if (it != m.end()) return it->second->usable ? it->second.get() : nullptr;
-    if (m.size() >= 64) m.clear();
+    if (it != m.end()) {
+        it->second->last_used = ++tick;
+        return it->second->usable ? it->second.get() : nullptr;
+    }
+    while (m.size() >= 3) {
+        auto oldest = m.begin();
+        for (auto k = m.begin(); k != m.end(); ++k)
+            if (k->second->last_used < oldest->second->last_used) oldest = k;
+        m.erase(oldest);
+    }
     std::unique_ptr<Scanned> sc(new Scanned());
     if (sc->file.open(path)) {
         std::vector<std::pair<std::string, uint64_t>> top;
@@ -188,6 +201,7 @@ Scanned* scan_file(const char* path) {
         }
     }
     if (!sc->usable) sc->file.close();
+    sc->last_used = ++tick;
     Scanned* raw = sc.get();
     m[path] = std::move(sc);
     return raw->usable ? raw : nullptr;

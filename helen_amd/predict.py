@@ -336,14 +336,31 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         # Tear-down in parallel with the writer's last slots and the file's close (the group structures of the
         # prediction file are written there): the reader pool, the page-locks, the 16 GB of device scratch and the
         # shared-memory slots each take 0.1-0.3 s to let go of.
+        took = {}
+        writer_done = threading.Event()
+
         def release_device():
+            t = time.time()
             if stage is not None:
                 stage.close()
+            took["PAGE-LOCKS"] = time.time() - t
+            t = time.time()
             if engine is not None:
                 engine.close()
+            took["DEVICE MEMORY"] = time.time() - t
+            writer_done.wait()          # the writer reads labels and positions out of the slots
+            t = time.time()
+            for sl in slots:
+                sl.close()
+            took["SLOTS"] = time.time() - t
+
+        def release_readers():
+            t = time.time()
+            pool.shutdown(wait=True, cancel_futures=True)
+            took["READERS"] = time.time() - t
         side = [threading.Thread(target=release_device, daemon=True)]
         if pool is not None:
-            side.append(threading.Thread(target=lambda: pool.shutdown(wait=True, cancel_futures=True), daemon=True))
+            side.append(threading.Thread(target=release_readers, daemon=True))
         if writer_pool is None:
             wq.put(None)
         for t in side:
@@ -354,6 +371,7 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         else:
             writer_pool.close()
         t_drained = time.time()
+        writer_done.set()
         close_error = None
         if prediction_data_file is not None and not (ferr or werr):
             try:
@@ -363,8 +381,6 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         t_closed = time.time()
         for t in side:
             t.join()
-        for sl in slots:
-            sl.close()
     if ferr:
         raise ferr[0]
     if werr:
@@ -374,11 +390,12 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     if rank == 0:
         sys.stderr.write("INFO: %d WINDOWS IN %.1f SECS (WAITING FOR READERS %.1f, DEVICE %.1f, WRITER BUSY %.1f; "
                          "MODEL + ENGINE SET-UP %.1f, FLUSH + CLOSE %.1f = LAST SLOTS %.2f + FILE CLOSE %.2f + "
-                         "RELEASE %.2f).\n"
+                         "RELEASE %.2f [%s]).\n"
                          % (len(pairs), time.time() - start_time, STAGE_SECONDS["read_wait"],
                             STAGE_SECONDS["device"], STAGE_SECONDS["write"], t_setup - start_time,
                             time.time() - t_loop_end, t_drained - t_side, t_closed - t_drained,
-                            time.time() - t_closed))
+                            time.time() - t_closed,
+                            ", ".join("%s %.2f" % kv for kv in sorted(took.items()))))
         if through_library:
             sys.stderr.write("INFO: %d OF THEM WERE READ THROUGH LIBHDF5: THE DIRECT IMAGE SCANNER DOES NOT TAKE THEIR "
                              "STORAGE (CHUNKED / FILTERED / NEW-STYLE FILE); SEE python -m helen_amd check_images.\n"

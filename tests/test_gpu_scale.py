@@ -116,6 +116,32 @@ def test_every_fp32_kernel_choice_gives_the_same_bits(scale_case):
         e.close()
 
 
+def test_bf16_kernel_choice_gives_the_same_bits(scale_case):
+    """bf16 mode: calls of more than 128 tiles take gru_fused_bf16_pair_kernel (two tiles per workgroup), smaller
+    ones gru_fused_bf16_kernel; an odd tile count makes the last pair workgroup walk its one tile twice.
+    Accumulators and labels must be EQUAL."""
+    from helen_amd.engine import HelenEngine
+    w, img, _ = scale_case
+    dev = torch.from_numpy(img[6144:6144 + 4096]).cuda()
+    big = HelenEngine(w, device=0, max_windows=4096, precision="bf16")      # 256 tiles: pair
+    small = HelenEngine(w, device=0, max_windows=1024, precision="bf16")    # 64 tiles: one tile per workgroup
+    odd = HelenEngine(w, device=0, max_windows=4080, precision="bf16")      # 255 tiles: pair, odd
+    a = big.polish(dev, want_acc=True)
+    b = small.polish(dev, want_acc=True)
+    c = odd.polish(dev[:4080], want_acc=True)
+    torch.cuda.synchronize()
+    for name, x, y, z in zip(("bases", "rles", "acc_base", "acc_rle"), a, b, c):
+        assert torch.equal(x, y), name + ": 4096-window bf16 call differs from 1024-window calls"
+        assert torch.equal(x[:4080], z), name + ": 255-tile bf16 call differs"
+    x = torch.rand((4096, 100, 90), device="cuda") * 255
+    h = torch.rand((4096, 2, 128), device="cuda") - 0.5
+    parts = [small.chunk_forward(x[i:i + 1024], h[i:i + 1024]) for i in range(0, 4096, 1024)]
+    for u, v_ in zip(big.chunk_forward(x, h), (torch.cat(t) for t in zip(*parts))):
+        assert torch.equal(u, v_)
+    for e in (big, small, odd):
+        e.close()
+
+
 def test_host_path_survives_an_injected_failure():
     """helen_polish_host: a failure in the middle of the pipeline must leave nothing in flight, leak nothing,
     and the handle must work afterwards; page-locked and pageable callers get the same labels."""
