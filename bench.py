@@ -385,7 +385,7 @@ def main():
                        "resident_windows_per_gpu": n_res, "sharding": "by rank, no collective"},
             "roofline": {"bound": bound, "kernel": {"fp32": "gru_pair_kernel (GRU recurrence of two window tiles per 8-wave workgroup, fp32 MFMA; "
                                             "decoder launches include the heads' product)",
-                                    "bf16": "gru_fused_bf16_kernel (projection + recurrence per layer, bf16 MFMA; "
+                                    "bf16": "gru_fused_bf16_pair_kernel (projection + recurrence per layer, two window tiles per workgroup, bf16 MFMA; "
                                             "bound in practice by the fp32 gate math, not the matrix pipe)",
                                     "fp32x3": "gru_x3_kernel (GRU recurrence, 6 bf16 MFMAs per fp32 product "
                                               "group; fraction is of the fp32 MFMA peak)"}[args.precision],
