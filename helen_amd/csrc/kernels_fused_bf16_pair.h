@@ -235,7 +235,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_pair_kernel(
 #ifdef HELEN_BP_NOGATES   // timing probes: results are garbage
         const f32x4 hn4 = ar + az + ahn + gn;
 #else
-        const f32x4 hn4 = gru_cell4(ar, az, ahn, splat4(0.f), splat4(0.f), gn, hprev[x]);
+        const f32x4 hn4 = gru_cell4(ar, az, ahn, gn, hprev[x]);
 #endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

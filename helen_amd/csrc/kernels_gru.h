@@ -51,13 +51,23 @@ __device__ __forceinline__ f32x2 exp2_pair(f32x2 v) {
 __device__ __forceinline__ f32x2 rcp_pair(f32x2 v) {
     return f32x2{__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y)};
 }
-__device__ __forceinline__ f32x2 gru_cell2(f32x2 ar, f32x2 az, f32x2 an, f32x2 gr, f32x2 gz, f32x2 gn, f32x2 hp) {
+// (pre-activations of r and z complete: the kernels whose accumulators start from the input part -- hipcc does not
+// fold an `x + 0`, which differs from x for -0)
+__device__ __forceinline__ f32x2 gru_cell2(f32x2 sr, f32x2 sz, f32x2 an, f32x2 gn, f32x2 hp) {
     const f32x2 one = {1.0f, 1.0f}, m2 = {-2.0f, -2.0f};
-    const f32x2 rg = rcp_pair(one + exp2_pair((ar + gr) * -1.4426950408889634f));
-    const f32x2 zg = rcp_pair(one + exp2_pair((az + gz) * -1.4426950408889634f));
+    const f32x2 rg = rcp_pair(one + exp2_pair(sr * -1.4426950408889634f));
+    const f32x2 zg = rcp_pair(one + exp2_pair(sz * -1.4426950408889634f));
     const f32x2 pre = __builtin_elementwise_fma(rg, an, gn);
     const f32x2 ng = __builtin_elementwise_fma(m2, rcp_pair(one + exp2_pair(pre * 2.8853900817779268f)), one);
     return __builtin_elementwise_fma(zg, hp - ng, ng);  // (1-z)*n + z*h
+}
+__device__ __forceinline__ f32x2 gru_cell2(f32x2 ar, f32x2 az, f32x2 an, f32x2 gr, f32x2 gz, f32x2 gn, f32x2 hp) {
+    return gru_cell2(ar + gr, az + gz, an, gn, hp);
+}
+__device__ __forceinline__ f32x4 gru_cell4(f32x4 sr, f32x4 sz, f32x4 an, f32x4 gn, const float (&hp)[4]) {
+    const f32x2 lo = gru_cell2(sr.xy, sz.xy, an.xy, gn.xy, f32x2{hp[0], hp[1]});
+    const f32x2 hi = gru_cell2(sr.zw, sz.zw, an.zw, gn.zw, f32x2{hp[2], hp[3]});
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
 }
 __device__ __forceinline__ f32x4 gru_cell4(f32x4 ar, f32x4 az, f32x4 an, f32x4 gr, f32x4 gz, f32x4 gn,
                                            const float (&hp)[4]) {
