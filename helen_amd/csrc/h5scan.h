@@ -83,7 +83,7 @@ class File {
 
     // members of an old-style group in name order; false if the object is not such a group
     bool children(uint64_t header, std::vector<std::pair<std::string, uint64_t>>* out) const {
-        uint64_t btree, heap;
+        uint64_t btree = 0, heap = 0;
         if (!symbol_table(header, &btree, &heap)) return false;
         const Names names = heap_data(heap);
         uint64_t budget = size_ / 8 + 16;    // no well-formed file has more nodes than that: loops end here
@@ -91,7 +91,7 @@ class File {
     }
     // one member by name (descends the B-tree by key comparison); false if absent or not an old-style group
     bool lookup(uint64_t header, const char* name, uint64_t* child) const {
-        uint64_t node, heap;
+        uint64_t node = 0, heap = 0;
         if (!symbol_table(header, &node, &heap)) return false;
         const Names names = heap_data(heap);
         if (!names.p) return false;

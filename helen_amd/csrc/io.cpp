@@ -639,8 +639,145 @@ int helen_io_write_predictions(void* handle, int n, const char* contigs, const i
  * skipped by the reference's `< 0` test: all of them share one key, which sorts last -- reproduced.
  * Writes the NUL-terminated sequence into out (capacity cap); returns its length, -2 if cap is too
  * small (call again with a larger buffer), -1 on error. */
+struct Rec {
+    int64_t pos, indx, split;
+    uint8_t base, rle;
+    uint32_t order;
+};
+
+// One region's records through the scanner (prediction files written by this package's emitter, by libhdf5 with
+// default settings, or by h5py: old-style groups, contiguous datasets).  0: done; 1: not for the scanner.
+static int fast_region_records(Scanned* sc, const char* contig, const char* region, std::vector<Rec>* recs) {
+    const h5scan::File& f = sc->file;
+    uint64_t g;
+    if (!f.lookup(f.root(), "predictions", &g) || !f.lookup(g, contig, &g) || !f.lookup(g, region, &g)) return 1;
+    std::vector<std::pair<std::string, uint64_t>> kids;
+    if (!f.children(g, &kids)) return 1;
+    // chunk ids in STRING order (sorted(set of str)): the B-tree order of an old-style group is exactly that
+    uint32_t order = 0;
+    std::vector<int64_t> pos;
+    std::vector<uint8_t> bases, rles;
+    for (auto& kv : kids) {
+        if (kv.first == "contig_start" || kv.first == "contig_end") continue;
+        uint64_t h;
+        h5scan::Dataset db, dr, dp;
+        if (!f.lookup(kv.second, "bases", &h) || !f.dataset(h, &db)) return 1;
+        if (!f.lookup(kv.second, "rles", &h) || !f.dataset(h, &dr)) return 1;
+        if (!f.lookup(kv.second, "position", &h) || !f.dataset(h, &dp)) return 1;
+        const uint64_t n = db.count();
+        if (db.cls != 0 || dr.cls != 0 || dp.cls != 0 || n == 0 || n > (1u << 24) || dr.count() != n ||
+            dp.count() != 3 * n)
+            return 1;
+        pos.resize((size_t)n * 3);
+        bases.resize((size_t)n);
+        rles.resize((size_t)n);
+        if (!scan_2d<uint8_t>(db, bases.data()) || !scan_2d<uint8_t>(dr, rles.data()) ||
+            !scan_2d<int64_t>(dp, pos.data()))
+            return 1;
+        // (libhdf5 reads `position` as uint32 below: the values of a signed file type would wrap the same way)
+        for (uint64_t k = 0; k < n; ++k)
+            recs->push_back({(int64_t)(uint32_t)pos[(size_t)k * 3], (int64_t)(uint32_t)pos[(size_t)k * 3 + 1],
+                             (int64_t)(uint32_t)pos[(size_t)k * 3 + 2], bases[(size_t)k], rles[(size_t)k], order++});
+    }
+    return 0;
+}
+
+static long long decode_records(std::vector<Rec>& recs, char* out, long long cap);
+
+/* The regions of predictions/<contig> of one file, in name order (what sorted(h5py keys) yields), with the
+ * contig_start / contig_end each of them stores (StitchInterface.py:84-95 reads these two scalars per region:
+ * 300 k regions x 2 dataset opens through a Python binding is minutes).  Two calls: with names == NULL only
+ * sizes[0] = number of regions and sizes[1] = bytes of the '\n'-joined names are set; then names (capacity
+ * sizes[1] + 1), starts and ends (sizes[0] entries each) are filled.  Returns 0, 1 if the file has no such
+ * contig, -1 on error. */
+int helen_io_list_regions(const char* path, const char* contig, long long* sizes, char* names, int64_t* starts,
+                          int64_t* ends) {
+    std::vector<std::string> region;
+    std::vector<int64_t> st, en;
+    bool listed = false;
+    if (Scanned* sc = scan_file(path)) {
+        const h5scan::File& f = sc->file;
+        uint64_t g;
+        std::vector<std::pair<std::string, uint64_t>> kids;
+        if (f.lookup(f.root(), "predictions", &g)) {
+            if (!f.lookup(g, contig, &g)) {
+                // absent, or not an old-style group: only the first is an answer
+                std::vector<std::pair<std::string, uint64_t>> top;
+                uint64_t pg;
+                if (f.lookup(f.root(), "predictions", &pg) && f.children(pg, &top)) return 1;
+            } else if (f.children(g, &kids)) {
+                listed = true;
+                for (auto& kv : kids) {
+                    int64_t a, b;
+                    if (!scan_i64_first(f, kv.second, "contig_start", &a) || !scan_i64_first(f, kv.second, "contig_end", &b)) {
+                        listed = false;
+                        break;
+                    }
+                    region.push_back(kv.first);
+                    st.push_back(a);
+                    en.push_back(b);
+                }
+            }
+        }
+    }
+    if (!listed) {
+        static const bool direct_only = reader_mode_is("direct");
+        if (direct_only) return fail("%s: not a file the direct scanner takes", path);
+        region.clear();
+        st.clear();
+        en.clear();
+        hid_t f = get_file(path);
+        if (f < 0) return fail("cannot open '%s'", path);
+        const std::string gpath = std::string("predictions/") + contig;
+        if (H5Lexists(f, "predictions", H5P_DEFAULT) <= 0 || H5Lexists(f, gpath.c_str(), H5P_DEFAULT) <= 0) return 1;
+        hid_t g = H5Gopen2(f, gpath.c_str(), H5P_DEFAULT);
+        if (g < 0) return fail("%s: cannot open group '%s'", path, gpath.c_str());
+        auto cb = [](hid_t, const char* name, const H5L_info_t*, void* ud) -> herr_t {
+            ((std::vector<std::string>*)ud)->push_back(name);
+            return 0;
+        };
+        const herr_t it = H5Literate(g, H5_INDEX_NAME, H5_ITER_INC, nullptr, cb, &region);
+        bool good = it >= 0;
+        for (size_t k = 0; good && k < region.size(); ++k) {
+            hid_t rg = H5Gopen2(g, region[k].c_str(), H5P_DEFAULT);
+            int64_t a = 0, b = 0;
+            good = rg >= 0 && read_i64_first(rg, "contig_start", &a) == 0 && read_i64_first(rg, "contig_end", &b) == 0;
+            if (rg >= 0) H5Gclose(rg);
+            st.push_back(a);
+            en.push_back(b);
+        }
+        H5Gclose(g);
+        if (!good) return fail("%s: cannot list the regions of '%s'", path, gpath.c_str());
+    }
+    size_t bytes = 0;
+    for (auto& r : region) bytes += r.size() + 1;
+    if (!names) {
+        sizes[0] = (long long)region.size();
+        sizes[1] = (long long)bytes;
+        return 0;
+    }
+    if (sizes[0] != (long long)region.size() || sizes[1] < (long long)bytes) return fail("%s: changed between two calls", path);
+    size_t o = 0;
+    for (size_t k = 0; k < region.size(); ++k) {
+        memcpy(names + o, region[k].data(), region[k].size());
+        o += region[k].size();
+        names[o++] = '\n';
+        starts[k] = st[k];
+        ends[k] = en[k];
+    }
+    names[o ? o - 1 : 0] = 0;
+    return 0;
+}
+
 long long helen_io_region_sequence(const char* path, const char* contig, const char* region, char* out,
                                    long long cap) {
+    std::vector<Rec> recs;
+    if (Scanned* sc = scan_file(path)) {
+        if (fast_region_records(sc, contig, region, &recs) == 0) return decode_records(recs, out, cap);
+        recs.clear();
+    }
+    static const bool direct_only = reader_mode_is("direct");
+    if (direct_only) return fail("%s: not a file the direct scanner takes", path);
     hid_t f = get_file(path);
     if (f < 0) return fail("cannot open '%s'", path);
     const std::string gpath = std::string("predictions/") + contig + "/" + region;
@@ -657,12 +794,6 @@ long long helen_io_region_sequence(const char* path, const char* contig, const c
         if (s != "contig_start" && s != "contig_end") chunks.push_back(s);
     }
     std::sort(chunks.begin(), chunks.end());   // sorted(set of str): lexicographic
-    struct Rec {
-        int64_t pos, indx, split;
-        uint8_t base, rle;
-        uint32_t order;
-    };
-    std::vector<Rec> recs;
     std::vector<uint32_t> pos;
     std::vector<uint8_t> bases, rles;
     uint32_t order = 0;
@@ -703,12 +834,19 @@ long long helen_io_region_sequence(const char* path, const char* contig, const c
                             (int64_t)pos[(size_t)k * 3 + 2], bases[(size_t)k], rles[(size_t)k], order++});
     }
     H5Gclose(g);
-    std::sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) {
+    return decode_records(recs, out, cap);
+}
+
+// first writer wins per (pos, indx, split) key, keys in numeric order, base x run length
+static long long decode_records(std::vector<Rec>& recs, char* out, long long cap) {
+    auto before = [](const Rec& a, const Rec& b) {
         if (a.pos != b.pos) return a.pos < b.pos;
         if (a.indx != b.indx) return a.indx < b.indx;
         if (a.split != b.split) return a.split < b.split;
         return a.order < b.order;
-    });
+    };
+    // (an image's rows come in key order: a region of one chunk id needs no sorting at all)
+    if (!std::is_sorted(recs.begin(), recs.end(), before)) std::sort(recs.begin(), recs.end(), before);
     static const char kDecode[5] = {0, 'A', 'C', 'G', 'T'};
     long long len = 0;
     for (size_t k = 0; k < recs.size(); ++k) {

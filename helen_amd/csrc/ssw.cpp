@@ -13,8 +13,8 @@
 //     reaches the forward score;
 //   * the CIGAR comes from a banded global-in-the-box DP (band doubled until the score is reached)
 //     with a fixed preference order in its traceback (diagonal on ties, deletion over insertion).
-// No SIMD is needed here (stitch aligns ~200-base overlaps); the lanes are emulated with plain
-// loops so that the arithmetic, including its saturation behaviour, is the library's.
+// The lanes are emulated with plain loops so that the arithmetic, including its saturation behaviour, is the
+// library's; the version stitch actually runs (striped_pass_small) keeps them in the compiler's vector types.
 // Checked cell-for-cell against the reference library itself (oracle/_ref/libssw_ref.so, built from
 // the reference's own sources) on randomised inputs: tests/test_stitch.py.
 #include <algorithm>
@@ -161,6 +161,166 @@ Best striped_pass(const int8_t* ref, bool backwards, int n, const int8_t* read, 
     return b;
 }
 
+// The same pass for scores that stay clear of the 16-bit cap (every alignment stitch makes: a few hundred bases),
+// on the compiler's vector types: one vector of LANES 16-bit values per segment, so the lane loops above become
+// single SSE2 / NEON operations (pmaxsw, paddw, ...).  Cell for cell the same values (tests/test_stitch.py runs this
+// against the reference library and against striped_pass).  With long match runs F stays above H - gap_open for
+// many cells, and the lazy-F loop -- 40-50 segment visits per column against `seg` in the main loop -- is where the
+// time goes: its "is any lane still open" test is one compare and an OR of the mask's halves.
+// The caller guarantees  min(n, m) * max(mat) + max(mat) + bias < 32000.
+template <int LANES>
+struct Lanes;
+#define HELEN_SSW_INLINE static inline __attribute__((always_inline))
+#define HELEN_SSW_COMMON(N, T, M)                                                            \
+    typedef T V __attribute__((vector_size(16)));                                            \
+    typedef long long W __attribute__((vector_size(16)));                                    \
+    HELEN_SSW_INLINE V splat(int x) {                                                        \
+        V v;                                                                                 \
+        for (int l = 0; l < N; ++l) v[l] = (T)x;                                             \
+        return v;                                                                            \
+    }                                                                                        \
+    HELEN_SSW_INLINE V vmax(V a, V b) { return a > b ? a : b; }                              \
+    HELEN_SSW_INLINE bool any_set(V v) {                                                     \
+        const W w = (W)v;                                                                    \
+        return (w[0] | w[1]) != 0;                                                           \
+    }                                                                                        \
+    HELEN_SSW_INLINE V shift_up(V v) { /* lane l takes lane l-1's value, lane 0 gets 0 */    \
+        typedef M Mask __attribute__((vector_size(16)));                                     \
+        Mask k;                                                                              \
+        k[0] = 0;                                                                            \
+        for (int l = 1; l < N; ++l) k[l] = (M)(N + l - 1);                                   \
+        return __builtin_shuffle(splat(0), v, k);       /* one byte shift of the register */ \
+    }                                                                                        \
+    HELEN_SSW_INLINE int hmax(V v) {                                                         \
+        int m = v[0];                                                                        \
+        for (int l = 1; l < N; ++l) m = std::max<int>(m, v[l]);                              \
+        return m;                                                                            \
+    }
+template <>
+struct Lanes<8> {   // the 16-bit pass: signed words, nowhere near saturation (see the caller)
+    HELEN_SSW_COMMON(8, int16_t, short)
+    HELEN_SSW_INLINE V sub0(V a, V b) { return vmax(a - b, splat(0)); }
+    HELEN_SSW_INLINE bool any_above(V a, V b) { return any_set((V)(a > b)); }
+    HELEN_SSW_INLINE V add_profile(V h, V p, V) { return h + p; }
+    static int profile_entry(int score, int) { return score; }
+};
+template <>
+struct Lanes<16> {  // the 8-bit pass: unsigned bytes, saturating at 255; profile entries carry the bias
+    HELEN_SSW_COMMON(16, uint8_t, unsigned char)
+    HELEN_SSW_INLINE V sub0(V a, V b) { return vmax(a, b) - b; }                       // subs_epu8
+    HELEN_SSW_INLINE bool any_above(V a, V b) { return any_set(sub0(a, b)); }
+    HELEN_SSW_INLINE V add_profile(V h, V p, V bias) {
+        V sum = h + p;
+        sum |= (V)(sum < h);                                                             // adds_epu8: 255 on wrap
+        return sub0(sum, bias);
+    }
+    static int profile_entry(int score, int bias) { return score + bias; }
+};
+#undef HELEN_SSW_COMMON
+#undef HELEN_SSW_INLINE
+
+template <int LANES>
+Best striped_pass_small(const int8_t* ref, bool backwards, int n, const int8_t* read, int m, int gap_open,
+                        int gap_ext, const int8_t* mat, int bias, int terminate) {
+    typedef Lanes<LANES> L;
+    typedef typename L::V V;
+    const int seg = (m + LANES - 1) / LANES;
+    thread_local std::vector<V> scratch;
+    scratch.assign((size_t)9 * seg, L::splat(0));
+    V* const prof = scratch.data();             // [5][seg]
+    V* Hs = prof + 5 * seg;                     // H of the current column (store) ...
+    V* Hl = Hs + seg;                           // ... and of the previous one (load)
+    V* const E = Hl + seg;
+    V* const Hbest = E + seg;
+    constexpr bool kByte = LANES == 16;
+    for (int r = 0; r < 5; ++r)
+        for (int s = 0; s < seg; ++s)
+            for (int l = 0; l < LANES; ++l) {
+                const int q = l * seg + s;    // padding cells score 0 (the bias alone in the 8-bit pass)
+                prof[(size_t)r * seg + s][l] = L::profile_entry(q < m ? mat[r * 5 + read[q]] : 0, bias);
+            }
+    const V zero = L::splat(0), go = L::splat(gap_open), ge = L::splat(gap_ext), bs = L::splat(bias);
+    int best = 0, best_ref = kByte ? -1 : 0, best_read = m - 1;
+    bool overflow = false;
+    for (int step = 0; step < n; ++step) {
+        const int i = backwards ? n - 1 - step : step;
+        const V* P = prof + (size_t)ref[i] * seg;
+        V F = zero, cm = zero;
+        V Hv = L::shift_up(Hs[seg - 1]);        // diagonal predecessors of the first segment
+        std::swap(Hs, Hl);
+        for (int s = 0; s < seg; ++s) {
+            V h = L::add_profile(Hv, P[s], bs);
+            h = L::vmax(L::vmax(h, E[s]), F);
+            cm = L::vmax(cm, h);
+            Hs[s] = h;
+            const V open = L::sub0(h, go);
+            E[s] = L::vmax(L::sub0(E[s], ge), open);   // from H before the lazy-F fix-up
+            F = L::vmax(L::sub0(F, ge), open);
+            Hv = Hl[s];
+        }
+        // lazy F: carry gaps across lane boundaries; E is deliberately left alone
+        if (kByte) {
+            int s = 0;
+            F = L::shift_up(F);
+            while (L::any_above(F, L::sub0(Hs[s], go))) {
+                Hs[s] = L::vmax(Hs[s], F);
+                cm = L::vmax(cm, Hs[s]);
+                F = L::sub0(F, ge);
+                if (++s >= seg) {
+                    s = 0;
+                    F = L::shift_up(F);
+                }
+            }
+        } else {
+            bool done = false;
+            for (int k = 0; k < LANES && !done; ++k) {
+                F = L::shift_up(F);
+                for (int s = 0; s < seg && !done; ++s) {
+                    Hs[s] = L::vmax(Hs[s], F);
+                    cm = L::vmax(cm, Hs[s]);
+                    F = L::sub0(F, ge);
+                    if (!L::any_above(F, L::sub0(Hs[s], go))) done = true;
+                }
+            }
+        }
+        const int col_max = L::hmax(cm);
+        if (col_max > best) {
+            best = col_max;
+            if (kByte && best + bias >= 255) {
+                overflow = true;
+                break;
+            }
+            best_ref = i;
+            memcpy(Hbest, Hs, sizeof(V) * seg);
+        }
+        if (col_max == terminate) break;
+    }
+    for (int s = 0; s < seg; ++s)
+        for (int l = 0; l < LANES; ++l)
+            if (Hbest[s][l] == best) {
+                const int q = s + l * seg;
+                if (q < best_read) best_read = q;
+            }
+    Best b;
+    b.score = (kByte && (overflow || best + bias >= 255)) ? 255 : best;
+    b.ref = best_ref;
+    b.read = best_read;
+    return b;
+}
+
+// dispatch: the fast version whenever no score can come near the 16-bit cap
+Best striped(const int8_t* ref, bool backwards, int n, const int8_t* read, int m, int gap_open, int gap_ext,
+             const int8_t* mat, int lanes, int bias, int terminate) {
+    int top = 0;
+    for (int k = 0; k < 25; ++k) top = std::max<int>(top, mat[k]);
+    const long long bound = (long long)std::min(n, m) * top + top + bias;
+    static const bool general_only = getenv("HELEN_SSW_GENERAL") != nullptr;   // tests: exercise the version below
+    if (!general_only && bound < 32000 && gap_open < 32000 && gap_ext < 32000)
+        return lanes == 16 ? striped_pass_small<16>(ref, backwards, n, read, m, gap_open, gap_ext, mat, bias, terminate)
+                           : striped_pass_small<8>(ref, backwards, n, read, m, gap_open, gap_ext, mat, bias, terminate);
+    return striped_pass(ref, backwards, n, read, m, gap_open, gap_ext, mat, lanes, bias, terminate);
+}
+
 struct Op {
     char op;
     int len;
@@ -285,19 +445,17 @@ int helen_ssw_align(const char* ref_seq, int ref_len, const char* query_seq, int
     // 8-bit pass first; the 16-bit pass replaces it when the score saturates
     const int bias = mismatch;  // |most negative matrix entry|
     int lanes = 16;
-    Best fwd = striped_pass(ref.data(), false, ref_len, read.data(), query_len, gap_open, gap_extend,
-                            mat, 16, bias, -1);
+    Best fwd = striped(ref.data(), false, ref_len, read.data(), query_len, gap_open, gap_extend, mat, 16, bias, -1);
     if (fwd.score == 255) {
         lanes = 8;
-        fwd = striped_pass(ref.data(), false, ref_len, read.data(), query_len, gap_open, gap_extend, mat,
-                           8, 0, -1);
+        fwd = striped(ref.data(), false, ref_len, read.data(), query_len, gap_open, gap_extend, mat, 8, 0, -1);
     }
     const int score = fwd.score, ref_end = fwd.ref, read_end = fwd.read;
     // begin cell: reversed query prefix against the reference prefix, walked backwards
     std::vector<int8_t> rq(read.begin(), read.begin() + read_end + 1);
     std::reverse(rq.begin(), rq.end());
-    const Best bwd = striped_pass(ref.data(), true, ref_end + 1, rq.data(), read_end + 1, gap_open,
-                                  gap_extend, mat, lanes, lanes == 16 ? bias : 0, score);
+    const Best bwd = striped(ref.data(), true, ref_end + 1, rq.data(), read_end + 1, gap_open, gap_extend, mat, lanes,
+                             lanes == 16 ? bias : 0, score);
     const int ref_begin = bwd.ref, read_begin = read_end - bwd.read;
     out[0] = score;
     out[1] = ref_begin;

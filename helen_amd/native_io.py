@@ -50,6 +50,9 @@ def load():
     lib.helen_io_write_predictions_sel.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, vp]
     lib.helen_io_writer_close.restype = ctypes.c_int
     lib.helen_io_writer_close.argtypes = [vp]
+    lib.helen_io_list_regions.restype = ctypes.c_int
+    lib.helen_io_list_regions.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong),
+                                          ctypes.c_char_p, vp, vp]
     lib.helen_io_region_sequence.restype = ctypes.c_longlong
     lib.helen_io_region_sequence.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
                                              ctypes.c_char_p, ctypes.c_longlong]
@@ -177,7 +180,29 @@ class Writer(object):
                 raise IOError(_err(self._lib))
 
 
-def region_sequence(path, contig, region):
+def list_regions(path, contig):
+    """[(region name, contig_start, contig_end)] of predictions/<contig> in name order; None if the file has no such
+    contig."""
+    lib = load()
+    sizes = (ctypes.c_longlong * 2)()
+    rc = lib.helen_io_list_regions(os.fsencode(path), contig.encode(), sizes, None, None, None)
+    if rc == 1:
+        return None
+    if rc != 0:
+        raise IOError(_err(lib))
+    n = int(sizes[0])
+    if n == 0:
+        return []
+    names = ctypes.create_string_buffer(int(sizes[1]) + 1)
+    starts = np.zeros(n, np.int64)
+    ends = np.zeros(n, np.int64)
+    if lib.helen_io_list_regions(os.fsencode(path), contig.encode(), sizes, names, starts.ctypes.data,
+                                 ends.ctypes.data) != 0:
+        raise IOError(_err(lib))
+    return list(zip(names.value.decode().split("\n"), starts.tolist(), ends.tolist()))
+
+
+def region_sequence(path, contig, region, as_bytes=False):
     """Decoded sequence of one region of a prediction file (Stitch.small_chunk_stitch's inner loop)."""
     lib = load()
     cap = 1 << 16
@@ -189,7 +214,7 @@ def region_sequence(path, contig, region):
             continue
         if n < 0:
             raise IOError(_err(lib))
-        return buf.raw[:n].decode()
+        return buf.raw[:n] if as_bytes else buf.raw[:n].decode()
 
 
 class Alignment(object):
@@ -202,7 +227,8 @@ def ssw_align(reference, query, match, mismatch, gap_open, gap_extend):
     """Aligner(match, mismatch, gap_open, gap_extend).SetReferenceSequence(reference);
     Align_cpp(query, Filter(), alignment, 0) -> Alignment (same numbers as the reference's SSW)."""
     lib = load()
-    r, q = reference.encode(), query.encode()
+    r = reference.encode() if isinstance(reference, str) else bytes(reference)
+    q = query.encode() if isinstance(query, str) else bytes(query)
     out = (ctypes.c_int * 6)()
     cap = 16 * (len(r) + len(q)) + 64
     cig = ctypes.create_string_buffer(cap)

@@ -65,18 +65,31 @@ def get_confident_positions(alignment):
 
 def alignment_stitch(sequence_chunks):
     """Join (contig, start, end, sequence) chunks in position order (Stitch.py:96-190)."""
+    contig, running_start, running_end, running = _alignment_stitch(sequence_chunks)
+    return contig, running_start, running_end, running.decode()
+
+
+def _as_bytes(sequence):
+    return sequence.encode() if isinstance(sequence, str) else sequence
+
+
+def _alignment_stitch(sequence_chunks):
+    """alignment_stitch on bytes: the sequences of a contig are hundreds of megabytes, and every str <-> bytes
+    conversion of the running sequence is a copy of all of it.  Chunk sequences may be str or bytes; the running
+    sequence comes back as a bytearray."""
     sequence_chunks = sorted(sequence_chunks, key=lambda e: (e[1], e[2]))
     contig, running_start, running_end, first = sequence_chunks[0]
-    running = bytearray(first.encode())
+    running = bytearray(_as_bytes(first))
     fill = b'N' * 10
     for i in range(1, len(sequence_chunks)):
         _, this_start, this_end, this_sequence = sequence_chunks[i]
+        this_sequence = _as_bytes(this_sequence)
         if this_start < running_end:
             overlap_bases = running_end - this_start
             overlap_bases = overlap_bases + int(overlap_bases * StitchOptions.BASE_ERROR_RATE)
             # python slicing semantics of the reference: s[-n:] is all of s when n >= len(s)
-            left_chunk = bytes(running[-overlap_bases:]).decode()
-            right_chunk = this_sequence[:overlap_bases]
+            left_chunk = bytes(running[-overlap_bases:])
+            right_chunk = bytes(this_sequence[:overlap_bases])
             if len(left_chunk) > 0 and len(right_chunk) > 0:
                 alignment = native_io.ssw_align(left_chunk, right_chunk, StitchOptions.MATCH_PENALTY,
                                                 StitchOptions.MISMATCH_PENALTY, StitchOptions.GAP_PENALTY,
@@ -88,34 +101,34 @@ def alignment_stitch(sequence_chunks):
                 sys.stderr.write("WARNING: NO ALIGNMENT FOUND: " + str(this_start) + " " + str(this_end) + "\n")
                 if len(right_chunk) > 10:
                     running += fill
-                    running += right_chunk.encode()
+                    running += right_chunk
                     running_end = this_end
             else:
                 pos_a, pos_b = get_confident_positions(alignment)
                 if pos_a == -1 or pos_b == -1:
                     sys.stderr.write("WARNING: NO OVERLAPS IN ALIGNMENT : \n")
-                    sys.stderr.write("LEFT : " + left_chunk + "\n")
-                    sys.stderr.write("RIGHT: " + right_chunk + "\n")
+                    sys.stderr.write("LEFT : " + left_chunk.decode() + "\n")
+                    sys.stderr.write("RIGHT: " + right_chunk.decode() + "\n")
                     sys.stderr.write("CIGAR: " + alignment.cigar_string + "\n")
                     if len(this_sequence) > 10:
                         # left_sequence + overlap_sequence is the running sequence itself
                         running += fill
-                        running += this_sequence.encode()
+                        running += this_sequence
                         running_end = this_end
                 else:
                     # running[:-overlap] + left_chunk[:pos_a] + this[pos_b:]
                     keep = len(running) - len(left_chunk) + pos_a
                     del running[keep:]
-                    running += this_sequence[pos_b:].encode()
+                    running += memoryview(this_sequence)[pos_b:]
                     running_end = this_end
         else:
             sys.stderr.write("WARNING: NO OVERLAP IN CHUNKS:  " + str(contig) + " " + str(this_start) + " "
                              + str(running_end) + "\n")
             if len(this_sequence) > 10:
                 running += fill
-                running += this_sequence.encode()
+                running += this_sequence
                 running_end = this_end
-    return contig, running_start, running_end, running.decode()
+    return contig, running_start, running_end, running
 
 
 def _region_sequence_py(file_name, contig, chunk_name):
@@ -143,21 +156,23 @@ def small_chunk_stitch(contig, small_chunk_keys):
     name_sequence_tuples = []
     for contig_name, file_name, chunk_name, contig_start, contig_end in small_chunk_keys:
         if native_io.available():
-            sequence = native_io.region_sequence(file_name, contig, chunk_name)
+            sequence = native_io.region_sequence(file_name, contig, chunk_name, as_bytes=True)
         else:
             sequence = _region_sequence_py(file_name, contig, chunk_name)
         name_sequence_tuples.append((contig, contig_start, contig_end, sequence))
     name_sequence_tuples = sorted(name_sequence_tuples, key=lambda e: (e[1], e[2]))
-    return alignment_stitch(name_sequence_tuples)
+    contig, start, end, running = _alignment_stitch(name_sequence_tuples)
+    return contig, start, end, bytes(running)        # (bytes: what travels back from a worker process)
 
 
-def create_consensus_sequence(contig, sequence_chunk_keys, threads):
+def create_consensus_sequence(contig, sequence_chunk_keys, threads, executor=None):
     """(Stitch.py:257-301): sort the regions, stitch runs of them in worker processes, then stitch the
-    partial sequences."""
+    partial sequences.  `executor`: a process pool to use (perform_stitch keeps one for all contigs; the
+    reference starts a new one per contig)."""
     key_list = sorted(((contig, f, key, int(st), int(end)) for f, key, st, end in sequence_chunk_keys),
                       key=lambda e: (e[3], e[4]))
     if not key_list:
-        return ""
+        return b""
     n = max(StitchOptions.MIN_SEQUENCE_REQUIRED_FOR_MULTITHREADING, int(len(key_list) / threads) + 1)
     file_chunks = [key_list[i:i + n] for i in range(0, len(key_list), n)]   # FileManager.chunks
     sequence_chunks = []
@@ -165,17 +180,42 @@ def create_consensus_sequence(contig, sequence_chunk_keys, threads):
         for fc in file_chunks:
             sequence_chunks.append(small_chunk_stitch(contig, fc))
     else:
-        import multiprocessing as mp
-        with concurrent.futures.ProcessPoolExecutor(max_workers=threads,
-                                                    mp_context=mp.get_context("spawn")) as ex:
+        own = executor is None
+        ex = _new_pool(threads) if own else executor
+        try:
             futures = [ex.submit(small_chunk_stitch, contig, fc) for fc in file_chunks]
             for fut in concurrent.futures.as_completed(futures):
                 if fut.exception() is None:
                     sequence_chunks.append(fut.result())
                 else:
                     sys.stderr.write("ERROR: " + str(fut.exception()) + "\n")
+        finally:
+            if own:
+                ex.shutdown()
     sequence_chunks = sorted(sequence_chunks, key=lambda e: (e[1], e[2]))
-    return alignment_stitch(sequence_chunks)[3]
+    return _alignment_stitch(sequence_chunks)[3]     # bytes-like
+
+
+def _new_pool(threads):
+    import multiprocessing as mp
+    return concurrent.futures.ProcessPoolExecutor(max_workers=threads, mp_context=mp.get_context("spawn"))
+
+
+def _regions_of(prediction_file, contig):
+    """[(file, region name, contig_start, contig_end)] of one file for `contig`, regions in name order
+    (StitchInterface.py:84-95) -- through the native lister when there is one: two dataset reads per region
+    through a Python binding are minutes at 300 k regions."""
+    if native_io.available():
+        listed = native_io.list_regions(prediction_file, contig)
+        return [] if listed is None else [(prediction_file, name, st, en) for name, st, en in listed]
+    out = []
+    with hdf5.File(prediction_file, "r") as f:
+        if contig not in f.keys("predictions"):
+            return out
+        for chunk_key in sorted(f.keys("predictions/" + contig)):
+            root = "predictions/%s/%s/" % (contig, chunk_key)
+            out.append((prediction_file, chunk_key, int(f.read(root + "contig_start")), int(f.read(root + "contig_end"))))
+    return out
 
 
 def get_file_paths_from_directory(directory_path):
@@ -198,24 +238,23 @@ def perform_stitch(input_directory, output_path, output_prefix, threads):
     output_dir = file_manager.handle_output_directory(output_path)
     output_filename = os.path.join(output_dir, output_prefix + '.fa')
     sys.stderr.write("INFO: OUTPUT FILE: " + output_filename + "\n")
-    with open(output_filename, 'w') as fasta:
-        for i, contig in enumerate(sorted(all_contigs)):
-            prefix = "{:04d}/{:04d}:".format(i, len(all_contigs))
-            sys.stderr.write("INFO: " + prefix + " PROCESSING CONTIG: " + contig + "\n")
-            chunk_name_tuple = []
-            for prediction_file in all_prediction_files:
-                with hdf5.File(prediction_file, "r") as f:
-                    if contig not in f.keys("predictions"):
-                        continue
-                    for chunk_key in sorted(f.keys("predictions/" + contig)):
-                        root = "predictions/%s/%s/" % (contig, chunk_key)
-                        chunk_name_tuple.append((prediction_file, chunk_key,
-                                                 int(f.read(root + "contig_start")),
-                                                 int(f.read(root + "contig_end"))))
-            consensus_sequence = create_consensus_sequence(contig, chunk_name_tuple, threads)
-            sys.stderr.write("INFO: " + prefix + " FINISHED PROCESSING " + contig
-                             + ", POLISHED SEQUENCE LENGTH: " + str(len(consensus_sequence)) + ".\n")
-            if consensus_sequence is not None and len(consensus_sequence) > 0:
-                fasta.write('>' + contig + "\n")
-                fasta.write(consensus_sequence + "\n")
+    executor = _new_pool(threads) if threads > 1 else None      # one pool for all contigs
+    try:
+        with open(output_filename, 'wb') as fasta:
+            for i, contig in enumerate(sorted(all_contigs)):
+                prefix = "{:04d}/{:04d}:".format(i, len(all_contigs))
+                sys.stderr.write("INFO: " + prefix + " PROCESSING CONTIG: " + contig + "\n")
+                chunk_name_tuple = []
+                for prediction_file in all_prediction_files:
+                    chunk_name_tuple.extend(_regions_of(prediction_file, contig))
+                consensus_sequence = create_consensus_sequence(contig, chunk_name_tuple, threads, executor)
+                sys.stderr.write("INFO: " + prefix + " FINISHED PROCESSING " + contig
+                                 + ", POLISHED SEQUENCE LENGTH: " + str(len(consensus_sequence)) + ".\n")
+                if consensus_sequence is not None and len(consensus_sequence) > 0:
+                    fasta.write(b'>' + contig.encode() + b"\n")
+                    fasta.write(consensus_sequence)
+                    fasta.write(b"\n")
+    finally:
+        if executor is not None:
+            executor.shutdown()
     return output_filename

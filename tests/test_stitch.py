@@ -72,6 +72,18 @@ def test_aligner_equals_reference_ssw_on_random_pairs():
     assert checked > 2000
 
 
+@pytest.mark.skipif(not os.path.exists(REF_SSW), reason="oracle/_ref/libssw_ref.so not built (make -C oracle ref)")
+def test_general_aligner_path_equals_reference_ssw_too():
+    """Stitch's alignments all take the vectorised 16-bit pass (striped_pass_small); the general pass behind it
+    (any length, exact saturation) is forced with HELEN_SSW_GENERAL=1 and put through the same comparison."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.abspath(__file__), "-k",
+                        "test_aligner_equals_reference_ssw_on_random_pairs"],
+                       env=dict(os.environ, HELEN_SSW_GENERAL="1"), capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_aligner_known_answers():
     a = native_io.ssw_align("ACGTTGCATGCATGCAAGGCTTAGGACCATTTACGGCATG", "TGCATGCATGCAGGCTTAGGACCTTTTACGGC", 4, 6, 8, 2)
     # produced by the reference library (oracle/_ref) for this pair
@@ -185,3 +197,82 @@ def test_stitch_gap_and_no_alignment_paths():
     # a short chunk (<= 10 bases) without an anchor is dropped (Stitch.py:163)
     c, st, en, seq = alignment_stitch([("c", 0, 300, s1), ("c", 400, 405, "ACGTA")])
     assert seq == s1 and en == 300
+
+
+READERS_CHILD = r'''
+import json, sys
+sys.path.insert(0, %(root)r)
+from helen_amd import native_io
+out = {}
+for path in %(paths)r:
+    for contig in ("ctgA", "ctgB", "nope"):
+        listed = native_io.list_regions(path, contig)
+        out[path + "|" + contig] = None if listed is None else [
+            [name, st, en, native_io.region_sequence(path, contig, name)] for name, st, en in listed]
+print(json.dumps(out))
+'''
+
+
+@pytest.mark.parametrize("writer", [None, "libhdf5"])
+def test_prediction_readers_agree(tmp_path, monkeypatch, writer):
+    """Region listing and region decoding walk prediction files through the direct scanner, with libhdf5 behind it:
+    the scanner alone (HELEN_IO_READER=direct), libhdf5 alone and the default must give the same regions, bounds
+    and sequences, for files of either writer -- and the same as the Python statement of the decode."""
+    import json
+    import subprocess
+    import sys
+    from helen_amd.stitch import _region_sequence_py
+    if writer:
+        monkeypatch.setenv("HELEN_IO_WRITER", writer)
+    else:
+        monkeypatch.delenv("HELEN_IO_WRITER", raising=False)
+    rng = np.random.default_rng(9)
+    paths = []
+    for k in range(2):
+        path = str(tmp_path / ("p_%d.hdf" % k))
+        for contig in (("ctgA", "ctgB") if k == 0 else ("ctgB",)):
+            regions = []
+            for r in range(23):                              # > 16 members: more than two symbol table nodes
+                chunks = []
+                for cid in range(1 + r % 3):
+                    n = 30 + r
+                    pos = np.stack([1000 * r + np.sort(rng.integers(0, 50, n)), rng.integers(0, 2, n), np.zeros(n)], 1)
+                    chunks.append((cid, pos.astype(np.int64), rng.integers(0, 5, n), rng.integers(0, 4, n)))
+                regions.append((1000 * r, 1000 * r + 1000 + k, chunks))
+            # (one DataStore per file: append both contigs of file 0 through the same store)
+            if contig == "ctgA" or k == 1:
+                from helen_amd.data_store import DataStore
+                store = DataStore(path, "w")
+            for start, end, chunks in regions:
+                for chunk_id, pos, bases, rles in chunks:
+                    n = len(bases)
+                    P = np.full((1000, 3), -1, np.int64)
+                    B = np.zeros(1000, np.uint8)
+                    R = np.zeros(1000, np.uint8)
+                    P[:n], B[:n], R[:n] = pos, bases, rles
+                    store.write_prediction(contig, start, end, chunk_id, P, B, R)
+        store.close()
+        paths.append(path)
+    got = {}
+    for reader in ("", "libhdf5", "direct"):
+        env = dict(os.environ)
+        env.pop("HELEN_IO_READER", None)
+        if reader:
+            env["HELEN_IO_READER"] = reader
+        r = subprocess.run([sys.executable, "-c", READERS_CHILD % {"root": ROOT, "paths": paths}], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[reader] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got[""] == got["libhdf5"] == got["direct"]
+    ref = got[""]
+    assert ref[paths[0] + "|nope"] is None and ref[paths[1] + "|ctgA"] is None
+    assert len(ref[paths[0] + "|ctgA"]) == 23 and len(ref[paths[1] + "|ctgB"]) == 23
+    names = [e[0] for e in ref[paths[0] + "|ctgB"]]
+    assert names == sorted(names)
+    for key, entries in ref.items():
+        if entries is None:
+            continue
+        path, contig = key.split("|")
+        for name, st, en, seq in entries[::5]:
+            assert name == "%s-%d-%d" % (contig, st, en)
+            assert seq == _region_sequence_py(path, contig, name)
