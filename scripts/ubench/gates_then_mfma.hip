@@ -4,6 +4,8 @@
 // gate_math_cost.hip) once MFMA phases follow?  Prints per wave the average cycles of each phase.
 //   MODE 0 plain   1 s_setprio 3 during the gates (all waves)   2 ... only waves 4-7   3 second barrier behind the gates
 //        4 waves 0-3 s_sleep 2 first   5 gates split: waves 4-7 first, then barrier, then waves 0-3 (serial reference)
+//        6 barrier | MFMAs | gates  (the barrier behind the gates instead of in front of them: the older wave's gate
+//          math, which has issue priority, then runs beside the younger wave's MFMAs)   7 = 6 with setprio 3 in the gates
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I helen_amd/csrc -o /tmp/gates_then_mfma scripts/ubench/gates_then_mfma.hip
 #include <hip/hip_runtime.h>
 
@@ -27,6 +29,20 @@ __global__ __launch_bounds__(512, 1) void phases(const float* in, float* out, in
     for (int t = 0; t < trips; ++t) {
         __builtin_amdgcn_s_barrier();
         TICK(0)
+        if (MODE >= 6) {
+#pragma unroll
+            for (int i = 0; i < NM; ++i)
+                asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[i % 3]) : "v"(a), "v"(b));
+            TICK(2)
+            if (MODE == 7) __builtin_amdgcn_s_setprio(3);
+            const f32x4 hn6 = gru_cell4(acc[0], acc[1], acc[2], splat4(0.f), splat4(0.f), gn, hp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hp[r] = hn6[r];
+            asm volatile("" : "+v"(hp[0]), "+v"(hp[1]), "+v"(hp[2]), "+v"(hp[3]));
+            if (MODE == 7) __builtin_amdgcn_s_setprio(0);
+            TICK(1)
+            continue;
+        }
         if (MODE == 1 || (MODE == 2 && v >= 4)) __builtin_amdgcn_s_setprio(3);
         if (MODE == 4 && v < 4) __builtin_amdgcn_s_sleep(2);
         if (MODE == 5 && v < 4) __builtin_amdgcn_s_barrier();
@@ -73,6 +89,10 @@ int main() {
     run<3, 96>("second barrier behind the gates", in, out, cyc);
     run<4, 96>("waves 0-3 sleep first", in, out, cyc);
     run<5, 96>("gates one wave at a time", in, out, cyc);
+    run<6, 96>("barrier | MFMAs | gates", in, out, cyc);
+    run<7, 96>("barrier | MFMAs | gates, setprio 3", in, out, cyc);
+    run<6, 24>("barrier | MFMAs | gates", in, out, cyc);
+    run<7, 24>("barrier | MFMAs | gates, setprio 3", in, out, cyc);
     run<0, 24>("plain", in, out, cyc);
     run<3, 24>("second barrier behind the gates", in, out, cyc);
     run<0, 0>("plain (no MFMAs)", in, out, cyc);
