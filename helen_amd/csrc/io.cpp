@@ -674,10 +674,13 @@ static int fast_region_records(Scanned* sc, const char* contig, const char* regi
         if (!scan_2d<uint8_t>(db, bases.data()) || !scan_2d<uint8_t>(dr, rles.data()) ||
             !scan_2d<int64_t>(dp, pos.data()))
             return 1;
-        // (libhdf5 reads `position` as uint32 below: the values of a signed file type would wrap the same way)
-        for (uint64_t k = 0; k < n; ++k)
-            recs->push_back({(int64_t)(uint32_t)pos[(size_t)k * 3], (int64_t)(uint32_t)pos[(size_t)k * 3 + 1],
-                             (int64_t)(uint32_t)pos[(size_t)k * 3 + 2], bases[(size_t)k], rles[(size_t)k], order++});
+        // values as the file's own type holds them: the reference's `indx < 0 or pos < 0` test never fires on the
+        // uint32 its DataStore writes (wrapped -1 padding included) and does on a signed file of another writer
+        for (uint64_t k = 0; k < n; ++k) {
+            if (pos[(size_t)k * 3] < 0 || pos[(size_t)k * 3 + 1] < 0) continue;
+            recs->push_back({pos[(size_t)k * 3], pos[(size_t)k * 3 + 1], pos[(size_t)k * 3 + 2], bases[(size_t)k],
+                             rles[(size_t)k], order++});
+        }
     }
     return 0;
 }
@@ -794,7 +797,7 @@ long long helen_io_region_sequence(const char* path, const char* contig, const c
         if (s != "contig_start" && s != "contig_end") chunks.push_back(s);
     }
     std::sort(chunks.begin(), chunks.end());   // sorted(set of str): lexicographic
-    std::vector<uint32_t> pos;
+    std::vector<int64_t> pos;
     std::vector<uint8_t> bases, rles;
     uint32_t order = 0;
     for (const std::string& c : chunks) {
@@ -820,7 +823,7 @@ long long helen_io_region_sequence(const char* path, const char* contig, const c
             hid_t dp = H5Dopen2(cg, "position", H5P_DEFAULT);
             ok = dr >= 0 && dp >= 0 &&
                  H5Dread(dr, H5T_NATIVE_UINT8, H5S_ALL, H5S_ALL, H5P_DEFAULT, rles.data()) >= 0 &&
-                 H5Dread(dp, H5T_NATIVE_UINT32, H5S_ALL, H5S_ALL, H5P_DEFAULT, pos.data()) >= 0;
+                 H5Dread(dp, H5T_NATIVE_INT64, H5S_ALL, H5S_ALL, H5P_DEFAULT, pos.data()) >= 0;
             if (dr >= 0) H5Dclose(dr);
             if (dp >= 0) H5Dclose(dp);
         }
@@ -829,9 +832,11 @@ long long helen_io_region_sequence(const char* path, const char* contig, const c
             H5Gclose(g);
             return fail("%s: cannot read chunk '%s/%s'", path, gpath.c_str(), c.c_str());
         }
-        for (hssize_t k = 0; k < n; ++k)
-            recs.push_back({(int64_t)pos[(size_t)k * 3], (int64_t)pos[(size_t)k * 3 + 1],
-                            (int64_t)pos[(size_t)k * 3 + 2], bases[(size_t)k], rles[(size_t)k], order++});
+        for (hssize_t k = 0; k < n; ++k) {
+            if (pos[(size_t)k * 3] < 0 || pos[(size_t)k * 3 + 1] < 0) continue;   // Stitch.py:226 (see above)
+            recs.push_back({pos[(size_t)k * 3], pos[(size_t)k * 3 + 1], pos[(size_t)k * 3 + 2], bases[(size_t)k],
+                            rles[(size_t)k], order++});
+        }
     }
     H5Gclose(g);
     return decode_records(recs, out, cap);

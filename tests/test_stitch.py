@@ -276,3 +276,34 @@ def test_prediction_readers_agree(tmp_path, monkeypatch, writer):
         for name, st, en, seq in entries[::5]:
             assert name == "%s-%d-%d" % (contig, st, en)
             assert seq == _region_sequence_py(path, contig, name)
+
+
+def test_signed_positions_of_another_writer_are_skipped_like_the_reference_does(tmp_path):
+    """Stitch.py:226 skips rows with a negative pos or indx.  The reference's own writer stores uint32 (its -1 padding
+    wraps and is NOT skipped, tested above); a file whose positions are a signed type keeps its negatives, and every
+    reader here must then drop those rows like the reference's loop does."""
+    import subprocess
+    import sys
+    from helen_amd.stitch import _region_sequence_py
+    path = str(tmp_path / "other.hdf")
+    pos = np.array([[5, 0, 0], [-1, -1, -1], [6, 0, 0], [7, -1, 0], [-3, 0, 0], [8, 0, 0]], np.int64)
+    bases = np.array([1, 2, 3, 4, 1, 2], np.uint8)
+    rles = np.array([1, 3, 2, 2, 5, 1], np.uint8)
+    with hdf5.File(path, "w") as f:
+        f.write("predictions/c/c-0-9/contig_start", np.int64(0))
+        f.write("predictions/c/c-0-9/contig_end", np.int64(9))
+        f.write("predictions/c/c-0-9/0/position", pos, np.int64)
+        f.write("predictions/c/c-0-9/0/bases", bases, np.uint8)
+        f.write("predictions/c/c-0-9/0/rles", rles, np.uint8)
+    want = "A" + "GG" + "C"                      # rows 0, 2, 5
+    assert _region_sequence_py(path, "c", "c-0-9") == want
+    child = ("import sys; sys.path.insert(0, %r); from helen_amd import native_io; "
+             "print(native_io.region_sequence(%r, 'c', 'c-0-9'), native_io.list_regions(%r, 'c'))" % (ROOT, path, path))
+    for reader in ("", "libhdf5", "direct"):
+        env = dict(os.environ)
+        env.pop("HELEN_IO_READER", None)
+        if reader:
+            env["HELEN_IO_READER"] = reader
+        r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert r.stdout.strip() == want + " [('c-0-9', 0, 9)]", (reader, r.stdout)
