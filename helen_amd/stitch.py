@@ -196,9 +196,17 @@ def create_consensus_sequence(contig, sequence_chunk_keys, threads, executor=Non
     return _alignment_stitch(sequence_chunks)[3]     # bytes-like
 
 
+def _worker_ready():
+    return native_io.available()
+
+
 def _new_pool(threads):
+    """A pool whose workers start (and import this module) right away, while the parent lists the regions."""
     import multiprocessing as mp
-    return concurrent.futures.ProcessPoolExecutor(max_workers=threads, mp_context=mp.get_context("spawn"))
+    pool = concurrent.futures.ProcessPoolExecutor(max_workers=threads, mp_context=mp.get_context("spawn"))
+    for _ in range(threads):
+        pool.submit(_worker_ready)
+    return pool
 
 
 def _regions_of(prediction_file, contig):
