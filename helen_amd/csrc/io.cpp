@@ -6,6 +6,7 @@
 // 30x more than the MI355X needs for the window itself, so the same semantics are restated here
 // against the HDF5 C API: whole batches per call, file handles kept open, types converted by HDF5.
 // C ABI (extern "C"), no exceptions across it; helen_io_last_error() describes the last failure.
+#include "../../include/helen_io.h"
 #include <hdf5.h>
 
 #include "h5emit.h"

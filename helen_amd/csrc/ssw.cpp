@@ -17,6 +17,7 @@
 // library's; the version stitch actually runs (striped_pass_small) keeps them in the compiler's vector types.
 // Checked cell-for-cell against the reference library itself (oracle/_ref/libssw_ref.so, built from
 // the reference's own sources) on randomised inputs: tests/test_stitch.py.
+#include "../../include/helen_io.h"
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>

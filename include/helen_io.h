@@ -1,0 +1,106 @@
+/*
+ * helen_io.h -- C ABI of libhelen_io.so, the host-side companion of libhelen_hip.so: the HDF5 reader and writer of
+ * the `call_consensus` path and the two native pieces of `stitch`.
+ *
+ * Plain C++ on the host (no GPU, no torch).  Files are walked directly where their layout allows it -- MarginPolish
+ * image files and prediction files as the HDF5 C library / h5py write them by default (h5scan.h), prediction files
+ * emitted byte by byte (h5emit.h) -- with libhdf5 behind both for anything else.  Citations are file:line into the
+ * reference tree.
+ *
+ * Conventions
+ *   - functions returning int give 0 on success, -1 on error (helen_io_last_error() then describes it; the string
+ *     is thread-local), and the small positive codes documented per function; nothing throws across the ABI;
+ *   - all buffers are the caller's, C-contiguous; strings are NUL-terminated UTF-8;
+ *   - HELEN_IO_SEQ (1000) positions and HELEN_IO_FEATURES (90) features per window (`Options.py:13-21`);
+ *     HELEN_IO_NAME (256) bytes per contig name slot.
+ */
+#ifndef HELEN_IO_H
+#define HELEN_IO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HELEN_IO_ABI_VERSION 1
+#define HELEN_IO_SEQ 1000
+#define HELEN_IO_FEATURES 90
+#define HELEN_IO_NAME 256
+
+int helen_io_abi_version(void);
+const char* helen_io_last_error(void);
+
+/* ---- reader: `SequenceDataset` (`models/dataloader_predict.py:18-95`) ------------------------------------------ */
+
+/* Names of the members of group `images` of one file in name order -- what h5py's .keys() yields (:38-52) --
+ * '\n'-separated into `out` (capacity `cap`); *n_out = their number.  Returns 1 (and *n_out = 0) if the file has no
+ * `images` group (the reference warns and skips it, :47-49), -2 if `cap` is too small (*n_out = bytes needed). */
+int helen_io_list_images(const char* path, char* out, size_t cap, long long* n_out);
+
+/* `__getitem__` (:54-88) for `n` images of one file (names '\n'-separated): image -> uint8, position -> int64,
+ * short images padded with zero rows / (-1,-1,-1) rows (:74-82); an image that is not [<= 1000, 90] with a
+ * [same, 3] position is the reference's "IMAGE SIZE ERROR" (:85-86; the message starts with that text).
+ *   images    [n, 1000, 90] uint8       positions [n, 1000, 3] int64
+ *   meta      [n, 3] int64 = contig_start, contig_end, feature_chunk_idx        contigs [n, 256] char */
+int helen_io_read_images(const char* path, const char* names, int n, uint8_t* images, int64_t* positions,
+                         int64_t* meta, char* contigs);
+
+/* out[0] / out[1] = images this process has read through the direct scanner / through libhdf5. */
+void helen_io_reader_counts(long long* out);
+/* Drop every cached file handle and mapping of this process. */
+void helen_io_close_readers(void);
+
+/* Benchmark inputs: a MarginPolish-shaped image file through the direct emitter (`n` windows named
+ * <contig>-<start>-<end>-<chunk>, the six datasets of :64-70).  starts, chunks int64 [n]; lengths int32 [n] (rows
+ * stored, <= 1000); images uint8 [n, 1000, 90]. */
+int helen_io_emit_images(const char* path, int n, const char* contig, const int64_t* starts, const int64_t* chunks,
+                         const int32_t* lengths, const uint8_t* images);
+
+/* ---- writer: `DataStore.write_prediction` (`DataStore.py:83-133`) ---------------------------------------------- */
+
+/* DataStore(filename, 'w') (`predict_gpu.py:55`); NULL on error. */
+void* helen_io_writer_open(const char* path);
+/* `n` windows: scalar int64 contig_start / contig_end once per region predictions/<contig>/<contig-start-end>
+ * (:115-120), then position uint32 [1000, 3] (-1 wraps to 4294967295), bases uint8 [1000], rles uint8 [1000] once per
+ * (region, chunk id) (:123-133); repeats are skipped silently.
+ *   contigs [n, 256] char; meta [n, 3] int64 = contig_start, contig_end, chunk id; positions [n, 1000, 3] int64;
+ *   bases, rles [n, 1000] uint8.  `_sel`: only the rows sel[0..n_sel) of those arrays. */
+int helen_io_write_predictions(void* writer, int n, const char* contigs, const int64_t* meta,
+                               const int64_t* positions, const uint8_t* bases, const uint8_t* rles);
+int helen_io_write_predictions_sel(void* writer, int n_sel, const int32_t* sel, const char* contigs,
+                                   const int64_t* meta, const int64_t* positions, const uint8_t* bases,
+                                   const uint8_t* rles);
+/* Writes the group structures and closes the file; a failure here (disk full) is an error, not a short file. */
+int helen_io_writer_close(void* writer);
+
+/* ---- stitch (`Stitch.py:14-301`, `StitchInterface.py:40-106`) -------------------------------------------------- */
+
+/* The regions of predictions/<contig> of one prediction file in name order with the contig_start / contig_end each
+ * stores (`StitchInterface.py:84-95`).  Two calls: with names == NULL only sizes[0] = number of regions and
+ * sizes[1] = bytes of the '\n'-joined names are set; then names (capacity sizes[1] + 1), starts and ends (sizes[0]
+ * entries) are filled.  Returns 1 if the file has no such contig. */
+int helen_io_list_regions(const char* path, const char* contig, long long* sizes, char* names, int64_t* starts,
+                          int64_t* ends);
+
+/* The sequence of one region as `small_chunk_stitch` builds it (`Stitch.py:204-247`): chunk ids in STRING order, the
+ * first image to mention a (pos, indx, split) key wins, rows with a negative pos or indx are skipped (the uint32-wrapped
+ * padding of the reference's writer is not negative), keys in numeric order, label_decoder[base] x run length.
+ * Returns the length (NUL-terminated in `out`), -2 if `cap` is too small. */
+long long helen_io_region_sequence(const char* path, const char* contig, const char* region, char* out,
+                                   long long cap);
+
+/* HELEN.Aligner(match, mismatch, gap_open, gap_extend) + SetReferenceSequence(ref) + Align_cpp(query, Filter(), &al, 0)
+ * (`Stitch.py:110-134`; native `ssw.c` / `ssw_cpp.cpp`): the same score, begin / end cells, extended CIGAR and
+ * mismatch count as the striped Smith-Waterman library the reference vendors.
+ *   out[6] = score, ref_begin, ref_end, query_begin, query_end, mismatches (0-based, inclusive)
+ *   cigar  = extended CIGAR with soft clips, truncated to cigar_cap
+ * Returns 1 if either sequence is empty (Align_cpp returns false). */
+int helen_ssw_align(const char* ref_seq, int ref_len, const char* query_seq, int query_len, int match, int mismatch,
+                    int gap_open, int gap_extend, int* out, char* cigar, int cigar_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HELEN_IO_H */

@@ -21,6 +21,25 @@ def test_library_exports_every_declared_symbol():
     assert lib.helen_last_error() == b""
 
 
+def test_io_library_exports_exactly_what_its_header_declares():
+    """include/helen_io.h <-> libhelen_io.so: every declared entry point is exported, and nothing named helen_* is
+    exported that the header does not declare (both sources include the header, so the signatures are the compiler's
+    business)."""
+    import subprocess
+
+    from helen_amd import native_io
+    if not native_io.available():
+        pytest.skip("libhelen_io.so not available")
+    header = open(os.path.join(ROOT, "include", "helen_io.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(helen_[a-z_0-9]+)\s*\(", header))
+    out = subprocess.run(["nm", "-D", "--defined-only", native_io.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\b[TB] (helen_[a-z_0-9]+)$", out, flags=re.M))
+    assert declared == exported, declared ^ exported
+    lib = native_io.load()
+    assert lib.helen_io_abi_version() == 1
+
+
 def test_abi_rejects_bad_arguments_without_a_gpu():
     import ctypes
 
