@@ -80,8 +80,6 @@ def usable_cpus():
 
 def cpu_baseline(batch, seconds_target=12.0):
     """Time the CPU oracle (port of the reference path) on this box's host cores, bounded."""
-    import numpy as np
-
     import oracle
     from helen_amd.weights import make_images, make_weights
     threads = min(oracle.max_threads(), usable_cpus())

@@ -26,7 +26,6 @@ import sys
 import threading
 import time
 
-import numpy as np
 
 from .data_store import DataStore
 from .options import ImageSizeOptions
