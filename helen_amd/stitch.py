@@ -165,35 +165,48 @@ def small_chunk_stitch(contig, small_chunk_keys):
     return contig, start, end, bytes(running)        # (bytes: what travels back from a worker process)
 
 
+def _submit_contig(contig, sequence_chunk_keys, threads, executor):
+    """First half of create_consensus_sequence: sort the regions, cut them into runs (FileManager.chunks), hand the
+    runs to the pool.  -> list of futures / finished (contig, start, end, sequence) tuples, in any order."""
+    key_list = sorted(((contig, f, key, int(st), int(end)) for f, key, st, end in sequence_chunk_keys),
+                      key=lambda e: (e[3], e[4]))
+    if not key_list:
+        return []
+    n = max(StitchOptions.MIN_SEQUENCE_REQUIRED_FOR_MULTITHREADING, int(len(key_list) / threads) + 1)
+    file_chunks = [key_list[i:i + n] for i in range(0, len(key_list), n)]   # FileManager.chunks
+    if executor is None:
+        return [small_chunk_stitch(contig, fc) for fc in file_chunks]
+    return [executor.submit(small_chunk_stitch, contig, fc) for fc in file_chunks]
+
+
+def _finish_contig(jobs):
+    """Second half: collect the runs' sequences and stitch them (bytes-like)."""
+    sequence_chunks = []
+    for job in jobs:
+        if isinstance(job, concurrent.futures.Future):
+            if job.exception() is None:
+                sequence_chunks.append(job.result())
+            else:
+                sys.stderr.write("ERROR: " + str(job.exception()) + "\n")
+        else:
+            sequence_chunks.append(job)
+    if not sequence_chunks:
+        return b""
+    sequence_chunks = sorted(sequence_chunks, key=lambda e: (e[1], e[2]))
+    return _alignment_stitch(sequence_chunks)[3]
+
+
 def create_consensus_sequence(contig, sequence_chunk_keys, threads, executor=None):
     """(Stitch.py:257-301): sort the regions, stitch runs of them in worker processes, then stitch the
     partial sequences.  `executor`: a process pool to use (perform_stitch keeps one for all contigs; the
     reference starts a new one per contig)."""
-    key_list = sorted(((contig, f, key, int(st), int(end)) for f, key, st, end in sequence_chunk_keys),
-                      key=lambda e: (e[3], e[4]))
-    if not key_list:
-        return b""
-    n = max(StitchOptions.MIN_SEQUENCE_REQUIRED_FOR_MULTITHREADING, int(len(key_list) / threads) + 1)
-    file_chunks = [key_list[i:i + n] for i in range(0, len(key_list), n)]   # FileManager.chunks
-    sequence_chunks = []
-    if threads <= 1 or len(file_chunks) == 1:
-        for fc in file_chunks:
-            sequence_chunks.append(small_chunk_stitch(contig, fc))
-    else:
-        own = executor is None
-        ex = _new_pool(threads) if own else executor
-        try:
-            futures = [ex.submit(small_chunk_stitch, contig, fc) for fc in file_chunks]
-            for fut in concurrent.futures.as_completed(futures):
-                if fut.exception() is None:
-                    sequence_chunks.append(fut.result())
-                else:
-                    sys.stderr.write("ERROR: " + str(fut.exception()) + "\n")
-        finally:
-            if own:
-                ex.shutdown()
-    sequence_chunks = sorted(sequence_chunks, key=lambda e: (e[1], e[2]))
-    return _alignment_stitch(sequence_chunks)[3]     # bytes-like
+    own = executor is None and threads > 1
+    ex = _new_pool(threads) if own else executor
+    try:
+        return _finish_contig(_submit_contig(contig, sequence_chunk_keys, threads, ex if threads > 1 else None))
+    finally:
+        if own:
+            ex.shutdown()
 
 
 def _worker_ready():
@@ -247,15 +260,30 @@ def perform_stitch(input_directory, output_path, output_prefix, threads):
     output_filename = os.path.join(output_dir, output_prefix + '.fa')
     sys.stderr.write("INFO: OUTPUT FILE: " + output_filename + "\n")
     executor = _new_pool(threads) if threads > 1 else None      # one pool for all contigs
+    # Contigs are pipelined: the runs of the next contigs are already with the workers while the parent stitches
+    # and writes the current one (an assembly is thousands of contigs, most of them a few regions long; the
+    # reference finishes one contig -- and one process pool -- before it looks at the next).  FASTA order is the
+    # contig order either way.
+    contigs = sorted(all_contigs)
+    look_ahead = 64 * max(1, threads)           # regions handed out and not yet collected
+    pending, in_flight, nxt = [], 0, 0
     try:
         with open(output_filename, 'wb') as fasta:
-            for i, contig in enumerate(sorted(all_contigs)):
-                prefix = "{:04d}/{:04d}:".format(i, len(all_contigs))
-                sys.stderr.write("INFO: " + prefix + " PROCESSING CONTIG: " + contig + "\n")
-                chunk_name_tuple = []
-                for prediction_file in all_prediction_files:
-                    chunk_name_tuple.extend(_regions_of(prediction_file, contig))
-                consensus_sequence = create_consensus_sequence(contig, chunk_name_tuple, threads, executor)
+            while nxt < len(contigs) or pending:
+                while nxt < len(contigs) and (not pending or (executor is not None and in_flight < look_ahead)):
+                    contig = contigs[nxt]
+                    prefix = "{:04d}/{:04d}:".format(nxt, len(contigs))
+                    sys.stderr.write("INFO: " + prefix + " PROCESSING CONTIG: " + contig + "\n")
+                    chunk_name_tuple = []
+                    for prediction_file in all_prediction_files:
+                        chunk_name_tuple.extend(_regions_of(prediction_file, contig))
+                    pending.append((contig, prefix, len(chunk_name_tuple),
+                                    _submit_contig(contig, chunk_name_tuple, threads, executor)))
+                    in_flight += len(chunk_name_tuple)
+                    nxt += 1
+                contig, prefix, regions, jobs = pending.pop(0)
+                consensus_sequence = _finish_contig(jobs)
+                in_flight -= regions
                 sys.stderr.write("INFO: " + prefix + " FINISHED PROCESSING " + contig
                                  + ", POLISHED SEQUENCE LENGTH: " + str(len(consensus_sequence)) + ".\n")
                 if consensus_sequence is not None and len(consensus_sequence) > 0:

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--windows", type=int, default=50000)
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--files", type=int, default=4)
+    ap.add_argument("--contigs", type=int, default=1, help="cut the sequence into this many contigs (an assembly "
+                                                              "is thousands of contigs, most of them short)")
     a = ap.parse_args()
     rng = np.random.default_rng(0)
     n = a.windows
@@ -40,15 +42,18 @@ def main():
             meta = np.stack([starts, starts + 1000, np.zeros(m, np.int64)], axis=1)
             pos[:m, :, 0] = starts[:, None] + np.arange(1000)[None, :]
             idx = starts[:, None] + np.arange(1000)[None, :]
-            stores[(s // B) % a.files].write_batch(["contig_s"] * m, meta, pos[:m], seq_b[idx], seq_r[idx])
+            per = -(-n // a.contigs)                              # windows per contig
+            names = ["contig_%05d" % (w // per) for w in range(s, e)]
+            stores[(s // B) % a.files].write_batch(names, meta, pos[:m], seq_b[idx], seq_r[idx])
         for st in stores:
             st.close()
         t1 = time.time()
         out = perform_stitch(d, os.path.join(d, "out"), "asm", a.threads)
         t2 = time.time()
         length = sum(len(line) for line in open(out).read().split("\n")[1::2])
-        print("wrote %d windows in %.1f s; stitched in %.2f s with %d threads = %.0f windows/s, %.1f Mbase/s "
-              "(FASTA %d bases)" % (n, t1 - t0, t2 - t1, a.threads, n / (t2 - t1), length / (t2 - t1) / 1e6, length))
+        print("wrote %d windows (%d contigs) in %.1f s; stitched in %.2f s with %d threads = %.0f windows/s, %.1f Mbase/s "
+              "(FASTA %d bases)" % (n, a.contigs, t1 - t0, t2 - t1, a.threads, n / (t2 - t1), length / (t2 - t1) / 1e6,
+                                    length))
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
