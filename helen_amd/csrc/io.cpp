@@ -381,7 +381,9 @@ int helen_io_list_images(const char* path, char* out, size_t cap, long long* n_o
     hid_t f = get_file(path);
     if (f < 0) return fail("cannot open '%s'", path);
     *n_out = 0;
-    if (H5Lexists(f, "images", H5P_DEFAULT) <= 0) return 1;
+    const htri_t has_images = H5Lexists(f, "images", H5P_DEFAULT);
+    if (has_images < 0) return fail("%s: cannot look up 'images'", path);   // damaged, not absent
+    if (has_images == 0) return 1;
     hid_t g = H5Gopen2(f, "images", H5P_DEFAULT);
     if (g < 0) return fail("%s: cannot open group 'images'", path);
     // one pass in name order (H5Lget_name_by_idx per member is O(n) each on symbol-table groups)
@@ -733,7 +735,10 @@ int helen_io_list_regions(const char* path, const char* contig, long long* sizes
         hid_t f = get_file(path);
         if (f < 0) return fail("cannot open '%s'", path);
         const std::string gpath = std::string("predictions/") + contig;
-        if (H5Lexists(f, "predictions", H5P_DEFAULT) <= 0 || H5Lexists(f, gpath.c_str(), H5P_DEFAULT) <= 0) return 1;
+        const htri_t has_p = H5Lexists(f, "predictions", H5P_DEFAULT);
+        const htri_t has_c = has_p > 0 ? H5Lexists(f, gpath.c_str(), H5P_DEFAULT) : has_p;
+        if (has_p < 0 || has_c < 0) return fail("%s: cannot look up '%s'", path, gpath.c_str());   // damaged, not absent
+        if (has_c == 0) return 1;
         hid_t g = H5Gopen2(f, gpath.c_str(), H5P_DEFAULT);
         if (g < 0) return fail("%s: cannot open group '%s'", path, gpath.c_str());
         auto cb = [](hid_t, const char* name, const H5L_info_t*, void* ud) -> herr_t {
