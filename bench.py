@@ -167,9 +167,19 @@ def end_to_end(n_windows, workers, batch, weights):
         files = sorted(os.listdir(out))
         with hdf5.File(os.path.join(out, files[0])) as f:
             stored = sum(len(f.keys("predictions/" + c)) for c in f.keys("predictions"))
+        # the second half of `helen polish`: prediction HDF5 -> FASTA (random weights call random labels, so the
+        # regions' overlaps do not agree: a scale check of stitch; scripts/stitch_bench.py measures it on consistent ones)
+        from helen_amd.stitch import perform_stitch
+        threads = max(1, min(16, usable_cpus()))
+        t0 = time.time()
+        with contextlib.redirect_stdout(sys.stderr):
+            fasta = perform_stitch(out, os.path.join(d, "fa"), "asm", threads)
+        dt_stitch = time.time() - t0
         return {"value": round(n_windows / dt, 1), "unit": "windows/s", "windows": n_windows, "seconds": round(dt, 3),
                 "reader_workers": workers, "output_files": files, "regions_stored": stored,
                 "stage_seconds": {k: round(v, 3) for k, v in P.STAGE_SECONDS.items()},
+                "stitch": {"seconds": round(dt_stitch, 3), "threads": threads, "fasta_bytes": os.path.getsize(fasta)},
+                "polish_seconds": round(dt + dt_stitch, 3),
                 "what": "call_consensus(image_dir -> prediction HDF5) incl. process start-up, model load and close; "
                         "synthetic inputs written in %.1f s to %s" % (t_write, base or tempfile.gettempdir())}
     finally:
