@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_pair_kernel(
     __syncthreads();
     bf16x8 a_pref = ((const bf16x8*)(smem + 1024))[lane];   // group 0 of tile 0's h plane
 
-#ifdef HELEN_BP_TIMING   // developer probe: where a wave's cycles go (scripts/dev/run_bp.sh)
+#ifdef HELEN_BP_TIMING   // developer probe: where a wave's cycles go (scripts/dev/run_bp2.sh)
     long long tk[4] = {0, 0, 0, 0};
 #define HELEN_BP_TICK(i) { __builtin_amdgcn_sched_barrier(0); long long now_ = __builtin_readcyclecounter(); tk[i] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
     long long tlast = __builtin_readcyclecounter();
