@@ -476,6 +476,72 @@ int helen_io_read_images(const char* path, const char* names, int n, uint8_t* im
     return 0;
 }
 
+/* Labeled images for the evaluation path (`models/dataloader.py:48-61`, the loader of `helen_train test`): for `n`
+ * images of one file (names '\n'-separated) the image as uint8 [1000, 90] and label_base / label_run_length as uint8
+ * [1000], exactly as stored -- that loader does not pad, so anything else is an "IMAGE SIZE ERROR".
+ *   images [n, 1000, 90] uint8      label_base, label_rle [n, 1000] uint8 */
+int helen_io_read_labeled(const char* path, const char* names, int n, uint8_t* images, uint8_t* label_base,
+                          uint8_t* label_rle) {
+    Scanned* sc = scan_file(path);
+    bool fast = sc && sc->has_images;
+    hid_t f = -1;
+    const char* p = names;
+    for (int i = 0; i < n; ++i) {
+        const char* e = strchr(p, '\n');
+        const std::string name = e ? std::string(p, e - p) : std::string(p);
+        p = e ? e + 1 : p + name.size();
+        uint8_t* img = images + (size_t)i * kSeq * kFeat;
+        uint8_t* lb = label_base + (size_t)i * kSeq;
+        uint8_t* lr = label_rle + (size_t)i * kSeq;
+        if (fast) {
+            const h5scan::File& sf = sc->file;
+            uint64_t g, h;
+            h5scan::Dataset di, db, dr;
+            bool took = sf.lookup(sc->images, name.c_str(), &g) && sf.lookup(g, "image", &h) && sf.dataset(h, &di) &&
+                        sf.lookup(g, "label_base", &h) && sf.dataset(h, &db) && sf.lookup(g, "label_run_length", &h) &&
+                        sf.dataset(h, &dr) && di.cls <= 1 && db.cls == 0 && dr.cls == 0;
+            if (took) {
+                if (di.rank != 2 || di.dims[0] != (uint64_t)kSeq || di.dims[1] != (uint64_t)kFeat || db.rank != 1 ||
+                    db.dims[0] != (uint64_t)kSeq || dr.rank != 1 || dr.dims[0] != (uint64_t)kSeq)
+                    return fail("IMAGE SIZE ERROR: %s image '%s'", path, name.c_str());
+                took = scan_2d<uint8_t>(di, img) && scan_2d<uint8_t>(db, lb) && scan_2d<uint8_t>(dr, lr);
+            }
+            if (took) {
+                ++g_fast_windows;
+                continue;
+            }
+            fast = false;     // this file is libhdf5's from here on
+        }
+        static const bool direct_only = reader_mode_is("direct");
+        if (direct_only) return fail("%s: not a file the direct scanner takes", path);
+        if (f < 0) f = get_file(path);
+        if (f < 0) return fail("cannot open '%s'", path);
+        const std::string gpath = "images/" + name;
+        hid_t g = H5Gopen2(f, gpath.c_str(), H5P_DEFAULT);
+        if (g < 0) return fail("%s: no image '%s'", path, name.c_str());
+        int rows = 0;
+        const int r1 = read_2d(g, "image", H5T_NATIVE_UINT8, kFeat, kSeq, img, &rows);
+        bool good = r1 == 0 && rows == kSeq;
+        for (int which = 0; good && which < 2; ++which) {
+            hid_t d = H5Dopen2(g, which ? "label_run_length" : "label_base", H5P_DEFAULT);
+            good = d >= 0;
+            if (good) {
+                hid_t sp = H5Dget_space(d);
+                hsize_t dim = 0;
+                good = H5Sget_simple_extent_ndims(sp) == 1 && H5Sget_simple_extent_dims(sp, &dim, nullptr) == 1 &&
+                       dim == (hsize_t)kSeq &&
+                       H5Dread(d, H5T_NATIVE_UINT8, H5S_ALL, H5S_ALL, H5P_DEFAULT, which ? lr : lb) >= 0;
+                H5Sclose(sp);
+                H5Dclose(d);
+            }
+        }
+        H5Gclose(g);
+        if (!good) return fail("IMAGE SIZE ERROR: %s image '%s'", path, name.c_str());
+        ++g_library_windows;
+    }
+    return 0;
+}
+
 /* Synthetic MarginPolish image file through the direct emitter (helen_amd.synthetic: benchmark inputs; the files the
  * reader TESTS use are written by libhdf5): `n` windows named <contig>-<start>-<end>-<chunk> under `images/`, each with
  * the six datasets of dataloader_predict.py:64-70 -- contig (fixed string [1]), contig_start / contig_end /

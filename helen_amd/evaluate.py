@@ -14,7 +14,7 @@ import sys
 
 import numpy as np
 
-from . import hdf5
+from . import hdf5, native_io
 from .file_manager import get_file_paths_from_directory
 from .options import ImageSizeOptions, TrainOptions
 
@@ -29,11 +29,15 @@ class SequenceDataset(object):
     def __init__(self, image_directory):
         pairs = []
         for path in get_file_paths_from_directory(image_directory):
-            with hdf5.File(path, "r") as f:
-                if "images" in f:
-                    pairs.extend((path, name) for name in f.keys("images"))
-                else:
-                    sys.stderr.write("WARN: NO IMAGES FOUND IN FILE: " + path + "\n")
+            if native_io.available():
+                names = native_io.list_images(path)
+            else:
+                with hdf5.File(path, "r") as f:
+                    names = f.keys("images") if "images" in f else None
+            if names is None:
+                sys.stderr.write("WARN: NO IMAGES FOUND IN FILE: " + path + "\n")
+            else:
+                pairs.extend((path, name) for name in names)
         self.all_images = pairs
         self._files = {}
 
@@ -62,7 +66,19 @@ class SequenceDataset(object):
         images = np.empty((n, L, H), np.uint8)
         lb = np.empty((n, L), np.uint8)
         lr = np.empty((n, L), np.uint8)
-        for k in range(n):
+        if native_io.available():
+            # whole runs of one file per call, through the direct scanner (three dataset opens per image through the
+            # ctypes binding are 0.3 ms: 3 k images/s against 80 k/s of device throughput)
+            k = 0
+            while k < n:
+                path = self.all_images[lo + k][0]
+                e = k
+                while e < n and self.all_images[lo + e][0] == path:
+                    e += 1
+                native_io.read_labeled(path, [name for _, name in self.all_images[lo + k:lo + e]], images[k:e],
+                                       lb[k:e], lr[k:e])
+                k = e
+        for k in range(0 if not native_io.available() else n, n):
             image, b, r = self[lo + k]
             if image.shape != (L, H) or b.shape != (L,) or r.shape != (L,):
                 raise ValueError("IMAGE SIZE ERROR: " + str(self.all_images[lo + k][0]) + " "

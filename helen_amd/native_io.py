@@ -36,6 +36,8 @@ def load():
     lib.helen_io_list_images.restype = ctypes.c_int
     lib.helen_io_list_images.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t,
                                          ctypes.POINTER(ctypes.c_longlong)]
+    lib.helen_io_read_labeled.restype = ctypes.c_int
+    lib.helen_io_read_labeled.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, vp, vp, vp]
     lib.helen_io_emit_images.restype = ctypes.c_int
     lib.helen_io_emit_images.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, vp, vp, vp, vp]
     lib.helen_io_reader_counts.restype = None
@@ -121,6 +123,19 @@ def read_images(path, names, images, positions, meta, contigs):
     if rc != 0:
         msg = _err(lib)
         if msg.startswith("IMAGE SIZE ERROR") or "contig name longer than" in msg:
+            raise ValueError(msg)
+        raise IOError(msg)
+
+
+def read_labeled(path, names, images, label_base, label_rle):
+    """Fill images u8 [n,1000,90] and label_base / label_rle u8 [n,1000] with the `names` of one file (the loader of
+    the evaluation path: nothing is padded, any other shape is the reader's IMAGE SIZE ERROR)."""
+    lib = load()
+    rc = lib.helen_io_read_labeled(os.fsencode(path), "\n".join(names).encode(), len(names), images.ctypes.data,
+                                   label_base.ctypes.data, label_rle.ctypes.data)
+    if rc != 0:
+        msg = _err(lib)
+        if msg.startswith("IMAGE SIZE ERROR"):
             raise ValueError(msg)
         raise IOError(msg)
 

@@ -47,6 +47,12 @@ int helen_io_list_images(const char* path, char* out, size_t cap, long long* n_o
 int helen_io_read_images(const char* path, const char* names, int n, uint8_t* images, int64_t* positions,
                          int64_t* meta, char* contigs);
 
+/* The loader of `helen_train test` (`models/dataloader.py:48-61`): image uint8 [1000, 90], label_base and
+ * label_run_length uint8 [1000] of `n` images of one file, exactly as stored (that loader does not pad: any other
+ * shape is an "IMAGE SIZE ERROR").  images [n, 1000, 90]; label_base, label_rle [n, 1000]. */
+int helen_io_read_labeled(const char* path, const char* names, int n, uint8_t* images, uint8_t* label_base,
+                          uint8_t* label_rle);
+
 /* out[0] / out[1] = images this process has read through the direct scanner / through libhdf5. */
 void helen_io_reader_counts(long long* out);
 /* Drop every cached file handle and mapping of this process. */

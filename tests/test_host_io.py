@@ -342,3 +342,60 @@ def test_call_consensus_vets_the_image_directory_first(tmp_path, capsys):
     with pytest.raises(ValueError, match="IMAGE SIZE ERROR"):
         vet_image_directory(str(bad))
     assert "expected integers" in capsys.readouterr().err
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+LABELED_CHILD = r'''
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from helen_amd import native_io
+from helen_amd.evaluate import SequenceDataset
+ds = SequenceDataset(%(dir)r)
+images, lb, lr = ds.read_range(0, len(ds))
+np.savez(%(out)r, images=images, lb=lb, lr=lr, counts=np.array(native_io.reader_counts()))
+'''
+
+
+def test_labeled_images_native_reader_equals_the_per_item_reader(tmp_path):
+    """The evaluation loader (models/dataloader.py:48-61) through helen_io_read_labeled -- scanner, libhdf5 fallback
+    (a deflated file), either alone -- against the per-item ctypes reader; a short labeled image is the loader's
+    IMAGE SIZE ERROR, not padded."""
+    import subprocess
+    import sys
+    from helen_amd.evaluate import SequenceDataset
+    from helen_amd.synthetic import write_image_file
+    from helen_amd.weights import make_images
+    rng = np.random.default_rng(4)
+    img = make_images(10, seed=8)
+    lb = rng.integers(0, 5, (10, 1000), dtype=np.uint8)
+    lr = rng.integers(0, 11, (10, 1000), dtype=np.uint8)
+    d = tmp_path / "labeled"
+    d.mkdir()
+    write_image_file(str(d / "a.h5"), img[:6], first_window=0, labels=(lb[:6], lr[:6]))
+    write_image_file(str(d / "b.h5"), img[6:], first_window=6, labels=(lb[6:], lr[6:]), gzip=4)   # libhdf5's business
+    ds = SequenceDataset(str(d))
+    order = [int(name.split("-")[1]) // 800 for _, name in ds.all_images]
+    want = [np.stack([ds[i][k] for i in range(len(ds))]) for k in range(3)]          # per-item reader
+    assert np.array_equal(want[0], img[order]) and np.array_equal(want[1], lb[order]) and np.array_equal(want[2], lr[order])
+    got = {}
+    for reader in ("", "libhdf5"):
+        env = dict(os.environ)
+        env.pop("HELEN_IO_READER", None)
+        if reader:
+            env["HELEN_IO_READER"] = reader
+        out = str(tmp_path / ("l_%s.npz" % (reader or "default")))
+        r = subprocess.run([sys.executable, "-c", LABELED_CHILD % {"root": ROOT, "dir": str(d), "out": out}], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[reader] = dict(np.load(out))
+        for k, w in zip(("images", "lb", "lr"), want):
+            assert np.array_equal(got[reader][k], w), (reader, k)
+    assert tuple(got[""]["counts"]) == (6, 4) and tuple(got["libhdf5"]["counts"]) == (0, 10)
+    short = tmp_path / "short"
+    short.mkdir()
+    write_image_file(str(short / "s.h5"), img[:2], lengths=[1000, 999], labels=(lb[:2], lr[:2]))
+    ds = SequenceDataset(str(short))
+    with pytest.raises(ValueError, match="IMAGE SIZE ERROR"):
+        ds.read_range(0, 2)
