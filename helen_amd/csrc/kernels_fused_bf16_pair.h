@@ -21,11 +21,12 @@ namespace helen {
 //           k-slice of the head product of h_x(s-1) (decoder); then the input part x . W_ih^T + b of the OTHER
 //           tile's next step from its LDS ring (independent of any h) -- last, so that the gates behind the
 //           barrier find their accumulators finished and the next phase starts from registers;
-//   the barrier publishes the OTHER tile's h (written in the previous half-step's G) and this tile's input rows
-//           of step s+2... (see the counted vmcnt below);
+//   the barrier publishes the OTHER tile's h (written in the previous half-step's G) and the input rows the
+//           previous half-step's DMA brought in (see the counted vmcnt below);
 //   G(x,s): gates, new h -> LDS (fp32 + bf16 plane), head partials -> LDS.
-// The weights (W_hh 48 + W_ih 36 / 96 registers) are shared by both tiles; each tile has its own h buffers,
-// input ring (3 deep, LDS-DMA two steps ahead) and partial-logit slots: 33 / 64 KiB of LDS per tile.
+// The weights (W_hh 48 + W_ih 36 / 96 registers; the decoder keeps the last K32 group of W_ih in LDS) are shared by
+// both tiles; each tile has its own h buffers, input ring (3 deep, LDS-DMA two steps ahead) and partial-logit
+// slots: 33 / 64 KiB of LDS per tile.  Measured: 1830 / 2750 cycles per tile-step.
 // Input rows arrive by LDS-DMA issued at the start of M(x,s) for step s+2; the issuing wave waits for them with a
 // COUNTED vmcnt at the next half-step's barrier (everything older than that half-step's own operations), so a
 // row has a half-step plus an MFMA phase (~1.3 us) to arrive, and it is first read after that barrier.
