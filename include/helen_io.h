@@ -11,6 +11,9 @@
  *   - functions returning int give 0 on success, -1 on error (helen_io_last_error() then describes it; the string
  *     is thread-local), and the small positive codes documented per function; nothing throws across the ABI;
  *   - all buffers are the caller's, C-contiguous; strings are NUL-terminated UTF-8;
+ *   - the file functions (helen_io_*) keep per-process caches of open files and mappings and are NOT thread-safe:
+ *     call them from one thread per process (this package parallelises with processes); helen_ssw_align is
+ *     re-entrant and may be called from any number of threads;
  *   - HELEN_IO_SEQ (1000) positions and HELEN_IO_FEATURES (90) features per window (`Options.py:13-21`);
  *     HELEN_IO_NAME (256) bytes per contig name slot.
  */
