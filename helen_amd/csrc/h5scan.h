@@ -80,6 +80,7 @@ class File {
     }
 
     uint64_t root() const { return root_header_; }
+    size_t mapped_bytes() const { return map_ ? size_ : 0; }
 
     // members of an old-style group in name order; false if the object is not such a group
     bool children(uint64_t header, std::vector<std::pair<std::string, uint64_t>>* out) const {

@@ -173,17 +173,23 @@ bool reader_mode_is(const char* what) {
 Scanned* scan_file(const char* path) {
     static const bool off = reader_mode_is("libhdf5");
     if (off) return nullptr;
-    // A reader walks its files one after the other: only the newest few stay mapped.  (A process that had read
-    // a 27 GB directory through eight mappings took up to 2 s to exit -- the kernel unmaps page by page -- and
-    // predict waits for its readers; dropped when the reader moves on, that cost runs beside the device instead.)
+    // A reader walks its files one after the other: only the newest few GIGABYTES stay mapped.  (A process that had
+    // read a 27 GB image directory through eight mappings took up to 2 s to exit -- the kernel unmaps page by
+    // page -- and predict waits for its readers; dropped when the reader moves on, that cost runs beside the device
+    // instead.  Prediction files are an eighth of that size, and stitch alternates between all of them: up to 64 of
+    // those stay.)
     static uint64_t tick = 0;
+    constexpr size_t kKeepBytes = (size_t)4 << 30;
     auto& m = scanned_files();
     auto it = m.find(path);
     if (it != m.end()) {
         it->second->last_used = ++tick;
         return it->second->usable ? it->second.get() : nullptr;
     }
-    while (m.size() >= 3) {
+    for (;;) {
+        size_t held = 0;
+        for (auto& kv : m) held += kv.second->file.mapped_bytes();
+        if (m.size() < 64 && (held < kKeepBytes || m.size() < 3)) break;
         auto oldest = m.begin();
         for (auto k = m.begin(); k != m.end(); ++k)
             if (k->second->last_used < oldest->second->last_used) oldest = k;

@@ -250,12 +250,20 @@ def perform_stitch(input_directory, output_path, output_prefix, threads):
     (StitchInterface.py:40-106)."""
     all_prediction_files = get_file_paths_from_directory(input_directory)
     all_contigs = set()
+    contigs_of = {}
     for prediction_file in sorted(all_prediction_files):
         with hdf5.File(prediction_file, "r") as f:
             if "predictions" in f:
-                all_contigs.update(f.keys("predictions"))
+                contigs_of[prediction_file] = f.keys("predictions")
+                all_contigs.update(contigs_of[prediction_file])
             else:
                 raise ValueError("ERROR: INVALID HDF5 FILE, FILE DOES NOT CONTAIN predictions KEY.\n")
+    # Region lists file by file (one file mapped at a time), not contig by contig across all files: an assembly is
+    # thousands of contigs in a handful of files.  Per contig the files keep the order of all_prediction_files.
+    regions_of = {contig: [] for contig in all_contigs}
+    for prediction_file in all_prediction_files:
+        for contig in contigs_of[prediction_file]:
+            regions_of[contig].extend(_regions_of(prediction_file, contig))
     output_dir = file_manager.handle_output_directory(output_path)
     output_filename = os.path.join(output_dir, output_prefix + '.fa')
     sys.stderr.write("INFO: OUTPUT FILE: " + output_filename + "\n")
@@ -274,9 +282,7 @@ def perform_stitch(input_directory, output_path, output_prefix, threads):
                     contig = contigs[nxt]
                     prefix = "{:04d}/{:04d}:".format(nxt, len(contigs))
                     sys.stderr.write("INFO: " + prefix + " PROCESSING CONTIG: " + contig + "\n")
-                    chunk_name_tuple = []
-                    for prediction_file in all_prediction_files:
-                        chunk_name_tuple.extend(_regions_of(prediction_file, contig))
+                    chunk_name_tuple = regions_of.pop(contig)
                     pending.append((contig, prefix, len(chunk_name_tuple),
                                     _submit_contig(contig, chunk_name_tuple, threads, executor)))
                     in_flight += len(chunk_name_tuple)
