@@ -162,7 +162,48 @@ def small_chunk_stitch(contig, small_chunk_keys):
         name_sequence_tuples.append((contig, contig_start, contig_end, sequence))
     name_sequence_tuples = sorted(name_sequence_tuples, key=lambda e: (e[1], e[2]))
     contig, start, end, running = _alignment_stitch(name_sequence_tuples)
-    return contig, start, end, bytes(running)        # (bytes: what travels back from a worker process)
+    return contig, start, end, bytes(running)
+
+
+_SPILL_BYTES = 1 << 20
+
+
+def _small_chunk_stitch_worker(contig, small_chunk_keys, spill_dir):
+    """small_chunk_stitch in a worker process: a long sequence goes back through a file in `spill_dir` (RAM-backed when
+    there is one) instead of the result pipe -- a pickle through a pipe moves about 1 GB/s, and a contig's runs are
+    tens of megabytes each, collected by one thread of the parent."""
+    contig, start, end, sequence = small_chunk_stitch(contig, small_chunk_keys)
+    if spill_dir is None or len(sequence) < _SPILL_BYTES:
+        return contig, start, end, sequence
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix="helen_stitch_", suffix=".seq", dir=spill_dir)
+    with os.fdopen(fd, "wb") as f:
+        f.write(sequence)
+    return contig, start, end, _Spilled(path)
+
+
+class _Spilled(object):
+    def __init__(self, path):
+        self.path = path
+
+    def take(self):
+        try:
+            with open(self.path, "rb") as f:
+                return f.read()
+        finally:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
+
+
+def _spill_dir():
+    if os.environ.get("HELEN_STITCH_SPILL", "1") == "0":
+        return None
+    for d in ("/dev/shm",):
+        if os.path.isdir(d) and os.access(d, os.W_OK):
+            return d
+    return None
 
 
 def _submit_contig(contig, sequence_chunk_keys, threads, executor):
@@ -176,7 +217,8 @@ def _submit_contig(contig, sequence_chunk_keys, threads, executor):
     file_chunks = [key_list[i:i + n] for i in range(0, len(key_list), n)]   # FileManager.chunks
     if executor is None:
         return [small_chunk_stitch(contig, fc) for fc in file_chunks]
-    return [executor.submit(small_chunk_stitch, contig, fc) for fc in file_chunks]
+    spill = _spill_dir()
+    return [executor.submit(_small_chunk_stitch_worker, contig, fc, spill) for fc in file_chunks]
 
 
 def _finish_contig(jobs):
@@ -185,7 +227,10 @@ def _finish_contig(jobs):
     for job in jobs:
         if isinstance(job, concurrent.futures.Future):
             if job.exception() is None:
-                sequence_chunks.append(job.result())
+                contig, start, end, sequence = job.result()
+                if isinstance(sequence, _Spilled):
+                    sequence = sequence.take()
+                sequence_chunks.append((contig, start, end, sequence))
             else:
                 sys.stderr.write("ERROR: " + str(job.exception()) + "\n")
         else:
