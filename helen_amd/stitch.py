@@ -176,7 +176,7 @@ def _small_chunk_stitch_worker(contig, small_chunk_keys, spill_dir):
     if spill_dir is None or len(sequence) < _SPILL_BYTES:
         return contig, start, end, sequence
     import tempfile
-    fd, path = tempfile.mkstemp(prefix="helen_stitch_", suffix=".seq", dir=spill_dir)
+    fd, path = tempfile.mkstemp(prefix="helen_stitch_%d_" % os.getppid(), suffix=".seq", dir=spill_dir)
     with os.fdopen(fd, "wb") as f:
         f.write(sequence)
     return contig, start, end, _Spilled(path)
@@ -344,4 +344,12 @@ def perform_stitch(input_directory, output_path, output_prefix, threads):
     finally:
         if executor is not None:
             executor.shutdown()
+            spill = _spill_dir()      # whatever an interrupted run left behind
+            if spill is not None:
+                import glob
+                for leftover in glob.glob(os.path.join(spill, "helen_stitch_%d_*.seq" % os.getpid())):
+                    try:
+                        os.unlink(leftover)
+                    except OSError:
+                        pass
     return output_filename
