@@ -1,0 +1,334 @@
+"""TEST INFRASTRUCTURE -- generates tests/golden/stitch_ref.json.gz by RUNNING the reference's own stitch logic.
+
+Runs only in the build container (needs /root/reference and oracle/_ref/libssw_ref.so, `make -C oracle ref`):
+
+    python tests/golden/make_golden_stitch.py
+
+What is executed is the reference's `Stitch.alignment_stitch` (helen/modules/python/Stitch.py:96-190: overlap
+arithmetic, anchor search, the N x 10 fillers, the short-chunk and empty-region rules) and its
+`Stitch.get_confident_positions` (Stitch.py:33-94), imported from /root/reference, on seeded chains of chunks and on
+seeded CIGARs.  The fixture holds inputs and the reference's outputs (data only).
+
+A second part runs the reference's `Stitch.small_chunk_stitch` (Stitch.py:192-255: the per-position dictionaries, first
+writer wins over chunk ids in string order) and `Stitch.create_consensus_sequence` (Stitch.py:257-301, 1 and 3
+workers) on prediction FILES written here by this package's DataStore from seeded regions (duplicate keys across
+chunk ids, gaps, padding rows, noisy regions, holes); the fixture stores the regions' rows and the reference's results.
+
+Things the image lacks are supplied so that `import helen.modules.python.Stitch` succeeds and those methods run:
+  * `from helen.build import HELEN` is the reference's pybind11 module around its vendored striped Smith-Waterman
+    (modules/headers/pybind_api.h:16-47).  Here `HELEN.Aligner / Filter / Alignment` are thin Python classes over
+    oracle/_ref/libssw_ref.so -- the REFERENCE's own ssw.c / ssw_cpp.cpp compiled in place (oracle/Makefile `ref`) --
+    with the attribute names the binding gives them (best_score, reference_begin, cigar_string, ...).  The alignments
+    are the reference library's, not this package's.
+  * `import h5py`: h5py is not installed.  The module registered under that name is a read-only veneer with the
+    handful of h5py calls Stitch.py makes -- File(path, 'r') as a context manager, `name in file`, group[name],
+    group.keys(), dataset[()] -- on top of libhdf5 itself (helen_amd/hdf5.py, the ctypes binding): the bytes come
+    from the HDF5 library, only the Python spelling of the calls is h5py's.
+  * `np.int` (Stitch.py:225-226) was removed from numpy; it is aliased to the builtin `int` it used to name.
+"""
+import ctypes
+import gzip
+import io
+import json
+import os
+import random
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF_SSW = os.path.join(ROOT, "oracle", "_ref", "libssw_ref.so")
+OUT = os.path.join(ROOT, "tests", "golden", "stitch_ref.json.gz")
+
+
+def install_reference_bindings():
+    lib = ctypes.CDLL(REF_SSW)
+
+    class Alignment(object):
+        def __init__(self):
+            self.Clear()
+
+        def Clear(self):
+            self.best_score = 0
+            self.best_score2 = 0
+            self.reference_begin = 0
+            self.reference_end = 0
+            self.query_begin = 0
+            self.query_end = 0
+            self.ref_end_next_best = 0
+            self.mismatches = 0
+            self.cigar_string = ""
+            self.cigar = []
+
+    class Filter(object):
+        def __init__(self, *a):
+            self.report_begin_position = True
+            self.report_cigar = True
+            self.score_filter = 0
+            self.distance_filter = 32767
+
+    class Aligner(object):
+        def __init__(self, match=2, mismatch=2, gap_open=3, gap_extend=1):
+            self.p = (match, mismatch, gap_open, gap_extend)
+            self.ref = b""
+
+        def SetReferenceSequence(self, seq, length):
+            self.ref = seq.encode()[:length]
+            return length
+
+        def Align_cpp(self, query, flt, alignment, mask_len):
+            alignment.Clear()
+            if not self.ref or not query:
+                return False
+            out = (ctypes.c_int * 6)()
+            cig = ctypes.create_string_buffer(16 * (len(self.ref) + len(query)) + 64)
+            rc = lib.ssw_ref_align(self.ref, len(self.ref), query.encode(), *self.p, out, cig, len(cig))
+            (alignment.best_score, alignment.reference_begin, alignment.reference_end, alignment.query_begin,
+             alignment.query_end, alignment.mismatches) = list(out)
+            alignment.cigar_string = cig.value.decode()
+            return rc == 0
+
+    helen_build = types.ModuleType("helen.build")
+    helen_build.HELEN = types.SimpleNamespace(Aligner=Aligner, Filter=Filter, Alignment=Alignment)
+    sys.modules["helen.build"] = helen_build
+
+    # h5py's spelling of the few calls Stitch.py makes, on libhdf5 through helen_amd/hdf5.py
+    sys.path.insert(0, ROOT)
+    from helen_amd import hdf5
+
+    class Node(object):
+        def __init__(self, f, path):
+            self.f, self.path = f, path
+
+        def _child(self, name):
+            return (self.path.rstrip("/") + "/" + name) if self.path else name
+
+        def __contains__(self, name):
+            return self.f.exists(self._child(name))
+
+        def keys(self):
+            return self.f.keys(self.path or "/")
+
+        def __getitem__(self, name):
+            if name == ():
+                return self.f.read(self.path)                 # dataset[()]
+            return Node(self.f, self._child(name))
+
+    class File(Node):
+        def __init__(self, path, mode="r"):
+            assert mode == "r"
+            Node.__init__(self, hdf5.File(path, "r"), "")
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            self.f.close()
+
+    h5py = types.ModuleType("h5py")
+    h5py.File = File
+    sys.modules["h5py"] = h5py
+    import numpy as np
+    if not hasattr(np, "int"):
+        np.int = int
+    return Alignment
+
+
+def region_rows(rng, truth_b, truth_r, p0, length, noisy):
+    """Rows of one region as chunk id -> (positions [n,3], bases, rles): the region's positions cut into 1-3 chunk ids
+    whose key ranges overlap (the later id, in STRING order, repeats keys with other labels: first writer wins),
+    insert columns, gap labels, padding rows in the middle."""
+    import numpy as np
+    keys = []
+    for p in range(p0, p0 + length):
+        keys.append((p, 0, 0))
+        if rng.random() < 0.15:
+            keys.append((p, 1, rng.randrange(0, 2)))
+    labels = {}
+    for (p, i, sp) in keys:
+        if noisy:
+            labels[(p, i, sp)] = (rng.randrange(0, 5), rng.randrange(0, 4))
+        elif i == 0:
+            labels[(p, i, sp)] = (int(truth_b[p]), int(truth_r[p]))
+        else:
+            labels[(p, i, sp)] = (0, 0) if rng.random() < 0.7 else (rng.randrange(1, 5), 1)
+    n_ids = rng.randrange(1, 4)
+    ids = rng.sample([0, 1, 2, 10, 11], n_ids)
+    chunks = {}
+    for k, cid in enumerate(sorted(ids, key=str)):
+        lo = 0 if k == 0 else max(0, len(keys) * k // n_ids - 8)
+        hi = len(keys) if k == n_ids - 1 else len(keys) * (k + 1) // n_ids
+        rows = keys[lo:hi]
+        b = [labels[q][0] for q in rows]
+        r = [labels[q][1] for q in rows]
+        if k > 0:                                            # repeated keys come with other labels
+            for t in range(min(8, len(rows))):
+                b[t], r[t] = rng.randrange(0, 5), rng.randrange(0, 4)
+        pos = [list(q) for q in rows]
+        if rng.random() < 0.3:                               # padding rows in the middle of an image
+            at = rng.randrange(0, len(pos))
+            pos[at:at] = [[-1, -1, -1]] * 2
+            b[at:at] = [rng.randrange(0, 5)] * 2
+            r[at:at] = [rng.randrange(0, 4)] * 2
+        chunks[str(cid)] = {"position": pos, "bases": b, "rles": r}
+    return chunks
+
+
+def write_case(directory, case):
+    import numpy as np
+    from helen_amd.data_store import DataStore
+    stores = {}
+    for region in case["regions"]:
+        path = os.path.join(directory, region["file"])
+        if path not in stores:
+            stores[path] = DataStore(path, "w")
+        for cid, rows in sorted(region["chunks"].items()):
+            n = len(rows["bases"])
+            P = np.full((1000, 3), -1, np.int64)
+            B = np.zeros(1000, np.uint8)
+            R = np.zeros(1000, np.uint8)
+            P[:n], B[:n], R[:n] = np.array(rows["position"], np.int64).reshape(n, 3), rows["bases"], rows["rles"]
+            stores[path].write_prediction(region["contig"], region["start"], region["end"], int(cid), P, B, R)
+    for st in stores.values():
+        st.close()
+    return sorted(stores)
+
+
+def directory_case(rng):
+    import numpy as np
+    total = 700
+    truth_b = np.array([rng.randrange(1, 5) for _ in range(total)])
+    truth_r = np.array([rng.randrange(1, 4) for _ in range(total)])
+    regions, p0, k = [], 0, 0
+    while p0 + 20 < total and len(regions) < 9:
+        length = rng.choice([30, 60, 60, 90])
+        length = min(length, total - p0)
+        noisy = rng.random() < 0.12
+        regions.append({"file": "p_%d.hdf" % (k % 2), "contig": "ctg", "start": p0, "end": p0 + length,
+                        "chunks": region_rows(rng, truth_b, truth_r, p0, length, noisy)})
+        step = rng.random()
+        p0 = p0 + length - rng.choice([25, 25, 12]) if step < 0.8 else p0 + length + (0 if step < 0.9 else 7)
+        k += 1
+    return {"regions": regions}
+
+
+def rand_seq(rng, n):
+    return "".join(rng.choice("ACGT") for _ in range(n))
+
+
+def mutate(rng, s, rate):
+    out = []
+    for c in s:
+        x = rng.random()
+        if x < rate / 3:
+            continue
+        if x < 2 * rate / 3:
+            out.append(rng.choice("ACGT"))
+            out.append(c)
+        elif x < rate:
+            out.append(rng.choice("ACGTN"))
+        else:
+            out.append(c)
+    return "".join(out)
+
+
+def chain(rng):
+    """2-6 chunks cut from one truth sequence: mutated / unrelated / empty / tiny chunks, overlaps above and below the
+    anchor run of 8, abutting, gapped and nested chunks, homopolymer-rich truth, shuffled order."""
+    if rng.random() < 0.3:
+        truth = "".join(rng.choice("ACGT") * rng.randrange(1, 7) for _ in range(rng.choice([20, 100, 300])))
+    else:
+        truth = rand_seq(rng, rng.choice([60, 300, 1200]))
+    chunks, start = [], 0
+    for _ in range(rng.randrange(2, 7)):
+        length = rng.choice([3, 9, 10, 11, 40, 150, 400])
+        end = min(len(truth), start + length)
+        seq = truth[start:end]
+        kind = rng.random()
+        if kind < 0.35:
+            seq = mutate(rng, seq, rng.choice([0.01, 0.05, 0.2, 0.5]))
+        elif kind < 0.45:
+            seq = rand_seq(rng, len(seq))
+        elif kind < 0.5:
+            seq = ""
+        chunks.append(["ctg", start, end, seq])
+        step = rng.random()
+        if step < 0.55:
+            start = max(start + 1, end - rng.choice([1, 3, 7, 8, 9, 20, 60, 200]))
+        elif step < 0.7:
+            start = end
+        elif step < 0.85:
+            start = end + rng.choice([1, 50])
+        else:
+            start = start + rng.choice([1, 5])
+        if start >= len(truth):
+            break
+    rng.shuffle(chunks)
+    return chunks
+
+
+def main():
+    if not os.path.isdir("/root/reference") or not os.path.exists(REF_SSW):
+        sys.exit("needs /root/reference and oracle/_ref/libssw_ref.so (make -C oracle ref)")
+    Alignment = install_reference_bindings()
+    sys.path.insert(0, "/root/reference")
+    from helen.modules.python.Stitch import Stitch           # the reference's own module
+    rng = random.Random(20260929)
+    joins, anchors = [], []
+    stderr, sys.stderr = sys.stderr, io.StringIO()            # the procedure warns on stderr
+    try:
+        while len(joins) < 400:
+            chunks = chain(rng)
+            if len(chunks) < 2:
+                continue
+            contig, start, end, seq = Stitch().alignment_stitch([tuple(c) for c in chunks])
+            joins.append({"chunks": chunks, "result": [contig, start, end, seq]})
+        for _ in range(1500):
+            parts, last = [], None
+            for _ in range(rng.randrange(1, 9)):
+                op = rng.choice([o for o in "=XIDSM" if o != last or o in "=X"])
+                parts.append("%d%s" % (rng.choice([1, 2, 3, 5, 7, 8, 9, 30]), op))
+                last = op
+            a = Alignment()
+            a.cigar_string = "".join(parts)
+            a.reference_begin = rng.randrange(0, 50)
+            try:
+                got = list(Stitch.get_confident_positions(a))
+            except ValueError:
+                got = "ValueError"
+            anchors.append({"cigar": a.cigar_string, "reference_begin": a.reference_begin, "result": got})
+    finally:
+        sys.stderr = stderr
+    import shutil
+    import tempfile
+    directories = []
+    stderr, sys.stderr = sys.stderr, io.StringIO()
+    try:
+        for _ in range(14):
+            case = directory_case(rng)
+            d = tempfile.mkdtemp(prefix="helen_golden_")
+            try:
+                files = write_case(d, case)
+                keys = sorted((("ctg", os.path.join(d, r["file"]), "ctg-%d-%d" % (r["start"], r["end"]), r["start"], r["end"])
+                               for r in case["regions"]), key=lambda e: (e[3], e[4]))
+                run = Stitch().small_chunk_stitch("ctg", keys)
+                case["small_chunk_stitch"] = [run[0], int(run[1]), int(run[2]), run[3]]
+                tuples = [(k[1], k[2], k[3], k[4]) for k in keys]
+                case["create_consensus_sequence"] = {str(t): Stitch().create_consensus_sequence("ctg", tuples, t)
+                                                     for t in (1, 3)}
+                case["files"] = [os.path.basename(f) for f in files]
+                directories.append(case)
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+    finally:
+        sys.stderr = stderr
+    with gzip.open(OUT, "wt") as f:
+        json.dump({"made_by": "tests/golden/make_golden_stitch.py (reference Stitch.py executed, reference ssw.c alignments)",
+                   "joins": joins, "anchors": anchors, "directories": directories}, f)
+    fillers = sum("N" * 10 in j["result"][3] for j in joins)
+    print("wrote %s: %d joins (%d with fillers), %d anchor cases, %d directories (%d with fillers), %d bytes"
+          % (OUT, len(joins), fillers, len(anchors), len(directories),
+             sum("N" * 10 in d["small_chunk_stitch"][3] for d in directories), os.path.getsize(OUT)))
+
+
+if __name__ == "__main__":
+    main()

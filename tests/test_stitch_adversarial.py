@@ -198,3 +198,88 @@ def test_directories_equal_the_naive_statement(tmp_path, threads, capfd):
     for contig in want:
         assert got[contig] == want[contig], contig
     assert "N" * 10 in got["chrC"]                          # the hole was filled, in both
+
+
+def _reference_fixture():
+    import gzip
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stitch_ref.json.gz")
+    with gzip.open(path, "rt") as f:
+        return json.load(f)
+
+
+def test_joins_equal_the_reference_stitch_itself(capfd):
+    """tests/golden/stitch_ref.json.gz holds what the REFERENCE's own Stitch.alignment_stitch (Stitch.py:96-190), imported
+    from the reference tree and run on the reference's own SSW library, returned for 400 seeded chains of chunks
+    (tests/golden/make_golden_stitch.py).  This package's alignment_stitch -- its own aligner included -- and the naive
+    statement must return exactly that."""
+    from helen_amd.stitch import alignment_stitch
+    cases = _reference_fixture()["joins"]
+    assert len(cases) == 400
+    fillers = 0
+    for case in cases:
+        chunks = [tuple(c) for c in case["chunks"]]
+        want = tuple(case["result"])
+        assert alignment_stitch(list(chunks)) == want, chunks
+        assert naive_stitch.join(list(chunks)) == want, chunks
+        fillers += "N" * 10 in want[3]
+    capfd.readouterr()
+    assert 100 < fillers < 300
+
+
+def test_anchors_equal_the_reference_stitch_itself():
+    """... and Stitch.get_confident_positions (Stitch.py:33-94) on 1,500 seeded CIGARs."""
+    from helen_amd.stitch import get_confident_positions
+
+    class A(object):
+        pass
+    cases = _reference_fixture()["anchors"]
+    assert len(cases) == 1500
+    hits = 0
+    for case in cases:
+        a = A()
+        a.cigar_string, a.reference_begin = case["cigar"], case["reference_begin"]
+        if case["result"] == "ValueError":
+            with pytest.raises(ValueError):
+                get_confident_positions(a)
+            continue
+        assert list(get_confident_positions(a)) == case["result"], case
+        assert list(naive_stitch.anchor(a.reference_begin, a.cigar_string)) == case["result"], case
+        hits += case["result"][0] != -1
+    assert hits > 200
+
+
+@pytest.mark.parametrize("writer", [None, "libhdf5"])
+def test_region_decode_and_contig_stitch_equal_the_reference_stitch_itself(tmp_path, monkeypatch, capfd, writer):
+    """14 prediction directories (seeded regions: duplicate keys across chunk ids in string order, insert columns, gap
+    labels, padding rows, noisy regions, holes) on which the REFERENCE's own Stitch.small_chunk_stitch and
+    create_consensus_sequence (1 and 3 workers) were run (tests/golden/make_golden_stitch.py).  Rebuilt here from the
+    fixture's rows, through either writer, this package's small_chunk_stitch / create_consensus_sequence and the naive
+    statement must give the reference's sequences."""
+    import importlib.util
+    from helen_amd.stitch import create_consensus_sequence, small_chunk_stitch
+    if writer:
+        monkeypatch.setenv("HELEN_IO_WRITER", writer)
+    else:
+        monkeypatch.delenv("HELEN_IO_WRITER", raising=False)
+    spec = importlib.util.spec_from_file_location(
+        "make_golden_stitch", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden_stitch.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)                         # only its write_case helper is used: nothing of the reference
+    cases = _reference_fixture()["directories"]
+    assert len(cases) == 14
+    for k, case in enumerate(cases):
+        d = tmp_path / ("case%d" % k)
+        d.mkdir()
+        gen.write_case(str(d), case)
+        keys = sorted((("ctg", str(d / r["file"]), "ctg-%d-%d" % (r["start"], r["end"]), r["start"], r["end"])
+                       for r in case["regions"]), key=lambda e: (e[3], e[4]))
+        got = small_chunk_stitch("ctg", keys)
+        assert [got[0], got[1], got[2], got[3].decode() if isinstance(got[3], bytes) else got[3]] == \
+            case["small_chunk_stitch"], k
+        tuples = [(key[1], key[2], key[3], key[4]) for key in keys]
+        for threads in (1, 3):
+            seq = create_consensus_sequence("ctg", tuples, threads)
+            assert bytes(seq).decode() == case["create_consensus_sequence"][str(threads)], (k, threads)
+        assert naive_stitch.stitch_directory(str(d), threads=3)["ctg"] == case["create_consensus_sequence"]["3"], k
+    capfd.readouterr()
