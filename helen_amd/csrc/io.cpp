@@ -265,6 +265,41 @@ bool scan_2d(const h5scan::Dataset& d, T* dst) {
     return false;
 }
 
+// The contig string as the reference's reader returns it (dataloader_predict.py:64):
+//     np.array2string(name.astype(np.str)).replace("'", '')
+// array2string prints a string scalar as Python's repr does -- in single quotes, or in DOUBLE quotes when the name holds a
+// single quote and no double quote; backslashes doubled, a quote of the delimiter's kind and control characters escaped --
+// and the replace then drops every single quote.  For an ordinary name that is the name; "c'q" comes back as "cq" WITH
+// its double quotes (checked against the reference's reader itself: tests/golden/make_golden_io.py).
+std::string reference_contig_text(const std::string& raw) {
+    const bool has_sq = raw.find('\'') != std::string::npos, has_dq = raw.find('"') != std::string::npos;
+    const char quote = (has_sq && !has_dq) ? '"' : '\'';
+    std::string r(1, quote);
+    char esc[8];
+    for (unsigned char c : raw) {
+        if (c == (unsigned char)quote || c == '\\') {
+            r += '\\';
+            r += (char)c;
+        } else if (c == '\t') {
+            r += "\\t";
+        } else if (c == '\n') {
+            r += "\\n";
+        } else if (c == '\r') {
+            r += "\\r";
+        } else if (c < 0x20 || c == 0x7f) {
+            snprintf(esc, sizeof(esc), "\\x%02x", c);
+            r += esc;
+        } else {
+            r += (char)c;
+        }
+    }
+    r += quote;
+    std::string out;
+    for (char c : r)
+        if (c != '\'') out.push_back(c);
+    return out;
+}
+
 // helen_io_read_images through the scanner.  0: done; -1: the reader's error (message set); 1: something this
 // scanner does not take -- the caller reads the batch through libhdf5 instead.
 int fast_read_images(Scanned* sc, const char* path, const char* names, int n, uint8_t* images, int64_t* positions,
@@ -299,10 +334,7 @@ int fast_read_images(Scanned* sc, const char* path, const char* names, int n, ui
             memset(img + (size_t)rows * kFeat, 0, (size_t)(kSeq - rows) * kFeat);
             for (int k = rows * 3; k < kSeq * 3; ++k) pos[k] = -1;
         }
-        // np.array2string(...).replace("'", "") of the reader: strip quotes
-        std::string clean;
-        for (char c : contig)
-            if (c != '\'') clean.push_back(c);
+        const std::string clean = reference_contig_text(contig);
         if (clean.size() > (size_t)kName - 1)
             return fail("%s: image '%s': contig name longer than %d bytes", path, name.c_str(), kName - 1);
         char* c = contigs + (size_t)i * kName;
@@ -472,12 +504,11 @@ int helen_io_read_images(const char* path, const char* names, int n, uint8_t* im
             memset(img + (size_t)rows * kFeat, 0, (size_t)(kSeq - rows) * kFeat);
             for (int k = rows * 3; k < kSeq * 3; ++k) pos[k] = -1;
         }
-        // np.array2string(...).replace("'", "") of the reader: strip quotes
         char* c = contigs + (size_t)i * kName;
-        size_t o = 0;
-        for (size_t k = 0; c[k]; ++k)
-            if (c[k] != '\'') c[o++] = c[k];
-        c[o] = 0;
+        const std::string clean = reference_contig_text(c);
+        if (clean.size() > (size_t)kName - 1)
+            return fail("%s: image '%s': contig name longer than %d bytes", path, name.c_str(), kName - 1);
+        memcpy(c, clean.c_str(), clean.size() + 1);
     }
     return 0;
 }

@@ -47,7 +47,9 @@ def read_item(hdf5_filepath, image_name):
     """One image with its bookkeeping, padded to SEQ_LENGTH (dataloader_predict.py:54-88)."""
     f = _cache.get(hdf5_filepath)
     base = "images/" + image_name + "/"
-    contig = str(f.read(base + "contig").reshape(-1)[0]).replace("'", "")
+    # np.array2string(name.astype(np.str)).replace("'", '') (dataloader_predict.py:64): array2string prints the string
+    # scalar as repr() does -- in double quotes when the name holds a single quote and no double quote
+    contig = repr(str(f.read(base + "contig").reshape(-1)[0])).replace("'", "")
     contig_start = int(f.read(base + "contig_start", np.int64).reshape(-1)[0])
     contig_end = int(f.read(base + "contig_end", np.int64).reshape(-1)[0])
     chunk_id = int(f.read(base + "feature_chunk_idx", np.int64).reshape(-1)[0])

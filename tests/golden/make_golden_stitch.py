@@ -14,123 +14,21 @@ writer wins over chunk ids in string order) and `Stitch.create_consensus_sequenc
 workers) on prediction FILES written here by this package's DataStore from seeded regions (duplicate keys across
 chunk ids, gaps, padding rows, noisy regions, holes); the fixture stores the regions' rows and the reference's results.
 
-Things the image lacks are supplied so that `import helen.modules.python.Stitch` succeeds and those methods run:
-  * `from helen.build import HELEN` is the reference's pybind11 module around its vendored striped Smith-Waterman
-    (modules/headers/pybind_api.h:16-47).  Here `HELEN.Aligner / Filter / Alignment` are thin Python classes over
-    oracle/_ref/libssw_ref.so -- the REFERENCE's own ssw.c / ssw_cpp.cpp compiled in place (oracle/Makefile `ref`) --
-    with the attribute names the binding gives them (best_score, reference_begin, cigar_string, ...).  The alignments
-    are the reference library's, not this package's.
-  * `import h5py`: h5py is not installed.  The module registered under that name is a read-only veneer with the
-    handful of h5py calls Stitch.py makes -- File(path, 'r') as a context manager, `name in file`, group[name],
-    group.keys(), dataset[()] -- on top of libhdf5 itself (helen_amd/hdf5.py, the ctypes binding): the bytes come
-    from the HDF5 library, only the Python spelling of the calls is h5py's.
-  * `np.int` (Stitch.py:225-226) was removed from numpy; it is aliased to the builtin `int` it used to name.
+What the image lacks for importing and running the reference's module (its pybind11 aligner module `HELEN`, `h5py`,
+`np.int`) is supplied by tests/golden/reference_env.py, which documents each item: the aligner is the reference's own
+ssw.c compiled in place, h5py's few calls are spelled on top of libhdf5.
 """
-import ctypes
 import gzip
 import io
 import json
 import os
 import random
 import sys
-import types
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-REF_SSW = os.path.join(ROOT, "oracle", "_ref", "libssw_ref.so")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from reference_env import REF_SSW, ROOT, install  # noqa: E402
+
 OUT = os.path.join(ROOT, "tests", "golden", "stitch_ref.json.gz")
-
-
-def install_reference_bindings():
-    lib = ctypes.CDLL(REF_SSW)
-
-    class Alignment(object):
-        def __init__(self):
-            self.Clear()
-
-        def Clear(self):
-            self.best_score = 0
-            self.best_score2 = 0
-            self.reference_begin = 0
-            self.reference_end = 0
-            self.query_begin = 0
-            self.query_end = 0
-            self.ref_end_next_best = 0
-            self.mismatches = 0
-            self.cigar_string = ""
-            self.cigar = []
-
-    class Filter(object):
-        def __init__(self, *a):
-            self.report_begin_position = True
-            self.report_cigar = True
-            self.score_filter = 0
-            self.distance_filter = 32767
-
-    class Aligner(object):
-        def __init__(self, match=2, mismatch=2, gap_open=3, gap_extend=1):
-            self.p = (match, mismatch, gap_open, gap_extend)
-            self.ref = b""
-
-        def SetReferenceSequence(self, seq, length):
-            self.ref = seq.encode()[:length]
-            return length
-
-        def Align_cpp(self, query, flt, alignment, mask_len):
-            alignment.Clear()
-            if not self.ref or not query:
-                return False
-            out = (ctypes.c_int * 6)()
-            cig = ctypes.create_string_buffer(16 * (len(self.ref) + len(query)) + 64)
-            rc = lib.ssw_ref_align(self.ref, len(self.ref), query.encode(), *self.p, out, cig, len(cig))
-            (alignment.best_score, alignment.reference_begin, alignment.reference_end, alignment.query_begin,
-             alignment.query_end, alignment.mismatches) = list(out)
-            alignment.cigar_string = cig.value.decode()
-            return rc == 0
-
-    helen_build = types.ModuleType("helen.build")
-    helen_build.HELEN = types.SimpleNamespace(Aligner=Aligner, Filter=Filter, Alignment=Alignment)
-    sys.modules["helen.build"] = helen_build
-
-    # h5py's spelling of the few calls Stitch.py makes, on libhdf5 through helen_amd/hdf5.py
-    sys.path.insert(0, ROOT)
-    from helen_amd import hdf5
-
-    class Node(object):
-        def __init__(self, f, path):
-            self.f, self.path = f, path
-
-        def _child(self, name):
-            return (self.path.rstrip("/") + "/" + name) if self.path else name
-
-        def __contains__(self, name):
-            return self.f.exists(self._child(name))
-
-        def keys(self):
-            return self.f.keys(self.path or "/")
-
-        def __getitem__(self, name):
-            if name == ():
-                return self.f.read(self.path)                 # dataset[()]
-            return Node(self.f, self._child(name))
-
-    class File(Node):
-        def __init__(self, path, mode="r"):
-            assert mode == "r"
-            Node.__init__(self, hdf5.File(path, "r"), "")
-
-        def __enter__(self):
-            return self
-
-        def __exit__(self, *exc):
-            self.f.close()
-
-    h5py = types.ModuleType("h5py")
-    h5py.File = File
-    sys.modules["h5py"] = h5py
-    import numpy as np
-    if not hasattr(np, "int"):
-        np.int = int
-    return Alignment
 
 
 def region_rows(rng, truth_b, truth_r, p0, length, noisy):
@@ -269,7 +167,7 @@ def chain(rng):
 def main():
     if not os.path.isdir("/root/reference") or not os.path.exists(REF_SSW):
         sys.exit("needs /root/reference and oracle/_ref/libssw_ref.so (make -C oracle ref)")
-    Alignment = install_reference_bindings()
+    Alignment = install()
     sys.path.insert(0, "/root/reference")
     from helen.modules.python.Stitch import Stitch           # the reference's own module
     rng = random.Random(20260929)
@@ -321,7 +219,7 @@ def main():
                 shutil.rmtree(d, ignore_errors=True)
     finally:
         sys.stderr = stderr
-    with gzip.open(OUT, "wt") as f:
+    with io.TextIOWrapper(gzip.GzipFile(OUT, "wb", mtime=0)) as f:      # mtime 0: the same bytes every time
         json.dump({"made_by": "tests/golden/make_golden_stitch.py (reference Stitch.py executed, reference ssw.c alignments)",
                    "joins": joins, "anchors": anchors, "directories": directories}, f)
     fillers = sum("N" * 10 in j["result"][3] for j in joins)

@@ -399,3 +399,88 @@ def test_labeled_images_native_reader_equals_the_per_item_reader(tmp_path):
     ds = SequenceDataset(str(short))
     with pytest.raises(ValueError, match="IMAGE SIZE ERROR"):
         ds.read_range(0, 2)
+
+
+def _load_generator(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tests", "golden", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)          # only its input builders are used here: nothing of the reference
+    return mod
+
+
+def _io_fixture():
+    import gzip
+    import json
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "io_ref.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+READER_CHILD = r'''
+import json, sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests/golden")
+from make_golden_io import digest
+from helen_amd.sequence_dataset import SequenceDataset, _load_batch
+ds = SequenceDataset(None, file_list=%(paths)r)
+b = _load_batch(ds.all_images)
+print(json.dumps([{"name": n, "contig": b.contig[k], "contig_start": int(b.contig_start[k]), "contig_end": int(b.contig_end[k]),
+                   "chunk_id": int(b.chunk_id[k]), "image": digest(b.images[k]), "position": digest(b.positions[k])}
+                  for k, (_, n) in enumerate(ds.all_images)]))
+'''
+
+
+def test_reader_equals_the_reference_reader_itself(tmp_path):
+    """tests/golden/io_ref.json.gz holds what the REFERENCE's own SequenceDataset (dataloader_predict.py:18-95), imported
+    from the reference tree and run on the image files of make_golden_io.io_case_files, returned item by item.  This
+    package's per-item reader and its native batch reader (scanner, libhdf5, either alone) must return the same
+    order, names, contig strings (quotes stripped), integers, padded images and positions."""
+    import json
+    import subprocess
+    import sys
+    from helen_amd.sequence_dataset import SequenceDataset
+    gen = _load_generator("make_golden_io")
+    want = _io_fixture()["reader"]
+    paths = gen.io_case_files(str(tmp_path))
+    ds = SequenceDataset(None, file_list=paths)
+    assert [(os.path.basename(p), n) for p, n in ds.all_images] == [(w["file"], w["name"]) for w in want]
+    for k, w in enumerate(want):
+        contig, start, end, chunk, image, position, path = ds[k]
+        assert (str(contig), int(start), int(end), int(chunk), os.path.basename(path)) == \
+            (w["contig"], w["contig_start"], w["contig_end"], w["chunk_id"], w["returned_file"]), k
+        assert gen.digest(image) == w["image"] and gen.digest(np.asarray(position, np.int64)) == w["position"], k
+    for reader in ("", "libhdf5", "direct"):
+        env = dict(os.environ)
+        env.pop("HELEN_IO_READER", None)
+        if reader:
+            env["HELEN_IO_READER"] = reader
+        r = subprocess.run([sys.executable, "-c", READER_CHILD % {"root": ROOT, "paths": paths}], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = json.loads(r.stdout.strip().splitlines()[-1])
+        for g, w in zip(got, want):
+            for key in ("name", "contig", "contig_start", "contig_end", "chunk_id", "image", "position"):
+                assert g[key] == w[key], (reader, key, g["name"])
+
+
+@pytest.mark.parametrize("writer", [None, "libhdf5"])
+def test_writer_equals_the_reference_writer_itself(tmp_path, monkeypatch, writer):
+    """... and what the REFERENCE's own DataStore.write_prediction (DataStore.py:83-133) stored for the windows of
+    make_golden_io.writer_case: the same tree of dataset names, dtypes (position uint32 with wrapped -1 padding,
+    labels uint8, scalar int64 bounds), shapes and bytes, the repeated window skipped -- from either writer here."""
+    from helen_amd.data_store import DataStore
+    if writer:
+        monkeypatch.setenv("HELEN_IO_WRITER", writer)
+    else:
+        monkeypatch.delenv("HELEN_IO_WRITER", raising=False)
+    gen = _load_generator("make_golden_io")
+    want = _io_fixture()["writer"]
+    path = str(tmp_path / "pred.hdf")
+    store = DataStore(path, mode="w")
+    for contig, start, end, chunk, pos, bases, rles in gen.writer_case():
+        store.write_prediction(contig, np.int64(start), np.int64(end), np.int64(chunk), pos, bases, rles, "x.h5")
+    store.close()
+    with hdf5.File(path, "r") as f:
+        got = gen.walk(f)
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert got[k] == want[k], k
