@@ -268,3 +268,39 @@ def test_fallback_reads_are_reported(tmp_path, monkeypatch, capfd):
         total = sum(len([k for k in f.keys("predictions/chr20_synth/" + r) if k not in ("contig_start", "contig_end")])
                     for r in f.keys("predictions/chr20_synth"))
         assert total == 40
+
+
+def test_oracle_reader_and_writer_reproduce_the_reference_predict_itself(tmp_path):
+    """The CPU-side pieces against tests/golden/predict_ref.json.gz -- the prediction file the REFERENCE's own `predict`
+    (models/predict.py:38-175) wrote for make_golden_predict.predict_case: this package's reader feeds the oracle, this
+    package's writer stores the oracle's labels, and the file must equal the reference's, labels byte for byte (the
+    oracle pinned once more, through the reference's whole function rather than a restated loop)."""
+    import gzip
+    import importlib.util
+    import json
+    import sys
+    import oracle
+    from helen_amd.data_store import DataStore
+    from helen_amd.sequence_dataset import SequenceDataset, _load_batch
+    from helen_amd.weights import make_weights
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
+    spec = importlib.util.spec_from_file_location("make_golden_predict",
+                                                  os.path.join(root, "tests", "golden", "make_golden_predict.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    with gzip.open(os.path.join(root, "tests", "golden", "predict_ref.json.gz"), "rt") as f:
+        want = json.load(f)["tree"]
+    image_dir, _ = gen.predict_case(str(tmp_path))
+    ds = SequenceDataset(image_dir)
+    b = _load_batch(ds.all_images)
+    ref = oracle.polish_batch(make_weights(seed=20260928, head_scale=8.0, input_scale=1.0 / 64.0), b.images)
+    out = str(tmp_path / "oracle.hdf")
+    with DataStore(out, "w") as store:
+        store.write_batch(b.contig, np.stack([b.contig_start, b.contig_end, b.chunk_id], 1), b.positions,
+                          ref["bases"], ref["rles"])
+    got = gen.tree_of(out)
+    assert sorted(got) == sorted(want)
+    for path in want:
+        assert (got[path]["dtype"], got[path]["shape"], got[path]["sha1"]) == \
+            (want[path]["dtype"], want[path]["shape"], want[path]["sha1"]), path
