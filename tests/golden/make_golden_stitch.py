@@ -91,21 +91,24 @@ def write_case(directory, case):
     return sorted(stores)
 
 
-def directory_case(rng):
+def directory_case(rng, second_contig=False):
     import numpy as np
-    total = 700
-    truth_b = np.array([rng.randrange(1, 5) for _ in range(total)])
-    truth_r = np.array([rng.randrange(1, 4) for _ in range(total)])
-    regions, p0, k = [], 0, 0
-    while p0 + 20 < total and len(regions) < 9:
-        length = rng.choice([30, 60, 60, 90])
-        length = min(length, total - p0)
-        noisy = rng.random() < 0.12
-        regions.append({"file": "p_%d.hdf" % (k % 2), "contig": "ctg", "start": p0, "end": p0 + length,
-                        "chunks": region_rows(rng, truth_b, truth_r, p0, length, noisy)})
-        step = rng.random()
-        p0 = p0 + length - rng.choice([25, 25, 12]) if step < 0.8 else p0 + length + (0 if step < 0.9 else 7)
-        k += 1
+    regions = []
+    for contig in (("ctg", "a_second_contig") if second_contig else ("ctg",)):
+        total = 700 if contig == "ctg" else 260
+        truth_b = np.array([rng.randrange(1, 5) for _ in range(total)])
+        truth_r = np.array([rng.randrange(1, 4) for _ in range(total)])
+        p0, k, count = 0, 0, 0
+        while p0 + 20 < total and count < 9:
+            length = rng.choice([30, 60, 60, 90])
+            length = min(length, total - p0)
+            noisy = rng.random() < 0.12
+            regions.append({"file": "p_%d.hdf" % (k % 2), "contig": contig, "start": p0, "end": p0 + length,
+                            "chunks": region_rows(rng, truth_b, truth_r, p0, length, noisy)})
+            step = rng.random()
+            p0 = p0 + length - rng.choice([25, 25, 12]) if step < 0.8 else p0 + length + (0 if step < 0.9 else 7)
+            k += 1
+            count += 1
     return {"regions": regions}
 
 
@@ -201,13 +204,19 @@ def main():
     directories = []
     stderr, sys.stderr = sys.stderr, io.StringIO()
     try:
-        for _ in range(14):
-            case = directory_case(rng)
+        from helen.modules.python.StitchInterface import perform_stitch       # the reference's own driver
+        for n in range(14):
+            case = directory_case(rng, second_contig=n % 3 == 0)
             d = tempfile.mkdtemp(prefix="helen_golden_")
             try:
                 files = write_case(d, case)
+                case["perform_stitch"] = {}
+                for t in (1, 3):            # StitchInterface.py:40-106: every contig of every file -> FASTA
+                    fasta = perform_stitch(d, os.path.join(d, "fasta%d" % t), "asm", t)
+                    case["perform_stitch"][str(t)] = open(os.path.join(d, "fasta%d" % t, "asm.fa")).read()
+                    assert fasta is None or True
                 keys = sorted((("ctg", os.path.join(d, r["file"]), "ctg-%d-%d" % (r["start"], r["end"]), r["start"], r["end"])
-                               for r in case["regions"]), key=lambda e: (e[3], e[4]))
+                               for r in case["regions"] if r["contig"] == "ctg"), key=lambda e: (e[3], e[4]))
                 run = Stitch().small_chunk_stitch("ctg", keys)
                 case["small_chunk_stitch"] = [run[0], int(run[1]), int(run[2]), run[3]]
                 tuples = [(k[1], k[2], k[3], k[4]) for k in keys]

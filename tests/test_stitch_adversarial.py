@@ -253,11 +253,12 @@ def test_anchors_equal_the_reference_stitch_itself():
 def test_region_decode_and_contig_stitch_equal_the_reference_stitch_itself(tmp_path, monkeypatch, capfd, writer):
     """14 prediction directories (seeded regions: duplicate keys across chunk ids in string order, insert columns, gap
     labels, padding rows, noisy regions, holes) on which the REFERENCE's own Stitch.small_chunk_stitch and
-    create_consensus_sequence (1 and 3 workers) were run (tests/golden/make_golden_stitch.py).  Rebuilt here from the
-    fixture's rows, through either writer, this package's small_chunk_stitch / create_consensus_sequence and the naive
-    statement must give the reference's sequences."""
+    create_consensus_sequence and the whole StitchInterface.perform_stitch (1 and 3 workers, one or two contigs) were run
+    (tests/golden/make_golden_stitch.py).  Rebuilt here from the fixture's rows, through either writer, this package's
+    small_chunk_stitch / create_consensus_sequence / perform_stitch and the naive statement must give the reference's
+    sequences and the reference's FASTA file."""
     import importlib.util
-    from helen_amd.stitch import create_consensus_sequence, small_chunk_stitch
+    from helen_amd.stitch import create_consensus_sequence, perform_stitch, small_chunk_stitch
     if writer:
         monkeypatch.setenv("HELEN_IO_WRITER", writer)
     else:
@@ -272,8 +273,11 @@ def test_region_decode_and_contig_stitch_equal_the_reference_stitch_itself(tmp_p
         d = tmp_path / ("case%d" % k)
         d.mkdir()
         gen.write_case(str(d), case)
+        for threads in (1, 3):            # the reference's whole driver, StitchInterface.perform_stitch: the FASTA itself
+            out = perform_stitch(str(d), str(d / ("fasta%d" % threads)), "asm", threads)
+            assert open(out).read() == case["perform_stitch"][str(threads)], (k, threads)
         keys = sorted((("ctg", str(d / r["file"]), "ctg-%d-%d" % (r["start"], r["end"]), r["start"], r["end"])
-                       for r in case["regions"]), key=lambda e: (e[3], e[4]))
+                       for r in case["regions"] if r["contig"] == "ctg"), key=lambda e: (e[3], e[4]))
         got = small_chunk_stitch("ctg", keys)
         assert [got[0], got[1], got[2], got[3].decode() if isinstance(got[3], bytes) else got[3]] == \
             case["small_chunk_stitch"], k
