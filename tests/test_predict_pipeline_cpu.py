@@ -304,3 +304,28 @@ def test_oracle_reader_and_writer_reproduce_the_reference_predict_itself(tmp_pat
     for path in want:
         assert (got[path]["dtype"], got[path]["shape"], got[path]["sha1"]) == \
             (want[path]["dtype"], want[path]["shape"], want[path]["sha1"]), path
+
+
+def test_command_line_options_equal_the_reference_definition():
+    """tests/golden/cli_ref.json: the option tables the REFERENCE's own helen/helen.py builds for `polish`,
+    `call_consensus` and `stitch` (flags, destinations, defaults, types, required).  `python -m helen_amd` must define the
+    same options with the same defaults -- a command line written for the reference runs unchanged."""
+    import importlib.util
+    import json
+    from helen_amd.cli import build_parser
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_golden_cli", os.path.join(root, "tests", "golden", "make_golden_cli.py"))
+    import sys
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    want = json.load(open(os.path.join(root, "tests", "golden", "cli_ref.json")))["options"]
+    subs = [a for a in build_parser()._actions if a.dest == "sub_command"][0].choices
+    for name in ("polish", "call_consensus", "stitch"):
+        got = {tuple(o["flags"]): o for o in gen.option_table(subs[name])}
+        for o in want[name]:
+            mine = got.get(tuple(o["flags"]))
+            assert mine is not None, (name, o["flags"])
+            for key in ("dest", "default", "required", "type", "nargs", "const"):
+                assert mine[key] == o[key], (name, o["flags"], key, mine[key], o[key])
+        assert len(got) == len(want[name]), (name, sorted(set(got) - {tuple(o["flags"]) for o in want[name]}))
