@@ -176,9 +176,18 @@ def _small_chunk_stitch_worker(contig, small_chunk_keys, spill_dir):
     if spill_dir is None or len(sequence) < _SPILL_BYTES:
         return contig, start, end, sequence
     import tempfile
-    fd, path = tempfile.mkstemp(prefix="helen_stitch_%d_" % os.getppid(), suffix=".seq", dir=spill_dir)
-    with os.fdopen(fd, "wb") as f:
-        f.write(sequence)
+    path = None
+    try:
+        fd, path = tempfile.mkstemp(prefix="helen_stitch_%d_" % os.getppid(), suffix=".seq", dir=spill_dir)
+        with os.fdopen(fd, "wb") as f:
+            f.write(sequence)
+    except OSError:                      # no room there: the pipe it is
+        if path is not None:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        return contig, start, end, sequence
     return contig, start, end, _Spilled(path)
 
 
