@@ -316,7 +316,10 @@ Best striped(const int8_t* ref, bool backwards, int n, const int8_t* read, int m
     for (int k = 0; k < 25; ++k) top = std::max<int>(top, mat[k]);
     const long long bound = (long long)std::min(n, m) * top + top + bias;
     static const bool general_only = getenv("HELEN_SSW_GENERAL") != nullptr;   // tests: exercise the version below
-    if (!general_only && bound < 32000 && gap_open < 32000 && gap_ext < 32000)
+    // (the 8-bit lanes hold the penalties and the biased profile as bytes)
+    const bool fits = lanes == 16 ? (gap_open <= 255 && gap_ext <= 255 && top + bias <= 255 && bias >= 0)
+                                  : (gap_open < 32000 && gap_ext < 32000);
+    if (!general_only && bound < 32000 && fits)
         return lanes == 16 ? striped_pass_small<16>(ref, backwards, n, read, m, gap_open, gap_ext, mat, bias, terminate)
                            : striped_pass_small<8>(ref, backwards, n, read, m, gap_open, gap_ext, mat, bias, terminate);
     return striped_pass(ref, backwards, n, read, m, gap_open, gap_ext, mat, lanes, bias, terminate);
