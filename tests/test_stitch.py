@@ -307,3 +307,34 @@ def test_signed_positions_of_another_writer_are_skipped_like_the_reference_does(
         r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-1500:]
         assert r.stdout.strip() == want + " [('c-0-9', 0, 9)]", (reader, r.stdout)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SSW), reason="oracle/_ref/libssw_ref.so not built (make -C oracle ref)")
+@pytest.mark.parametrize("penalties", [(2, 2, 3, 1), (1, 4, 6, 1), (5, 4, 10, 3), (4, 6, 30, 7)])
+def test_aligner_equals_reference_ssw_with_other_penalties(penalties):
+    """Stitch only ever passes (4, 6, 8, 2); the entry point takes any penalties, and so does the reference library:
+    the library's defaults, a mismatch-heavy set, a match-heavy one and large gap costs."""
+    ref = ctypes.CDLL(REF_SSW)
+    rng = random.Random(hash(penalties) & 0xffff)
+    checked = 0
+    for t in range(400):
+        L = rng.choice([5, 30, 100, 200, 300])
+        base = "".join(rng.choice("ACGT") for _ in range(L))
+        r = base
+        q = _mutate(base, rng.choice([0, 0.02, 0.1, 0.3]), rng)
+        if rng.random() < 0.5 and len(q) > 10:
+            k = rng.randrange(0, min(40, len(q) // 2))
+            q = q[k:]
+        if not q:
+            continue
+        out = (ctypes.c_int * 6)()
+        cig = ctypes.create_string_buffer(1 << 16)
+        ref.ssw_ref_align(r.encode(), len(r), q.encode(), *penalties, out, cig, 1 << 16)
+        a = native_io.ssw_align(r, q, *penalties)
+        assert a.best_score == out[0], (penalties, r, q)
+        if out[0] > 0:
+            assert (a.reference_begin, a.reference_end, a.query_begin, a.query_end, a.mismatches) == tuple(out[1:6]), \
+                (penalties, r, q)
+            assert a.cigar_string == cig.value.decode(), (penalties, r, q)
+            checked += 1
+    assert checked > 300
