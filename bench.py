@@ -60,22 +60,8 @@ def pmc_traffic(windows_per_launch):
 
 
 def usable_cpus():
-    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota (a container
-    that sees 256 CPUs may be limited to 16 CPUs' worth of time)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        try:
-            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())        # cgroup v1
-            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if quota > 0:
-                n = min(n, max(1, quota // period))
-        except Exception:
-            pass
-    return n
+    from helen_amd.host_plan import usable_cpus as f
+    return f()
 
 
 def cpu_baseline(batch, seconds_target=12.0):
@@ -132,41 +118,85 @@ def precision_check(eng, precision, images, dev):
             "max_abs_logit": round(biggest, 3), "precision": precision}
 
 
-def end_to_end(n_windows, workers, batch, weights):
-    """Opt-in leg (--e2e N): the whole `call_consensus` of the product -- synthetic MarginPolish image directory (HDF5,
-    16 files) -> reader processes -> device -> ONE prediction HDF5 -- wall-clocked from the call to its return, start-up,
-    model load and the final close included (SURVEY.md 8d "end-to-end").  Inputs are written by the direct emitter of
-    libhelen_io.so into a RAM-backed directory when /dev/shm has room, the temp directory otherwise."""
+E2E_DEFAULT_WINDOWS = 49152        # per rank: 12 device calls of 4096 windows, ~0.6 s of device time
+E2E_FILES_PER_RANK = 16
+
+
+def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_device, dist):
+    """The whole `call_consensus` of the product over `world` ranks -- synthetic MarginPolish image directory (HDF5,
+    16 files per rank, sharded round-robin by file as CallConsensusInterface.py:138-145) -> per rank: reader processes
+    -> device -> ONE prediction HDF5 -- wall-clocked from the call to its return: host budgeting, process start-up,
+    model load and the final close included (SURVEY.md 8d "end-to-end").  Every bench rank writes its share of the
+    inputs (direct emitter of libhelen_io.so, RAM-backed directory); rank 0 then runs call_consensus, which starts
+    its OWN process per device exactly as the CLI does, while the other bench ranks sleep on a file (not in a
+    collective: their GPUs must be idle).  Returns the `end_to_end` object on rank 0, None elsewhere."""
     import shutil
     import tempfile
 
     from helen_amd import hdf5
     from helen_amd import predict as P
     from helen_amd.call_consensus import call_consensus
+    from helen_amd.host_plan import SLOT_BYTES_PER_WINDOW, shm_free_bytes
     from helen_amd.model_handler import ModelHandler
-    from helen_amd.synthetic import write_image_dir
-    need = n_windows * 120000 * 2
-    base = None
-    if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK):
-        st = os.statvfs("/dev/shm")
-        if st.f_bavail * st.f_frsize > need:
-            base = "/dev/shm"
-    d = tempfile.mkdtemp(prefix="helen_e2e_", dir=base)
+    from helen_amd.synthetic import write_image_file_direct
+    from helen_amd.weights import make_images
+    total = windows_per_rank * world
+    need = total * 116000 + world * 5 * 4096 * SLOT_BYTES_PER_WINDOW + total * 16000   # inputs + slots + outputs
+    box = [None]
+    if rank == 0:
+        if shm_free_bytes() > need * 1.1:
+            box[0] = tempfile.mkdtemp(prefix="helen_e2e_", dir="/dev/shm")
+        elif world == 1:
+            box[0] = tempfile.mkdtemp(prefix="helen_e2e_")
+    if dist is not None:
+        dist.broadcast_object_list(box, src=0)
+    d = box[0]
+    if d is None:
+        return {"value": None, "skipped": "/dev/shm has %.1f GB free, the %d-rank leg needs %.1f GB"
+                                          % (shm_free_bytes() / 1e9, world, need / 1e9)} if rank == 0 else None
+    done = os.path.join(d, "done")
     try:
+        img_dir = os.path.join(d, "img")
+        os.makedirs(img_dir, exist_ok=True)
+        per_file = -(-windows_per_rank // E2E_FILES_PER_RANK)
+        t0 = time.time()
+        write_error = None
+        try:
+            for k in range(E2E_FILES_PER_RANK):            # file index fi = k * world + rank: round-robin gives them back
+                fi = k * world + rank
+                n = min(per_file, windows_per_rank - k * per_file)
+                if n <= 0:
+                    break
+                write_image_file_direct(os.path.join(img_dir, "synthetic_images_%04d.h5" % fi),
+                                        make_images(n, seed=20260928 + fi), first_window=fi * per_file)
+        except Exception as e:          # noqa: BLE001 -- agreed on by all ranks below
+            write_error = "%s: %s" % (type(e).__name__, e)
+        t_write = time.time() - t0
+        if dist is not None:            # doubles as the barrier: every rank learns whether all inputs exist
+            errs = [None] * world
+            dist.all_gather_object(errs, write_error)
+            write_error = next((e for e in errs if e), None)
+        if write_error:
+            return {"value": None, "error": "writing the synthetic inputs failed: " + write_error} if rank == 0 else None
+        if rank != 0:
+            while not os.path.exists(done):
+                time.sleep(0.05)
+            return None
         model = os.path.join(d, "model.pkl")
         ModelHandler.save_model(weights, None, 128, 1, 0, model)
-        t0 = time.time()
-        write_image_dir(os.path.join(d, "img"), n_windows, n_files=16, direct=True)
-        t_write = time.time() - t0
         out = os.path.join(d, "out")
         import contextlib
+        device_ids = ",".join("0" if single_device else str(r) for r in range(world))
         t0 = time.time()
         with contextlib.redirect_stdout(sys.stderr):     # the CLI prints the output file name: keep stdout to the JSON line
-            call_consensus(os.path.join(d, "img"), model, batch, workers, 1, out, "p", True, "0", 1)
+            call_consensus(img_dir, model, batch, workers, 1, out, "p", True, device_ids, world)
         dt = time.time() - t0
+        run = dict(P.LAST_RUN)
         files = sorted(os.listdir(out))
-        with hdf5.File(os.path.join(out, files[0])) as f:
-            stored = sum(len(f.keys("predictions/" + c)) for c in f.keys("predictions"))
+        stored = 0
+        for name in files:
+            with hdf5.File(os.path.join(out, name)) as f:
+                stored += sum(len(f.keys("predictions/" + c)) for c in f.keys("predictions"))
         # the second half of `helen polish`: prediction HDF5 -> FASTA (random weights call random labels, so the
         # regions' overlaps do not agree: a scale check of stitch; scripts/stitch_bench.py measures it on consistent ones)
         from helen_amd.stitch import perform_stitch
@@ -175,15 +205,29 @@ def end_to_end(n_windows, workers, batch, weights):
         with contextlib.redirect_stdout(sys.stderr):
             fasta = perform_stitch(out, os.path.join(d, "fa"), "asm", threads)
         dt_stitch = time.time() - t0
-        return {"value": round(n_windows / dt, 1), "unit": "windows/s", "windows": n_windows, "seconds": round(dt, 3),
-                "reader_workers": workers, "output_files": files, "regions_stored": stored,
-                "stage_seconds": {k: round(v, 3) for k, v in P.STAGE_SECONDS.items()},
+        plan = run.get("host_plan", {})
+        return {"value": round(total / dt, 1), "unit": "windows/s", "n_ranks": world, "windows": total,
+                "seconds": round(dt, 3), "usable_cpus": plan.get("usable_cpus"),
+                "reader_workers_requested": workers,
+                "reader_workers_per_rank": plan.get("reader_workers_per_rank"),
+                "predicted_host_ceiling": plan.get("predicted_host_ceiling_windows_per_s"),
+                "predicted_device_ceiling": plan.get("predicted_device_ceiling_windows_per_s"),
+                "predicted_bound": plan.get("predicted_bound"),
+                "per_rank": [{k: r.get(k) for k in ("rank", "device", "windows", "seconds", "stage_seconds",
+                                                    "setup_seconds", "close_seconds", "reader_workers", "slots",
+                                                    "cpus_pinned", "numa_node")} for r in run.get("ranks", [])],
+                "host_plan_notes": plan.get("notes"),
+                "output_files": files, "regions_stored": stored,
                 "stitch": {"seconds": round(dt_stitch, 3), "threads": threads, "fasta_bytes": os.path.getsize(fasta)},
                 "polish_seconds": round(dt + dt_stitch, 3),
-                "what": "call_consensus(image_dir -> prediction HDF5) incl. process start-up, model load and close; "
-                        "synthetic inputs written in %.1f s to %s" % (t_write, base or tempfile.gettempdir())}
+                "what": "call_consensus(image_dir -> one prediction HDF5 per rank) over %d rank(s) incl. host "
+                        "budgeting, process start-up, model load and close; %d synthetic windows per rank written in "
+                        "%.1f s to %s" % (world, windows_per_rank, t_write, os.path.dirname(d))}
     finally:
-        shutil.rmtree(d, ignore_errors=True)
+        if rank == 0:
+            open(done, "w").close()
+            time.sleep(0.2)
+            shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
@@ -196,9 +240,10 @@ def main():
     ap.add_argument("--mode", default="uniform", choices=["uniform", "pileup"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-memory -> host-memory leg")
-    ap.add_argument("--e2e", type=int, default=0, metavar="WINDOWS",
-                    help="also run the product's call_consensus over a synthetic HDF5 image directory of this many "
-                         "windows (e.g. 300000 = chr20 scale; needs ~120 KB of /dev/shm or temp space per window)")
+    ap.add_argument("--e2e", type=int, default=None, metavar="WINDOWS",
+                    help="windows PER RANK of the end-to-end leg: the product's call_consensus over a synthetic HDF5 "
+                         "image directory, N ranks under --gpus N (default %d: a bounded leg in every line; 300000 = "
+                         "chr20 scale, needs ~120 KB of /dev/shm per window; 0 = off)" % E2E_DEFAULT_WINDOWS)
     ap.add_argument("--e2e-workers", type=int, default=8, help="reader processes of the --e2e leg")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp32x3"],
                     help="gate-matmul arithmetic; fp32 (true fp32 MFMA) is BASELINE.json configs[1], the "
@@ -418,14 +463,22 @@ def main():
                 "h2d_GBps": round(hv / world * 90000 / 1e9, 2)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B)
-        if args.e2e > 0 and world == 1:
-            eng.close()        # call_consensus builds its own engine (15.9 GB of scratch)
-            out["end_to_end"] = end_to_end(args.e2e, args.e2e_workers, B, make_weights(input_scale=1.0 / 64.0))
+    eng.close()                # call_consensus builds its own engines (15.9 GB of scratch each)
+    e2e_windows = E2E_DEFAULT_WINDOWS if args.e2e is None else args.e2e
+    e2e = None
+    if e2e_windows > 0:
+        try:
+            e2e = end_to_end(e2e_windows, args.e2e_workers, B, make_weights(input_scale=1.0 / 64.0), rank, world,
+                             args.single_device, dist)
+        except Exception as e:          # noqa: BLE001 -- this leg must not take the headline down with it
+            e2e = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+    if rank == 0:
+        if e2e is not None:
+            out["end_to_end"] = e2e
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
 
 
 if __name__ == "__main__":

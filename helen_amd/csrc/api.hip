@@ -49,7 +49,10 @@ struct HelenModel {
     int precision = 0;
     int max_windows = 0;
     int max_tiles = 0;
+    int cus = 256;             // compute units of the device (hipDeviceProp_t::multiProcessorCount): what a "round" of workgroups is
+    bool debug_hooks = false;  // $HELEN_DEBUG_HOOKS=1 when the model was created: helen_debug_inject_failure is armed-able
     size_t device_bytes = 0;
+    size_t ring_in_bytes = 0, ring_out_bytes = 0;   // what each dev_in / dev_out slot of the staging ring added to device_bytes
     // packed parameters (device)
     f32x4* wp_enc = nullptr;   // [2][24][6][64]
     f32x4* wp_dec = nullptr;   // [2][24][16][64]
@@ -299,9 +302,9 @@ void launch_enc_gemm(HelenModel* m, hipStream_t s, int tiles, int npos) {
     // All three give the same gi bit for bit (same MFMA order per accumulator); HELEN_ENC_WS8=0/1 forces the
     // one-workgroup-per-tile kernel off / on (A/B probes).
     static const char* force8 = getenv("HELEN_ENC_WS8");
-    const int cus = 256, rounds = (tiles + cus - 1) / cus;
+    const int cus = m->cus, rounds = (tiles + cus - 1) / cus;
     const bool ws8 = (force8 && *force8) ? *force8 == '1'
-                                         : (tiles > cus / 2 && rounds * cus - tiles <= cus / 8) || (rounds == 1 && tiles > 170);
+                                         : (tiles > cus / 2 && rounds * cus - tiles <= cus / 8) || (rounds == 1 && 3 * tiles > 2 * cus);
     if (ws8)
         // one long workgroup per tile, one per CU: wants whole rounds of 256 tiles
         LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_ws8_kernel, dim3(tiles), dim3(512), m->xa, kXaTileStride, m->wp_enc,
@@ -319,10 +322,11 @@ void launch_enc_gemm(HelenModel* m, hipStream_t s, int tiles, int npos) {
 // Which fp32 recurrence kernel: gru_kernel puts one tile per workgroup, two workgroups per CU; gru_pair_kernel
 // two tiles per workgroup, one workgroup per CU (same results bit for bit).  A launch of either lasts as long
 // as its longest CU queue: `rounds` x the time of one resident set.  (HELEN_GRU_PAIR=0/1 forces one: A/B probes.)
-bool use_pair_recurrence(int tiles) {
+// The per-set times below were measured at 100 steps; both kernels' time is proportional to the step count (6 us
+// per step, scripts/dev/step_slope.py), so the comparison holds for the operator entry's shorter T as well.
+bool use_pair_recurrence(int tiles, int cus) {
     static const char* force = getenv("HELEN_GRU_PAIR");
     if (force && *force) return *force == '1';
-    const int cus = 256;
     const int wg_single = 2 * tiles, wg_pair = 2 * ((tiles + 1) / 2);
     // measured per resident set at 100 steps: one workgroup per CU alone 0.36 ms, two per CU 0.635 ms, a pair
     // workgroup 0.617 ms
@@ -337,19 +341,19 @@ bool use_pair_recurrence(int tiles) {
 // bf16 mode: gru_fused_bf16_kernel (one tile per workgroup, one workgroup per CU) or gru_fused_bf16_pair_kernel
 // (two tiles per workgroup; same results bit for bit).  The pair needs more than one round of single workgroups to
 // pay: below that every tile has a CU of its own anyway.  (HELEN_BF16_PAIR=0/1 forces one: A/B probes.)
-bool use_bf16_pair(int tiles) {
+bool use_bf16_pair(int tiles, int cus) {
     static const char* force = getenv("HELEN_BF16_PAIR");
     if (force && *force) return *force == '1';
-    return 2 * tiles > 256;
+    return 2 * tiles > cus;
 }
 
 // Which decoder projection: gemm_dec_ws_kernel has one long workgroup per (tile, direction) and one workgroup per
 // CU, so it wants whole rounds of 256; gemm_gi_kernel is fine-grained (same gi bit for bit).
 // (HELEN_DEC_WS=0/1 forces one: A/B probes.)
-bool use_ws_dec_projection(int tiles) {
+bool use_ws_dec_projection(int tiles, int cus) {
     static const char* force = getenv("HELEN_DEC_WS");
     if (force && *force) return *force == '1';
-    const int wgs = 2 * tiles, cus = 256;
+    const int wgs = 2 * tiles;
     const int rounds = (wgs + cus - 1) / cus;
     return wgs >= cus && rounds * cus - wgs <= cus / 8;   // at most an eighth of the last round idle
 }
@@ -363,7 +367,7 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
     if (m->precision == HELEN_PRECISION_BF16) {
         // projection fused into the recurrence: no gi at all; the encoder reads the packed pileup counts,
         // the decoder the encoder's bf16 output plane
-        if (use_bf16_pair(tiles)) {
+        if (use_bf16_pair(tiles, m->cus)) {
             LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_pair_kernel<3, false>), dim3((tiles + 1) / 2, 2), dim3(512), m->xb,
                    (long)kSeq * 192, pos0, T, m->w3i_enc, m->w3h_enc, m->bias_enc, m->bhn_enc, m->hid, m->y1p,
                    kY1bTileStride, (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride, tiles);
@@ -391,7 +395,7 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
                m->w3h_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kY1pTileStride, m->whd, m->plogit, kPlTileStride);
         return;
     }
-    const bool pair = use_pair_recurrence(tiles);
+    const bool pair = use_pair_recurrence(tiles, m->cus);
     if (pair)
         LAUNCH(HELEN_K_GRU_ENC, gru_pair_kernel<false>, dim3((tiles + 1) / 2, 2), dim3(512), m->gi_enc,
                kGiEncTileStride, pos0, enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride,
@@ -400,7 +404,7 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
         LAUNCH(HELEN_K_GRU_ENC, gru_kernel<false>, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
                enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride, (const f32x4*)nullptr,
                (f32x4*)nullptr, kPlTileStride);
-    if (use_ws_dec_projection(tiles))
+    if (use_ws_dec_projection(tiles, m->cus))
         LAUNCH(HELEN_K_GEMM_DEC, gemm_dec_ws_kernel, dim3(2 * ((tiles + 7) / 8 * 8)), dim3(512), m->y1, kYTileStride,
                m->wp_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
     else
@@ -419,8 +423,8 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
 // only for pageable caller memory), two copy streams and the events that chain them.
 void free_ring(HelenModel* m) {
     for (int i = 0; i < 2; ++i) {
-        if (m->dev_in[i]) { (void)hipFree(m->dev_in[i]); m->device_bytes -= (size_t)m->max_windows * kSeq * kF; }
-        if (m->dev_out[i]) { (void)hipFree(m->dev_out[i]); m->device_bytes -= (size_t)m->max_windows * 2 * kSeq; }
+        if (m->dev_in[i]) { (void)hipFree(m->dev_in[i]); m->device_bytes -= m->ring_in_bytes; }
+        if (m->dev_out[i]) { (void)hipFree(m->dev_out[i]); m->device_bytes -= m->ring_out_bytes; }
         if (m->pin_in[i]) (void)hipHostFree(m->pin_in[i]);
         if (m->pin_out[i]) (void)hipHostFree(m->pin_out[i]);
         if (m->ev_in[i]) (void)hipEventDestroy(m->ev_in[i]);
@@ -465,6 +469,11 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
         return fail(HELEN_ENODEV, "device %d is %s; this library is built for gfx950 only", device,
                     prop.gcnArchName);
     m->device = device;
+    m->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {
+        const char* hooks = getenv("HELEN_DEBUG_HOOKS");
+        m->debug_hooks = hooks && hooks[0] == '1';
+    }
     m->precision = precision;
     m->max_windows = max_windows;
     m->max_tiles = (max_windows + kTile - 1) / kTile;
@@ -694,6 +703,9 @@ static int build_ring(HelenModel* m) {
         HIP_TRY(hipStreamCreateWithFlags(&m->d2h_stream, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) {
             int rc;
+            // (free_ring gives back exactly what dev_alloc added here)
+            m->ring_in_bytes = sub * img_bytes * sizeof(uint8_t);
+            m->ring_out_bytes = sub * 2 * lab_bytes * sizeof(uint8_t);
             if ((rc = dev_alloc(m, &m->dev_in[i], sub * img_bytes))) return rc;
             if ((rc = dev_alloc(m, &m->dev_out[i], sub * 2 * lab_bytes))) return rc;
             HIP_TRY(hipEventCreateWithFlags(&m->ev_in[i], hipEventDisableTiming));
@@ -843,6 +855,9 @@ int helen_polish_host(HelenModel* m, const uint8_t* images, int n_windows, uint8
 
 int helen_debug_inject_failure(HelenModel* m, int sub_batch) {
     if (!m) return fail(HELEN_EINVAL, "null argument");
+    if (!m->debug_hooks)
+        return fail(HELEN_EINVAL, "debug hooks are off: the model was not created under HELEN_DEBUG_HOOKS=1");
+    HELEN_ENTER(m);      // never while another thread is inside a call on this handle
     m->fail_at_sub = sub_batch;
     return HELEN_OK;
 }

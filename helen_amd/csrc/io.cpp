@@ -12,11 +12,14 @@
 #include "h5emit.h"
 #include "h5scan.h"
 
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <set>
@@ -45,24 +48,64 @@ struct Quiet {
 };
 
 // ---- reader side: per-process cache of open files -------------------------------------------
-std::map<std::string, hid_t>& open_files() {
-    static std::map<std::string, hid_t> m;
+// What a cached handle / mapping was opened on.  A path can be rewritten while this process lives (a second
+// polish into the same output, a test that reuses a name): the writers here truncate in place (same inode,
+// smaller size: touching the old mapping past the new end is a SIGBUS) or a caller unlinks and recreates
+// (new inode: the old one would be served silently).  Every cache hit is checked against stat().
+struct FileIdentity {
+    dev_t dev = 0;
+    ino_t ino = 0;
+    off_t size = -1;
+    long long mtime_ns = 0;
+    bool read(const char* path) {
+        struct stat st;
+        if (stat(path, &st) != 0) return false;
+        dev = st.st_dev;
+        ino = st.st_ino;
+        size = st.st_size;
+        mtime_ns = (long long)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
+        return true;
+    }
+    bool operator==(const FileIdentity& o) const {
+        return dev == o.dev && ino == o.ino && size == o.size && mtime_ns == o.mtime_ns;
+    }
+};
+struct OpenFile {
+    hid_t id = -1;
+    FileIdentity identity;
+};
+std::map<std::string, OpenFile>& open_files() {
+    static std::map<std::string, OpenFile> m;
     return m;
 }
 
 hid_t get_file(const char* path) {
     static Quiet q;
     auto& m = open_files();
+    FileIdentity now;
+    const bool present = now.read(path);
     auto it = m.find(path);
-    if (it != m.end()) return it->second;
+    if (it != m.end()) {
+        if (present && it->second.identity == now) return it->second.id;
+        H5Fclose(it->second.id);     // the path names another file now (or none)
+        m.erase(it);
+    }
     if (m.size() >= 64) {
-        for (auto& kv : m) H5Fclose(kv.second);
+        for (auto& kv : m) H5Fclose(kv.second.id);
         m.clear();
     }
     hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
-    if (f >= 0) m[path] = f;
+    if (f >= 0) {
+        OpenFile of;
+        of.id = f;
+        of.identity = now;
+        m[path] = of;
+    }
     return f;
 }
+
+// a path is about to be (or has just been) written by this process: no reader state of it may survive
+void forget_path(const char* path);
 
 // read a 1-element-or-more integer dataset, return element 0 as int64
 int read_i64_first(hid_t loc, const char* name, int64_t* out) {
@@ -157,6 +200,7 @@ int read_2d(hid_t loc, const char* name, hid_t memtype, int cols, int max_rows, 
 long long g_fast_windows = 0, g_library_windows = 0;   // images read by the scanner / by libhdf5 in this process
 struct Scanned {
     h5scan::File file;
+    FileIdentity identity;
     bool usable = false;
     bool has_images = false;
     uint64_t images = 0;
@@ -165,6 +209,15 @@ struct Scanned {
 std::map<std::string, std::unique_ptr<Scanned>>& scanned_files() {
     static std::map<std::string, std::unique_ptr<Scanned>> m;
     return m;
+}
+void forget_path(const char* path) {
+    auto& of = open_files();
+    auto it = of.find(path);
+    if (it != of.end()) {
+        H5Fclose(it->second.id);
+        of.erase(it);
+    }
+    scanned_files().erase(path);
 }
 bool reader_mode_is(const char* what) {
     const char* e = getenv("HELEN_IO_READER");
@@ -181,10 +234,15 @@ Scanned* scan_file(const char* path) {
     static uint64_t tick = 0;
     constexpr size_t kKeepBytes = (size_t)4 << 30;
     auto& m = scanned_files();
+    FileIdentity now;
+    const bool present = now.read(path);
     auto it = m.find(path);
     if (it != m.end()) {
-        it->second->last_used = ++tick;
-        return it->second->usable ? it->second.get() : nullptr;
+        if (present && it->second->identity == now) {
+            it->second->last_used = ++tick;
+            return it->second->usable ? it->second.get() : nullptr;
+        }
+        m.erase(it);     // rewritten, replaced or removed since it was mapped: never touch the old mapping again
     }
     for (;;) {
         size_t held = 0;
@@ -196,7 +254,8 @@ Scanned* scan_file(const char* path) {
         m.erase(oldest);
     }
     std::unique_ptr<Scanned> sc(new Scanned());
-    if (sc->file.open(path)) {
+    sc->identity = now;
+    if (present && sc->file.open(path)) {
         std::vector<std::pair<std::string, uint64_t>> top;
         if (sc->file.children(sc->file.root(), &top)) {
             sc->usable = true;
@@ -358,6 +417,7 @@ struct Writer {
     std::vector<uint32_t> pos32;
     // direct emitter (h5emit.h): the default; $HELEN_IO_WRITER=libhdf5 selects the library path above
     h5emit::File* fast = nullptr;
+    std::string path;
     std::map<std::string, std::map<std::string, Region>> tree;   // contig -> region name -> members
     Region* open_region = nullptr;   // the region of the newest window: its group is emitted when the next begins
 };
@@ -586,6 +646,7 @@ int helen_io_read_labeled(const char* path, const char* names, int n, uint8_t* i
  *   starts, chunks  int64 [n];  lengths int32 [n] (rows stored, <= 1000);  images uint8 [n, 1000, 90] */
 int helen_io_emit_images(const char* path, int n, const char* contig, const int64_t* starts, const int64_t* chunks,
                          const int32_t* lengths, const uint8_t* images) {
+    forget_path(path);
     h5emit::File f;
     if (!f.open(path)) return fail("cannot create '%s'", path);
     std::vector<h5emit::Child> all;
@@ -624,7 +685,7 @@ void helen_io_reader_counts(long long* out) {
 
 /* Drop every cached read handle of this process. */
 void helen_io_close_readers(void) {
-    for (auto& kv : open_files()) H5Fclose(kv.second);
+    for (auto& kv : open_files()) H5Fclose(kv.second.id);
     open_files().clear();
     scanned_files().clear();
 }
@@ -632,7 +693,9 @@ void helen_io_close_readers(void) {
 /* Prediction file writer (DataStore(filename, 'w'), predict_gpu.py:55). */
 void* helen_io_writer_open(const char* path) {
     static Quiet q;
+    forget_path(path);
     Writer* w = new Writer();
+    w->path = path;
     w->pos32.resize((size_t)kSeq * 3);
     const char* which = getenv("HELEN_IO_WRITER");
     if (!(which && strcmp(which, "libhdf5") == 0)) {
@@ -989,22 +1052,52 @@ int helen_io_writer_close(void* handle) {
         // now every name is known: region groups, contig groups, `predictions`, the root group, the superblock.
         // A file that received no window at all gets an empty root group -- no `predictions` member, which is what
         // the reference's DataStore leaves behind in that case (and what stitch reports as an invalid file).
-        std::vector<h5emit::Child> contigs;
-        for (auto& c : w->tree) {
+        // `predictions/{contig}/{contig}-{start}-{end}/...` is an HDF5 PATH for the reference's h5py writer and for
+        // libhdf5 with intermediate-group creation (DataStore.py:117-133): a contig named 'a/b' makes groups
+        // a -> b -> a -> 'b-0-1000', empty components and '.' vanish.  The same tree here: every region's full path
+        // split into a trie of groups, the region's group attached under its last component.
+        struct Node {
+            std::map<std::string, Node> sub;
             std::vector<h5emit::Child> regions;
+        };
+        Node rootn;
+        for (auto& c : w->tree) {
             for (auto& r : c.second) {
                 settle_region(w, &r.second);
-                regions.push_back({r.first, r.second.header});
+                const std::string full = c.first + "/" + r.first;
+                std::vector<std::string> parts;
+                for (size_t b = 0; b <= full.size();) {
+                    size_t e = full.find('/', b);
+                    if (e == std::string::npos) e = full.size();
+                    const std::string part = full.substr(b, e - b);
+                    if (!part.empty() && part != ".") parts.push_back(part);
+                    b = e + 1;
+                }
+                Node* n = &rootn;
+                for (size_t k = 0; k + 1 < parts.size(); ++k) n = &n->sub[parts[k]];
+                n->regions.push_back({parts.empty() ? std::string(".") : parts.back(), r.second.header});
             }
-            contigs.push_back({c.first, w->fast->group(regions)});
         }
+        bool clash = false;
+        std::function<uint64_t(Node&)> emit = [&](Node& n) -> uint64_t {
+            std::vector<h5emit::Child> kids = n.regions;
+            std::set<std::string> names;
+            for (auto& k : kids) names.insert(k.name);
+            for (auto& kv : n.sub) {
+                if (!names.insert(kv.first).second) clash = true;   // a region and a contig component of one name
+                kids.push_back({kv.first, emit(kv.second)});
+            }
+            return w->fast->group(kids);
+        };
         std::vector<h5emit::Child> top;
-        if (!contigs.empty()) top.push_back({"predictions", w->fast->group(contigs)});
+        if (!w->tree.empty()) top.push_back({"predictions", emit(rootn)});
         uint64_t bt = 0, hp = 0;
         const uint64_t root = w->fast->group(top, &bt, &hp);
         const bool good = w->fast->finish(root, bt, hp);
+        forget_path(w->path.c_str());
         delete w->fast;
         delete w;
+        if (clash) return fail("a contig name component equals a region name of the same group: the prediction file is ambiguous");
         return good ? 0 : fail("writing the prediction file failed");
     }
     H5Sclose(w->space_pos);

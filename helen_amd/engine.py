@@ -180,9 +180,12 @@ class HelenEngine(object):
         base = torch.empty((B, T, ImageSizeOptions.TOTAL_BASE_LABELS), dtype=torch.float32, device=x.device)
         rle = torch.empty((B, T, ImageSizeOptions.TOTAL_RLE_LABELS), dtype=torch.float32, device=x.device)
         h_out = torch.empty((B, 2, TrainOptions.HIDDEN_SIZE), dtype=torch.float32, device=x.device)
-        _lib.check(self._lib.helen_gru_chunk_forward(
-            self._handle, x.data_ptr(), hidden.data_ptr(), B, T, base.data_ptr(), rle.data_ptr(),
-            h_out.data_ptr(), self._stream()))
+        # rows of a batch never interact: a batch above the engine's capacity goes through in slices, like polish()
+        for s in range(0, B, self.max_windows):
+            e = min(B, s + self.max_windows)
+            _lib.check(self._lib.helen_gru_chunk_forward(
+                self._handle, x[s:e].data_ptr(), hidden[s:e].data_ptr(), e - s, T, base[s:e].data_ptr(),
+                rle[s:e].data_ptr(), h_out[s:e].data_ptr(), self._stream()))
         return base, rle, h_out
 
     def inject_failure(self, sub_batch):

@@ -42,6 +42,8 @@ def load():
     lib.helen_io_emit_images.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, vp, vp, vp, vp]
     lib.helen_io_reader_counts.restype = None
     lib.helen_io_reader_counts.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
+    lib.helen_io_close_readers.restype = None
+    lib.helen_io_close_readers.argtypes = []
     lib.helen_io_read_images.restype = ctypes.c_int
     lib.helen_io_read_images.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, vp, vp, vp, vp]
     lib.helen_io_writer_open.restype = vp
@@ -103,6 +105,15 @@ def emit_images(path, contig, starts, chunks, lengths, images):
                                   chunks.ctypes.data, lengths.ctypes.data, images.ctypes.data)
     if rc != 0:
         raise IOError(_err(lib))
+
+
+def close_readers():
+    """Drop every cached read handle and mapping of this process (helen_io_close_readers).  The caches check a
+    path's identity (device, inode, size, mtime) on every hit, so this is tidiness, not correctness: predict and
+    perform_stitch call it when they start."""
+    lib = load()
+    if lib is not None:
+        lib.helen_io_close_readers()
 
 
 def reader_counts():

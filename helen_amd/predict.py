@@ -37,6 +37,10 @@ DEVICE_CALL_WINDOWS = 4096
 
 # wall seconds per pipeline stage of the last predict() in this process (reported by rank 0)
 STAGE_SECONDS = {"read_wait": 0.0, "device": 0.0, "write": 0.0}
+# what the last predict() of this process did (windows, seconds, stage seconds, reader processes, ...)
+LAST_PREDICT = {}
+# what the last predict_gpu() of this process did: the host plan and every rank's LAST_PREDICT
+LAST_RUN = {}
 
 
 def _writer_loop(wq, store, free_slots, err):
@@ -220,15 +224,33 @@ def _get_or_error(q, *error_lists):
                 return None
 
 
-def predict(test_file, output_filename, model_path, batch_size, num_workers, rank, device_id):
+def _remove_stale_outputs(output_filename, rank):
+    """A reused output directory may hold `<output>_<rank>.hdf` / `<output>_<rank>_w<k>.hdf` of an earlier run with
+    another writer count; stitch takes every *.hdf of the directory (StitchInterface.py:35-36) and would merge them
+    in.  The reference truncates its one file (DataStore mode 'w'); this rank's shards get the same treatment."""
+    import glob
+    stale = [prediction_file_name(output_filename, rank)] + \
+        glob.glob(glob.escape(output_filename + "_" + str(rank)) + "_w*.hdf")
+    for path in stale:
+        if os.path.isfile(path):
+            os.unlink(path)
+
+
+def predict(test_file, output_filename, model_path, batch_size, num_workers, rank, device_id, plan=None):
     """Run inference over the image files `test_file` (a list) on device `device_id` and write
-    `<output_filename>_<rank>.hdf` (predict_gpu.py:38-179).
+    `<output_filename>_<rank>.hdf` (predict_gpu.py:38-179).  `plan` (helen_amd.host_plan.RankPlan, from
+    predict_gpu) caps the reader processes at what the host grants this rank and names its slots.
 
     Pipeline over shared-memory slots of one device call each:
       reader processes fill slot k+2 | H2D k+1 | kernels k | D2H k-1 | writer(s) store slot k-2."""
     import torch
 
+    from . import native_io
     from .model_handler import ModelHandler
+    if plan is not None:
+        num_workers = min(num_workers, plan.reader_workers) if num_workers > 0 else 0
+    native_io.close_readers()          # a long-lived process may have these paths mapped from an earlier run
+    _remove_stale_outputs(output_filename, rank)
     writers = writer_count(num_workers)
     prediction_data_file = DataStore(prediction_file_name(output_filename, rank), mode="w") \
         if writers == 1 else None
@@ -244,7 +266,8 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     total_batches = len(batches)
 
     # reader filling | H2D | kernels | D2H | writer: five slots keep every stage busy
-    slots = [SharedSlot(cap) for _ in range(min(5, max(1, len(calls))))]
+    n_slots = min(plan.slots if plan is not None else 5, max(1, len(calls)))
+    slots = [SharedSlot(cap, prefix=plan.slot_prefix if plan is not None else "helen_slot_") for _ in range(n_slots)]
     free_slots, ready_q, wq = queue.Queue(), queue.Queue(maxsize=2), queue.Queue()
     for sl in slots:
         free_slots.put(sl)
@@ -386,6 +409,14 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         raise werr[0]
     if close_error is not None:
         raise close_error
+    LAST_PREDICT.clear()
+    LAST_PREDICT.update({
+        "rank": rank, "device": device_id, "windows": len(pairs), "seconds": round(time.time() - start_time, 3),
+        "stage_seconds": {k: round(v, 3) for k, v in STAGE_SECONDS.items()},
+        "setup_seconds": round(t_setup - start_time, 3), "close_seconds": round(time.time() - t_loop_end, 3),
+        "reader_workers": num_workers, "slots": n_slots, "device_calls": len(calls),
+        "cpus_pinned": None if plan is None or not plan.cpus else len(plan.cpus),
+        "numa_node": None if plan is None else plan.numa_node})
     if rank == 0:
         sys.stderr.write("INFO: %d WINDOWS IN %.1f SECS (WAITING FOR READERS %.1f, DEVICE %.1f, WRITER BUSY %.1f; "
                          "MODEL + ENGINE SET-UP %.1f, FLUSH + CLOSE %.1f = LAST SLOTS %.2f + FILE CLOSE %.2f + "
@@ -401,30 +432,108 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
                              % through_library)
 
 
-def _setup(rank, total_callers, args, all_input_files, all_devices):
+def _setup(rank, total_callers, args, all_input_files, all_devices, plans=None, result_q=None):
     output_filepath, model_path, batch_size, num_workers = args
+    plan = plans[rank] if plans is not None else None
+    if result_q is not None:
+        # a spawned rank: SIGTERM from the parent (a sibling failed) must unwind through predict()'s tear-down --
+        # reader pool, page-locks, slot files -- instead of leaving them behind
+        import signal
+
+        def on_term(signum, frame):
+            raise SystemExit(143)
+        signal.signal(signal.SIGTERM, on_term)
+        try:
+            os.setpgid(0, 0)          # own process group: the parent's last resort is killpg
+        except OSError:
+            pass
+    from .host_plan import apply_rank_plan
+    apply_rank_plan(plan)
     predict(all_input_files[rank], output_filepath, model_path, batch_size, num_workers, rank,
-            all_devices[rank])
+            all_devices[rank], plan=plan)
+    if result_q is not None:
+        result_q.put((rank, dict(LAST_PREDICT)))
+
+
+def run_ranks(target, argsets, slot_prefixes=(), grace_seconds=10.0):
+    """Start one spawned process per entry of `argsets` running `target(*args, result_q)`, wait for ALL of them at
+    once, and when one exits non-zero terminate the others: SIGTERM first (a rank turns it into its normal
+    tear-down), SIGKILL to the rank's process group after `grace_seconds`, then sweep the slot files a killed rank
+    could not remove.  -> ({rank: what it put on result_q}, [(rank, exit code), ...])."""
+    from multiprocessing.connection import wait
+
+    from .host_plan import sweep_slots
+    ctx = mp.get_context("spawn")
+    result_q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=tuple(a) + (result_q,)) for a in argsets]
+    for p in procs:
+        p.start()
+    failed, alive = [], {p.sentinel: (r, p) for r, p in enumerate(procs)}
+    results = {}
+
+    def drain():
+        while True:
+            try:
+                r, info = result_q.get_nowait()
+            except queue.Empty:
+                return
+            results[r] = info
+    while alive:
+        for sentinel in wait(list(alive), timeout=0.5):
+            r, p = alive.pop(sentinel)
+            p.join()
+            if p.exitcode != 0:
+                failed.append((r, p.exitcode))
+        drain()
+        if failed and alive:
+            first = failed[0]
+            sys.stderr.write("ERROR: RANK %d EXITED WITH %s: TERMINATING THE OTHER %d RANK(S).\n"
+                             % (first[0], first[1], len(alive)))
+            for r, p in alive.values():
+                p.terminate()
+            deadline = time.time() + grace_seconds
+            for r, p in alive.values():
+                p.join(max(0.1, deadline - time.time()))
+                if p.is_alive():
+                    try:
+                        os.killpg(p.pid, 9)
+                    except OSError:
+                        p.kill()
+                    p.join()
+            alive = {}
+            sweep_slots(list(slot_prefixes))
+    time.sleep(0.05)
+    drain()
+    return results, failed
 
 
 def predict_gpu(file_chunks, output_filepath, model_path, batch_size, total_callers, devices,
                 num_workers):
-    """One process per device, each over its own file list (predict_gpu.py:207-226).  A failing
-    child raises here, like mp.spawn(join=True) does."""
+    """One process per device, each over its own file list (predict_gpu.py:207-226).  A failing child raises
+    here AND takes its siblings down, as mp.spawn(join=True) does (predict_gpu.py:223): the parent waits on all
+    ranks at once, and the first non-zero exit terminates the others (SIGTERM, which a rank turns into its normal
+    tear-down; SIGKILL to its process group after ten seconds; slot files swept).
+
+    Before anything starts the host is budgeted over all ranks (helen_amd.host_plan): reader processes per rank
+    from the usable CPUs, NUMA pinning of each rank to its GPU's node, one RAM-backed slot budget."""
+    from .host_plan import plan_host
     args = (output_filepath, model_path, batch_size, num_workers)
+    group = max(1, DEVICE_CALL_WINDOWS // batch_size)
+    host = plan_host(list(devices[:total_callers]), num_workers, group * batch_size)
+    host.describe()
+    LAST_RUN.clear()
+    LAST_RUN.update({"host_plan": host.as_dict(), "ranks": []})
+    t0 = time.time()
     if total_callers == 1:
-        _setup(0, 1, args, file_chunks, devices)
+        _setup(0, 1, args, file_chunks, devices, plans=host.ranks)
+        LAST_RUN["ranks"] = [dict(LAST_PREDICT)]
+        LAST_RUN["seconds"] = round(time.time() - t0, 3)
         return
-    ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_setup, args=(r, total_callers, args, file_chunks, devices))
-             for r in range(total_callers)]
-    for p in procs:
-        p.start()
-    failed = []
-    for r, p in enumerate(procs):
-        p.join()
-        if p.exitcode != 0:
-            failed.append((r, p.exitcode))
+    results, failed = run_ranks(_setup, [(r, total_callers, args, file_chunks, devices, host.ranks)
+                                         for r in range(total_callers)],
+                                [rp.slot_prefix for rp in host.ranks])
+    LAST_RUN["ranks"] = [results[r] for r in sorted(results)]
+    LAST_RUN["seconds"] = round(time.time() - t0, 3)
     if failed:
         raise RuntimeError("prediction process(es) failed: " + ", ".join(
-            "rank %d exit %s" % f for f in failed))
+            "rank %d exit %s" % f for f in failed) + "; the other ranks were terminated")

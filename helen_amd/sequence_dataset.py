@@ -121,7 +121,7 @@ def _load_batch(pairs):
 class SharedSlot(object):
     """`cap` windows worth of reader output in one file-backed shared mapping (/dev/shm)."""
 
-    def __init__(self, cap, path=None, create=True):
+    def __init__(self, cap, path=None, create=True, prefix="helen_slot_"):
         import os
         import tempfile
         self.cap = int(cap)
@@ -136,7 +136,7 @@ class SharedSlot(object):
             # check -- and a refusal (ENOSPC) sends this slot to the temp directory instead.
             fd = path = None
             if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK):
-                fd, path = tempfile.mkstemp(prefix="helen_slot_", dir="/dev/shm")
+                fd, path = tempfile.mkstemp(prefix=prefix, dir="/dev/shm")
                 try:
                     os.posix_fallocate(fd, 0, total)
                 except OSError:
@@ -144,7 +144,7 @@ class SharedSlot(object):
                     _unlink_quietly(path)
                     fd = path = None
             if fd is None:
-                fd, path = tempfile.mkstemp(prefix="helen_slot_", dir=None)
+                fd, path = tempfile.mkstemp(prefix=prefix, dir=None)
                 try:
                     os.posix_fallocate(fd, 0, total)
                 except OSError:      # a file system without fallocate: plain (sparse) truncate

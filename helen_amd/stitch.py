@@ -215,6 +215,10 @@ def _spill_dir():
     return None
 
 
+# exceptions of worker runs since perform_stitch started (the reference only prints them)
+FAILED_RUNS = []
+
+
 def _submit_contig(contig, sequence_chunk_keys, threads, executor):
     """First half of create_consensus_sequence: sort the regions, cut them into runs (FileManager.chunks), hand the
     runs to the pool.  -> list of futures / finished (contig, start, end, sequence) tuples, in any order."""
@@ -241,7 +245,14 @@ def _finish_contig(jobs):
                     sequence = sequence.take()
                 sequence_chunks.append((contig, start, end, sequence))
             else:
+                # the reference prints the exception and stitches the contig from the runs that survived
+                # (Stitch.py:283-291); a DEAD WORKER is different: the pool is broken for every contig still to come
+                from concurrent.futures.process import BrokenProcessPool
+                if isinstance(job.exception(), BrokenProcessPool):
+                    raise RuntimeError("a stitch worker process died (%s): the FASTA would be truncated"
+                                       % job.exception())
                 sys.stderr.write("ERROR: " + str(job.exception()) + "\n")
+                FAILED_RUNS.append(str(job.exception()))
         else:
             sequence_chunks.append(job)
     if not sequence_chunks:
@@ -301,7 +312,10 @@ def get_file_paths_from_directory(directory_path):
 
 def perform_stitch(input_directory, output_path, output_prefix, threads):
     """Every contig of every prediction file -> `<output_path>/<output_prefix>.fa`
-    (StitchInterface.py:40-106)."""
+    (StitchInterface.py:40-106).  Unlike the reference, which prints a failed run's exception and returns a FASTA
+    stitched from what survived, this raises after writing that FASTA when any run failed."""
+    native_io.close_readers() if native_io.available() else None
+    del FAILED_RUNS[:]
     all_prediction_files = get_file_paths_from_directory(input_directory)
     all_contigs = set()
     contigs_of = {}
@@ -361,4 +375,7 @@ def perform_stitch(input_directory, output_path, output_prefix, threads):
                         os.unlink(leftover)
                     except OSError:
                         pass
+    if FAILED_RUNS:
+        raise RuntimeError("%d stitch run(s) failed, %s is incomplete; first error: %s"
+                           % (len(FAILED_RUNS), output_filename, FAILED_RUNS[0]))
     return output_filename

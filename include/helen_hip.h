@@ -153,6 +153,8 @@ int helen_polish_host(HelenModel* model, const uint8_t* images, int n_windows, u
  * Test hook for the error path of helen_polish_host: the NEXT call fails with HELEN_EHIP right after it has
  * enqueued sub-batch `sub_batch` (copies and kernels of that and earlier sub-batches are in flight at that
  * moment).  The call must still return with nothing in flight and the handle usable.  -1 disarms.
+ * INERT IN PRODUCTION: returns HELEN_EINVAL unless the environment held HELEN_DEBUG_HOOKS=1 when the model was
+ * created (the test suite sets it for the one test that needs it); refused while another thread is in a call.
  */
 int helen_debug_inject_failure(HelenModel* model, int sub_batch);
 

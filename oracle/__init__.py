@@ -4,6 +4,7 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 nothing under helen_amd/ does (tests/test_layout.py checks that).
 """
 from .oracle import (  # noqa: F401
-    HelenWeightsC, build, evaluate, gru_chunk_forward, polish_batch, max_threads, set_precision, set_threads,
+    HelenWeightsC, arbitrate, build, evaluate, gru_chunk_forward, polish_batch, polish_batch_f64, max_threads,
+    set_precision, set_threads,
     weights_struct,
 )

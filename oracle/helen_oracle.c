@@ -365,6 +365,107 @@ int oracle_polish_batch(const HelenWeights* w, const uint8_t* images, int B, uin
     return 0;
 }
 
+/* ---- float64 arbiter ------------------------------------------------------------------------
+ * The same path (`models/TransducerModel.py:60-79`, `models/predict_gpu.py:97-159`) evaluated in
+ * double precision end to end: fp32 parameters and uint8 inputs converted exactly, every product,
+ * sum, exp() and tanh() in IEEE double (libm).  Its accumulated softmax is correct to ~1e-13 (3,800
+ * dependent steps x 2^-53), seven orders of magnitude below fp32's own rounding, so it can say which of
+ * two fp32 implementations that disagree on an argmax label is "right" -- or that the true margin is
+ * below fp32 resolution and neither is.  Used by the tests only where labels differ (a handful of
+ * windows): plain loops, one window at a time, OpenMP over windows.
+ *   images [B,1000,F] u8 -> acc_base [B,1000,nb] f64, acc_rle [B,1000,nr] f64 */
+static void gru_dir_f64(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int K, int H,
+                        const double* x, int xs, int T, int reverse, double* h, double* y, int ys, int yoff) {
+    double gi[3 * 512], gh[3 * 512];
+    const int G = 3 * H;
+    for (int s = 0; s < T; ++s) {
+        const int t = reverse ? (T - 1 - s) : s;
+        const double* xt = x + (size_t)t * xs;
+        for (int j = 0; j < G; ++j) {
+            double a = 0.0, c = 0.0;
+            const float* wi = w_ih + (size_t)j * K;
+            const float* wh = w_hh + (size_t)j * H;
+            for (int k = 0; k < K; ++k) a += xt[k] * (double)wi[k];
+            for (int k = 0; k < H; ++k) c += h[k] * (double)wh[k];
+            gi[j] = a + (double)b_ih[j];
+            gh[j] = c + (double)b_hh[j];
+        }
+        for (int j = 0; j < H; ++j) {
+            const double r = 1.0 / (1.0 + exp(-(gi[j] + gh[j])));
+            const double z = 1.0 / (1.0 + exp(-(gi[H + j] + gh[H + j])));
+            const double n = tanh(gi[2 * H + j] + r * gh[2 * H + j]);
+            h[j] = (1.0 - z) * n + z * h[j];
+        }
+        memcpy(y + (size_t)t * ys + yoff, h, sizeof(double) * H);
+    }
+}
+
+static void softmax_add_f64(const double* logits, int C, double* acc) {
+    double m = logits[0], e[16], s = 0.0;
+    for (int c = 1; c < C; ++c)
+        if (logits[c] > m) m = logits[c];
+    for (int c = 0; c < C; ++c) {
+        e[c] = exp(logits[c] - m);
+        s += e[c];
+    }
+    for (int c = 0; c < C; ++c) acc[c] += e[c] / s;
+}
+
+int oracle_polish_batch_f64(const HelenWeights* w, const uint8_t* images, int B, double* acc_base, double* acc_rle) {
+    if (!w || !images || !acc_base || !acc_rle || B < 0) return -1;
+    const int H = w->hidden, F = w->features, nb = w->n_base, nr = w->n_rle;
+    if (H <= 0 || H > 512 || F <= 0 || nb > 16 || nr > 16) return -1;
+#pragma omp parallel
+    {
+        double* xf = (double*)malloc(sizeof(double) * (size_t)SEQ * F);
+        double* y1 = (double*)malloc(sizeof(double) * (size_t)WIN * 2 * H);
+        double* y2 = (double*)malloc(sizeof(double) * (size_t)WIN * 2 * H);
+        double* hid = (double*)malloc(sizeof(double) * 2 * H);
+#pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < B; ++b) {
+            const uint8_t* img = images + (size_t)b * SEQ * F;
+            for (size_t i = 0; i < (size_t)SEQ * F; ++i) xf[i] = (double)img[i];
+            double* ab = acc_base + (size_t)b * SEQ * nb;
+            double* ar = acc_rle + (size_t)b * SEQ * nr;
+            memset(hid, 0, sizeof(double) * 2 * H);
+            memset(ab, 0, sizeof(double) * (size_t)SEQ * nb);
+            memset(ar, 0, sizeof(double) * (size_t)SEQ * nr);
+            for (int i = 0; i + WIN <= SEQ; i += JUMP) {
+                const double* x = xf + (size_t)i * F;
+                gru_dir_f64(w->enc_w_ih[0], w->enc_w_hh[0], w->enc_b_ih[0], w->enc_b_hh[0], F, H, x, F, WIN, 0, hid,
+                            y1, 2 * H, 0);
+                gru_dir_f64(w->enc_w_ih[1], w->enc_w_hh[1], w->enc_b_ih[1], w->enc_b_hh[1], F, H, x, F, WIN, 1,
+                            hid + H, y1, 2 * H, H);
+                gru_dir_f64(w->dec_w_ih[0], w->dec_w_hh[0], w->dec_b_ih[0], w->dec_b_hh[0], 2 * H, H, y1, 2 * H, WIN,
+                            0, hid, y2, 2 * H, 0);
+                gru_dir_f64(w->dec_w_ih[1], w->dec_w_hh[1], w->dec_b_ih[1], w->dec_b_hh[1], 2 * H, H, y1, 2 * H, WIN,
+                            1, hid + H, y2, 2 * H, H);
+                for (int t = 0; t < WIN; ++t) {
+                    const double* y = y2 + (size_t)t * 2 * H;
+                    double lb[16], lr[16];
+                    for (int c = 0; c < nb; ++c) {
+                        double a = 0.0;
+                        for (int k = 0; k < 2 * H; ++k) a += y[k] * (double)w->base_w[(size_t)c * 2 * H + k];
+                        lb[c] = a + (double)w->base_b[c];
+                    }
+                    for (int c = 0; c < nr; ++c) {
+                        double a = 0.0;
+                        for (int k = 0; k < 2 * H; ++k) a += y[k] * (double)w->rle_w[(size_t)c * 2 * H + k];
+                        lr[c] = a + (double)w->rle_b[c];
+                    }
+                    softmax_add_f64(lb, nb, ab + (size_t)(i + t) * nb);
+                    softmax_add_f64(lr, nr, ar + (size_t)(i + t) * nr);
+                }
+            }
+        }
+        free(xf);
+        free(y1);
+        free(y2);
+        free(hid);
+    }
+    return 0;
+}
+
 int oracle_max_threads(void) {
 #ifdef _OPENMP
     extern int omp_get_max_threads(void);

@@ -55,6 +55,9 @@ def _load():
         lib.oracle_polish_batch.argtypes = [
             ctypes.POINTER(HelenWeightsC), _u8p, ctypes.c_int, _u8p, _u8p, _f32p, _f32p, _f32p,
             _f32p, _f32p]
+        lib.oracle_polish_batch_f64.restype = ctypes.c_int
+        lib.oracle_polish_batch_f64.argtypes = [ctypes.POINTER(HelenWeightsC), _u8p, ctypes.c_int,
+                                                ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         lib.oracle_max_threads.restype = ctypes.c_int
         lib.oracle_set_precision.argtypes = [ctypes.c_int]
         lib.oracle_set_threads.argtypes = [ctypes.c_int]
@@ -157,6 +160,43 @@ def polish_batch(weights, images, traces=False):
         out["rles"].ctypes.data_as(_u8p), _fp(out["acc_base"]), _fp(out["acc_rle"]), ht, lb, lr)
     if rc != 0:
         raise RuntimeError("oracle_polish_batch failed: %d" % rc)
+    return out
+
+
+def polish_batch_f64(weights, images):
+    """The float64 arbiter (oracle_polish_batch_f64): images [B,1000,F] u8 -> (acc_base f64 [B,1000,5],
+    acc_rle f64 [B,1000,11]), the accumulated softmax of the same network evaluated in double precision end
+    to end.  ~4 windows/s per thread: meant for the few windows on which two fp32 implementations disagree."""
+    lib = _load()
+    s, keep = weights_struct(weights)
+    images = np.ascontiguousarray(images, dtype=np.uint8)
+    B, L, F = images.shape
+    assert L == 1000 and F == s.features
+    ab = np.empty((B, L, s.n_base), np.float64)
+    ar = np.empty((B, L, s.n_rle), np.float64)
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = lib.oracle_polish_batch_f64(ctypes.byref(s), images.ctypes.data_as(_u8p), B, ab.ctypes.data_as(dp),
+                                     ar.ctypes.data_as(dp))
+    if rc != 0:
+        raise RuntimeError("oracle_polish_batch_f64 failed: %d" % rc)
+    return ab, ar
+
+
+def arbitrate(weights, images, windows, kind, positions, labels_a, labels_b):
+    """For label disagreements between two fp32 implementations A and B -- parallel arrays `windows` (index into
+    `images`), `kind` ('bases' | 'rles'), `positions`, `labels_a`, `labels_b` -- evaluate those windows in float64
+    and return one dict per disagreement: the float64 argmax, the float64 top-1 / top-2 margin and the float64
+    gap between the two contested classes."""
+    uniq = sorted(set(int(w) for w in windows))
+    ab, ar = polish_batch_f64(weights, np.ascontiguousarray(images[uniq]))
+    at = {w: i for i, w in enumerate(uniq)}
+    out = []
+    for w, k, p, la, lb in zip(windows, kind, positions, labels_a, labels_b):
+        acc = (ab if k == "bases" else ar)[at[int(w)], int(p)]
+        srt = np.sort(acc)
+        out.append({"window": int(w), "kind": k, "position": int(p), "a": int(la), "b": int(lb),
+                    "f64_argmax": int(acc.argmax()), "f64_margin": float(srt[-1] - srt[-2]),
+                    "f64_gap_a_b": float(abs(acc[int(la)] - acc[int(lb)]))})
     return out
 
 

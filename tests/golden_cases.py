@@ -68,3 +68,43 @@ def label_mismatch_report(acc_ref, lab_ref, lab_got, name):
         lines.append("%s window %d pos %d ref %d got %d margin %.3g"
                      % (name, w, p, lab_ref[w, p], lab_got[w, p], margin))
     return len(bad), "\n".join(lines)
+
+
+# ---- label disagreements between two fp32 implementations, arbitrated in float64 -------------------------------
+FP32_RESOLUTION = 1e-6       # accumulated softmax values are ~1 (two contributions: up to 2): 4-8 ulps of fp32
+
+
+def arbitrate_label_differences(weights, images, labels_a, labels_b, name_a, name_b, out=None):
+    """labels_* = {"bases": u8 [n,1000], "rles": u8 [n,1000]} of two fp32 evaluations A and B of the same windows.
+    Every differing label is put to the oracle's float64 evaluation of the network (oracle_polish_batch_f64): the
+    float64 argmax says which side is right, the float64 top-1 / top-2 margin whether the question is below fp32
+    resolution anyway.  Returns (rows, summary): rows = the arbiter's dicts, summary = counts.  Prints the table."""
+    import numpy as np
+
+    import oracle
+    win, kind, pos, la, lb = [], [], [], [], []
+    for k in ("bases", "rles"):
+        d = np.argwhere(labels_a[k] != labels_b[k])
+        win += list(d[:, 0])
+        pos += list(d[:, 1])
+        kind += [k] * len(d)
+        la += list(labels_a[k][d[:, 0], d[:, 1]])
+        lb += list(labels_b[k][d[:, 0], d[:, 1]])
+    total = 2 * labels_a["bases"].size
+    rows = oracle.arbitrate(weights, images, win, kind, pos, la, lb) if win else []
+    a_right = sum(1 for r in rows if r["f64_argmax"] == r["a"])
+    b_right = sum(1 for r in rows if r["f64_argmax"] == r["b"])
+    summary = {"labels": total, "differ": len(rows), "rate": len(rows) / float(total), name_a + "_right": a_right,
+               name_b + "_right": b_right, "neither": len(rows) - a_right - b_right,
+               "max_f64_margin": max([r["f64_margin"] for r in rows], default=0.0)}
+    import sys
+    out = out or sys.stdout
+    out.write("%s vs %s: %d of %d labels differ (%.2g); float64 says %s right %d, %s right %d, neither %d; "
+              "largest float64 top1-top2 margin %.3g\n"
+              % (name_a, name_b, len(rows), total, summary["rate"], name_a, a_right, name_b, b_right,
+                 summary["neither"], summary["max_f64_margin"]))
+    for r in rows:
+        out.write("    window %d %s[%d]: %s %d, %s %d, float64 argmax %d, float64 margin %.3g\n"
+                  % (r["window"], r["kind"], r["position"], name_a, r["a"], name_b, r["b"], r["f64_argmax"],
+                     r["f64_margin"]))
+    return rows, summary

@@ -1,0 +1,44 @@
+"""Process targets of tests/test_host_plan.py (spawned: they must be importable by module path)."""
+import os
+import signal
+import sys
+import time
+
+
+def sleeper(rank, marker_dir, result_q):
+    """A rank that would run for a minute; SIGTERM makes it unwind (its `finally` leaves a marker)."""
+    def on_term(signum, frame):
+        raise SystemExit(143)
+    signal.signal(signal.SIGTERM, on_term)
+    try:
+        os.setpgid(0, 0)
+    except OSError:
+        pass
+    try:
+        open(os.path.join(marker_dir, "started_%d" % rank), "w").close()
+        time.sleep(60)
+        result_q.put((rank, {"slept": True}))
+    finally:
+        open(os.path.join(marker_dir, "unwound_%d" % rank), "w").close()
+
+
+def stubborn(rank, marker_dir, result_q):
+    """A rank that ignores SIGTERM: only the group kill ends it."""
+    signal.signal(signal.SIGTERM, signal.SIG_IGN)
+    try:
+        os.setpgid(0, 0)
+    except OSError:
+        pass
+    open(os.path.join(marker_dir, "started_%d" % rank), "w").close()
+    time.sleep(60)
+
+
+def failing(rank, marker_dir, result_q):
+    deadline = time.time() + 20
+    while time.time() < deadline and not os.path.exists(os.path.join(marker_dir, "started_0")):
+        time.sleep(0.05)
+    sys.exit(3)
+
+
+def quick(rank, marker_dir, result_q):
+    result_q.put((rank, {"rank": rank, "pid": os.getpid()}))

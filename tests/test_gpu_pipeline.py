@@ -245,3 +245,99 @@ def test_prediction_file_equals_the_reference_predict_itself(tmp_path, workers):
         return acc[:, -1] - acc[:, -2]
     ties = _assert_same_tree(gen.tree_of(out + "_0.hdf"), fixture["tree"], "helen_amd.predict on the GPU", margins)
     assert ties <= 2          # of 44,000 labels (measured: 1, margin 3.4e-7)
+
+
+def test_prediction_file_equals_the_reference_predict_at_scale(tmp_path):
+    """tests/golden/predict_ref_large.npz holds the labels the REFERENCE's own `predict` (models/predict.py:38-175, run on
+    CPU in the build container by make_golden_predict_large.py) wrote for 4,096 seeded windows = 8.19 M labels.
+    `helen_amd.predict.predict` on the MI355X, from the same image directory (regenerated here from the seeds) and the
+    same `.pkl`, must write the same tree (names, bounds, uint32 positions: one digest) and the same labels.  Where a
+    label differs, the float64 evaluation of the network (oracle_polish_batch_f64) arbitrates: the stated bar is that
+    the float64 top-1 / top-2 margin there is below fp32 resolution (1e-6) -- neither fp32 implementation can know --
+    and that at most 2e-6 of the labels differ.  The table (who float64 sides with) is printed."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import make_golden_predict_large as G
+    from golden_cases import FP32_RESOLUTION, arbitrate_label_differences
+    from helen_amd.predict import predict
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "predict_ref_large.npz"))
+    image_dir, model, images = G.large_case(str(tmp_path))
+    files = sorted(os.path.join(image_dir, f) for f in os.listdir(image_dir))
+    out = str(tmp_path / "hip")
+    predict(files, out, model, int(fx["batch"]), 4, 0, 0)
+    bases, rles, rest = G.labels_of(out + "_0.hdf")
+    assert rest == str(fx["rest_sha1"]), "region names / bounds / positions differ from the reference's file"
+    rows, summary = arbitrate_label_differences(
+        G.large_weights(), images, {"bases": bases, "rles": rles}, {"bases": fx["bases"], "rles": fx["rles"]},
+        "hip", "reference")
+    assert summary["rate"] <= 2e-6, summary
+    assert all(r["f64_margin"] < FP32_RESOLUTION for r in rows), rows
+
+
+def test_two_rank_end_to_end(tmp_path):
+    """The multi-rank product path at a size where the pipeline is in steady state: call_consensus over TWO callers
+    (both on GPU 0 here, one per GPU in production) with reader processes, 2 x 6,144 windows.  The union of
+    `<prefix>_0.hdf` and `<prefix>_1.hdf` holds every window once with the labels a direct engine call gives for the
+    same images (and, on a 192-window sample, the oracle's); the host plan and both ranks' stage seconds are
+    reported (helen_amd.predict.LAST_RUN)."""
+    import torch
+
+    import oracle
+    from helen_amd import predict as P
+    from helen_amd.call_consensus import call_consensus
+    from helen_amd.engine import HelenEngine
+    from helen_amd.model_handler import ModelHandler
+    from helen_amd.synthetic import write_image_dir
+    from helen_amd.weights import make_images
+    w = make_weights(seed=20260928, head_scale=8.0, input_scale=1.0 / 64.0)
+    model = str(tmp_path / "m.pkl")
+    ModelHandler.save_model(w, None, 128, 1, 0, model)
+    per_file, n_files = 1536, 8
+    img_dir = str(tmp_path / "img")
+    write_image_dir(img_dir, per_file * n_files, n_files=n_files, seed=900, direct=True)
+    out = str(tmp_path / "out")
+    call_consensus(img_dir, model, 256, 3, 1, out, "p", True, "0,0", 2)
+    run = dict(P.LAST_RUN)
+    assert [r["rank"] for r in run["ranks"]] == [0, 1]
+    assert [r["windows"] for r in run["ranks"]] == [per_file * n_files // 2] * 2
+    assert run["host_plan"]["n_ranks"] == 2 and all(k >= 1 for k in run["host_plan"]["reader_workers_per_rank"])
+    print("two-rank run: %.2f s; plan %s; ranks %s" % (run["seconds"], run["host_plan"], run["ranks"]))
+    files = sorted(os.listdir(out))
+    assert files == ["p_0.hdf", "p_1.hdf"]
+    eng = HelenEngine(w, device=0, max_windows=4096)
+    seen = 0
+    for fi in range(n_files):
+        img = make_images(per_file, seed=900 + fi)
+        b, r = eng.polish(torch.from_numpy(img).cuda())
+        b, r = b.cpu().numpy(), r.cpu().numpy()
+        ref = oracle.polish_batch(w, img[:24]) if fi < 2 else None
+        with hdf5.File(os.path.join(out, files[fi % 2])) as f:      # file fi goes to rank fi % 2
+            for i in range(per_file):
+                start = 800 * (fi * per_file + i)
+                root = "predictions/chr20_synth/chr20_synth-%d-%d/0/" % (start, start + 1000)
+                gb, gr = f.read(root + "bases"), f.read(root + "rles")
+                assert np.array_equal(gb, b[i]) and np.array_equal(gr, r[i]), (fi, i)
+                if ref is not None and i < 24:
+                    assert np.array_equal(gb, ref["bases"][i]) and np.array_equal(gr, ref["rles"][i]), (fi, i)
+                seen += 1
+    eng.close()
+    total = 0
+    for name in files:
+        with hdf5.File(os.path.join(out, name)) as f:
+            total += len(f.keys("predictions/chr20_synth"))
+    assert seen == total == per_file * n_files
+
+
+def test_bench_two_ranks_end_to_end_line():
+    """`bench.py --gpus 2 --single-device --e2e N`: the JSON line carries the N-rank end-to-end leg."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-device", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-host-path", "--e2e", "8192", "--e2e-workers", "3"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    e = line["end_to_end"]
+    assert line["n_gpus"] == 2 and e["n_ranks"] == 2 and e["windows"] == 16384 and e["regions_stored"] == 16384, e
+    assert e["output_files"] == ["p_0.hdf", "p_1.hdf"] and len(e["per_rank"]) == 2
+    assert e["value"] > 0 and e["usable_cpus"] >= 1 and e["predicted_host_ceiling"] > 0
+    print(json.dumps(e))

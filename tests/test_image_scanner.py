@@ -96,7 +96,7 @@ def test_damaged_files_are_libhdf5s_business(tmp_path):
     for k, blob in enumerate((raw[:len(raw) // 2], raw[:2000] + os.urandom(4000) + raw[6000:], b"not an hdf5 file" * 100)):
         bad = str(tmp_path / ("bad%d.h5" % k))
         open(bad, "wb").write(blob)
-        native_io.close_readers() if hasattr(native_io, "close_readers") else None
+        native_io.close_readers()
         try:
             ds = SequenceDataset(None, file_list=[bad])
             got = _load_batch(ds.all_images)

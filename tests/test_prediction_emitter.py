@@ -134,3 +134,57 @@ def test_a_full_disk_is_an_error_not_a_short_file(monkeypatch):
         w = native_io.Writer("/dev/full")
         w.write(native_io.pack_contigs(names), meta, pos, b, r)
         w.close()
+
+
+def test_contig_names_that_are_hdf5_paths(tmp_path, monkeypatch):
+    """`predictions/{contig}/{contig}-{start}-{end}/...` is a PATH for the reference's h5py writer and for libhdf5:
+    a contig named 'a/b' makes nested groups, empty components and '.' vanish.  The emitter builds the same tree
+    (it used to store 'a/b' as ONE link name, which libhdf5 / h5py cannot open)."""
+    rng = np.random.default_rng(11)
+    batches = [_batch(40, rng, contigs=("plain", "a/b", "a/c//d", "./lead", "trail/"))]
+    a, b = str(tmp_path / "emit.hdf"), str(tmp_path / "lib.hdf")
+    _write(a, batches, monkeypatch, None)
+    _write(b, batches, monkeypatch, "libhdf5")
+    with hdf5.File(a) as fa, hdf5.File(b) as fb:
+        wa, wb = _walk(fa), _walk(fb)
+        assert list(wa) == list(wb) and len(wa) > 100
+        for k in wa:
+            assert wa[k].dtype == wb[k].dtype and np.array_equal(wa[k], wb[k]), k
+        assert fa.keys("predictions") == fb.keys("predictions") == ["a", "lead", "plain", "trail"]
+        assert fa.keys("predictions/a/b/a") == fb.keys("predictions/a/b/a") and fa.keys("predictions/a/b/a")[0].startswith("b-")
+    if os.path.exists(H5DIFF):
+        r = subprocess.run([H5DIFF, a, b], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_a_rewritten_path_is_never_served_from_the_old_mapping(tmp_path, monkeypatch):
+    """The reader caches (mapped scanner, libhdf5 handles) are keyed by path for the life of the process; a path that
+    is rewritten -- truncated in place to a smaller file (touching the old mapping past the new end is a SIGBUS), or
+    unlinked and recreated (the old inode would be served silently) -- must be noticed on the next call: every cache
+    hit is checked against the path's device, inode, size and mtime."""
+    rng = np.random.default_rng(5)
+    p = str(tmp_path / "p_0.hdf")
+    big = _batch(300, rng, contigs=("first",))
+    small = _batch(5, rng, contigs=("second",))
+    for mode in (None, "libhdf5"):
+        if mode:
+            monkeypatch.setenv("HELEN_IO_READER", mode)
+        else:
+            monkeypatch.delenv("HELEN_IO_READER", raising=False)
+        _write(p, [big], monkeypatch, None)
+        assert len(native_io.list_regions(p, "first")) == 24
+        _write(p, [small], monkeypatch, None)                     # same inode, truncated: a smaller file
+        assert native_io.list_regions(p, "first") in (None, [])
+        assert len(native_io.list_regions(p, "second")) == 1
+        os.unlink(p)                                              # new inode under the old name
+        _write(str(tmp_path / "tmp.hdf"), [big], monkeypatch, None)
+        os.rename(str(tmp_path / "tmp.hdf"), p)
+        assert len(native_io.list_regions(p, "first")) == 24
+        assert native_io.list_regions(p, "second") in (None, [])
+        # rewritten by ANOTHER writer of the bytes (not this library): plain file copy over the path
+        _write(str(tmp_path / "tmp.hdf"), [small], monkeypatch, None)
+        with open(str(tmp_path / "tmp.hdf"), "rb") as src, open(p, "wb") as dst:
+            dst.write(src.read())
+        assert len(native_io.list_regions(p, "second")) == 1 and native_io.list_regions(p, "first") in (None, [])
+        os.unlink(p)
+    native_io.close_readers()
