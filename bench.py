@@ -87,11 +87,44 @@ def cpu_baseline(batch, seconds_target=12.0):
                       "8-window blocks, %d threads = usable CPUs under the cgroup quota), %.1f s" % (n, threads, dt)}
 
 
+def margin_report(images, dev, precision):
+    """Which labels can move: the top-1 / top-2 margin histogram of the fp32 path's accumulated softmax over up to
+    4096 windows of the shard, for the bench's random-init network (heads x8) and for the `peaked` stand-in of a
+    trained model (heads x64, helen_amd.weights.make_peaked_weights) -- and, for a reduced-precision mode, the share
+    of labels it has in common with the fp32 path on each.  `below_2e-06` is the fp32 tie rate: where two correct
+    fp32 evaluations may call different labels (tests/test_gpu_scale.py: 3.7e-7 of the labels do)."""
+    import numpy as np
+
+    from helen_amd.engine import HelenEngine
+    from helen_amd.weights import make_peaked_weights, make_weights, margin_histogram
+    n = min(images.shape[0], 4096)
+    out = {"windows": n, "what": "fractions of positions with top1-top2 margin of the accumulated softmax below each "
+                                 "edge (fp32 path), per head"}
+    for name, w in (("random_init_heads_x8", make_weights(input_scale=1.0 / 64.0)),
+                    ("peaked_heads_x64", make_peaked_weights())):
+        ref = HelenEngine(w, device=dev.index, max_windows=n, precision="fp32")
+        b0, r0, ab, ar = ref.polish(images[:n], want_acc=True)
+        entry = {"base": margin_histogram(ab.cpu().numpy()), "rle": margin_histogram(ar.cpu().numpy())}
+        entry["median_top1_of_2"] = {"base": round(float(np.median(ab.max(-1).values.cpu().numpy())), 4),
+                                     "rle": round(float(np.median(ar.max(-1).values.cpu().numpy())), 4)}
+        ref.close()
+        if precision != "fp32":
+            alt = HelenEngine(w, device=dev.index, max_windows=n, precision=precision)
+            b1, r1 = alt.polish(images[:n])
+            entry["label_identity_vs_fp32"] = {"base": round(float((b0 == b1).float().mean().item()), 6),
+                                               "rle": round(float((r0 == r1).float().mean().item()), 6)}
+            alt.close()
+        out[name] = entry
+    return out
+
+
 def precision_check(eng, precision, images, dev):
-    """BASELINE.json configs[3] asks for the reduced-precision mode's own check: argmax parity and logits
-    tolerance against the fp32 path on the same inputs.  Labels: one device call of each engine over the first
-    windows of the shard.  Logits: the reference's 19-chunk operator loop (predict_gpu.py:114-129, hidden
-    carried) on 512 of them, both engines, max |logit difference| over all chunks."""
+    """BASELINE.json configs[3] asks for the reduced-precision mode's own check: argmax parity and logits tolerance
+    against the fp32 path on the same inputs.  Labels: one device call of each engine over the first windows of the
+    shard.  Logits: the reference's 19-chunk operator loop (predict_gpu.py:114-129, hidden carried) on 512 of them,
+    both engines, max |logit difference| over all chunks.  ALL WEIGHTS ARE SYNTHETIC (no trained model exists
+    offline): `label_identity` is on the bench's random-init network, whose margins are thin; `margins` repeats it on
+    the peaked stand-in of a trained model."""
     import torch
 
     from helen_amd.engine import HelenEngine
@@ -113,7 +146,8 @@ def precision_check(eng, precision, images, dev):
         worst = max(worst, float((ob0 - ob1).abs().max().item()), float((or0 - or1).abs().max().item()))
         biggest = max(biggest, float(ob0.abs().max().item()), float(or0.abs().max().item()))
     ref.close()
-    return {"against": "the fp32 path of this library on the same windows", "windows_labels": n,
+    return {"against": "the fp32 path of this library on the same windows", "weights": "synthetic random-init (heads x8); "
+            "see `margins` for the peaked stand-in of a trained model", "windows_labels": n,
             "label_identity": round(same, 6), "windows_logits": m, "max_abs_logit_diff": float("%.3g" % worst),
             "max_abs_logit": round(biggest, 3), "precision": precision}
 
@@ -239,6 +273,7 @@ def main():
     ap.add_argument("--coalesce", type=int, default=16, help="loader batches per device call")
     ap.add_argument("--mode", default="uniform", choices=["uniform", "pileup"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-margins", action="store_true", help="skip the label-margin report (random-init and peaked weights)")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-memory -> host-memory leg")
     ap.add_argument("--e2e", type=int, default=None, metavar="WINDOWS",
                     help="windows PER RANK of the end-to-end leg: the product's call_consensus over a synthetic HDF5 "
@@ -451,6 +486,9 @@ def main():
         }
         if args.precision != "fp32":
             out["precision_check"] = precision_check(eng, args.precision, images, dev)
+        if not args.no_margins:
+            eng.close()            # the report builds engines of its own
+            out["margins"] = margin_report(images, dev, args.precision)
         if host_error is not None:
             out["host_path"] = {"value": None, "error": host_error}
         if host_elapsed is not None:
@@ -464,7 +502,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B)
     eng.close()                # call_consensus builds its own engines (15.9 GB of scratch each)
-    e2e_windows = E2E_DEFAULT_WINDOWS if args.e2e is None else args.e2e
+    # (call_consensus is the fp32 product path: the opt-in arithmetic modes carry the leg only on request)
+    e2e_windows = (E2E_DEFAULT_WINDOWS if args.precision == "fp32" else 0) if args.e2e is None else args.e2e
     e2e = None
     if e2e_windows > 0:
         try:

@@ -66,6 +66,10 @@ def build_parser():
     chk = sub.add_parser("check_images", help="vet the HDF5 schema of a MarginPolish image directory")
     chk.add_argument("-i", "--image_dir", type=str, required=True, help="directory of MarginPolish .h5 images")
     chk.add_argument("--images-per-file", type=int, default=8, help="images sampled per file")
+    chk.add_argument("--strict", action="store_true",
+                     help="inspect EVERY image and read every image through the product reader; exit 0 = ready, "
+                          "1 = schema problems, 2 = the reader refuses something")
+    chk.add_argument("--json", type=str, default=None, metavar="PATH", help="write the full report as JSON ('-' = stdout)")
     sub.add_parser("version", help="show the version")
     sub.add_parser("torch_stat", help="show torch / device configuration")
     return parser
@@ -93,8 +97,8 @@ def main(argv=None):
         test_interface(flags.test_image_dir, flags.batch_size, flags.gpu_mode, flags.num_workers,
                        flags.model_path, flags.output_dir, flags.print_details)
     elif flags.sub_command == "check_images":
-        from .check_images import check_image_directory
-        return 1 if check_image_directory(flags.image_dir, flags.images_per_file) else 0
+        from .check_images import main as check_main
+        return check_main(flags.image_dir, flags.images_per_file, flags.strict, flags.json)
     elif flags.sub_command == "version":
         print("HELEN-MI355X VERSION: " + __version__)
     elif flags.sub_command == "torch_stat":

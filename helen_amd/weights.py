@@ -50,6 +50,27 @@ def make_weights(seed=20260928, head_scale=8.0, input_scale=1.0,
     return out
 
 
+PEAKED_HEAD_SCALE = 64.0
+
+
+def make_peaked_weights(seed=20260928, input_scale=1.0 / 64.0):
+    """The same random network with its two head matrices scaled by 64 instead of 8: the per-chunk softmax is then as
+    sharp as a trained classifier's for most positions (median top-1 probability 0.999 for the base head and 0.90 for
+    the run-length head on synthetic windows, against 0.60 / 0.30 at x8; DESIGN.md 5 gives the margin histogram).  No
+    trained `.pkl` exists offline; this is the stand-in for "a trained, peaked model" when a reduced-precision mode's
+    label identity or the fp32 tie rate is quoted.  The recurrent weights keep PyTorch's default-init range: scaling
+    them saturates every gate and freezes the state, which is not what training does."""
+    return make_weights(seed=seed, head_scale=PEAKED_HEAD_SCALE, input_scale=input_scale)
+
+
+def margin_histogram(acc, edges=(2e-6, 1e-4, 1e-3, 1e-2, 1e-1)):
+    """Fractions of positions whose top-1 / top-2 margin of the accumulated softmax (`acc` [..., classes], numpy) is
+    below each edge -- 2e-6 is where two fp32 evaluations may legitimately call different labels."""
+    a = np.sort(np.asarray(acc, dtype=np.float64), axis=-1)
+    m = (a[..., -1] - a[..., -2]).ravel()
+    return {"below_%g" % e: float((m < e).mean()) for e in edges}
+
+
 def make_images(n_windows, seed=20260928, mode="uniform",
                 features=ImageSizeOptions.IMAGE_HEIGHT, seq_length=ImageSizeOptions.SEQ_LENGTH):
     """Synthetic pileup windows, uint8 [n, seq_length, features].

@@ -16,7 +16,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-src = os.path.join(ROOT, "gpurun_out")
+# optional: the directory holding pmc_FETCH_SIZE / pmc_WRITE_SIZE / pmc_sq (default gpurun_out) and a note on the command
+src = os.path.join(ROOT, sys.argv[2]) if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out")
+extra = sys.argv[3] if len(sys.argv) > 3 else ""
 
 
 def agg(path):
@@ -33,7 +35,8 @@ fetch = agg(os.path.join(src, "pmc_FETCH_SIZE", "p_counter_collection.csv"))
 write = agg(os.path.join(src, "pmc_WRITE_SIZE", "p_counter_collection.csv"))
 sq = agg(os.path.join(src, "pmc_sq", "p_counter_collection.csv"))
 out = {"command": "rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 1 --warmup 0 "
-                  "--no-cpu-baseline --no-host-path   (helen_polish_batch calls of 4096 windows)",
+                  "--no-cpu-baseline --no-host-path --e2e 0" + ((" " + extra) if extra else "") +
+                  ("   (helen_polish_batch calls of 4096 windows)" if not extra else ""),
        "notes": "FETCH_SIZE doubled (gfx950 wide-read correction); sizes in bytes per launch",
        "kernels": {}}
 for k in sorted(sq):

@@ -108,3 +108,13 @@ def arbitrate_label_differences(weights, images, labels_a, labels_b, name_a, nam
                   % (r["window"], r["kind"], r["position"], name_a, r["a"], name_b, r["b"], r["f64_argmax"],
                      r["f64_margin"]))
     return rows, summary
+
+
+def assert_wrong_only_below_fp32_resolution(rows, side="a"):
+    """The bar for an fp32 implementation (`side` of the arbiter's rows): wherever ITS label is not the float64
+    argmax, the float64 top-1 / top-2 margin must be below fp32 resolution.  (Where the other side is the wrong
+    one, the margin says how far that side's rounding reaches -- reported, not this side's business.)"""
+    wrong = [r for r in rows if r["f64_argmax"] != r[side]]
+    bad = [r for r in wrong if r["f64_margin"] >= FP32_RESOLUTION]
+    assert not bad, bad
+    return len(wrong)

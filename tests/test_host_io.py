@@ -264,14 +264,8 @@ def test_compressed_images_and_schema_check(tmp_path):
     assert n >= 2 and "missing dataset 'feature_chunk_idx'" in text and "expected integers [l <= 1000, 90]" in text
 
 
-def test_reader_takes_every_plausible_schema_variant(tmp_path):
-    """SURVEY.md 8f-2 without real data: whatever h5py or MarginPolish could plausibly have written for the six
-    datasets the reference reader touches (dataloader_predict.py:64-70) must read the same through the native
-    batch reader and the per-item reader: `contig` as a fixed-length, variable-length or scalar string; the three
-    integers in any width, signed or not, as [1] arrays or scalars; `image` as uint8, a wider integer or a
-    float; `position` as int32 / int64 / uint32 / uint64 (the reader casts it to int); chunked + shuffle +
-    deflate storage; label datasets present in an inference directory."""
-    from helen_amd.sequence_dataset import _load_batch
+def _write_schema_variants(tmp_path):
+    """One image file holding eight storage variants of the reader's six datasets.  -> (path, variants, images)"""
     img = make_images(8, seed=33)
     rng = np.random.default_rng(3)
     variants = [
@@ -309,6 +303,18 @@ def test_reader_takes_every_plausible_schema_variant(tmp_path):
                 f.write(base + "label_base", np.zeros(L, np.uint8))
                 f.write(base + "label_run_length", np.zeros(L, np.uint8))
             v["want"] = ("chr%d_variant" % i, start, start + (27 if small else 1000), chunk, L, pos)
+    return path, variants, img
+
+
+def test_reader_takes_every_plausible_schema_variant(tmp_path):
+    """SURVEY.md 8f-2 without real data: whatever h5py or MarginPolish could plausibly have written for the six
+    datasets the reference reader touches (dataloader_predict.py:64-70) must read the same through the native
+    batch reader and the per-item reader: `contig` as a fixed-length, variable-length or scalar string; the three
+    integers in any width, signed or not, as [1] arrays or scalars; `image` as uint8, a wider integer or a
+    float; `position` as int32 / int64 / uint32 / uint64 (the reader casts it to int); chunked + shuffle +
+    deflate storage; label datasets present in an inference directory."""
+    from helen_amd.sequence_dataset import _load_batch
+    path, variants, img = _write_schema_variants(tmp_path)
     ds = SequenceDataset(None, file_list=[path])
     assert len(ds) == 8
     batch = _load_batch(ds.all_images)                            # native reader when libhelen_io.so is built
@@ -484,3 +490,76 @@ def test_writer_equals_the_reference_writer_itself(tmp_path, monkeypatch, writer
     assert sorted(got) == sorted(want)
     for k in want:
         assert got[k] == want[k], k
+
+
+def _strict_check_cases(tmp_path):
+    """Directories for check_images --strict: plain files (direct emitter and libhdf5 writer), deflated storage,
+    every schema variant, and one the reader must refuse."""
+    import io
+    import json
+
+    from helen_amd.check_images import main as check_main
+    from helen_amd.synthetic import write_image_dir
+    plain = str(tmp_path / "plain")
+    write_image_dir(plain, 40, n_files=2, seed=5, short_every=7, direct=True)
+    write_image_file(os.path.join(plain, "lib.h5"), make_images(5, seed=6), first_window=500)
+    rep = str(tmp_path / "plain.json")
+    out = io.StringIO()
+    assert check_main(plain, strict=True, json_path=rep, out=out) == 0, out.getvalue()
+    r = json.load(open(rep))
+    assert r["verdict"] == "ready" and r["images"] == r["images_inspected"] == r["images_read"] == 45
+    assert [f["reader_path"] for f in r["files"]] == ["direct scanner"] * 3
+    assert r["files"][0]["datasets"]["image"]["types"] == ["uint8"] and r["files"][1]["datasets"]["image"]["rows_min"] == 613
+    # deflated storage: read through libhdf5, and the report says so
+    z = tmp_path / "deflated"
+    z.mkdir()
+    write_image_file(str(z / "z.h5"), make_images(6, seed=9), first_window=100, gzip=4)
+    out = io.StringIO()
+    assert check_main(str(z), strict=True, json_path=rep, out=out) == 0, out.getvalue()
+    r = json.load(open(rep))
+    assert r["files"][0]["reader_path"] == "libhdf5" and r["files"][0]["datasets"]["image"]["filters"] == [["deflate"]]
+    assert "read through the libhdf5" in out.getvalue()
+    # every schema variant in one file: all eight images are taken
+    v = tmp_path / "variants"
+    v.mkdir()
+    _write_schema_variants(v)
+    out = io.StringIO()
+    assert check_main(str(v), strict=True, json_path=rep, out=out) == 0, out.getvalue()
+    r = json.load(open(rep))
+    assert r["images_read"] == 8 and sorted(r["files"][0]["datasets"]["position"]["types"]) == [
+        "int16", "int32", "int64", "uint32", "uint64"]
+    # an image the reader refuses: exit code 2, the refusal carries the reader's own text
+    bad = tmp_path / "bad"
+    bad.mkdir()
+    write_image_file(str(bad / "ok.h5"), make_images(3, seed=1))
+    with hdf5.File(str(bad / "wide.h5"), "w") as f:
+        base = "images/x-0-1000-0/"
+        f.write(base + "contig", "x")
+        for k in ("contig_start", "contig_end", "feature_chunk_idx"):
+            f.write(base + k, np.array([0], np.int64))
+        f.write(base + "image", np.zeros((1000, 10), np.uint8))
+        f.write(base + "position", np.zeros((1000, 3), np.int64))
+    out = io.StringIO()
+    assert check_main(str(bad), strict=True, json_path="-", out=out) == 2
+    assert "REFUSED x-0-1000-0" in out.getvalue() and "IMAGE SIZE ERROR" in out.getvalue()
+    # without --strict / --json the command is the sampled report it was
+    out = io.StringIO()
+    assert check_main(plain, out=out) == 0 and "0 problem(s)" in out.getvalue()
+
+
+def test_check_images_strict_and_json(tmp_path):
+    """`python -m helen_amd check_images -i <dir> --strict --json report.json`: the one command a user with real
+    MarginPolish output runs before the first polish."""
+    _strict_check_cases(tmp_path)
+
+
+@pytest.mark.gpu
+def test_check_images_strict_on_the_gpu_box(tmp_path):
+    """The same on the GPU box's host (its libhdf5, its file system), through the command line."""
+    import subprocess
+    import sys
+    _strict_check_cases(tmp_path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "helen_amd", "check_images", "-i", str(tmp_path / "plain"), "--strict",
+                        "--json", str(tmp_path / "cli.json")], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0 and "ready" in r.stdout, r.stdout + r.stderr
