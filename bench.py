@@ -481,6 +481,8 @@ def main():
                          "peak": peak / (1e12 if bound == "mfma" else 1e9), "unit": unit,
                          "frac": round(achieved * (1e12 if bound == "mfma" else 1e9) / peak, 4),
                          "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "launches": gru_n,
+                         "avg_launch_ms_encoder": round(stats["gru_enc"][0] / max(stats["gru_enc"][1], 1), 4),
+                         "avg_launch_ms_decoder": round(stats["gru_dec"][0] / max(stats["gru_dec"][1], 1), 4),
                          "path_frac": round(value / world * FLOP_PER_WINDOW /
                                             (BF16_MFMA_PEAK if args.precision == "bf16" else FP32_MFMA_PEAK), 4)},
         }

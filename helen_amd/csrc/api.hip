@@ -18,6 +18,13 @@
 
 using namespace helen;
 
+#ifndef HELEN_BF16_IL_ENC_DEFAULT
+#define HELEN_BF16_IL_ENC_DEFAULT true
+#endif
+#ifndef HELEN_BF16_IL_DEC_DEFAULT
+#define HELEN_BF16_IL_DEC_DEFAULT false
+#endif
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -367,13 +374,32 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
     if (m->precision == HELEN_PRECISION_BF16) {
         // projection fused into the recurrence: no gi at all; the encoder reads the packed pileup counts,
         // the decoder the encoder's bf16 output plane
+        // Two tiles per workgroup: gru_fused_bf16_il_kernel interleaves the gate math with the other tile's MFMAs,
+        // gru_fused_bf16_pair_kernel runs them one after the other (all bit-identical).  Measured per launch of 4096
+        // windows (profiles/r03_bf16_probes.txt): encoder 0.157 against 0.162 ms, decoder 0.254 against 0.241 (no
+        // registers for its LDS prefetch): interleaved encoder, pair decoder.  HELEN_BF16_IL = two digits, encoder
+        // then decoder, 1 = interleaved (A/B probes).
+        const char* il = getenv("HELEN_BF16_IL");      // (read per call: the tests flip it within one process)
+        const bool il_enc = il && il[0] ? il[0] == '1' : HELEN_BF16_IL_ENC_DEFAULT;
+        const bool il_dec = il && il[0] && il[1] ? il[1] == '1' : HELEN_BF16_IL_DEC_DEFAULT;
         if (use_bf16_pair(tiles, m->cus)) {
-            LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_pair_kernel<3, false>), dim3((tiles + 1) / 2, 2), dim3(512), m->xb,
-                   (long)kSeq * 192, pos0, T, m->w3i_enc, m->w3h_enc, m->bias_enc, m->bhn_enc, m->hid, m->y1p,
-                   kY1bTileStride, (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride, tiles);
-            LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_pair_kernel<8, true>), dim3((tiles + 1) / 2, 2), dim3(512), m->y1p,
-                   kY1bTileStride, 0, T, m->w3i_dec, m->w3h_dec, m->bias_dec, m->bhn_dec, m->hid, (f32x4*)nullptr,
-                   kY1bTileStride, m->whd, m->plogit, kPlTileStride, tiles);
+            const dim3 grid((tiles + 1) / 2, 2), block(512);
+            if (il_enc)
+                LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_il_kernel<3, false>), grid, block, m->xb, (long)kSeq * 192, pos0, T,
+                       m->w3i_enc, m->w3h_enc, m->bias_enc, m->bhn_enc, m->hid, m->y1p, kY1bTileStride,
+                       (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride, tiles);
+            else
+                LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_pair_kernel<3, false>), grid, block, m->xb, (long)kSeq * 192, pos0, T,
+                       m->w3i_enc, m->w3h_enc, m->bias_enc, m->bhn_enc, m->hid, m->y1p, kY1bTileStride,
+                       (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride, tiles);
+            if (il_dec)
+                LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_il_kernel<8, true>), grid, block, m->y1p, kY1bTileStride, 0, T,
+                       m->w3i_dec, m->w3h_dec, m->bias_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kY1bTileStride, m->whd,
+                       m->plogit, kPlTileStride, tiles);
+            else
+                LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_pair_kernel<8, true>), grid, block, m->y1p, kY1bTileStride, 0, T,
+                       m->w3i_dec, m->w3h_dec, m->bias_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kY1bTileStride, m->whd,
+                       m->plogit, kPlTileStride, tiles);
             return;
         }
         LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_kernel<3, false>), dim3(tiles, 2), dim3(512), m->xb,

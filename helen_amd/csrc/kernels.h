@@ -13,4 +13,5 @@
 #include "kernels_x3.h"
 #include "kernels_fused_bf16.h"
 #include "kernels_fused_bf16_pair.h"
+#include "kernels_fused_bf16_il.h"
 #include "kernels_heads.h"

@@ -1,0 +1,486 @@
+// kernels_fused_bf16_il.h -- HELEN_PRECISION_BF16: fused projection + recurrence, two window tiles per workgroup,
+// gate math INTERLEAVED with the other tile's MFMAs in one instruction stream
+#pragma once
+#include <type_traits>
+
+#include "kernels_fused_bf16_pair.h"
+
+#ifndef HELEN_BF16_IL_PARKED
+#define HELEN_BF16_IL_PARKED 2      // K32 groups of the decoder's W_ih kept in LDS instead of registers
+#endif
+
+#define HELEN_PIN(x) asm volatile("" : "+v"(x))
+#ifndef HELEN_BF16_IL_LEAD        // gate slots ahead of the first MFMA of a region (asm-load variant)
+#define HELEN_BF16_IL_LEAD 6
+#endif
+#ifndef HELEN_BF16_IL_ADEPTH      // A fragments in flight (registers: 4 each): all seven of the encoder's, three of the decoder's
+#define HELEN_BF16_IL_ADEPTH(dec) ((dec) ? 3 : 7)
+#endif
+
+namespace helen {
+
+// ------------------------------------------------------------------------------------------------
+// Same arithmetic as gru_fused_bf16_kernel / gru_fused_bf16_pair_kernel (same MFMA order per accumulator, the same
+// IEEE operations per gate component, same order of the head partial sums: results are bit-identical) and the
+// same two-tile structure as gru_fused_bf16_pair_kernel:
+//     M(0,s) | G(0,s) M(1,s) | G(1,s) M(0,s+1) | ...        M = MFMA phase, G = gate math, | = the barrier
+// What changes is the order of instructions BETWEEN two barriers.  The pair kernel runs G(x,s) and then M(o,.) --
+// and measured (scripts/ubench/bf16_mfma_valu_overlap.hip, profiles/ub_bf16_overlap.txt) a SIMD then pays the MFMAs
+// plus the gate math in full: v_mfma_f32_16x16x32_bf16 issues every 17 cycles, but
+//   - in the SAME wave's stream one transcendental (v_exp_f32 / v_rcp_f32) or two plain fp32 VALU instructions
+//     behind each MFMA are free (17.0 -> 17.7 / 17.2 cycles per MFMA; a second transcendental costs 8.2, a third
+//     plain instruction 4.7);
+//   - a PACKED fp32 instruction behind an MFMA costs 16 cycles (17 -> 33 per MFMA): the packed gate cell of the
+//     other kernels is the wrong form beside bf16 MFMAs;
+//   - a VALU-only wave beside an MFMA-only wave on the same SIMD overlaps only partly (24 MFMAs + 48 v_exp per
+//     wave: phases aligned 1588 cycles, offset 1466, one interleaved stream 1291).
+// So here the region between two barriers is ONE stream: MFMA i of M(x,s) followed by slot i of G(o,.) -- a slot is
+// one transcendental or two plain scalar instructions of the gate math of the other tile's newest step, four cells
+// per lane staggered so that no slot waits for the one before it.  The decoder's 40 MFMAs per region hide all 24
+// transcendentals and most of the plain work; the encoder's 21 hide half and the rest follows the last MFMA.
+// ------------------------------------------------------------------------------------------------
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+template <int MI, bool DEC>
+__global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
+    const f32x4* __restrict__ in, long in_tile_stride, int pos0, int T, const bf16x8* __restrict__ Wi3,
+    const bf16x8* __restrict__ Wh3, const float* __restrict__ bias, const float* __restrict__ bhn,
+    f32x4* __restrict__ hid, f32x4* __restrict__ yplane_out, long yp_tile_stride,
+    const f32x4* __restrict__ Whd, f32x4* __restrict__ plogit, long pl_tile_stride, int ntiles) {
+    // LDS per tile: fp32 h [2][512 f4] | bf16 h plane [2][256] | input ring [RD][MI * 64] | (DEC) head partials [2][8][64]
+    // (DEC) after both tiles: the last kParked K32 groups of W_ih of every wave [8][kParked][3][64].  The ring is two
+    // deep: the row of step s+2 is DMA'd at the start of M(x,s) into the slot whose row (step s) the whole workgroup
+    // finished reading before the previous barrier (input part of step s, computed in the other tile's M phase).
+    // Decoder: 2 x 56 KiB + 48 KiB of parked weights = 160 KiB, all of a CU's LDS.
+    constexpr int RD = 2;
+    constexpr int kRing = 1024 + 512, kPart = kRing + RD * MI * 64, kPerTile = kPart + (DEC ? 2 * 8 * 64 : 0);
+    constexpr int kParked = DEC ? HELEN_BF16_IL_PARKED : 0, MR = MI - kParked;
+    __shared__ f32x4 smem[2 * kPerTile + kParked * 8 * 3 * 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15;
+    const int q = lane >> 4;
+    const int dir = blockIdx.y;
+    const int u = 16 * v + j;
+    const int tile_of[2] = {min(2 * (int)blockIdx.x, ntiles - 1), min(2 * (int)blockIdx.x + 1, ntiles - 1)};
+
+    bf16x8 Wh[3][4], Wi[3][MR];
+    bf16x8* const wpark = (bf16x8*)(smem + 2 * kPerTile) + v * (kParked * 3 * 64) + lane;
+    {
+        const bf16x8* wh = Wh3 + (size_t)((dir * 8 + v) * 36) * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+#pragma unroll
+            for (int M = 0; M < 4; ++M) Wh[g][M] = wh[((g * 4 + M) * 3) * 64];
+            const bf16x8* wi = Wi3 + (size_t)((dir * kNTile + g * 8 + v) * MI) * 3 * 64 + lane;
+#pragma unroll
+            for (int M = 0; M < MR; ++M) Wi[g][M] = wi[(M * 3) * 64];
+#pragma unroll
+            for (int M = MR; M < MI; ++M) wpark[((M - MR) * 3 + g) * 64] = wi[(M * 3) * 64];
+        }
+    }
+    f32x4 Bh = splat4(0.f);   // DEC: head weights for k = dir*128 + 16v + 4q + e, class j
+    if (DEC) Bh = Whd[(dir * 8 + v) * 64 + lane];
+    float bi[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bi[g] = bias[dir * kG + g * kH + u];
+    const float bn = bhn[dir * kH + u];
+
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(char*)smem;
+    const char* in_next[2];
+    long in_step;
+    {
+        long first;
+        if (DEC) {
+            const int p = v >> 2;
+            const bool up = p == dir;
+            first = ((long)(up ? 0 : T - 1) * 2 + p) * 256 + (v & 3) * 64;
+            in_step = (up ? 1 : -1) * 512L * 16;
+        } else {
+            first = (long)(pos0 + (dir ? T - 1 : 0)) * (MI * 64) + (v < MI ? v : 0) * 64;
+            in_step = (dir ? -1 : 1) * (long)(MI * 64) * 16;
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) in_next[x] = (const char*)(in + (size_t)tile_of[x] * in_tile_stride + first);
+    }
+    unsigned ring_dma[2], ring_rd[2];
+    auto dma_in = [&](int x) __attribute__((always_inline)) {
+        if (v < MI) dma_row_to_lds(lds0 + (unsigned)((x * kPerTile + kRing) * 16) + ring_dma[x] + (unsigned)v * 1024u,
+                                   in_next[x], in_block(lane16));
+        in_next[x] += in_step;
+        ring_dma[x] = ring_dma[x] == (RD - 1u) * MI * 1024u ? 0u : ring_dma[x] + MI * 1024u;
+    };
+    const int hoff = ((u >> 2) * kTile + 4 * q) * 4 + (u & 3);
+    const int poff = ((u >> 3) * kTile + 4 * q) * 8 + (u & 7);
+
+    f32x4* hid_p[2];
+    char* y_next[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        hid_p[x] = hid + ((size_t)tile_of[x] * 2 + dir) * (kHidDirStride / 4);
+        y_next[x] = DEC ? (char*)(plogit + (size_t)tile_of[x] * pl_tile_stride + (size_t)dir * 64)
+                        : (char*)(yplane_out + (size_t)tile_of[x] * yp_tile_stride + (size_t)dir * 256);
+    }
+    auto store_logits = [&](int x, int pb, unsigned voff) __attribute__((always_inline)) {
+        const float* pp = (const float*)(smem + x * kPerTile + kPart + pb * 8 * 64) + tid;
+        float sum = pp[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) sum += pp[k * 256];
+        *(float*)(y_next[x] + voff) = sum;
+    };
+
+    // ---- prologue: initial h, the rows of steps 0 and 1 -- for both tiles
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        smem[x * kPerTile + tid] = hid_p[x][tid];
+        ring_dma[x] = 0;
+        ring_rd[x] = 0;
+        dma_in(x);
+        if (T > 1) dma_in(x);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // (the previous h of a lane's four cells is re-read from the fp32 buffer by the gate slots: registers are what
+    // this kernel is short of)
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            ((unsigned short*)(smem + x * kPerTile + 1024))[poff + 8 * r] =
+                bf16_bits(((const float*)(smem + x * kPerTile))[hoff + 4 * r]);
+    // input part x . W_ih^T + b of a tile's next step (three accumulators), kept until that step's M phase
+    f32x4 gin[2][3];
+    {   // tile 0's first input part (tile 1's is computed in M(0,0))
+        const bf16x8* L = (const bf16x8*)(smem + kRing) + lane;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) gin[0][g] = splat4(bi[g]);
+#pragma unroll
+        for (int M = 0; M < MI; ++M) {
+            const bf16x8 a = L[M * 64];
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                gin[0][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    a, M < MR ? Wi[g][M < MR ? M : 0] : wpark[((M < MR ? 0 : M - MR) * 3 + g) * 64], gin[0][g], 0, 0, 0);
+        }
+        ring_rd[0] = MI * 1024u;
+    }
+    __syncthreads();
+    bf16x8 a_pref = ((const bf16x8*)(smem + 1024))[lane];   // group 0 of tile 0's h plane
+
+    // Pending gate math of each tile: the finished accumulators of its newest step.
+    f32x4 Pr[2], Pz[2], Pn[2], Pg[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) Pr[x] = Pz[x] = Pn[x] = Pg[x] = splat4(0.f);
+
+#ifdef HELEN_BIL_TIMING   // developer probe: where a wave's cycles go
+    long long tk[3] = {0, 0, 0};
+#define HELEN_BIL_TICK(i) { __builtin_amdgcn_sched_barrier(0); long long now_ = __builtin_readcyclecounter(); tk[i] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
+    long long tlast = __builtin_readcyclecounter();
+#else
+#define HELEN_BIL_TICK(i)
+#endif
+    constexpr int NM = 12 + (DEC ? 4 : 0) + 3 * MI;   // MFMAs of one M phase: recurrent, head slice, the other tile's input part
+    constexpr int NS = 44;                            // gate slots (below)
+
+    // One region between two barriers: the MFMA phase of tile X at step s, and -- if `gates` -- the gate math of
+    // tile O = 1 - X at its newest step so (whose accumulators are in P*[O]), slot by slot behind the MFMAs.
+    // CUR = s & 1; OW = the h buffer of tile O that its gates write ((so + 1) & 1).  The flags as in the pair kernel.
+    auto region = [&](auto X, auto CUR, auto OW, auto STEADY, auto GATES, int s, int so) __attribute__((always_inline)) {
+        constexpr int x = decltype(X)::value, o = 1 - x, cur = decltype(CUR)::value, ow = decltype(OW)::value;
+        constexpr bool steady = decltype(STEADY)::value, gates = decltype(GATES)::value;
+        const bool has_prev = steady || s > 0;
+        const bool has_prev2 = steady || s > 1;
+        const bool has_next = steady || s + 1 < T;      // tile o has a step after so: its input part is needed
+        const bool has_next2 = steady || s + 2 < T;
+        f32x4* const base = smem + x * kPerTile;
+        f32x4* const obase = smem + o * kPerTile;
+        const f32x4* hx = base + cur * 512;
+        const bf16x8* pa = (const bf16x8*)(base + 1024 + cur * 256) + lane;
+        const bf16x8* L = (const bf16x8*)((const char*)(obase + kRing) + ring_rd[o]) + lane;
+        int issued = 0;
+        if (has_next2) {
+            dma_in(x);
+            issued += v < MI;
+        }
+        f32x4 ar = gin[x][0], az = gin[x][1], ahn = splat4(bn), pl = splat4(0.f);
+        const f32x4 gnx = gin[x][2];
+        f32x4 ain[3];
+        // gate state of tile o: four cells (rows 4q + c of unit u)
+        const f32x4 gr = Pr[o], gz = Pz[o], gnn = Pn[o], ggn = Pg[o];
+        float t1[4], t2[4], e1[4], e2[4], rg[4], zg[4], t3[4], e3[4], u3[4], qq[4], ng[4], dd[4], hn[4], hp[4];
+        const float* hpo = (const float*)(obase + (ow ^ 1) * 512) + hoff;   // h_o(so - 1): fp32 buffer so & 1
+        const bool do_in = x == 0 || has_next;
+        // A fragments (K32 groups of h_x(s-1), then of the other tile's input rows), fetched AD - 1 groups ahead of the
+        // MFMAs that use them: an LDS read takes ~130 cycles here, a group of three MFMAs covers 51 (measured with
+        // one group of lookahead: 914 cycles for the encoder's 21 MFMAs, gate slots removed)
+        constexpr int NF = 4 + MI, AD = HELEN_BF16_IL_ADEPTH(DEC) < NF ? HELEN_BF16_IL_ADEPTH(DEC) : NF;
+        constexpr bool kAsmLoads = AD == NF;            // every fragment fetched at the top of the region
+        bf16x8 aq[AD];
+        // LDS byte addresses of this lane's 16 bytes of group 0 of h_x(s-1) and of the other tile's ring slot
+        const unsigned pa_lds = lds0 + (unsigned)((x * kPerTile + 1024 + cur * 256) * 16) + lane16;
+        const unsigned in_lds = lds0 + (unsigned)((o * kPerTile + kRing) * 16) + ring_rd[o] + lane16;
+        auto fetch_a = [&](auto F) __attribute__((always_inline)) {
+            constexpr int f = decltype(F)::value;
+            if constexpr (kAsmLoads) {
+                // Inline asm: an ordinary LDS load is as free to sink below the sched_barriers as the MFMAs were
+                // (and a volatile one turns into a flat load with a full wait).  hipcc's waitcnt pass does not see
+                // these: fragment f is waited for explicitly below, by position in the in-order LDS queue.
+                f32x4 t;
+                if constexpr (f < 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"(pa_lds), "n"(f * 1024));
+                else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"(in_lds), "n"((f - 4) * 1024));
+                aq[f % AD] = __builtin_bit_cast(bf16x8, t);
+            } else {
+                if constexpr (f < 4) aq[f % AD] = pa[f * 64];
+                else if constexpr (f < NF) { if (do_in) aq[f % AD] = L[(f - 4) * 64]; }
+            }
+        };
+        if constexpr (kAsmLoads) {
+            static_for<AD>([&](auto F) __attribute__((always_inline)) { fetch_a(F); });
+        } else {
+            aq[0] = a_pref;
+            static_for<AD - 1>([&](auto F) __attribute__((always_inline)) { fetch_a(std::integral_constant<int, decltype(F)::value + 1>{}); });
+        }
+        // fragment f has arrived when at most NF - 1 - f of the younger fetches are outstanding
+        auto wait_a = [&](auto F) __attribute__((always_inline)) {
+            constexpr int f = decltype(F)::value;
+            if constexpr (kAsmLoads) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NF - 1 - f) : "memory");
+        };
+        bf16x8 b_nxt = a_pref;                          // (DEC) the parked W_ih fragment of the next MFMA that needs one
+        f32x4 hd = splat4(0.f);
+        if (DEC && has_prev) hd = hx[v * 64 + lane];
+
+        auto gate_slot = [&](auto K) __attribute__((always_inline)) {
+            constexpr int k = decltype(K)::value;
+            if constexpr (!gates) {
+                return;
+            } else if constexpr (k < 4) {                 // P1
+                t1[k] = gr[k] * -1.4426950408889634f;
+                t2[k] = gz[k] * -1.4426950408889634f;
+            } else if constexpr (k < 12) {                // T: e1, e2
+                constexpr int c = (k - 4) >> 1;
+                if constexpr (((k - 4) & 1) == 0) e1[c] = __builtin_amdgcn_exp2f(t1[c]);
+                else e2[c] = __builtin_amdgcn_exp2f(t2[c]);
+            } else if constexpr (k < 16) {                // P2
+                constexpr int c = k - 12;
+                e1[c] = 1.0f + e1[c];
+                e2[c] = 1.0f + e2[c];
+            } else if constexpr (k < 24) {                // T: r, z
+                constexpr int c = (k - 16) >> 1;
+                if constexpr (((k - 16) & 1) == 0) rg[c] = __builtin_amdgcn_rcpf(e1[c]);
+                else zg[c] = __builtin_amdgcn_rcpf(e2[c]);
+            } else if constexpr (k < 28) {                // P3 (and this cell's previous h on its way from LDS)
+                constexpr int c = k - 24;
+                t3[c] = __builtin_fmaf(rg[c], gnn[c], ggn[c]) * 2.8853900817779268f;
+                hp[c] = hpo[4 * c];
+            } else if constexpr (k < 32) {                // T: e3
+                constexpr int c = k - 28;
+                e3[c] = __builtin_amdgcn_exp2f(t3[c]);
+            } else if constexpr (k < 34) {                // P4
+                constexpr int c = 2 * (k - 32);
+                u3[c] = 1.0f + e3[c];
+                u3[c + 1] = 1.0f + e3[c + 1];
+            } else if constexpr (k < 38) {                // T: 1 / (1 + e3)
+                constexpr int c = k - 34;
+                qq[c] = __builtin_amdgcn_rcpf(u3[c]);
+            } else if constexpr (k < 42) {                // P5
+                constexpr int c = k - 38;
+                ng[c] = __builtin_fmaf(-2.0f, qq[c], 1.0f);
+                dd[c] = hp[c] - ng[c];
+            } else {                                      // P6
+                constexpr int c = 2 * (k - 42);
+                hn[c] = __builtin_fmaf(zg[c], dd[c], ng[c]);
+                hn[c + 1] = __builtin_fmaf(zg[c + 1], dd[c + 1], ng[c + 1]);
+            }
+        };
+        // MFMA i of the phase, its operand loads one group ahead
+        auto mfma_item = [&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (i < 12) {
+                constexpr int M = i / 3, g = i % 3;
+                if constexpr (g == 0) wait_a(std::integral_constant<int, M>{});
+                const bf16x8 a_cur = aq[M % AD];
+                // (PIN: LLVM sinks a pure MFMA chain whose result is only needed at the end of the block below every
+                // sched_barrier in between -- at IR level, where sched_barrier orders nothing; an empty volatile asm
+                // that "modifies" the accumulator keeps each MFMA in its slot)
+                if constexpr (g == 0) { ar = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, Wh[0][M], ar, 0, 0, 0); HELEN_PIN(ar); }
+                if constexpr (g == 1) { az = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, Wh[1][M], az, 0, 0, 0); HELEN_PIN(az); }
+                if constexpr (g == 2) {
+                    ahn = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, Wh[2][M], ahn, 0, 0, 0);
+                    HELEN_PIN(ahn);
+                    if constexpr (!kAsmLoads) fetch_a(std::integral_constant<int, M + AD>{});      // the slot of group M is free again
+                }
+            } else if constexpr (DEC && i < 16) {
+                constexpr int e = i - 12;
+                if (has_prev) { pl = mfma4(hd[e], Bh[e], pl); HELEN_PIN(pl); }
+            } else {
+                constexpr int ii = i - 12 - (DEC ? 4 : 0), M = ii / 3, g = ii % 3;
+                // the head slice of h_x(s-1) (slot s-1) is parked while the partials of slot s-2 (the other parity) are
+                // still to be read at the end of this region
+                if constexpr (DEC && ii == 6)
+                    if (has_prev) (base + kPart + (((s - 1) & 1) * 8 + v) * 64)[lane] = pl;
+                if (do_in) {
+                    if constexpr (g == 0) wait_a(std::integral_constant<int, 4 + M>{});
+                    const bf16x8 a_cur = aq[(4 + M) % AD];
+                    if constexpr (M == 0) ain[g] = splat4(bi[g]);
+                    // a parked W_ih fragment is fetched behind the MFMA before the one that needs it
+                    if constexpr (M < MR)
+                        ain[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, Wi[g][M < MR ? M : 0], ain[g], 0, 0, 0);
+                    else
+                        ain[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, b_nxt, ain[g], 0, 0, 0);
+                    if constexpr (kParked > 0 && ii + 1 < 3 * MI && (ii + 1) / 3 >= MR)
+                        b_nxt = wpark[(((ii + 1) / 3 - MR) * 3 + (ii + 1) % 3) * 64];
+                    HELEN_PIN(ain[g]);
+                    if constexpr (g == 2 && !kAsmLoads) fetch_a(std::integral_constant<int, 4 + M + AD>{});
+                }
+            }
+        };
+        // kLead gate slots go first: they cover the LDS latency of the first A fragment (fetched at the top of the region
+        // when kAsmLoads; the decoder's comes from before the barrier)
+        constexpr int kLead = kAsmLoads ? HELEN_BF16_IL_LEAD : 0;
+        static_for<(NM + kLead > NS ? NM + kLead : NS)>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef HELEN_BIL_NOMFMA     // (timing probes: results are garbage)
+            if constexpr (i >= kLead && i - kLead < NM) mfma_item(std::integral_constant<int, (i >= kLead ? i - kLead : 0)>{});
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef HELEN_BIL_NOGATES
+            if constexpr (i < NS) gate_slot(I);
+#endif
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_in) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gin[o][g] = ain[g];
+            ring_rd[o] = ring_rd[o] == (RD - 1u) * MI * 1024u ? 0u : ring_rd[o] + MI * 1024u;
+        }
+#ifdef HELEN_BIL_NOGATES
+        static_for<4>([&](auto C) { hn[decltype(C)::value] = gr[decltype(C)::value] + gz[decltype(C)::value] + gnn[decltype(C)::value] + ggn[decltype(C)::value]; });
+#endif
+#ifdef HELEN_BIL_NOMFMA
+        ain[0] = ain[1] = ain[2] = splat4(bn);
+#endif
+        if constexpr (gates) {     // new h of tile o -> LDS (fp32 state / layer output, bf16 plane), head partial of its previous h
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ((float*)(obase + ow * 512))[hoff + 4 * r] = hn[r];
+                ((unsigned short*)(obase + 1024 + ow * 256))[poff + 8 * r] = bf16_bits(hn[r]);
+            }
+        }
+        // this phase's results become tile x's pending gate math
+        Pr[x] = ar;
+        Pz[x] = az;
+        Pn[x] = ahn;
+        Pg[x] = gnx;
+        if (!DEC && has_prev) {                                  // h_x(s-1) as a bf16 plane = the layer output of slot s-1
+            *(uint2*)(y_next[x] + in_block((unsigned)tid * 8u)) = ((const uint2*)(base + 1024 + cur * 256))[tid];
+            y_next[x] += 512 * 16;
+            issued += 1;
+        }
+        if (DEC && has_prev2) {                                  // slot s-2: partials parked by tile x's gates of step s-1
+            if (v < 4) {
+                store_logits(x, s & 1, in_block((unsigned)tid * 4u));
+                issued += 1;
+            }
+            y_next[x] += 128 * 16;
+        }
+        HELEN_BIL_TICK(0)
+        if (issued == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (issued == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        HELEN_BIL_TICK(1)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        HELEN_BIL_TICK(2)
+        // next region: M(o, .) starts on h_o in buffer ow (just published), gates of tile x
+        if constexpr (HELEN_BF16_IL_ADEPTH(DEC) < 4 + MI) a_pref = ((const bf16x8*)(obase + 1024 + ow * 256))[lane];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using No = std::false_type;
+    using Yes = std::true_type;
+    // Regions in order: R(0,0) [no gates] | R(1,0) [G(0,0)] | R(0,1) [G(1,0)] | R(1,1) [G(0,1)] | ... | final G(1,T-1).
+    // R(0,s): gates of tile 1 at step s-1, written to its buffer (s-1+1)&1 = s&1;  R(1,s): gates of tile 0 at step s,
+    // written to buffer (s+1)&1.
+    auto step = [&](auto STEADY, int s_) __attribute__((always_inline)) {
+        if (s_ & 1) {
+            region(I0{}, I1{}, I1{}, STEADY, Yes{}, s_, s_ - 1);
+            region(I1{}, I1{}, I0{}, STEADY, Yes{}, s_, s_);
+        } else {
+            if (s_ == 0) region(I0{}, I0{}, I0{}, STEADY, No{}, 0, -1);
+            else region(I0{}, I0{}, I0{}, STEADY, Yes{}, s_, s_ - 1);
+            region(I1{}, I0{}, I1{}, STEADY, Yes{}, s_, s_);
+        }
+    };
+#ifdef HELEN_BF16_STATIC_PRIO   // probe: static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+    if (v >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+    int s = 0;
+    for (; s < T && s < 2; ++s) step(No{}, s);
+    for (; s + 3 < T; s += 2) {                           // steady state: s >= 2 and (s + 1) + 2 < T
+        region(I0{}, I0{}, I0{}, Yes{}, Yes{}, s, s - 1);
+        region(I1{}, I0{}, I1{}, Yes{}, Yes{}, s, s);
+        region(I0{}, I1{}, I1{}, Yes{}, Yes{}, s + 1, s);
+        region(I1{}, I1{}, I0{}, Yes{}, Yes{}, s + 1, s + 1);
+    }
+    for (; s < T; ++s) step(No{}, s);
+#ifdef HELEN_BIL_TIMING
+    if (blockIdx.x == 0 && lane == 0)
+        printf("bf16 il %s dir %d wave %d: cycles per region  stream %lld  waits %lld  barrier %lld\n", DEC ? "dec" : "enc", dir, v,
+               tk[0] / (2 * T), tk[1] / (2 * T), tk[2] / (2 * T));
+#endif
+    // the gates of tile 1's last step (nothing left to interleave them with), into buffer T & 1
+    {
+        const int last = T & 1;
+        f32x4* const obase = smem + kPerTile;
+        float hp[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hp[r] = ((const float*)(obase + (last ^ 1) * 512))[hoff + 4 * r];
+        const f32x4 hn4 = gru_cell4(Pr[1], Pz[1], Pn[1], Pg[1], hp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ((float*)(obase + last * 512))[hoff + 4 * r] = hn4[r];
+            ((unsigned short*)(obase + 1024 + last * 256))[poff + 8 * r] = bf16_bits(hn4[r]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int last = T & 1;   // buffers of h(T-1)
+    if (DEC) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            if (T >= 2) {
+                if (v < 4) store_logits(x, (T - 2) & 1, (unsigned)tid * 4u);
+                y_next[x] += 128 * 16;
+            }
+            const f32x4 a = (smem + x * kPerTile + last * 512)[v * 64 + lane];
+            f32x4 pl = splat4(0.f);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pl = mfma4(a[e], Bh[e], pl);
+            (smem + x * kPerTile + kPart + (((T - 1) & 1) * 8 + v) * 64)[lane] = pl;
+        }
+        __syncthreads();
+        if (v < 4) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x) store_logits(x, (T - 1) & 1, (unsigned)tid * 4u);
+        }
+    } else {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+            *(uint2*)(y_next[x] + (unsigned)tid * 8u) = ((const uint2*)(smem + x * kPerTile + 1024 + last * 256))[tid];
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x) hid_p[x][tid] = (smem + x * kPerTile + last * 512)[tid];
+}
+
+}  // namespace helen

@@ -263,6 +263,9 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_pair_kernel(
             half_step(I1{}, I0{}, STEADY, s_);
         }
     };
+#ifdef HELEN_BF16_STATIC_PRIO   // probe: static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+    if (v >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     int s = 0;
     for (; s < T && s < 2; ++s) step(No{}, s);
     for (; s + 3 < T; s += 2) {                           // steady state: s >= 2 and (s + 1) + 2 < T

@@ -21,10 +21,33 @@ src = os.path.join(ROOT, sys.argv[2]) if len(sys.argv) > 2 else os.path.join(ROO
 extra = sys.argv[3] if len(sys.argv) > 3 else ""
 
 
+_demangled = {}
+
+
+def demangle(name):
+    """rocprofv3 leaves some template instantiations mangled (_ZN5helen26gru_fused_bf16_pair_kernelILi3ELb0EE...: the
+    bf16 vector type in the signature is beyond its demangler).  Enough of the Itanium scheme for this library's
+    kernels: namespace helen, the name, integer / bool template arguments."""
+    import re
+    m = re.match(r"_ZN5helen(\d+)", name)
+    if not m:
+        return name
+    if name not in _demangled:
+        n = int(m.group(1))
+        base = name[m.end():m.end() + n]
+        rest = name[m.end() + n:]
+        args = []
+        if rest.startswith("I"):
+            for kind, val in re.findall(r"L([ib])(n?\d+)E", rest[1:rest.index("EE") + 1] if "EE" in rest else ""):
+                args.append(("true" if val != "0" else "false") if kind == "b" else val.replace("n", "-"))
+        _demangled[name] = "helen::" + base + ("<" + ", ".join(args) + ">" if args else "")
+    return _demangled[name]
+
+
 def agg(path):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+        name = demangle(r["Kernel_Name"]).split("(")[0].replace("void ", "").strip()
         d[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
         if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("End_Timestamp"):
             d[name]["_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))

@@ -164,11 +164,17 @@ def test_every_fp32_kernel_choice_gives_the_same_bits(scale_case):
         e.close()
 
 
-def test_bf16_kernel_choice_gives_the_same_bits(scale_case):
-    """bf16 mode: calls of more than 128 tiles take gru_fused_bf16_pair_kernel (two tiles per workgroup), smaller
-    ones gru_fused_bf16_kernel; an odd tile count makes the last pair workgroup walk its one tile twice.
-    Accumulators and labels must be EQUAL."""
+@pytest.mark.parametrize("two_tile_kernels", ["default", "00", "10", "01", "11"])
+def test_bf16_kernel_choice_gives_the_same_bits(scale_case, monkeypatch, two_tile_kernels):
+    """bf16 mode: calls of more than 128 tiles take a two-tiles-per-workgroup kernel -- gru_fused_bf16_il_kernel (gate
+    math interleaved with the other tile's MFMAs) or gru_fused_bf16_pair_kernel, per layer: HELEN_BF16_IL = encoder
+    digit, decoder digit --, smaller ones gru_fused_bf16_kernel; an odd tile count makes the last pair workgroup walk
+    its one tile twice.  Accumulators and labels must be EQUAL."""
     from helen_amd.engine import HelenEngine
+    if two_tile_kernels == "default":
+        monkeypatch.delenv("HELEN_BF16_IL", raising=False)
+    else:
+        monkeypatch.setenv("HELEN_BF16_IL", two_tile_kernels)
     w, img, _ = scale_case
     dev = torch.from_numpy(img[6144:6144 + 4096]).cuda()
     big = HelenEngine(w, device=0, max_windows=4096, precision="bf16")      # 256 tiles: pair
