@@ -40,21 +40,26 @@ FP32_MFMA_PEAK = 157.3e12             # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_
 BF16_MFMA_PEAK = 2.5e15               # MI355X_MICROARCH.md: bf16 MFMA, dense
 
 
-def pmc_traffic(windows_per_launch):
-    """HBM bytes per gru_kernel launch from the committed rocprofv3 PMC summary of this same
-    command (profiles/*_pmc_summary.json, FETCH_SIZE/WRITE_SIZE passes; see scripts/pmc_summary.py),
-    scaled to this run's windows per launch.  None if no summary is committed."""
+def pmc_traffic(windows_per_launch, precision="fp32"):
+    """HBM bytes per recurrence launch from the committed rocprofv3 PMC summary of this same command
+    (profiles/*_pmc_summary.json, FETCH_SIZE/WRITE_SIZE passes; see scripts/pmc_summary.py), scaled to this run's
+    windows per launch.  fp32: the newest summary without a mode tag, kernels gru_kernel / gru_pair_kernel; bf16: the
+    newest `*_bf16_pmc_summary.json`, the fused layer kernels.  None if no summary is committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))
+                   if ("bf16" in os.path.basename(f)) == (precision == "bf16"))
     if not files:
         return None, None
+    names = ("helen::gru_fused_bf16",) if precision == "bf16" else ("helen::gru_kernel", "helen::gru_pair_kernel")
     try:
-        # encoder and decoder launches of the recurrence (gru_kernel<false> / <true>), launch-weighted
-        ks = [v for k, v in json.load(open(files[-1]))["kernels"].items()
-              if k.startswith(("helen::gru_kernel", "helen::gru_pair_kernel"))]
-        n = sum(k["launches_profiled"] for k in ks)
-        per_launch = sum(k["hbm_bytes_per_launch"] * k["launches_profiled"] for k in ks) / n
-        return int(per_launch * windows_per_launch / 4096.0), os.path.basename(files[-1])
+        # encoder and decoder launches of the recurrence, launch-weighted; the two-tile kernels where both were profiled
+        ks = {k: v for k, v in json.load(open(files[-1]))["kernels"].items() if k.startswith(names)}
+        if any("pair" in k or "_il_" in k for k in ks):
+            ks = {k: v for k, v in ks.items() if "pair" in k or "_il_" in k}
+        n = sum(k["launches_profiled"] for k in ks.values())
+        per_launch = sum(k["hbm_bytes_per_launch"] * k["launches_profiled"] for k in ks.values()) / n
+        base = 8192.0 if precision == "bf16" else 4096.0          # windows per launch of the profiled command
+        return int(per_launch * windows_per_launch / base), os.path.basename(files[-1])
     except Exception:
         return None, None
 
@@ -445,7 +450,7 @@ def main():
         avg_ms = gru_ms / max(gru_n, 1)
         win_per_launch = call_windows
         achieved = GRU_FLOP_PER_WINDOW_LAUNCH * win_per_launch / (avg_ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(win_per_launch) if args.precision == "fp32" else (None, None)
+        traffic, traffic_src = pmc_traffic(win_per_launch, args.precision) if args.precision != "fp32x3" else (None, None)
         peak = BF16_MFMA_PEAK if args.precision == "bf16" else FP32_MFMA_PEAK
         bound, unit = "mfma", "TFLOP/s"
         if args.precision == "bf16":

@@ -3,17 +3,21 @@ pinned to, how much RAM-backed slot space all ranks together may take -- and wha
 
 The reference starts one process per device (models/predict_gpu.py:207-226) and gives each a DataLoader with `-w`
 workers, whatever the machine has.  At the device rate of this build (~81 k windows/s per MI355X, fp32) the host is
-the part that runs out first: a reader process delivers 25-28 k windows/s (helen_amd/csrc/h5scan.h), so one GPU wants
-three to four reader CPUs plus the rank's own two threads (device stage, writer).  Eight ranks want ~40 CPUs; a
-container may grant fewer than it shows (cgroup quota), and a two-socket box has the GPUs split over NUMA nodes.
+the part that runs out first: a reader process delivers 27-47 k windows/s when several run (71 k alone;
+helen_amd/csrc/h5scan.h, profiles/r03_reader_scaling.txt), so one GPU wants three reader CPUs plus the rank's own two
+threads (device stage, writer).  Eight ranks want ~40 CPUs; a container may grant fewer than it shows (cgroup quota:
+the 16-CPU box of this project tops out at 240-320 k windows/s of readers, under half of what eight MI355X take), and
+a two-socket box has the GPUs split over NUMA nodes.
 Nothing here touches torch: the device -> NUMA node map is read from sysfs by PCI address.
 """
 import os
 import sys
 
-# measured on the GPU box's host (EPYC 9575F), DESIGN.md 6: windows/s of one reader process through the direct
-# scanner into a shared slot, and of one rank's device stage (fp32, 4096-window calls)
-READER_WINDOWS_PER_S = 25000.0
+# measured on the GPU box's host (EPYC 9575F under a 16-CPU quota; scripts/reader_bench.py, profiles/r03_reader_scaling.txt):
+# one reader process through the direct scanner into a shared slot delivers 71 k windows/s alone, 42-47 k as one of
+# four to six, 27-30 k as one of eight to twelve (the quota and memory bandwidth are shared); the planning figure
+# is the crowded one.  Device stage of one rank (fp32, 4096-window calls): 81 k.
+READER_WINDOWS_PER_S = 30000.0
 DEVICE_WINDOWS_PER_S = 81000.0
 WRITER_WINDOWS_PER_S = 100000.0
 RANK_THREADS = 2            # the rank's own busy threads: device stage + writer (feeder and release threads sleep)

@@ -23,10 +23,10 @@ def main():
     ap.add_argument("--workers", default="8,16")
     ap.add_argument("--task", type=int, default=128, help="windows per task")
     a = ap.parse_args()
-    d = tempfile.mkdtemp(prefix="helen_rb_")
+    d = tempfile.mkdtemp(prefix="helen_rb_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         t0 = time.time()
-        write_image_dir(d, a.windows, n_files=16)
+        write_image_dir(d, a.windows, n_files=16, direct=True)
         print("wrote %d windows in %.1f s" % (a.windows, time.time() - t0), flush=True)
         pairs = SequenceDataset(d).all_images
         cap = 4096
