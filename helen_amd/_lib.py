@@ -16,7 +16,7 @@ HELEN_PRECISION_FP32 = 0
 HELEN_PRECISION_BF16 = 1
 HELEN_PRECISION_FP32X3 = 2
 
-KERNEL_CLASSES = ("pack", "gemm_enc", "gru_enc", "gemm_dec", "gru_dec", "heads")
+KERNEL_CLASSES = ("pack", "gemm_enc", "gru_enc", "gemm_dec", "gru_dec", "heads", "chunks")
 
 # every symbol include/helen_hip.h declares
 EXPORTS = (

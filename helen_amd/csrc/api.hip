@@ -18,6 +18,9 @@
 
 using namespace helen;
 
+#ifndef HELEN_PERSISTENT_DEFAULT      // the chunk loop as one launch where it applies (see use_persistent)
+#define HELEN_PERSISTENT_DEFAULT false
+#endif
 #ifndef HELEN_BF16_IL_ENC_DEFAULT
 #define HELEN_BF16_IL_ENC_DEFAULT true
 #endif
@@ -87,6 +90,11 @@ struct HelenModel {
     f32x4* y1 = nullptr;
     f32x4* hid = nullptr;
     f32x4* pending = nullptr;
+    // the 19-chunk loop as one launch (polish_persistent_kernel): ticket + progress counters, a host-visible error word
+    unsigned* sync_area = nullptr;       // device: [0] = ticket, [64 ...] = progress[pairs][2]
+    unsigned* persistent_error = nullptr;   // hipHostMalloc'd, mapped
+    unsigned ticket_next = 0, epoch_next = 0;
+    bool persistent_off = false;         // set after a reported wait time-out: the per-phase launches take over
     // host-streaming path (helen_polish_host)
     uint8_t* pin_in[2] = {nullptr, nullptr};
     uint8_t* pin_out[2] = {nullptr, nullptr};
@@ -471,9 +479,10 @@ void free_model(HelenModel* m) {
     free_ring(m);
     void* ptrs[] = {m->plogit, m->w3i_enc, m->xb, m->w3i_dec, m->y1p, m->w3h_enc, m->w3h_dec, m->wp_enc, m->wp_dec, m->whp_enc, m->whp_dec, m->whd, m->bias_enc, m->bias_dec,
                     m->bhn_enc, m->bhn_dec, m->bhd, m->xa, m->gi_enc, m->gi_dec, m->y1,
-                    m->hid, m->pending};
+                    m->hid, m->pending, m->sync_area};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (m->persistent_error) (void)hipHostFree(m->persistent_error);
     for (int c = 0; c < HELEN_K_COUNT; ++c)
         for (auto& e : m->prof[c]) m->prof_pool.push_back(e);
     for (auto& e : m->prof_pool) {
@@ -569,6 +578,13 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
     if ((rc = dev_alloc(m, &m->plogit, nt * kPlTileStride))) return rc;   // the decoder emits partial logits, no y2
     if ((rc = dev_alloc(m, &m->hid, nt * (kHidStride / 4)))) return rc;
     if ((rc = dev_alloc(m, &m->pending, nt * 2 * kJump * 64))) return rc;
+    if (precision == HELEN_PRECISION_FP32) {
+        const size_t words = 64 + (nt + 1) / 2 * 2;
+        if ((rc = dev_alloc(m, &m->sync_area, words))) return rc;
+        HIP_TRY(hipMemset(m->sync_area, 0, words * sizeof(unsigned)));
+        HIP_TRY(hipHostMalloc((void**)&m->persistent_error, sizeof(unsigned), hipHostMallocMapped));
+        *m->persistent_error = 0;
+    }
     return HELEN_OK;
 }
 
@@ -619,9 +635,20 @@ int helen_model_device_bytes(const HelenModel* m, size_t* out_bytes) {
     return HELEN_OK;
 }
 
+// The chunk loop as ONE launch (polish_persistent_kernel) where the per-phase path would take the two-tile recurrence
+// and the weight-stationary decoder projection anyway: the same device bodies, the same bits.  HELEN_PERSISTENT=0/1
+// forces it off / on (on: any tile count, A/B probes and tests).
+static bool use_persistent(const HelenModel* m, int tiles) {
+    if (m->precision != HELEN_PRECISION_FP32 || m->persistent_off || !m->sync_area) return false;
+    const char* force = getenv("HELEN_PERSISTENT");
+    if (force && *force) return *force == '1';
+    return HELEN_PERSISTENT_DEFAULT && use_pair_recurrence(tiles, m->cus) && use_ws_dec_projection(tiles, m->cus);
+}
+
 // uint8 windows -> operand tiles -> encoder input projection for all 1000 positions (overlapping chunks
 // share it) -> zero initial hidden (predict_gpu.py:97-99): everything before the chunk loop.
-static int launch_front(HelenModel* m, hipStream_t s, const uint8_t* images, int n_windows, int tiles) {
+static int launch_front(HelenModel* m, hipStream_t s, const uint8_t* images, int n_windows, int tiles,
+                        bool zero_hidden = true) {
     if (m->precision == HELEN_PRECISION_FP32X3 || m->precision == HELEN_PRECISION_BF16) {
         // pileup counts are exact in bf16: pack them straight into A fragments; three exact products per w
         // (fp32x3) or the one product with w rounded to bf16 (bf16)
@@ -638,8 +665,60 @@ static int launch_front(HelenModel* m, hipStream_t s, const uint8_t* images, int
                dim3(256), images, n_windows, kSeq, m->xa);
         launch_enc_gemm(m, s, tiles, kSeq);
     }
-    // zero initial hidden per batch (predict_gpu.py:99)
-    HIP_TRY(hipMemsetAsync(m->hid, 0, (size_t)tiles * kHidStride * sizeof(float), s));
+    // zero initial hidden per batch (predict_gpu.py:99; polish_persistent_kernel does it itself)
+    if (zero_hidden) HIP_TRY(hipMemsetAsync(m->hid, 0, (size_t)tiles * kHidStride * sizeof(float), s));
+    return HELEN_OK;
+}
+
+static int launch_persistent(HelenModel* m, hipStream_t s, int tiles, int n_windows, uint8_t* bases, uint8_t* rles,
+                             float* acc_base_opt, float* acc_rle_opt) {
+    if (*(volatile unsigned*)m->persistent_error) {
+        // a hand-off of an EARLIER call gave up waiting (its labels are not to be trusted): say so, reset, and leave
+        // this handle on the per-phase launches
+        *m->persistent_error = 0;
+        m->persistent_off = true;
+        (void)hipStreamSynchronize(s);
+        (void)hipMemset(m->sync_area, 0, (64 + (size_t)(m->max_tiles + 1) / 2 * 2) * sizeof(unsigned));
+        m->ticket_next = m->epoch_next = 0;
+        return fail(HELEN_EHIP, "polish_persistent_kernel: a workgroup hand-off of an earlier call timed out (device shared or "
+                                "wedged?); its results are invalid.  This handle now uses the per-phase launches");
+    }
+    const int npairs = (tiles + 1) / 2;
+    PolishPersistentArgs a;
+    a.gi_enc = m->gi_enc;
+    a.gi_enc_tile_stride = kGiEncTileStride;
+    a.whp_enc = m->whp_enc;
+    a.bhn_enc = m->bhn_enc;
+    a.hid = m->hid;
+    a.y1 = m->y1;
+    a.y_tile_stride = kYTileStride;
+    a.wp_dec = m->wp_dec;
+    a.bias_dec = m->bias_dec;
+    a.gi_dec = m->gi_dec;
+    a.gi_dec_tile_stride = kGiDecTileStride;
+    a.whp_dec = m->whp_dec;
+    a.bhn_dec = m->bhn_dec;
+    a.whd = m->whd;
+    a.plogit = m->plogit;
+    a.pl_tile_stride = kPlTileStride;
+    a.bhd = m->bhd;
+    a.pending = m->pending;
+    a.bases = bases;
+    a.rles = rles;
+    a.acc_base = acc_base_opt;
+    a.acc_rle = acc_rle_opt;
+    a.n_windows = n_windows;
+    a.ntiles = tiles;
+    a.ticket = m->sync_area;
+    a.ticket_base = m->ticket_next;
+    a.progress = m->sync_area + 64;
+    a.epoch_base = m->epoch_next;
+    void* dev_err = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dev_err, m->persistent_error, 0));
+    a.error = (unsigned*)dev_err;
+    m->ticket_next += 2u * (unsigned)npairs;
+    m->epoch_next += 2u * (unsigned)kChunks;
+    LAUNCH(HELEN_K_CHUNKS, polish_persistent_kernel, dim3(2 * npairs), dim3(512), a);
     return HELEN_OK;
 }
 
@@ -651,8 +730,13 @@ static int polish_batch_impl(HelenModel* m, const uint8_t* images, int n_windows
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
     const int tiles = (n_windows + kTile - 1) / kTile;
-    int rc = launch_front(m, s, images, n_windows, tiles);
+    const bool persistent = use_persistent(m, tiles);
+    int rc = launch_front(m, s, images, n_windows, tiles, !persistent);
     if (rc) return rc;
+    if (persistent) {                    // pack, encoder projection, the chunk loop: three launches
+        if ((rc = launch_persistent(m, s, tiles, n_windows, bases, rles, acc_base_opt, acc_rle_opt))) return rc;
+        return check_launch("helen_polish_batch");
+    }
     for (int c = 0; c < kChunks; ++c) {  // predict_gpu.py:114-149
         launch_chunk(m, s, tiles, c * kJump, kWin, kSeq);
         LAUNCH(HELEN_K_HEADS, heads_kernel, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->plogit, kPlTileStride,

@@ -15,3 +15,4 @@
 #include "kernels_fused_bf16_pair.h"
 #include "kernels_fused_bf16_il.h"
 #include "kernels_heads.h"
+#include "kernels_persistent.h"

@@ -227,22 +227,20 @@ __global__ __launch_bounds__(256, 2) void gemm_enc_ws_kernel(const f32x4* __rest
 #ifndef HELEN_DWS_PB
 #define HELEN_DWS_PB 4
 #endif
-__global__ __launch_bounds__(512, 1) void gemm_dec_ws_kernel(const f32x4* __restrict__ A, long a_tile_stride,
-                                                             const f32x4* __restrict__ Wp,
-                                                             const float* __restrict__ bias,
-                                                             f32x4* __restrict__ gi, long gi_tile_stride,
-                                                             int npos, int ntiles) {
+constexpr int kDecWsLdsF4 = 2 * HELEN_DWS_PB * 16 * 64;   // 2 x PB x 16 KiB
+// (the body is a device function over one (tile, direction) and a caller-provided LDS block of kDecWsLdsF4 float4:
+// gemm_dec_ws_kernel below is one call per workgroup; polish_persistent_kernel calls it per chunk and tile)
+__device__ __forceinline__ void gemm_dec_ws_body(f32x4* __restrict__ smem, const int tile, const int dir,
+                                                 const f32x4* __restrict__ A, long a_tile_stride,
+                                                 const f32x4* __restrict__ Wp,
+                                                 const float* __restrict__ bias,
+                                                 f32x4* __restrict__ gi, long gi_tile_stride, int npos) {
     constexpr int MG = 16, PB = HELEN_DWS_PB, N = 3;
     constexpr int ROWS = PB * MG;            // 1 KiB rows per stage
     constexpr int RPP = ROWS / 8 / PB;       // rows a wave brings in per position (2)
-    __shared__ f32x4 smem[2 * ROWS * 64];    // 2 x PB x 16 KiB
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int local = blockIdx.x >> 3;
-    const int dir = local & 1;
-    const int tile = (local >> 1) * 8 + (blockIdx.x & 7);
-    if (tile >= ntiles) return;
     const int nt0 = N * v;
     f32x4 B[N][MG];
 #pragma unroll
@@ -305,6 +303,20 @@ __global__ __launch_bounds__(512, 1) void gemm_dec_ws_kernel(const f32x4* __rest
         }
     }
 }
+
+__global__ __launch_bounds__(512, 1) void gemm_dec_ws_kernel(const f32x4* __restrict__ A, long a_tile_stride,
+                                                             const f32x4* __restrict__ Wp,
+                                                             const float* __restrict__ bias,
+                                                             f32x4* __restrict__ gi, long gi_tile_stride,
+                                                             int npos, int ntiles) {
+    __shared__ f32x4 smem[kDecWsLdsF4];
+    const int local = blockIdx.x >> 3;
+    const int dir = local & 1;
+    const int tile = (local >> 1) * 8 + (blockIdx.x & 7);
+    if (tile >= ntiles) return;
+    gemm_dec_ws_body(smem, tile, dir, A, a_tile_stride, Wp, bias, gi, gi_tile_stride, npos);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // Encoder input projection, weight-stationary, one workgroup per tile (fp32 MFMA, K = 96 of which 90 are features).

@@ -40,16 +40,19 @@ namespace helen {
 constexpr int kPairHF4 = 2 * 2 * 512;        // h[tile x][buffer][512]
 constexpr int kPairPF4 = 2 * 2 * 8 * 64;     // head partials [tile x][parity][wave][64]
 
+// The body is a device function over (tile pair, direction) and a caller-provided LDS block of kPairHF4 (+ kPairPF4)
+// float4: gru_pair_kernel below is one call per workgroup; polish_persistent_kernel (kernels_persistent.h) calls it
+// once per chunk and layer from its loop.
 template <bool DEC>
-__global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restrict__ gi, long gi_tile_stride,
-                                                          int slot0_fwd, int slot0_bwd, int T,
-                                                          const f32x4* __restrict__ Whp,
-                                                          const float* __restrict__ bhn,
-                                                          f32x4* __restrict__ hid, f32x4* __restrict__ y,
-                                                          long y_tile_stride, const f32x4* __restrict__ Whd,
-                                                          f32x4* __restrict__ plogit, long pl_tile_stride,
-                                                          int ntiles) {
-    __shared__ f32x4 smem[kPairHF4 + (DEC ? kPairPF4 : 0)];   // 32 (+32) KiB
+__device__ __forceinline__ void gru_pair_body(f32x4* __restrict__ smem, const int pair_index, const int dir,
+                                              const f32x4* __restrict__ gi, long gi_tile_stride,
+                                              int slot0_fwd, int slot0_bwd, int T,
+                                              const f32x4* __restrict__ Whp,
+                                              const float* __restrict__ bhn,
+                                              f32x4* __restrict__ hid, f32x4* __restrict__ y,
+                                              long y_tile_stride, const f32x4* __restrict__ Whd,
+                                              f32x4* __restrict__ plogit, long pl_tile_stride,
+                                              int ntiles) {
     f32x4* const hbuf = smem;
     f32x4* const part = smem + kPairHF4;
     const int tid = threadIdx.x;
@@ -57,9 +60,8 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
     const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15;
     const int q = lane >> 4;
-    const int dir = blockIdx.y;
     const int slot0 = dir ? slot0_bwd : slot0_fwd;
-    const int tile_of[2] = {min(2 * (int)blockIdx.x, ntiles - 1), min(2 * (int)blockIdx.x + 1, ntiles - 1)};
+    const int tile_of[2] = {min(2 * pair_index, ntiles - 1), min(2 * pair_index + 1, ntiles - 1)};
 
     // W_hh slice: W[gate][m] holds k = 16m + 4q + e of column (gate, unit 16v + j): pack_w_hh keeps it at
     // wave w = v >> 1, n = 2 gate + (v & 1)
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
     }
     for (; s < T; ++s) step(No{}, s);                     // the last one or two steps: no step s+1 to feed
 #ifdef HELEN_PAIR_TIMING
-    if (blockIdx.x == 0 && lane == 0)
+    if (pair_index == 0 && lane == 0)
         printf("pair %s dir %d wave %d: cycles per half-step  mfma phase %lld  barrier %lld  gates %lld\n", DEC ? "dec" : "enc",
                dir, v, tk[0] / (2 * T), tk[1] / (2 * T), tk[2] / (2 * T));
 #endif
@@ -285,6 +287,20 @@ __global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restric
     }
 #pragma unroll
     for (int x = 0; x < 2; ++x) *(f32x4*)(hid_s[x] + tid16) = hbuf[(x * 2 + last) * 512 + stid];
+}
+
+template <bool DEC>
+__global__ __launch_bounds__(512, 1) void gru_pair_kernel(const f32x4* __restrict__ gi, long gi_tile_stride,
+                                                          int slot0_fwd, int slot0_bwd, int T,
+                                                          const f32x4* __restrict__ Whp,
+                                                          const float* __restrict__ bhn,
+                                                          f32x4* __restrict__ hid, f32x4* __restrict__ y,
+                                                          long y_tile_stride, const f32x4* __restrict__ Whd,
+                                                          f32x4* __restrict__ plogit, long pl_tile_stride,
+                                                          int ntiles) {
+    __shared__ f32x4 smem[kPairHF4 + (DEC ? kPairPF4 : 0)];   // 32 (+32) KiB
+    gru_pair_body<DEC>(smem, (int)blockIdx.x, (int)blockIdx.y, gi, gi_tile_stride, slot0_fwd, slot0_bwd, T, Whp, bhn, hid,
+                       y, y_tile_stride, Whd, plogit, pl_tile_stride, ntiles);
 }
 
 }  // namespace helen

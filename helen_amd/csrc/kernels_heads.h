@@ -56,21 +56,23 @@ __device__ __forceinline__ f32x4 head_logits(const f32x4* __restrict__ plogit, l
     return p[((size_t)t * 2) * 64] + p[((size_t)(T - 1 - t) * 2 + 1) * 64] + splat4(bias);
 }
 
-__global__ __launch_bounds__(256) void heads_kernel(
+typedef uint8_t HeadsLabels[2][kTile][kHeadsSpan];   // LDS staging of one (tile, position group): labels written as rows
+
+// The body is a device function over one (tile, group of kHeadsSpan positions) for 256 threads `tid` and their LDS
+// staging block: heads_kernel below is one call per workgroup; polish_persistent_kernel runs two such groups of 256
+// threads side by side (all of them reach the one __syncthreads inside; `valid` = false computes nothing).
+__device__ __forceinline__ void heads_body(
+    HeadsLabels& lab, const int tid, const int tile, const int t0, const bool valid,
     const f32x4* __restrict__ plogit, long pl_tile_stride,
     const float* __restrict__ bhd, int mode, int chunk, int T, int n_windows,
     f32x4* __restrict__ pending, uint8_t* __restrict__ bases, uint8_t* __restrict__ rles,
     float* __restrict__ acc_base, float* __restrict__ acc_rle, float* __restrict__ logit_base,
     float* __restrict__ logit_rle) {
-    __shared__ uint8_t lab[2][kTile][kHeadsSpan];
-    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
     const int j = lane & 15;
     const int q = lane >> 4;
-    const int tile = blockIdx.x;
-    const int t0 = blockIdx.y * kHeadsSpan;
-    const int t1 = min(T, t0 + kHeadsSpan);
+    const int t1 = valid ? min(T, t0 + kHeadsSpan) : t0;
     const int half = t0 / kJump;
     const bool isb = j < kNB;
 
@@ -132,10 +134,10 @@ __global__ __launch_bounds__(256) void heads_kernel(
             }
         }
     }
-    if (mode != 0 || park) return;
+    if (mode != 0 || park) return;      // (uniform over the workgroup: mode, chunk and the half t0 sits in)
     __syncthreads();
     const int span = t1 - t0;
-    for (int g = tid; g < 2 * kTile * kHeadsSpan; g += 256) {
+    for (int g = tid; valid && g < 2 * kTile * kHeadsSpan; g += 256) {
         const int kind = g / (kTile * kHeadsSpan);
         const int rem = g % (kTile * kHeadsSpan);
         const int win = rem / kHeadsSpan;
@@ -146,6 +148,17 @@ __global__ __launch_bounds__(256) void heads_kernel(
             out[(size_t)window * kSeq + chunk * kJump + t0 + tl] = lab[kind][win][tl];
         }
     }
+}
+
+__global__ __launch_bounds__(256) void heads_kernel(
+    const f32x4* __restrict__ plogit, long pl_tile_stride,
+    const float* __restrict__ bhd, int mode, int chunk, int T, int n_windows,
+    f32x4* __restrict__ pending, uint8_t* __restrict__ bases, uint8_t* __restrict__ rles,
+    float* __restrict__ acc_base, float* __restrict__ acc_rle, float* __restrict__ logit_base,
+    float* __restrict__ logit_rle) {
+    __shared__ HeadsLabels lab;
+    heads_body(lab, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y * kHeadsSpan, true, plogit, pl_tile_stride, bhd, mode,
+               chunk, T, n_windows, pending, bases, rles, acc_base, acc_rle, logit_base, logit_rle);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -92,7 +92,8 @@ enum {
     HELEN_K_GEMM_DEC = 3,    /* decoder input projection  Y1.W_ih^T + b */
     HELEN_K_GRU_DEC = 4,     /* decoder recurrence */
     HELEN_K_HEADS = 5,       /* heads + softmax + accumulate + argmax (or + cross-entropy terms) */
-    HELEN_K_COUNT = 6
+    HELEN_K_CHUNKS = 6,      /* the whole 19-chunk loop as one launch: classes 2-5 of every chunk (fp32, large calls) */
+    HELEN_K_COUNT = 7
 };
 
 /* ABI version of the loaded library (== HELEN_ABI_VERSION of the header it was built from). */

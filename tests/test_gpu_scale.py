@@ -123,6 +123,51 @@ def test_bf16_matches_its_emulation_at_scale(scale_case):
     eng.close()
 
 
+def test_the_chunk_loop_as_one_launch_gives_the_same_bits(scale_case, monkeypatch):
+    """polish_persistent_kernel (the 19-chunk loop of a call as ONE launch: pairs of direction-workgroups handing the
+    encoder output and the partial logits to each other through progress counters) against the per-phase launch
+    sequence: accumulators and labels must be EQUAL -- at 4096 windows (its default range), at an odd tile count, at
+    sizes it is only forced onto (64 and 21 tiles), over repeated and alternating calls on one handle (tickets and
+    epochs carry over), and with more pairs than the device holds at once (8192 windows in one call)."""
+    from helen_amd.engine import HelenEngine
+    w, img, _ = scale_case
+    dev = torch.from_numpy(img[6144:6144 + 8192]).cuda()
+    names = ("bases", "rles", "acc_base", "acc_rle")
+    for cap, n in ((4096, 4096), (4080, 4080), (1024, 1024), (331, 331), (8192, 8192)):
+        eng = HelenEngine(w, device=0, max_windows=cap)
+        monkeypatch.setenv("HELEN_PERSISTENT", "0")
+        want = eng.polish(dev[:n], want_acc=True)
+        torch.cuda.synchronize()
+        monkeypatch.setenv("HELEN_PERSISTENT", "1")
+        eng.set_profiling(["chunks", "gru_enc"])
+        eng.reset_kernel_stats()
+        for rep in range(3):
+            got = eng.polish(dev[:n], want_acc=True)
+            torch.cuda.synchronize()
+            for name, x, y in zip(names, want, got):
+                assert torch.equal(x, y), "%s: one-launch chunk loop differs at %d windows (call %d)" % (name, n, rep)
+        st = eng.kernel_stats()
+        assert st["chunks"][1] == 3 and st["gru_enc"][1] == 0, st      # one launch per call, no per-phase launches
+        eng.set_profiling([])
+        # alternating with the per-phase path and with a smaller call on the same handle
+        monkeypatch.setenv("HELEN_PERSISTENT", "0")
+        eng.polish(dev[:n // 2])
+        monkeypatch.setenv("HELEN_PERSISTENT", "1")
+        part = eng.polish(dev[:n // 2], want_acc=True)
+        torch.cuda.synchronize()
+        for name, x, y in zip(names, want, part):
+            assert torch.equal(x[:n // 2], y), name + ": half-size call after a full one differs"
+        eng.close()
+    # it is opt-in (measured 0.6 % slower than the per-phase launches at 4096 windows, far slower below): unset = off
+    monkeypatch.delenv("HELEN_PERSISTENT", raising=False)
+    eng = HelenEngine(w, device=0, max_windows=4096)
+    eng.set_profiling(["chunks"])
+    eng.polish(dev[:4096])
+    torch.cuda.synchronize()
+    assert eng.kernel_stats()["chunks"][1] == 0
+    eng.close()
+
+
 def test_every_fp32_kernel_choice_gives_the_same_bits(scale_case):
     """A 4096-window call takes gru_pair_kernel, gemm_dec_ws_kernel and gemm_enc_ws8_kernel; 1024-window calls
     take gru_kernel, gemm_gi_kernel<16, true> and gemm_gi_kernel<6, false>; 3000 windows (188 tiles) take the
