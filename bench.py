@@ -109,19 +109,38 @@ def margin_report(images, dev, precision):
     n = min(images.shape[0], 4096)
     out = {"windows": n, "what": "fractions of positions with top1-top2 margin of the accumulated softmax below each "
                                  "edge (fp32 path), per head"}
-    for name, w in (("random_init_heads_x8", make_weights(input_scale=1.0 / 64.0)),
-                    ("peaked_heads_x64", make_peaked_weights())):
+    cases = [("random_init_heads_x8", make_weights(input_scale=1.0 / 64.0), images[:n], None),
+             ("peaked_heads_x64", make_peaked_weights(), images[:n], None)]
+    trained = os.path.join(ROOT, "tests", "golden", "trained_synth.npz")
+    if os.path.exists(trained):
+        # the reference model TRAINED on a synthetic polishing task (tests/golden/make_trained_synth.py), on 512 fresh
+        # windows of that task: the only network here whose outputs are confident because it learnt something
+        import torch
+
+        from helen_amd.synthetic import make_pileup_task
+        z = np.load(trained)
+        timg, tlb, tlr = make_pileup_task(512, seed=int(z["_task_seed"]) + 9000)
+        cases.append(("trained_on_synthetic_task", {k: z[k] for k in z.files if not k.startswith("_")},
+                      torch.from_numpy(timg).to(dev), (tlb, tlr)))
+    for name, w, imgs, truth in cases:
         ref = HelenEngine(w, device=dev.index, max_windows=n, precision="fp32")
-        b0, r0, ab, ar = ref.polish(images[:n], want_acc=True)
+        b0, r0, ab, ar = ref.polish(imgs, want_acc=True)
         entry = {"base": margin_histogram(ab.cpu().numpy()), "rle": margin_histogram(ar.cpu().numpy())}
         entry["median_top1_of_2"] = {"base": round(float(np.median(ab.max(-1).values.cpu().numpy())), 4),
                                      "rle": round(float(np.median(ar.max(-1).values.cpu().numpy())), 4)}
         ref.close()
+        entry["windows"] = int(imgs.shape[0])
+        if truth is not None:
+            entry["accuracy_vs_truth"] = {"base": round(float((b0.cpu().numpy() == truth[0]).mean()), 5),
+                                          "rle": round(float((r0.cpu().numpy() == truth[1]).mean()), 5)}
         if precision != "fp32":
             alt = HelenEngine(w, device=dev.index, max_windows=n, precision=precision)
-            b1, r1 = alt.polish(images[:n])
+            b1, r1 = alt.polish(imgs)
             entry["label_identity_vs_fp32"] = {"base": round(float((b0 == b1).float().mean().item()), 6),
                                                "rle": round(float((r0 == r1).float().mean().item()), 6)}
+            if truth is not None:
+                entry["accuracy_vs_truth_" + precision] = {"base": round(float((b1.cpu().numpy() == truth[0]).mean()), 5),
+                                                            "rle": round(float((r1.cpu().numpy() == truth[1]).mean()), 5)}
             alt.close()
         out[name] = entry
     return out

@@ -76,3 +76,41 @@ def write_image_dir(directory, n_windows, n_files=4, seed=20260928, mode="unifor
         files.append(path)
         done += n
     return files
+
+
+# ---- a learnable synthetic polishing task: what tests/golden/make_trained_synth.py trains the reference model on ----
+def make_pileup_task(n_windows, seed=20260928, coverage=14, base_error=0.12, rl_error=0.35):
+    """Synthetic pileup windows WITH a ground truth, shaped like a run-length-compressed MarginPolish image: every
+    position has a true base (label 0 = gap, 1..4 = A, C, G, T; gaps 10 % of the positions) and a true run length
+    (0 for gaps, else 1..10, geometric), and `coverage` reads vote for what they saw -- the true base with probability
+    1 - base_error (else another symbol), the true run length with probability 1 - rl_error (else one off: runs of
+    five and more are under-called three times out of four, as nanopore reads do) -- on one of two strands.  Feature layout: strand * 45 + (base - 1) * 11 + run_length for a base, strand * 45 + 44 for a
+    gap; a count of k votes is stored as min(255, 8 k).  Counts, labels and the noise process are all seeded numpy.
+    -> (images uint8 [n, 1000, 90], label_base uint8 [n, 1000], label_rle uint8 [n, 1000])
+
+    Nothing about real MarginPolish data is claimed: the point is a task on which the reference network can be
+    TRAINED offline, so that parity and reduced-precision figures can be quoted on a network with trained-looking
+    weights and confident outputs instead of random ones."""
+    rng = np.random.default_rng(seed)
+    L, F = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT
+    base = rng.integers(1, 5, size=(n_windows, L))
+    base[rng.random((n_windows, L)) < 0.10] = 0
+    rl = np.minimum(10, rng.geometric(0.55, size=(n_windows, L)))
+    rl[base == 0] = 0
+    votes = np.zeros(n_windows * L * F, np.uint16)
+    cell = np.arange(n_windows * L, dtype=np.int64).reshape(n_windows, L) * F
+    for _ in range(coverage):
+        strand = rng.integers(0, 2, size=(n_windows, L))
+        b = base.copy()
+        wrong = rng.random((n_windows, L)) < base_error
+        b[wrong] = rng.integers(0, 5, size=int(wrong.sum()))
+        r = rl.copy()
+        off = rng.random((n_windows, L)) < rl_error
+        step = np.where(rng.random(int(off.sum())) < np.where(rl[off] >= 5, 0.75, 0.5), -1, 1)
+        r[off] = np.clip(r[off] + step, 1, 10)
+        r[b == 0] = 0
+        r[(b > 0) & (r == 0)] = 1
+        feat = np.where(b == 0, strand * 45 + 44, strand * 45 + (b - 1) * 11 + r)
+        votes[(cell + feat).ravel()] += 8          # one vote per (window, position) and read: the indices are distinct
+    img = np.minimum(votes, 255).astype(np.uint8).reshape(n_windows, L, F)
+    return img, base.astype(np.uint8), rl.astype(np.uint8)

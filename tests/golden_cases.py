@@ -118,3 +118,22 @@ def assert_wrong_only_below_fp32_resolution(rows, side="a"):
     bad = [r for r in wrong if r["f64_margin"] >= FP32_RESOLUTION]
     assert not bad, bad
     return len(wrong)
+
+
+def load_trained_synth():
+    """tests/golden/trained_synth.npz: the reference's own TransducerGRU TRAINED (torch autograd, build container,
+    make_trained_synth.py) on helen_amd.synthetic.make_pileup_task.  -> (weights dict, golden dict): the state dict and,
+    for GOLDEN windows regenerated from the stored seed, the reference loop's labels and accumulated softmax."""
+    import os
+
+    import numpy as np
+
+    from helen_amd.synthetic import make_pileup_task
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_synth.npz"))
+    weights = {k: z[k] for k in z.files if not k.startswith("_")}
+    n = z["_ref_bases"].shape[0]
+    img, lb, lr = make_pileup_task(32, seed=int(z["_golden_seed"]))
+    golden = {"images": img[:n], "label_base": lb[:n], "label_rle": lr[:n], "bases": z["_ref_bases"], "rles": z["_ref_rles"],
+              "acc_base": z["_ref_acc_base"], "acc_rle": z["_ref_acc_rle"], "accuracy": z["_accuracy"],
+              "task_seed": int(z["_task_seed"])}
+    return weights, golden

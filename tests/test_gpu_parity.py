@@ -1,5 +1,8 @@
 """Parity of the HIP path (through the C ABI) against the golden vectors of the reference model
 and against the CPU oracle.  Run on the GPU box: pytest -m gpu."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -434,3 +437,36 @@ def test_evaluation_bf16_vs_emulation():
     assert cm_b.sum() == cm_r.sum() == total
     assert np.abs(cm_b - ref["base_confusion_matrix"]).sum() <= BF16_LABEL_MISMATCH_MAX * 2 * total
     assert np.abs(cm_r - ref["rle_confusion_matrix"]).sum() <= BF16_LABEL_MISMATCH_MAX * 2 * total
+
+
+def test_trained_network_fp32_and_bf16():
+    """The HIP path on TRAINED weights (tests/golden/trained_synth.npz: the reference model trained on a synthetic
+    polishing task in the build container, make_trained_synth.py).  fp32: labels identical to the reference loop's,
+    accumulated softmax within the stated tolerance.  bf16 (BASELINE.json configs[3]'s argmax-parity check where it
+    means something: a confident network): over 512 windows of the task every label the bf16 mode calls must be the
+    fp32 mode's except at most 1 in 10,000, and its accuracy against the task's ground truth may not be lower by more
+    than 0.0002."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from golden_cases import ACC_ATOL, load_trained_synth
+    from helen_amd.engine import HelenEngine
+    from helen_amd.synthetic import make_pileup_task
+    w, g = load_trained_synth()
+    eng = HelenEngine(w, device=0, max_windows=512)
+    b, r, ab, ar = eng.polish(torch.from_numpy(g["images"]).cuda(), want_acc=True)
+    assert np.array_equal(b.cpu().numpy(), g["bases"]) and np.array_equal(r.cpu().numpy(), g["rles"])
+    np.testing.assert_allclose(ab.cpu().numpy(), g["acc_base"], atol=ACC_ATOL, rtol=0)
+    np.testing.assert_allclose(ar.cpu().numpy(), g["acc_rle"], atol=ACC_ATOL, rtol=0)
+    img, lb, lr = make_pileup_task(512, seed=g["task_seed"] + 5000)
+    dev = torch.from_numpy(img).cuda()
+    b32, r32 = (t.cpu().numpy() for t in eng.polish(dev))
+    eng.close()
+    lo = HelenEngine(w, device=0, max_windows=512, precision="bf16")
+    b16, r16 = (t.cpu().numpy() for t in lo.polish(dev))
+    lo.close()
+    same = ((b32 == b16).mean() + (r32 == r16).mean()) / 2
+    acc32 = ((b32 == lb).mean(), (r32 == lr).mean())
+    acc16 = ((b16 == lb).mean(), (r16 == lr).mean())
+    print("trained network, 512 windows: bf16 labels identical to fp32 %.6f; accuracy vs truth fp32 %.5f / %.5f, bf16 %.5f / %.5f"
+          % (same, acc32[0], acc32[1], acc16[0], acc16[1]))
+    assert same >= 0.9999
+    assert acc16[0] >= acc32[0] - 2e-4 and acc16[1] >= acc32[1] - 2e-4

@@ -106,3 +106,21 @@ def test_oracle_against_the_reference_predict_sample():
     assert summary["differ"] <= 2
     # either side may be the wrong one; the oracle's k-ascending scalar sums reach ~1e-6 (tests/test_gpu_scale.py)
     assert all(r["f64_margin"] < 2e-6 for r in rows), rows
+
+
+def test_oracle_on_a_trained_network():
+    """tests/golden/trained_synth.npz: the reference's own TransducerGRU TRAINED in the build container on a synthetic
+    polishing task (make_trained_synth.py), and what its sliding-window loop gives on eight held-out windows.  Trained
+    parameters (large structured input weights, saturating gates, confident outputs) are another regime than the
+    random-init ones of every other fixture: the oracle must reproduce labels and accumulated softmax there too."""
+    from golden_cases import load_trained_synth
+    w, g = load_trained_synth()
+    o = oracle.polish_batch(w, g["images"])
+    assert np.array_equal(o["bases"], g["bases"]) and np.array_equal(o["rles"], g["rles"])
+    np.testing.assert_allclose(o["acc_base"], g["acc_base"], atol=ACC_ATOL, rtol=0)
+    np.testing.assert_allclose(o["acc_rle"], g["acc_rle"], atol=ACC_ATOL, rtol=0)
+    # the network does what it was trained for (held-out windows of the task), and its margins are wide:
+    # near-ties are a property of random weights, not of a trained model
+    assert (o["bases"] == g["label_base"]).mean() > 0.999 and (o["rles"] == g["label_rle"]).mean() > 0.99
+    a = np.sort(o["acc_rle"], -1)
+    assert np.quantile(a[..., -1] - a[..., -2], 0.001) > 0.05
