@@ -2,7 +2,8 @@
 
 Runs only in the build container (needs /root/reference and a few minutes of CPU):
 
-    python tests/golden/make_trained_synth.py            # writes tests/golden/trained_synth.npz
+    python tests/golden/make_trained_synth.py            # writes tests/golden/trained_synth.npz (4 epochs, ~100 s on 8 cores;
+                                                         # regenerates byte-identical here: seeded, 8 torch threads)
 
 No trained HELEN model exists offline (they are downloaded, helen/modules/python/DownloadModel.py:8-27), so every
 other fixture and the benchmark use random-init weights, whose softmax outputs are flat and whose gates sit in their
@@ -48,7 +49,7 @@ def main():
     W, J = TrainOptions.TRAIN_WINDOW, TrainOptions.WINDOW_JUMP
     t0 = time.time()
     steps = 0
-    for epoch in range(int(os.environ.get("EPOCHS", "6"))):
+    for epoch in range(int(os.environ.get("EPOCHS", "4"))):
         img, lb, lr = make_pileup_task(96, seed=TASK_SEED + epoch)
         x_all = torch.from_numpy(img).float()
         lb_t, lr_t = torch.from_numpy(lb).long(), torch.from_numpy(lr).long()
