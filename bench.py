@@ -184,7 +184,7 @@ E2E_DEFAULT_WINDOWS = 49152        # per rank: 12 device calls of 4096 windows, 
 E2E_FILES_PER_RANK = 16
 
 
-def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_device, dist):
+def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_device, dist, may_shrink=False):
     """The whole `call_consensus` of the product over `world` ranks -- synthetic MarginPolish image directory (HDF5,
     16 files per rank, sharded round-robin by file as CallConsensusInterface.py:138-145) -> per rank: reader processes
     -> device -> ONE prediction HDF5 -- wall-clocked from the call to its return: host budgeting, process start-up,
@@ -202,20 +202,25 @@ def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_de
     from helen_amd.model_handler import ModelHandler
     from helen_amd.synthetic import write_image_file_direct
     from helen_amd.weights import make_images
-    total = windows_per_rank * world
-    need = total * 116000 + world * 5 * 4096 * SLOT_BYTES_PER_WINDOW + total * 16000   # inputs + slots + outputs
-    box = [None]
+    def need_bytes(per_rank):     # inputs + slots + outputs, all ranks, all RAM-backed
+        return per_rank * world * (116000 + 16000) + world * 5 * 4096 * SLOT_BYTES_PER_WINDOW
+    box = [None, windows_per_rank]
     if rank == 0:
-        if shm_free_bytes() > need * 1.1:
+        free = shm_free_bytes()
+        # the default leg (no --e2e given) shrinks to what /dev/shm holds for all ranks, down to two device calls per rank
+        while may_shrink and box[1] > 8192 and free <= need_bytes(box[1]) * 1.1:
+            box[1] -= 4096
+        if free > need_bytes(box[1]) * 1.1:
             box[0] = tempfile.mkdtemp(prefix="helen_e2e_", dir="/dev/shm")
         elif world == 1:
             box[0] = tempfile.mkdtemp(prefix="helen_e2e_")
     if dist is not None:
         dist.broadcast_object_list(box, src=0)
-    d = box[0]
+    d, windows_per_rank = box
+    total = windows_per_rank * world
     if d is None:
         return {"value": None, "skipped": "/dev/shm has %.1f GB free, the %d-rank leg needs %.1f GB"
-                                          % (shm_free_bytes() / 1e9, world, need / 1e9)} if rank == 0 else None
+                                          % (shm_free_bytes() / 1e9, world, need_bytes(windows_per_rank) / 1e9)} if rank == 0 else None
     done = os.path.join(d, "done")
     try:
         img_dir = os.path.join(d, "img")
@@ -541,7 +546,7 @@ def main():
     if e2e_windows > 0:
         try:
             e2e = end_to_end(e2e_windows, args.e2e_workers, B, make_weights(input_scale=1.0 / 64.0), rank, world,
-                             args.single_device, dist)
+                             args.single_device, dist, may_shrink=args.e2e is None)
         except Exception as e:          # noqa: BLE001 -- this leg must not take the headline down with it
             e2e = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
