@@ -547,7 +547,7 @@ def main():
         try:
             e2e = end_to_end(e2e_windows, args.e2e_workers, B, make_weights(input_scale=1.0 / 64.0), rank, world,
                              args.single_device, dist, may_shrink=args.e2e is None)
-        except Exception as e:          # noqa: BLE001 -- this leg must not take the headline down with it
+        except (Exception, SystemExit) as e:    # noqa: BLE001 -- this leg must not take the headline down with it (call_consensus exits on bad input)
             e2e = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         if e2e is not None:
