@@ -442,7 +442,8 @@ def test_evaluation_bf16_vs_emulation():
 def test_trained_network_fp32_and_bf16():
     """The HIP path on TRAINED weights (tests/golden/trained_synth.npz: the reference model trained on a synthetic
     polishing task in the build container, make_trained_synth.py).  fp32: labels identical to the reference loop's,
-    accumulated softmax within the stated tolerance.  bf16 (BASELINE.json configs[3]'s argmax-parity check where it
+    accumulated softmax within the stated tolerance; over 512 fresh windows of the task all 1,024,000 labels equal the CPU
+    oracle's.  bf16 (BASELINE.json configs[3]'s argmax-parity check where it
     means something: a confident network): over 512 windows of the task every label the bf16 mode calls must be the
     fp32 mode's except at most 1 in 10,000, and its accuracy against the task's ground truth may not be lower by more
     than 0.0002."""
@@ -460,6 +461,12 @@ def test_trained_network_fp32_and_bf16():
     dev = torch.from_numpy(img).cuda()
     b32, r32 = (t.cpu().numpy() for t in eng.polish(dev))
     eng.close()
+    # ... and on these 512 windows (1,024,000 labels) the fp32 labels are the CPU oracle's, every one: a trained
+    # network has no ties for two fp32 evaluations to fall on different sides of
+    import oracle
+    oracle.set_threads(min(oracle.max_threads(), 16))
+    o = oracle.polish_batch(w, img)
+    assert np.array_equal(b32, o["bases"]) and np.array_equal(r32, o["rles"])
     lo = HelenEngine(w, device=0, max_windows=512, precision="bf16")
     b16, r16 = (t.cpu().numpy() for t in lo.polish(dev))
     lo.close()
