@@ -141,23 +141,9 @@ __global__ __launch_bounds__(512, 1) void polish_persistent_kernel(const PolishP
         gru_pair_body<true>(smem, pair, dir, a.gi_dec, a.gi_dec_tile_stride, 0, 0, kWin, a.whp_dec, a.bhn_dec, a.hid,
                             (f32x4*)nullptr, a.y_tile_stride, a.whd, a.plogit, a.pl_tile_stride, a.ntiles);
         pair_handoff(mine, theirs, ++epoch, a.error);                  // B: partial logits of both directions
-        // heads: this direction takes half `dir` of the chunk's positions of both tiles, two groups of 256 threads at a time
-        {
-            HeadsLabels* lab = (HeadsLabels*)smem;
-            const int grp = tid >> 8, vt = tid & 255;
-            constexpr int kGroupsPerHalf = kJump / kHeadsSpan;
-#pragma unroll 1
-            for (int r = 0; r < kGroupsPerHalf; ++r) {
-                const int vb = 2 * r + grp;                            // 0 .. 2 * kGroupsPerHalf - 1
-                const int which = vb / kGroupsPerHalf;
-                const int tile = which ? tile1 : tile0;
-                const bool valid = !(which == 1 && tile1 == tile0);
-                heads_body(lab[grp], vt, tile, dir * kJump + (vb % kGroupsPerHalf) * kHeadsSpan, valid, a.plogit,
-                           a.pl_tile_stride, a.bhd, 0, c, kWin, a.n_windows, a.pending, a.bases, a.rles, a.acc_base,
-                           a.acc_rle, (float*)nullptr, (float*)nullptr);
-                __syncthreads();
-            }
-        }
+        // heads: this direction takes half `dir` of the chunk's positions of both tiles, every wave its own positions
+        heads_half_body((uint8_t*)smem, tid, tile0, tile1, dir, a.plogit, a.pl_tile_stride, a.bhd, c, kWin, a.n_windows,
+                        a.pending, a.bases, a.rles, a.acc_base, a.acc_rle);
         own_data_fence();   // hid written by the decoder is the next chunk's encoder h0; LDS changes hands
     }
 }
