@@ -17,27 +17,51 @@ namespace helen {
 //     zero-pad-and-add into a [B,1000,C] accumulator.
 //   mode 1 (logits): write base[B,T,5] / rle[B,T,11] logits (the operator-level boundary).
 // ------------------------------------------------------------------------------------------------
+// Butterfly reductions over the 16 lanes of a row (= the 16 classes of one window) as DPP row operations instead of
+// ds_bpermute shuffles (128 LDS-crossbar round trips per position before): xor 1 and xor 2 are quad permutations;
+// after them the four lanes of a quad agree, so mirroring within 8 lanes (lane i <-> 7 - i) pairs every quad with the
+// other quad of its half exactly as xor 4 would, and mirroring the row (i <-> 15 - i) pairs the halves as xor 8 would.
+// Same operands at every level (a + b == b + a, max and the first-maximum rule are symmetric): the same bits as the
+// xor butterfly.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+
 __device__ __forceinline__ float group16_max(float v) {
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 16));
+    v = fmaxf(v, dpp_f32<kDppXor1>(v));
+    v = fmaxf(v, dpp_f32<kDppXor2>(v));
+    v = fmaxf(v, dpp_f32<kDppHalfMirror>(v));
+    v = fmaxf(v, dpp_f32<kDppMirror>(v));
     return v;
 }
 __device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 16);
+    v += dpp_f32<kDppXor1>(v);
+    v += dpp_f32<kDppXor2>(v);
+    v += dpp_f32<kDppHalfMirror>(v);
+    v += dpp_f32<kDppMirror>(v);
     return v;
 }
 // argmax with first-maximum tie-break (torch.max on CPU, predict_gpu.py:155)
-__device__ __forceinline__ int group16_argmax(float v, int idx) {
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-        const float ov = __shfl_xor(v, o, 16);
-        const int oi = __shfl_xor(idx, o, 16);
-        if (ov > v || (ov == v && oi < idx)) {
-            v = ov;
-            idx = oi;
-        }
+template <int CTRL>
+__device__ __forceinline__ void argmax_step(float& v, int& idx) {
+    const float ov = dpp_f32<CTRL>(v);
+    const int oi = dpp_i32<CTRL>(idx);
+    if (ov > v || (ov == v && oi < idx)) {
+        v = ov;
+        idx = oi;
     }
+}
+__device__ __forceinline__ int group16_argmax(float v, int idx) {
+    argmax_step<kDppXor1>(v, idx);
+    argmax_step<kDppXor2>(v, idx);
+    argmax_step<kDppHalfMirror>(v, idx);
+    argmax_step<kDppMirror>(v, idx);
     return idx;
 }
 
@@ -164,6 +188,9 @@ __device__ __forceinline__ void heads_body(
 // 33 us for the whole chip in heads_kernel.  Same per-position arithmetic (heads_softmax, first-maximum argmax), same
 // `pending` slots: same bits.  `lab` = 2 tiles x 2 kinds x 16 windows x 50 positions of LDS.
 constexpr int kHeadsHalfLdsBytes = 2 * 2 * kTile * kJump;
+#ifndef HELEN_HEADS_HALF_U
+#define HELEN_HEADS_HALF_U 4
+#endif
 __device__ __forceinline__ void heads_half_body(
     uint8_t* __restrict__ lab, const int tid, const int tile0, const int tile1, const int half,
     const f32x4* __restrict__ plogit, long pl_tile_stride, const float* __restrict__ bhd, int chunk, int T,
@@ -179,7 +206,7 @@ __device__ __forceinline__ void heads_half_body(
     const bool add_prev = (half == 0) && (chunk > 0);
     const int ntile = tile1 == tile0 ? 1 : 2;
     const int nitems = ntile * kJump;
-    constexpr int U = 4;
+    constexpr int U = HELEN_HEADS_HALF_U;   // items per wave in flight (their loads are issued together)
     for (int i0 = v * U; i0 < nitems; i0 += 8 * U) {
         f32x4 lg[U], pv[U];
 #pragma unroll
