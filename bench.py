@@ -509,8 +509,8 @@ def main():
                                             "the decoder projection and the heads, fp32 MFMA; 1.5098 GFLOP of the window's 1.7724)" if one_launch else
                                             "gru_pair_kernel (GRU recurrence of two window tiles per 8-wave workgroup, fp32 MFMA; "
                                             "decoder launches include the heads' product)",
-                                    "bf16": "gru_fused_bf16_pair_kernel (projection + recurrence per layer, two window tiles per workgroup, bf16 MFMA; "
-                                            "bound in practice by the fp32 gate math, not the matrix pipe)",
+                                    "bf16": "gru_fused_bf16_il_kernel (encoder) / gru_fused_bf16_pair_kernel (decoder): projection + recurrence per layer, "
+                                            "two window tiles per workgroup, bf16 MFMA; bound in practice by the fp32 gate math, not the matrix pipe",
                                     "fp32x3": "gru_x3_kernel (GRU recurrence, 6 bf16 MFMAs per fp32 product "
                                               "group; fraction is of the fp32 MFMA peak)"}[args.precision],
                          "achieved": round(achieved, 2),
