@@ -343,11 +343,11 @@ bool use_pair_recurrence(int tiles, int cus) {
     static const char* force = getenv("HELEN_GRU_PAIR");
     if (force && *force) return *force == '1';
     const int wg_single = 2 * tiles, wg_pair = 2 * ((tiles + 1) / 2);
-    // measured per resident set at 100 steps: one workgroup per CU alone 0.36 ms, two per CU 0.635 ms, a pair
-    // workgroup 0.617 ms
+    // measured per resident set at 100 steps: one workgroup per CU alone 0.36 ms (gru_kernel; gru_single8_kernel 0.30),
+    // two per CU 0.635 ms, a pair workgroup 0.617 ms
     auto t_single = [&](int wgs) {
         const int full = wgs / (2 * cus), rest = wgs % (2 * cus);
-        return full * 0.635 + (rest == 0 ? 0.0 : rest <= cus ? 0.36 : 0.635);
+        return full * 0.635 + (rest == 0 ? 0.0 : rest <= cus ? 0.31 : 0.635);
     };
     const double t_pair = ((wg_pair + cus - 1) / cus) * 0.617;
     return t_pair < t_single(wg_single);
@@ -356,6 +356,14 @@ bool use_pair_recurrence(int tiles, int cus) {
 // bf16 mode: gru_fused_bf16_kernel (one tile per workgroup, one workgroup per CU) or gru_fused_bf16_pair_kernel
 // (two tiles per workgroup; same results bit for bit).  The pair needs more than one round of single workgroups to
 // pay: below that every tile has a CU of its own anyway.  (HELEN_BF16_PAIR=0/1 forces one: A/B probes.)
+// One (tile, direction) per CU at most: the 8-wave single-tile recurrence instead of gru_kernel's four waves (same
+// results bit for bit).  (HELEN_GRU_SINGLE8=0/1 forces one: A/B probes.)
+bool use_single8_recurrence(int tiles, int cus) {
+    const char* force = getenv("HELEN_GRU_SINGLE8");
+    if (force && *force) return *force == '1';
+    return 2 * tiles <= cus;
+}
+
 bool use_bf16_pair(int tiles, int cus) {
     static const char* force = getenv("HELEN_BF16_PAIR");
     if (force && *force) return *force == '1';
@@ -434,6 +442,10 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
         LAUNCH(HELEN_K_GRU_ENC, gru_pair_kernel<false>, dim3((tiles + 1) / 2, 2), dim3(512), m->gi_enc,
                kGiEncTileStride, pos0, enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride,
                (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride, tiles);
+    else if (use_single8_recurrence(tiles, m->cus))
+        LAUNCH(HELEN_K_GRU_ENC, gru_single8_kernel<false>, dim3(tiles, 2), dim3(512), m->gi_enc, kGiEncTileStride, pos0,
+               enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride, (const f32x4*)nullptr,
+               (f32x4*)nullptr, kPlTileStride);
     else
         LAUNCH(HELEN_K_GRU_ENC, gru_kernel<false>, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
                enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride, (const f32x4*)nullptr,
@@ -448,6 +460,9 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
         LAUNCH(HELEN_K_GRU_DEC, gru_pair_kernel<true>, dim3((tiles + 1) / 2, 2), dim3(512), m->gi_dec,
                kGiDecTileStride, 0, 0, T, m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd,
                m->plogit, kPlTileStride, tiles);
+    else if (use_single8_recurrence(tiles, m->cus))
+        LAUNCH(HELEN_K_GRU_DEC, gru_single8_kernel<true>, dim3(tiles, 2), dim3(512), m->gi_dec, kGiDecTileStride, 0, 0, T,
+               m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd, m->plogit, kPlTileStride);
     else
         LAUNCH(HELEN_K_GRU_DEC, gru_kernel<true>, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, 0, T,
                m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd, m->plogit, kPlTileStride);

@@ -168,6 +168,28 @@ def test_the_chunk_loop_as_one_launch_gives_the_same_bits(scale_case, monkeypatc
     eng.close()
 
 
+def test_single_tile_recurrences_give_the_same_bits(scale_case, monkeypatch):
+    """Calls of at most 128 tiles (one (tile, direction) per CU) take gru_single8_kernel (eight waves per tile), larger
+    single-tile launches gru_kernel (four waves, two workgroups per CU); HELEN_GRU_SINGLE8 forces either.  Same bits,
+    also for an odd step count and a short operator call."""
+    from helen_amd.engine import HelenEngine
+    w, img, _ = scale_case
+    dev = torch.from_numpy(img[8000:8000 + 1500]).cuda()
+    eng = HelenEngine(w, device=0, max_windows=1500)
+    x = torch.rand((700, 37, 90), device="cuda") * 255
+    h = torch.rand((700, 2, 128), device="cuda") - 0.5
+    got = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("HELEN_GRU_SINGLE8", flag)
+        monkeypatch.setenv("HELEN_GRU_PAIR", "0")
+        got[flag] = (eng.polish(dev, want_acc=True), eng.chunk_forward(x, h), eng.chunk_forward(x[:33, :1], h[:33]))
+        torch.cuda.synchronize()
+    for a, b in zip(got["0"], got["1"]):
+        for u, v_ in zip(a, b):
+            assert torch.equal(u, v_)
+    eng.close()
+
+
 def test_every_fp32_kernel_choice_gives_the_same_bits(scale_case):
     """A 4096-window call takes gru_pair_kernel, gemm_dec_ws_kernel and gemm_enc_ws8_kernel; 1024-window calls
     take gru_kernel, gemm_gi_kernel<16, true> and gemm_gi_kernel<6, false>; 3000 windows (188 tiles) take the
