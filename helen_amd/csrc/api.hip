@@ -983,6 +983,12 @@ int helen_debug_inject_failure(HelenModel* m, int sub_batch) {
     if (!m->debug_hooks)
         return fail(HELEN_EINVAL, "debug hooks are off: the model was not created under HELEN_DEBUG_HOOKS=1");
     HELEN_ENTER(m);      // never while another thread is inside a call on this handle
+    if (sub_batch == HELEN_DEBUG_PERSISTENT_TIMEOUT) {
+        // pretend a workgroup hand-off of polish_persistent_kernel gave up: the word the device would have set
+        if (!m->persistent_error) return fail(HELEN_EINVAL, "this model has no one-launch chunk loop (fp32 only)");
+        *m->persistent_error = 1;
+        return HELEN_OK;
+    }
     m->fail_at_sub = sub_batch;
     return HELEN_OK;
 }

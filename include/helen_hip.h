@@ -158,6 +158,9 @@ int helen_polish_host(HelenModel* model, const uint8_t* images, int n_windows, u
  * created (the test suite sets it for the one test that needs it); refused while another thread is in a call.
  */
 int helen_debug_inject_failure(HelenModel* model, int sub_batch);
+/* sub_batch value that instead marks a hand-off time-out of the one-launch chunk loop (HELEN_PERSISTENT=1), as the
+ * device would: the next helen_polish_batch on that path must report it and fall back to the per-phase launches. */
+#define HELEN_DEBUG_PERSISTENT_TIMEOUT (-2)
 
 /*
  * One TransducerGRU.forward call (`models/TransducerModel.py:60-79`), the operator-level

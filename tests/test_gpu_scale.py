@@ -168,6 +168,31 @@ def test_the_chunk_loop_as_one_launch_gives_the_same_bits(scale_case, monkeypatc
     eng.close()
 
 
+def test_a_timed_out_hand_off_is_reported_and_the_handle_falls_back(scale_case, monkeypatch):
+    """polish_persistent_kernel gives up a hand-off after ~4 s and sets a host-visible word instead of hanging the queue;
+    the next call on that path must say so (its predecessor's labels are invalid) and the handle must keep working on the
+    per-phase launches.  The time-out itself is injected (HELEN_DEBUG_HOOKS)."""
+    from helen_amd._lib import HelenError
+    from helen_amd.engine import HelenEngine
+    w, img, _ = scale_case
+    dev = torch.from_numpy(img[:512]).cuda()
+    monkeypatch.setenv("HELEN_DEBUG_HOOKS", "1")
+    monkeypatch.setenv("HELEN_PERSISTENT", "1")
+    eng = HelenEngine(w, device=0, max_windows=512)
+    want = eng.polish(dev)
+    torch.cuda.synchronize()
+    eng.inject_failure(-2)
+    with pytest.raises(HelenError, match="hand-off of an earlier call timed out"):
+        eng.polish(dev)
+    eng.set_profiling(["chunks", "gru_enc"])
+    got = eng.polish(dev)                       # per-phase launches from now on, whatever the environment says
+    torch.cuda.synchronize()
+    st = eng.kernel_stats()
+    assert st["chunks"][1] == 0 and st["gru_enc"][1] == 19
+    assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])
+    eng.close()
+
+
 def test_single_tile_recurrences_give_the_same_bits(scale_case, monkeypatch):
     """Calls of at most 128 tiles (one (tile, direction) per CU) take gru_single8_kernel (eight waves per tile), larger
     single-tile launches gru_kernel (four waves, two workgroups per CU); HELEN_GRU_SINGLE8 forces either.  Same bits,
