@@ -95,6 +95,9 @@ struct HelenModel {
     unsigned* persistent_error = nullptr;   // hipHostMalloc'd, mapped
     unsigned ticket_next = 0, epoch_next = 0;
     bool persistent_off = false;         // set after a reported wait time-out: the per-phase launches take over
+    // calls that do not fill the chip run as two independent tile groups on two internal streams (polish_batch_impl)
+    hipStream_t sub_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     // host-streaming path (helen_polish_host)
     uint8_t* pin_in[2] = {nullptr, nullptr};
     uint8_t* pin_out[2] = {nullptr, nullptr};
@@ -498,6 +501,11 @@ void free_model(HelenModel* m) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (m->persistent_error) (void)hipHostFree(m->persistent_error);
+    for (int k = 0; k < 2; ++k) {
+        if (m->sub_stream[k]) (void)hipStreamDestroy(m->sub_stream[k]);
+        if (m->ev_join[k]) (void)hipEventDestroy(m->ev_join[k]);
+    }
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     for (int c = 0; c < HELEN_K_COUNT; ++c)
         for (auto& e : m->prof[c]) m->prof_pool.push_back(e);
     for (auto& e : m->prof_pool) {
@@ -737,6 +745,63 @@ static int launch_persistent(HelenModel* m, hipStream_t s, int tiles, int n_wind
     return HELEN_OK;
 }
 
+// The launch sequence of one call over `tiles` tiles whose scratch starts at the model's (possibly shifted) pointers.
+static int polish_range(HelenModel* m, hipStream_t s, const uint8_t* images, int n_windows, uint8_t* bases,
+                        uint8_t* rles, float* acc_base_opt, float* acc_rle_opt, bool allow_persistent) {
+    const int tiles = (n_windows + kTile - 1) / kTile;
+    const bool persistent = allow_persistent && use_persistent(m, tiles);
+    int rc = launch_front(m, s, images, n_windows, tiles, !persistent);
+    if (rc) return rc;
+    if (persistent)                      // pack, encoder projection, the chunk loop: three launches
+        return launch_persistent(m, s, tiles, n_windows, bases, rles, acc_base_opt, acc_rle_opt);
+    for (int c = 0; c < kChunks; ++c) {  // predict_gpu.py:114-149
+        launch_chunk(m, s, tiles, c * kJump, kWin, kSeq);
+        LAUNCH(HELEN_K_HEADS, heads_kernel, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->plogit, kPlTileStride,
+               m->bhd, 0, c, kWin, n_windows, m->pending, bases, rles, acc_base_opt, acc_rle_opt,
+               (float*)nullptr, (float*)nullptr);
+    }
+    return HELEN_OK;
+}
+
+// The per-tile scratch of the model seen from tile `tile0` on: every kernel indexes its buffers by tile from 0, so a
+// group of tiles is a call on shifted pointers.  Restored when the group's launches are enqueued (kernel arguments
+// are taken at launch).
+struct TileWindow {
+    HelenModel* m;
+    f32x4 *xa, *gi_enc, *gi_dec, *y1, *hid, *plogit, *pending;
+    TileWindow(HelenModel* model, int tile0)
+        : m(model), xa(m->xa), gi_enc(m->gi_enc), gi_dec(m->gi_dec), y1(m->y1), hid(m->hid), plogit(m->plogit),
+          pending(m->pending) {
+        const size_t t = (size_t)tile0;
+        if (m->xa) m->xa += t * kXaTileStride;
+        if (m->gi_enc) m->gi_enc += t * kGiEncTileStride;
+        if (m->gi_dec) m->gi_dec += t * kGiDecTileStride;
+        if (m->y1) m->y1 += t * kYTileStride;
+        m->hid += t * (kHidStride / 4);
+        m->plogit += t * kPlTileStride;
+        m->pending += t * 2 * kJump * 64;
+    }
+    ~TileWindow() {
+        m->xa = xa; m->gi_enc = gi_enc; m->gi_dec = gi_dec; m->y1 = y1; m->hid = hid; m->plogit = plogit;
+        m->pending = pending;
+    }
+};
+
+// fp32 calls of more than 128 and fewer than 240 tiles run as TWO independent groups of tiles on two internal streams.
+// Such a call is too large for one (tile, direction) per CU and too small to fill the chip with tile pairs: as one
+// lockstep sequence its recurrences take a pair launch's 0.62 ms with up to half the CUs idle and its projections a
+// partial second round.  Windows never interact, so each half is an ordinary call of at most 120 tiles (eight-wave
+// single-tile recurrences, one per CU), and whatever CUs one group's phase leaves idle the other group's kernels
+// take.  Same kernels on the same windows: same bits.  Measured (quick_bench.py, windows/s unsplit -> split): 2,112
+// windows 53.3 -> 62.6 k, 2,304: 56.2 -> 73.7 k, 2,560: 61.2 -> 72.3 k, 3,072: 67.6 -> 75.9 k, 3,584: 73.8 -> 78.4 k,
+// 3,840: 77.1 -> 77.5 k; at 128 tiles and below (the chip is not full either way, but the two queues do not
+// overlap better than one) and from 240 tiles on it loses 0.3-2 %.  (HELEN_SPLIT=0/1 forces it: A/B probes.)
+static bool use_split(const HelenModel* m, int tiles) {
+    const char* force = getenv("HELEN_SPLIT");
+    if (force && *force) return *force == '1' && tiles >= 2;
+    return m->precision == HELEN_PRECISION_FP32 && 2 * tiles > m->cus && 16 * tiles < 15 * m->cus;
+}
+
 static int polish_batch_impl(HelenModel* m, const uint8_t* images, int n_windows, uint8_t* bases,
                              uint8_t* rles, float* acc_base_opt, float* acc_rle_opt, void* stream) {
     if (!m || !images || !bases || !rles) return fail(HELEN_EINVAL, "null argument");
@@ -745,18 +810,43 @@ static int polish_batch_impl(HelenModel* m, const uint8_t* images, int n_windows
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
     const int tiles = (n_windows + kTile - 1) / kTile;
-    const bool persistent = use_persistent(m, tiles);
-    int rc = launch_front(m, s, images, n_windows, tiles, !persistent);
-    if (rc) return rc;
-    if (persistent) {                    // pack, encoder projection, the chunk loop: three launches
-        if ((rc = launch_persistent(m, s, tiles, n_windows, bases, rles, acc_base_opt, acc_rle_opt))) return rc;
-        return check_launch("helen_polish_batch");
+    if (!use_split(m, tiles) || use_persistent(m, tiles)) {
+        const int rc = polish_range(m, s, images, n_windows, bases, rles, acc_base_opt, acc_rle_opt, true);
+        return rc ? rc : check_launch("helen_polish_batch");
     }
-    for (int c = 0; c < kChunks; ++c) {  // predict_gpu.py:114-149
-        launch_chunk(m, s, tiles, c * kJump, kWin, kSeq);
-        LAUNCH(HELEN_K_HEADS, heads_kernel, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->plogit, kPlTileStride,
-               m->bhd, 0, c, kWin, n_windows, m->pending, bases, rles, acc_base_opt, acc_rle_opt,
-               (float*)nullptr, (float*)nullptr);
+    if (!m->ev_fork) {
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(hipStreamCreateWithFlags(&m->sub_stream[k], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&m->ev_join[k], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    }
+    // the first group takes the larger half, whole tiles
+    // From 160 tiles on the first group is what fills the chip with one (tile, direction) per CU and the second takes
+    // the rest (3,072 windows: 128 + 64 tiles 75.9 k windows/s, 96 + 96: 73.8 k, 112 + 80: 71.9 k; 2,560: 128 + 32
+    // 72.3 k, 80 + 80 71.2 k); below, two equal halves (2,304 windows: 72 + 72 tiles 73.7 k, 128 + 16: 68.6 k).
+    int t0 = 8 * tiles >= 5 * m->cus ? m->cus / 2 : (tiles + 1) / 2;
+    if (const char* at = getenv("HELEN_SPLIT_AT")) {      // (A/B probes: tiles of the first group)
+        const int v = atoi(at);
+        if (v > 0 && v < tiles) t0 = v;
+    }
+    const int w0 = t0 * kTile;
+    HIP_TRY(hipEventRecord(m->ev_fork, s));
+    for (int k = 0; k < 2; ++k) {
+        const int first = k ? w0 : 0, count = k ? n_windows - w0 : w0;
+        HIP_TRY(hipStreamWaitEvent(m->sub_stream[k], m->ev_fork, 0));
+        int rc;
+        {
+            TileWindow view(m, k ? t0 : 0);
+            rc = polish_range(m, m->sub_stream[k], images + (size_t)first * kSeq * kF, count,
+                              bases + (size_t)first * kSeq, rles + (size_t)first * kSeq,
+                              acc_base_opt ? acc_base_opt + (size_t)first * kSeq * kNB : nullptr,
+                              acc_rle_opt ? acc_rle_opt + (size_t)first * kSeq * kNR : nullptr, false);
+        }
+        // (whatever happened, the caller's stream waits for what was enqueued)
+        HIP_TRY(hipEventRecord(m->ev_join[k], m->sub_stream[k]));
+        HIP_TRY(hipStreamWaitEvent(s, m->ev_join[k], 0));
+        if (rc) return rc;
     }
     return check_launch("helen_polish_batch");
 }

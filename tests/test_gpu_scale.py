@@ -178,6 +178,7 @@ def test_a_timed_out_hand_off_is_reported_and_the_handle_falls_back(scale_case, 
     dev = torch.from_numpy(img[:512]).cuda()
     monkeypatch.setenv("HELEN_DEBUG_HOOKS", "1")
     monkeypatch.setenv("HELEN_PERSISTENT", "1")
+    monkeypatch.setenv("HELEN_SPLIT", "0")
     eng = HelenEngine(w, device=0, max_windows=512)
     want = eng.polish(dev)
     torch.cuda.synchronize()
@@ -191,6 +192,39 @@ def test_a_timed_out_hand_off_is_reported_and_the_handle_falls_back(scale_case, 
     assert st["chunks"][1] == 0 and st["gru_enc"][1] == 19
     assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])
     eng.close()
+
+
+def test_split_calls_give_the_same_bits(scale_case, monkeypatch):
+    """Calls of 129-239 tiles run as two independent tile groups on two internal streams (helen_amd/csrc/api.hip:
+    use_split); HELEN_SPLIT forces it on or off at any size.  Labels and accumulators must be EQUAL, for ragged sizes
+    (a last tile that is not full, an odd tile count), repeated calls, and through helen_polish_host."""
+    from helen_amd.engine import HelenEngine
+    w, img, _ = scale_case
+    names = ("bases", "rles", "acc_base", "acc_rle")
+    for n in (3072, 2309, 531, 17):
+        dev = torch.from_numpy(img[7000:7000 + n]).cuda()
+        eng = HelenEngine(w, device=0, max_windows=n)
+        monkeypatch.setenv("HELEN_SPLIT", "0")
+        want = eng.polish(dev, want_acc=True)
+        torch.cuda.synchronize()
+        monkeypatch.setenv("HELEN_SPLIT", "1")
+        for rep in range(2):
+            got = eng.polish(dev, want_acc=True)
+            torch.cuda.synchronize()
+            for name, x, y in zip(names, want, got):
+                assert torch.equal(x, y), "%s: split call differs at %d windows (call %d)" % (name, n, rep)
+        hb, hr = eng.polish_host(img[7000:7000 + n])
+        assert np.array_equal(hb, want[0].cpu().numpy()) and np.array_equal(hr, want[1].cpu().numpy())
+        eng.close()
+    # the default: on at 192 tiles, off at 64 and at 256
+    monkeypatch.delenv("HELEN_SPLIT", raising=False)
+    for n, launches in ((3072, 38), (1024, 19), (4096, 19)):
+        eng = HelenEngine(w, device=0, max_windows=n)
+        eng.set_profiling(["gru_enc"])
+        eng.polish(torch.from_numpy(img[:n]).cuda())
+        torch.cuda.synchronize()
+        assert eng.kernel_stats()["gru_enc"][1] == launches, (n, eng.kernel_stats())
+        eng.close()
 
 
 def test_single_tile_recurrences_give_the_same_bits(scale_case, monkeypatch):
