@@ -33,9 +33,12 @@ def stubborn(rank, marker_dir, result_q):
     time.sleep(60)
 
 
-def failing(rank, marker_dir, result_q):
+def failing(rank, marker_dir, result_q, wait_for=(0,)):
+    """Exits with 3 once every rank in `wait_for` is up (its handlers installed: a sibling that is terminated while it is
+    still importing dies of the signal without unwinding, which is not what the tests are about)."""
     deadline = time.time() + 20
-    while time.time() < deadline and not os.path.exists(os.path.join(marker_dir, "started_0")):
+    while time.time() < deadline and not all(os.path.exists(os.path.join(marker_dir, "started_%d" % r))
+                                             for r in wait_for):
         time.sleep(0.05)
     sys.exit(3)
 

@@ -105,7 +105,7 @@ def test_a_failing_rank_takes_its_siblings_down(tmp_path):
     from helen_amd.predict import run_ranks
     d = str(tmp_path)
     t0 = time.time()
-    # ranks 0 and 2 sleep, rank 1 fails once rank 0 is up
+    # ranks 0 and 2 sleep, rank 1 fails once both are up
     results, failed = _run_mixed(run_ranks, [rank_targets.sleeper, rank_targets.failing, rank_targets.sleeper],
                                  [(0, d), (1, d), (2, d)])
     took = time.time() - t0
@@ -122,7 +122,11 @@ def _run_mixed(run_ranks, targets, argsets, **kw):
 
 def _dispatch(rank, marker_dir, names, result_q):
     import rank_targets
-    getattr(rank_targets, names[rank])(rank, marker_dir, result_q)
+    if names[rank] == "failing":
+        rank_targets.failing(rank, marker_dir, result_q,
+                             wait_for=[r for r, n in enumerate(names) if n in ("sleeper", "stubborn")])
+    else:
+        getattr(rank_targets, names[rank])(rank, marker_dir, result_q)
 
 
 def test_a_rank_that_ignores_sigterm_is_killed(tmp_path):
