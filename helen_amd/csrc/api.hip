@@ -21,11 +21,11 @@ using namespace helen;
 #ifndef HELEN_PERSISTENT_DEFAULT      // the chunk loop as one launch where it applies (see use_persistent)
 #define HELEN_PERSISTENT_DEFAULT false
 #endif
-#ifndef HELEN_BF16_IL_ENC_DEFAULT
-#define HELEN_BF16_IL_ENC_DEFAULT true
+#ifndef HELEN_BF16_ENC_DEFAULT
+#define HELEN_BF16_ENC_DEFAULT '1'
 #endif
-#ifndef HELEN_BF16_IL_DEC_DEFAULT
-#define HELEN_BF16_IL_DEC_DEFAULT false
+#ifndef HELEN_BF16_DEC_DEFAULT
+#define HELEN_BF16_DEC_DEFAULT '0'
 #endif
 
 namespace {
@@ -397,28 +397,24 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
         // gru_fused_bf16_pair_kernel runs them one after the other (all bit-identical).  Measured per launch of 4096
         // windows (profiles/r03_bf16_probes.txt): encoder 0.157 against 0.162 ms, decoder 0.254 against 0.241 (no
         // registers for its LDS prefetch): interleaved encoder, pair decoder.  HELEN_BF16_IL = two digits, encoder
-        // then decoder, 1 = interleaved (A/B probes).
+        // then decoder: 0 = pair, 1 = interleaved, 2 = pair with waves 4-7 skewed by a phase (A/B probes).
         const char* il = getenv("HELEN_BF16_IL");      // (read per call: the tests flip it within one process)
-        const bool il_enc = il && il[0] ? il[0] == '1' : HELEN_BF16_IL_ENC_DEFAULT;
-        const bool il_dec = il && il[0] && il[1] ? il[1] == '1' : HELEN_BF16_IL_DEC_DEFAULT;
+        const char il_enc = il && il[0] ? il[0] : HELEN_BF16_ENC_DEFAULT;
+        const char il_dec = il && il[0] && il[1] ? il[1] : HELEN_BF16_DEC_DEFAULT;
         if (use_bf16_pair(tiles, m->cus)) {
             const dim3 grid((tiles + 1) / 2, 2), block(512);
-            if (il_enc)
-                LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_il_kernel<3, false>), grid, block, m->xb, (long)kSeq * 192, pos0, T,
-                       m->w3i_enc, m->w3h_enc, m->bias_enc, m->bhn_enc, m->hid, m->y1p, kY1bTileStride,
-                       (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride, tiles);
-            else
-                LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_pair_kernel<3, false>), grid, block, m->xb, (long)kSeq * 192, pos0, T,
-                       m->w3i_enc, m->w3h_enc, m->bias_enc, m->bhn_enc, m->hid, m->y1p, kY1bTileStride,
-                       (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride, tiles);
-            if (il_dec)
-                LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_il_kernel<8, true>), grid, block, m->y1p, kY1bTileStride, 0, T,
-                       m->w3i_dec, m->w3h_dec, m->bias_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kY1bTileStride, m->whd,
-                       m->plogit, kPlTileStride, tiles);
-            else
-                LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_pair_kernel<8, true>), grid, block, m->y1p, kY1bTileStride, 0, T,
-                       m->w3i_dec, m->w3h_dec, m->bias_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kY1bTileStride, m->whd,
-                       m->plogit, kPlTileStride, tiles);
+#define HELEN_ENC_ARGS m->xb, (long)kSeq * 192, pos0, T, m->w3i_enc, m->w3h_enc, m->bias_enc, m->bhn_enc, m->hid, m->y1p, \
+                       kY1bTileStride, (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride, tiles
+#define HELEN_DEC_ARGS m->y1p, kY1bTileStride, 0, T, m->w3i_dec, m->w3h_dec, m->bias_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, \
+                       kY1bTileStride, m->whd, m->plogit, kPlTileStride, tiles
+            if (il_enc == '1') LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_il_kernel<3, false>), grid, block, HELEN_ENC_ARGS);
+            else if (il_enc == '2') LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_pair_kernel<3, false, true>), grid, block, HELEN_ENC_ARGS);
+            else LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_pair_kernel<3, false>), grid, block, HELEN_ENC_ARGS);
+            if (il_dec == '1') LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_il_kernel<8, true>), grid, block, HELEN_DEC_ARGS);
+            else if (il_dec == '2') LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_pair_kernel<8, true, true>), grid, block, HELEN_DEC_ARGS);
+            else LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_pair_kernel<8, true>), grid, block, HELEN_DEC_ARGS);
+#undef HELEN_ENC_ARGS
+#undef HELEN_DEC_ARGS
             return;
         }
         LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_kernel<3, false>), dim3(tiles, 2), dim3(512), m->xb,
