@@ -791,11 +791,14 @@ struct TileWindow {
 // take.  Same kernels on the same windows: same bits.  Measured (quick_bench.py, windows/s unsplit -> split): 2,112
 // windows 53.3 -> 62.6 k, 2,304: 56.2 -> 73.7 k, 2,560: 61.2 -> 72.3 k, 3,072: 67.6 -> 75.9 k, 3,584: 73.8 -> 78.4 k,
 // 3,840: 77.1 -> 77.5 k; at 128 tiles and below (the chip is not full either way, but the two queues do not
-// overlap better than one) and from 240 tiles on it loses 0.3-2 %.  (HELEN_SPLIT=0/1 forces it: A/B probes.)
+// overlap better than one: 1,024 windows 53.1 -> 53.2 k, and 51.2 k with the second group started half a chunk
+// late so that one group's projection falls beside the other's recurrence) and from 240 tiles on it loses 0.3-2 %.
+// (HELEN_SPLIT=0/1 forces it: A/B probes.)
 static bool use_split(const HelenModel* m, int tiles) {
+    if (m->precision != HELEN_PRECISION_FP32) return false;   // (TileWindow shifts the fp32 scratch only)
     const char* force = getenv("HELEN_SPLIT");
     if (force && *force) return *force == '1' && tiles >= 2;
-    return m->precision == HELEN_PRECISION_FP32 && 2 * tiles > m->cus && 16 * tiles < 15 * m->cus;
+    return 2 * tiles > m->cus && 16 * tiles < 15 * m->cus;
 }
 
 static int polish_batch_impl(HelenModel* m, const uint8_t* images, int n_windows, uint8_t* bases,
