@@ -184,6 +184,20 @@ E2E_DEFAULT_WINDOWS = 49152        # per rank: 12 device calls of 4096 windows, 
 E2E_FILES_PER_RANK = 16
 
 
+def gather_strings(dist, world, text):
+    """Every rank's `text`, over CPU tensors (gloo) whatever other backend the group has."""
+    import torch
+    raw = torch.tensor(list(text.encode()[:4000]), dtype=torch.uint8)
+    n = torch.tensor([raw.numel()], dtype=torch.int64)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    padded = torch.zeros(4000, dtype=torch.uint8)
+    padded[:raw.numel()] = raw
+    every = [torch.zeros_like(padded) for _ in range(world)]
+    dist.all_gather(every, padded)
+    return [bytes(e[:int(k.item())].tolist()).decode(errors="replace") for e, k in zip(every, sizes)]
+
+
 def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_device, dist, may_shrink=False):
     """The whole `call_consensus` of the product over `world` ranks -- synthetic MarginPolish image directory (HDF5,
     16 files per rank, sharded round-robin by file as CallConsensusInterface.py:138-145) -> per rank: reader processes
@@ -240,9 +254,7 @@ def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_de
             write_error = "%s: %s" % (type(e).__name__, e)
         t_write = time.time() - t0
         if dist is not None:            # doubles as the barrier: every rank learns whether all inputs exist
-            errs = [None] * world
-            dist.all_gather_object(errs, write_error)
-            write_error = next((e for e in errs if e), None)
+            write_error = next((e for e in gather_strings(dist, world, write_error or "") if e), None)
         if write_error:
             return {"value": None, "error": "writing the synthetic inputs failed: " + write_error} if rank == 0 else None
         if rank != 0:
@@ -358,14 +370,38 @@ def main():
     dev = torch.device("cuda", local_rank)
     # under torch.distributed.run (any world size) the process group is used for the barrier and the
     # max-over-ranks time; a plain `python bench.py` needs none
+    rccl = None          # how the RCCL leg of the barrier came up ("ok" / why not); None without a process group
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
+        import datetime
+
         import torch.distributed as dist
-        if args.single_device:
+        if args.single_device and os.environ.get("HELEN_BENCH_TRY_RCCL", "") != "1":
             args.dist_backend = "gloo"      # RCCL refuses two ranks on one device
+        # The path has no data-path collective: the group only carries the barrier and the per-rank times.  Those
+        # go over gloo (CPU tensors) whatever happens; with --dist-backend nccl the barrier ALSO crosses RCCL, whose
+        # communicator is brought up here, guarded -- a node whose RCCL does not come up (IPC mode, duplicate
+        # devices) still gives its scaling line, and the line says so.
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("cpu:gloo,cuda:nccl", timeout=datetime.timedelta(seconds=600))
+            mine = 1
+            try:
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize(dev)
+                if int(probe.item()) != world:
+                    raise RuntimeError("all_reduce over RCCL returned %s for %d ranks" % (probe.item(), world))
+            except Exception as e:      # noqa: BLE001 -- reported in the JSON line
+                mine = 0
+                rccl = "failed on rank %d: %s: %s" % (rank, type(e).__name__, str(e).splitlines()[0][:200])
+            flag = torch.tensor([mine], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                rccl = "ok"
+            elif rccl is None:
+                rccl = "failed on another rank"
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+            rccl = "not used (--dist-backend gloo%s)" % ("; --single-device" if args.single_device else "")
     else:
         dist = None
 
@@ -407,10 +443,16 @@ def main():
                                               bases[s:e].data_ptr(), rles[s:e].data_ptr(), None, None,
                                               ctypes.c_void_p(stream)))
 
+    token_dev = torch.zeros(1, device=dev) if rccl == "ok" else None
+    token_cpu = torch.zeros(1)
+
     def barrier():
-        if dist is not None:
-            dist.barrier()
         torch.cuda.synchronize(dev)
+        if dist is not None:
+            if token_dev is not None:           # over RCCL / xGMI
+                dist.all_reduce(token_dev)
+                torch.cuda.synchronize(dev)
+            dist.all_reduce(token_cpu)          # over gloo: holds whatever RCCL does
 
     # HIP events around the dominant kernel only; the pairs are created during the warm-up (topped up to the
     # number of timed steps) and recycled afterwards: no event is created or destroyed inside the timed region
@@ -460,8 +502,7 @@ def main():
 
     per_rank = [my_elapsed]
     if dist is not None:
-        cdev = dev if args.dist_backend == "nccl" else "cpu"
-        t = torch.tensor([elapsed, host_elapsed or 0.0], dtype=torch.float64, device=cdev)
+        t = torch.tensor([elapsed, host_elapsed or 0.0], dtype=torch.float64)       # (CPU tensors: gloo)
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
         per_rank = [float(e[0].item()) for e in every]
@@ -492,6 +533,8 @@ def main():
             "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "ranks_seen": len(per_rank),
             "per_rank_windows_per_s": [round(args.steps * call_windows / t, 1) for t in per_rank],
             "devices": "cuda:0 for every rank (--single-device)" if args.single_device else "cuda:LOCAL_RANK",
+            "barrier": None if dist is None else ("RCCL all-reduce + gloo all-reduce" if rccl == "ok" else "gloo all-reduce"),
+            "rccl": rccl,
             "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16 operands, f32 accumulate/state",
@@ -554,7 +597,7 @@ def main():
             out["end_to_end"] = e2e
         print(json.dumps(out))
     if dist is not None:
-        dist.barrier()
+        dist.all_reduce(token_cpu)
         dist.destroy_process_group()
 
 

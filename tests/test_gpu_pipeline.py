@@ -342,4 +342,22 @@ def test_bench_two_ranks_end_to_end_line():
     assert line["n_gpus"] == 2 and e["n_ranks"] == 2 and e["windows"] == 16384 and e["regions_stored"] == 16384, e
     assert e["output_files"] == ["p_0.hdf", "p_1.hdf"] and len(e["per_rank"]) == 2
     assert e["value"] > 0 and e["usable_cpus"] >= 1 and e["predicted_host_ceiling"] > 0
+    assert line["barrier"] == "gloo all-reduce" and line["rccl"].startswith("not used"), line["rccl"]
     print(json.dumps(e))
+
+
+def test_bench_survives_an_rccl_that_does_not_come_up():
+    """The barrier of `bench.py --gpus N` crosses RCCL AND gloo; the times travel over gloo.  Two ranks on ONE device
+    is a configuration RCCL refuses: the line must still come out, say so, and have used the gloo barrier (on a node
+    whose RCCL works the same code prints "rccl": "ok")."""
+    import json
+    env = dict(os.environ, HELEN_BENCH_TRY_RCCL="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-device", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-host-path", "--no-margins", "--e2e", "0"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["value"] > 0
+    assert line["rccl"] == "ok" or line["rccl"].startswith("failed"), line["rccl"]
+    assert line["barrier"] == ("RCCL all-reduce + gloo all-reduce" if line["rccl"] == "ok" else "gloo all-reduce")
+    print(line["rccl"], line["barrier"])
