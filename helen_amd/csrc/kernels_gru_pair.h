@@ -182,7 +182,11 @@ __device__ __forceinline__ void gru_pair_body(f32x4* __restrict__ smem, const in
             for (int e = 0; e < 2; ++e)
 #pragma unroll
                 for (int g = 0; g < 3; ++g)   // the first MFMA of a chain takes its initial value as the C operand
+#ifdef HELEN_PAIR_SEED   // probe: r / z chains start from gi instead of adding it in the gates
+                    acc[g] = mfma4(a[m % 3][e], W[g][m][e], (m | e) ? acc[g] : g < 2 ? G[x][g] : bnv);
+#else
                     acc[g] = mfma4(a[m % 3][e], W[g][m][e], (m | e) ? acc[g] : g < 2 ? splat4(0.f) : bnv);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             if (m + 2 < 8) a[(m + 2) % 3] = hb[(m + 2) * 64];
             __builtin_amdgcn_sched_barrier(0);
@@ -219,6 +223,8 @@ __device__ __forceinline__ void gru_pair_body(f32x4* __restrict__ smem, const in
         __builtin_amdgcn_sched_barrier(0);
 #ifdef HELEN_PAIR_NOGATES   // timing probe: MFMA phase + barrier only (results are garbage)
         const f32x4 hn = acc[0] + acc[1] + acc[2] + G[x][0] + G[x][1] + G[x][2];
+#elif defined(HELEN_PAIR_SEED)
+        const f32x4 hn = gru_cell4(acc[0], acc[1], acc[2], G[x][2], hprev[x]);
 #else
         const f32x4 hn = gru_cell4(acc[0], acc[1], acc[2], G[x][0], G[x][1], G[x][2], hprev[x]);
 #endif
