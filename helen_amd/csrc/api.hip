@@ -367,6 +367,14 @@ bool use_single8_recurrence(int tiles, int cus) {
     return 2 * tiles <= cus;
 }
 
+// At most a quarter of the CUs in tiles: half tiles of 8 windows on v_mfma_f32_4x4x1_16b_f32, 4 x tiles workgroups (same
+// results bit for bit).  (HELEN_GRU_HALF8=0/1 forces one: A/B probes.)
+bool use_half8_recurrence(int tiles, int cus) {
+    const char* force = getenv("HELEN_GRU_HALF8");
+    if (force && *force) return *force == '1';
+    return 4 * tiles <= cus;
+}
+
 bool use_bf16_pair(int tiles, int cus) {
     static const char* force = getenv("HELEN_BF16_PAIR");
     if (force && *force) return *force == '1';
@@ -441,6 +449,10 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
         LAUNCH(HELEN_K_GRU_ENC, gru_pair_kernel<false>, dim3((tiles + 1) / 2, 2), dim3(512), m->gi_enc,
                kGiEncTileStride, pos0, enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride,
                (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride, tiles);
+    else if (use_half8_recurrence(tiles, m->cus))
+        LAUNCH(HELEN_K_GRU_ENC, gru_half8_kernel<false>, dim3(2 * tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
+               enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride, (const f32x4*)nullptr,
+               (f32x4*)nullptr, kPlTileStride);
     else if (use_single8_recurrence(tiles, m->cus))
         LAUNCH(HELEN_K_GRU_ENC, gru_single8_kernel<false>, dim3(tiles, 2), dim3(512), m->gi_enc, kGiEncTileStride, pos0,
                enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride, (const f32x4*)nullptr,
@@ -459,6 +471,9 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
         LAUNCH(HELEN_K_GRU_DEC, gru_pair_kernel<true>, dim3((tiles + 1) / 2, 2), dim3(512), m->gi_dec,
                kGiDecTileStride, 0, 0, T, m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd,
                m->plogit, kPlTileStride, tiles);
+    else if (use_half8_recurrence(tiles, m->cus))
+        LAUNCH(HELEN_K_GRU_DEC, gru_half8_kernel<true>, dim3(2 * tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, 0, T,
+               m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd, m->plogit, kPlTileStride);
     else if (use_single8_recurrence(tiles, m->cus))
         LAUNCH(HELEN_K_GRU_DEC, gru_single8_kernel<true>, dim3(tiles, 2), dim3(512), m->gi_dec, kGiDecTileStride, 0, 0, T,
                m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd, m->plogit, kPlTileStride);

@@ -11,6 +11,7 @@
 #include "kernels_gru.h"
 #include "kernels_gru_pair.h"
 #include "kernels_gru_single8.h"
+#include "kernels_gru_half8.h"
 #include "kernels_x3.h"
 #include "kernels_fused_bf16.h"
 #include "kernels_fused_bf16_pair.h"

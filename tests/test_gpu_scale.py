@@ -249,6 +249,35 @@ def test_single_tile_recurrences_give_the_same_bits(scale_case, monkeypatch):
     eng.close()
 
 
+def test_half_tile_recurrence_gives_the_same_bits(scale_case, monkeypatch):
+    """Calls of at most 64 tiles take gru_half8_kernel: 8 windows per workgroup on v_mfma_f32_4x4x1_16b_f32, whose
+    k-ordered chains are the 16x16x4 kernels' chains.  HELEN_GRU_HALF8 forces either; same bits for a call with a ragged
+    last tile, for an odd step count, for a single step and for a call that is larger than the kernel's default range."""
+    from helen_amd.engine import HelenEngine
+    w, img, _ = scale_case
+    dev = torch.from_numpy(img[3000:3000 + 1000]).cuda()            # 63 tiles, the last one half full
+    eng = HelenEngine(w, device=0, max_windows=1500)
+    x = torch.rand((700, 37, 90), device="cuda") * 255
+    h = torch.rand((700, 2, 128), device="cuda") - 0.5
+    big = torch.from_numpy(img[8000:8000 + 1500]).cuda()
+    got = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("HELEN_GRU_HALF8", flag)
+        monkeypatch.setenv("HELEN_GRU_PAIR", "0")
+        got[flag] = (eng.polish(dev, want_acc=True), eng.chunk_forward(x, h), eng.chunk_forward(x[:33, :1], h[:33]),
+                     eng.polish(dev[:9], want_acc=True), eng.polish(big, want_acc=True))
+        torch.cuda.synchronize()
+    for a, b in zip(got["0"], got["1"]):
+        for u, v_ in zip(a, b):
+            assert torch.equal(u, v_)
+    # the default takes it for this size
+    monkeypatch.delenv("HELEN_GRU_HALF8")
+    monkeypatch.delenv("HELEN_GRU_PAIR")
+    for u, v_ in zip(eng.polish(dev, want_acc=True), got["0"][0]):
+        assert torch.equal(u, v_)
+    eng.close()
+
+
 def test_every_fp32_kernel_choice_gives_the_same_bits(scale_case):
     """A 4096-window call takes gru_pair_kernel, gemm_dec_ws_kernel and gemm_enc_ws8_kernel; 1024-window calls
     take gru_kernel, gemm_gi_kernel<16, true> and gemm_gi_kernel<6, false>; 3000 windows (188 tiles) take the
