@@ -375,6 +375,13 @@ bool use_half8_recurrence(int tiles, int cus) {
     return 4 * tiles <= cus;
 }
 
+// ... and at most an eighth: quarter tiles of 4 windows, 8 x tiles workgroups.  (HELEN_GRU_QUARTER4=0/1 forces one.)
+bool use_quarter4_recurrence(int tiles, int cus) {
+    const char* force = getenv("HELEN_GRU_QUARTER4");
+    if (force && *force) return *force == '1';
+    return 8 * tiles <= cus;
+}
+
 bool use_bf16_pair(int tiles, int cus) {
     static const char* force = getenv("HELEN_BF16_PAIR");
     if (force && *force) return *force == '1';
@@ -449,6 +456,10 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
         LAUNCH(HELEN_K_GRU_ENC, gru_pair_kernel<false>, dim3((tiles + 1) / 2, 2), dim3(512), m->gi_enc,
                kGiEncTileStride, pos0, enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride,
                (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride, tiles);
+    else if (use_quarter4_recurrence(tiles, m->cus))
+        LAUNCH(HELEN_K_GRU_ENC, gru_quarter4_kernel<false>, dim3(4 * tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
+               enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride, (const f32x4*)nullptr,
+               (f32x4*)nullptr, kPlTileStride);
     else if (use_half8_recurrence(tiles, m->cus))
         LAUNCH(HELEN_K_GRU_ENC, gru_half8_kernel<false>, dim3(2 * tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
                enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride, (const f32x4*)nullptr,
@@ -471,6 +482,9 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
         LAUNCH(HELEN_K_GRU_DEC, gru_pair_kernel<true>, dim3((tiles + 1) / 2, 2), dim3(512), m->gi_dec,
                kGiDecTileStride, 0, 0, T, m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd,
                m->plogit, kPlTileStride, tiles);
+    else if (use_quarter4_recurrence(tiles, m->cus))
+        LAUNCH(HELEN_K_GRU_DEC, gru_quarter4_kernel<true>, dim3(4 * tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, 0, T,
+               m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd, m->plogit, kPlTileStride);
     else if (use_half8_recurrence(tiles, m->cus))
         LAUNCH(HELEN_K_GRU_DEC, gru_half8_kernel<true>, dim3(2 * tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, 0, T,
                m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd, m->plogit, kPlTileStride);

@@ -229,3 +229,211 @@ __global__ __launch_bounds__(256, 1) void gru_half8_kernel(const f32x4* __restri
 }
 
 }  // namespace helen
+
+namespace helen {
+
+// ------------------------------------------------------------------------------------------------
+// gru_quarter4_kernel: the same idea one step further, for calls of at most an eighth of the CUs in tiles (32 tiles =
+// 512 windows on 256 CUs): FOUR windows of a tile per workgroup, 8 x tiles workgroups.  All 16 blocks of an MFMA belong
+// to the one window group, so an instruction covers 64 columns and A is broadcast from one block to all sixteen
+// (CBSZ = 4: a register holds 16 k for the 4 windows, 8 registers per step).  A wave still owns 32 hidden units of all
+// three gates = 96 columns = one and a half instructions per k:
+//     MFMA 1: blocks 0-7 the r columns, blocks 8-15 the z columns of its units (one W register per k),
+//     MFMA 2: the n columns in both halves (BLGP: two k per W register; the second copy is idle work: 2 MFMAs per k
+//             where 1.5 would do, 256 per step = 2,222 cycles against gru_half8_kernel's 3,333).
+// Lane l < 32 then holds r and n of (4 windows, unit u), lane l + 32 holds z and n of the same unit: one exchange of
+// the r | z accumulator between the two halves (__shfl_xor 32), both halves do the same gate math, the lower one
+// writes.  Chains, gate cell and head sums as everywhere: the same bits.
+// Decoder heads: blocks (k-slice, class quad), four slices per instruction: waves 0 and 1 take slices 0-3 and 4-7.
+// grid (4 x tiles, 2 directions), 256 threads.
+// ------------------------------------------------------------------------------------------------
+constexpr int kQuarter4AF4 = 2 * 2 * 64;   // abuf [buffer][group of four k-sixteens][lane]
+constexpr int kQuarter4HF4 = 2 * 128;      // hbuf [buffer][unit quad][row of the quarter]
+constexpr int kQuarter4PF4 = 2 * 8 * 16;   // head partials [parity][k-slice][class]
+
+template <bool DEC>
+__global__ __launch_bounds__(256, 1) void gru_quarter4_kernel(const f32x4* __restrict__ gi, long gi_tile_stride,
+                                                              int slot0_fwd, int slot0_bwd, int T,
+                                                              const f32x4* __restrict__ Whp,
+                                                              const float* __restrict__ bhn,
+                                                              f32x4* __restrict__ hid, f32x4* __restrict__ y,
+                                                              long y_tile_stride, const f32x4* __restrict__ Whd,
+                                                              f32x4* __restrict__ plogit, long pl_tile_stride) {
+    __shared__ f32x4 smem[kQuarter4AF4 + kQuarter4HF4 + (DEC ? kQuarter4PF4 : 0)];
+    f32x4* const abuf = smem;
+    f32x4* const hbuf = smem + kQuarter4AF4;
+    f32x4* const part = smem + kQuarter4AF4 + kQuarter4HF4;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = lane >> 2, j = lane & 3;
+    const int upper = b >> 3, cq = b & 7;         // upper half of the wave: the z columns in MFMA 1
+    const int tile = blockIdx.x >> 2, qt = blockIdx.x & 3;
+    const int dir = blockIdx.y;
+    const int slot0 = dir ? slot0_bwd : slot0_fwd;
+    const int u = 32 * w + 4 * cq + j;            // this lane's hidden unit (rows r of the quarter)
+
+    // W_hh from the 16x16x4 packing (see gru_half8_kernel): Wrz[t] = column (upper ? z : r, u), k(t);
+    // Wn[tt] = column (n, u), k(t) of t = 2 tt + upper
+    float Wrz[128], Wn[64];
+    {
+        const int v8 = u >> 4, j16 = u & 15;
+        const float* wp = (const float*)(Whp + (size_t)((dir * 4 + (v8 >> 1)) * 48) * 64);
+#pragma unroll
+        for (int t = 0; t < 128; ++t) {
+            const int m = t >> 4, e = (t >> 2) & 3, q = t & 3;
+            Wrz[t] = wp[(((2 * upper + (v8 & 1)) * 8 + m) * 64 + j16 + 16 * q) * 4 + e];
+        }
+#pragma unroll
+        for (int tt = 0; tt < 64; ++tt) {
+            const int m = tt >> 3, e = (tt >> 1) & 3, q = 2 * (tt & 1) + upper;
+            Wn[tt] = wp[(((4 + (v8 & 1)) * 8 + m) * 64 + j16 + 16 * q) * 4 + e];
+        }
+    }
+    const f32x4 bnv = splat4(bhn[dir * kH + u]);
+    // decoder heads (waves 0 and 1): blocks bH = (slice sl = bH >> 2, class quad pH = bH & 3)
+    const int slH = b >> 2, pH = b & 3;
+    float HB[16];
+    if (DEC && w < 2) {
+        const float* hw = (const float*)(Whd + (size_t)(dir * 8 + 4 * w + slH) * 64);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) HB[e * 4 + q] = hw[(4 * pH + j + 16 * q) * 4 + e];
+    }
+
+    constexpr long kPosBytes = 2 * kNTile * 64 * 16;
+    const char* gi_next = (const char*)(gi + (size_t)tile * gi_tile_stride + (size_t)dir * (kNTile * 64) + 16 * qt) +
+                          (size_t)slot0 * kPosBytes;
+    const unsigned gi16 = (unsigned)((u >> 4) * 64 + (u & 15)) * 16u;
+    char* y_next = (char*)(y + (size_t)tile * y_tile_stride + (size_t)dir * (kHidDirStride / 4) + 4 * qt);
+    char* pl_next = (char*)(plogit + (size_t)tile * pl_tile_stride + (size_t)dir * 64 + 16 * qt);
+    f32x4* const hid_s = hid + ((size_t)tile * 2 + dir) * (kHidDirStride / 4) + 4 * qt;
+    // thread < 128 -> (unit quad, row of the quarter) of the tile layout
+    const unsigned tile16 = (unsigned)(((tid & 127) >> 2) * 16 + (tid & 3)) * 16u;
+    const bool mover = tid < 128;
+
+    f32x4 G[2][3];
+    auto load_gi = [&](int p) __attribute__((always_inline)) {
+        const unsigned l16 = in_block(gi16);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) G[p][g] = *(const f32x4*)(gi_next + (l16 + (unsigned)g * 8192u));
+        gi_next += kPosBytes;
+    };
+    int aoff, hoff;
+    {
+        const int m = u >> 4, e = u & 3, q = (u >> 2) & 3;
+        aoff = ((m >> 2) * 64 + 4 * (4 * e + q)) * 4 + (m & 3);
+        hoff = (u >> 2) * 16 + (u & 3);
+    }
+    if (mover) {   // initial state: the tile layout into hbuf[0], scattered into abuf[0]
+        const f32x4 h0 = *(const f32x4*)((const char*)hid_s + tile16);
+        hbuf[tid] = h0;
+        const int uq = tid >> 2, rho = tid & 3, m = uq >> 2, q = uq & 3;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ((float*)abuf)[((m >> 2) * 64 + 4 * (4 * c + q) + rho) * 4 + (m & 3)] = h0[c];
+    }
+    load_gi(0);
+    __syncthreads();
+    float hprev[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hprev[r] = ((const float*)hbuf)[hoff + 4 * r];
+    f32x4 A4[2];
+    A4[0] = abuf[lane];
+    A4[1] = abuf[64 + lane];
+
+    auto sum_partials = [&](int pb) __attribute__((always_inline)) {   // lanes 0..15: class
+        const f32x4* ps = part + pb * 128 + (lane & 15);
+        return (((ps[0] + ps[16]) + (ps[32] + ps[48])) + (ps[64] + ps[80])) + (ps[96] + ps[112]);
+    };
+    const unsigned plo = (unsigned)(lane & 15) * 16u;
+    auto head_product = [&](const f32x4 hd) __attribute__((always_inline)) {
+        f32x4 hp = splat4(0.f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hp = __builtin_amdgcn_mfma_f32_4x4x1f32(hd[e], HB[e * 4 + 0], hp, 2, 0, 0);
+            hp = __builtin_amdgcn_mfma_f32_4x4x1f32(hd[e], HB[e * 4 + 1], hp, 2, 1, 0);
+            hp = __builtin_amdgcn_mfma_f32_4x4x1f32(hd[e], HB[e * 4 + 2], hp, 2, 2, 0);
+            hp = __builtin_amdgcn_mfma_f32_4x4x1f32(hd[e], HB[e * 4 + 3], hp, 2, 3, 0);
+        }
+        return hp;
+    };
+    auto step = [&](auto CUR, int s) __attribute__((always_inline)) {
+        constexpr int cur = decltype(CUR)::value;
+        const bool has_prev = s > 0, has_prev2 = s > 1, has_next = s + 1 < T;
+        f32x4 arz = splat4(0.f), an = bnv, yv = splat4(0.f), hd = splat4(0.f), hp = splat4(0.f);
+        if (has_next) load_gi(cur ^ 1);
+        if (!DEC && has_prev && mover) yv = hbuf[cur * 128 + tid];
+        if (DEC && has_prev && w < 2) hd = hbuf[cur * 128 + (4 * (4 * w + slH) + pH) * 4 + j];
+        half8_for<128>([&](auto TT) __attribute__((always_inline)) {
+            constexpr int t = decltype(TT)::value;
+            if constexpr ((t & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+            arz = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[t >> 6][(t >> 4) & 3], Wrz[t], arz, 4, t & 15, 0);
+            an = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[t >> 6][(t >> 4) & 3], Wn[t >> 1], an, 4, t & 15, 1 + (t & 1));
+            if constexpr (t == 15 && DEC) {
+                if (has_prev && w < 2) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    hp = head_product(hd);
+                }
+            }
+            if constexpr (t == 31 && !DEC) {
+                if (has_prev) {
+                    if (mover) *(f32x4*)(y_next + in_block(tile16)) = yv;
+                    y_next += kYStride * 4;
+                }
+            }
+        });
+        if (DEC && has_prev2) {
+            if (w == ((s - 2) & 3) && lane < 16) *(f32x4*)(pl_next + in_block(plo)) = sum_partials(s & 1);
+            pl_next += 128 * 16;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // r | z: the lower half holds r and receives z, the upper half holds z and receives r
+        const f32x4 other = {__shfl_xor(arz.x, 32), __shfl_xor(arz.y, 32), __shfl_xor(arz.z, 32), __shfl_xor(arz.w, 32)};
+        const f32x4 ar = upper ? other : arz, az = upper ? arz : other;
+        const f32x4 hn = gru_cell4(ar, az, an, G[cur][0], G[cur][1], G[cur][2], hprev);
+        float* aw = (float*)(abuf + (cur ^ 1) * 128);
+        float* hw = (float*)(hbuf + (cur ^ 1) * 128);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            hprev[r] = hn[r];
+            if (!upper) {
+                aw[aoff + 4 * r] = hn[r];
+                hw[hoff + 4 * r] = hn[r];
+            }
+        }
+        if (DEC && has_prev && w < 2) part[(((s - 1) & 1) * 8 + 4 * w + slH) * 16 + 4 * pH + j] = hp;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        A4[0] = abuf[(cur ^ 1) * 128 + lane];
+        A4[1] = abuf[(cur ^ 1) * 128 + 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    int s = 0;
+    for (; s + 1 < T; s += 2) {
+        step(I0{}, s);
+        step(I1{}, s + 1);
+    }
+    if (s < T) step(I0{}, s);
+    const int last = T & 1;   // buffer of h(T-1)
+    if (DEC) {
+        if (T >= 2) {
+            if (w == ((T - 2) & 3) && lane < 16) *(f32x4*)(pl_next + plo) = sum_partials((T - 2) & 1);
+            pl_next += 128 * 16;
+        }
+        if (w < 2) {
+            const f32x4 hp = head_product(hbuf[last * 128 + (4 * (4 * w + slH) + pH) * 4 + j]);
+            part[(((T - 1) & 1) * 8 + 4 * w + slH) * 16 + 4 * pH + j] = hp;
+        }
+        __syncthreads();
+        if (w == ((T - 1) & 3) && lane < 16) *(f32x4*)(pl_next + plo) = sum_partials((T - 1) & 1);
+    } else if (mover) {
+        *(f32x4*)(y_next + tile16) = hbuf[last * 128 + tid];
+    }
+    if (mover) *(f32x4*)((char*)hid_s + tile16) = hbuf[last * 128 + tid];
+}
+
+}  // namespace helen

@@ -113,6 +113,9 @@ int main() {
     layout_case<0, 0, 1>("B of lanes 0-31 to all");
     layout_case<0, 0, 2>("B of lanes 32-63 to all");
     layout_case<3, 6, 2>("both");
+    layout_case<4, 0, 0>("A of block 0 to all 16 blocks");
+    layout_case<4, 11, 0>("A of block 11 to all 16 blocks");
+    layout_case<4, 11, 1>("A of block 11 to all, B of lanes 0-31");
     {   // bit identity of the k-ordered chain
         int differ = 0, total = 0;
         float *dh, *dw, *o4, *o16;

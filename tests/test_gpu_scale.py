@@ -249,10 +249,11 @@ def test_single_tile_recurrences_give_the_same_bits(scale_case, monkeypatch):
     eng.close()
 
 
-def test_half_tile_recurrence_gives_the_same_bits(scale_case, monkeypatch):
-    """Calls of at most 64 tiles take gru_half8_kernel: 8 windows per workgroup on v_mfma_f32_4x4x1_16b_f32, whose
-    k-ordered chains are the 16x16x4 kernels' chains.  HELEN_GRU_HALF8 forces either; same bits for a call with a ragged
-    last tile, for an odd step count, for a single step and for a call that is larger than the kernel's default range."""
+def test_part_tile_recurrences_give_the_same_bits(scale_case, monkeypatch):
+    """Calls of at most 64 tiles take gru_half8_kernel (8 windows per workgroup), of at most 32 tiles gru_quarter4_kernel
+    (4 windows), both on v_mfma_f32_4x4x1_16b_f32, whose k-ordered chains are the 16x16x4 kernels' chains.
+    HELEN_GRU_HALF8 / HELEN_GRU_QUARTER4 force either; same bits for calls with a ragged last tile, for an odd step
+    count, for a single step and for a call that is larger than the kernels' default range."""
     from helen_amd.engine import HelenEngine
     w, img, _ = scale_case
     dev = torch.from_numpy(img[3000:3000 + 1000]).cuda()            # 63 tiles, the last one half full
@@ -261,20 +262,24 @@ def test_half_tile_recurrence_gives_the_same_bits(scale_case, monkeypatch):
     h = torch.rand((700, 2, 128), device="cuda") - 0.5
     big = torch.from_numpy(img[8000:8000 + 1500]).cuda()
     got = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("HELEN_GRU_HALF8", flag)
+    for name, half, quarter in (("whole", "0", "0"), ("half", "1", "0"), ("quarter", "0", "1")):
+        monkeypatch.setenv("HELEN_GRU_HALF8", half)
+        monkeypatch.setenv("HELEN_GRU_QUARTER4", quarter)
         monkeypatch.setenv("HELEN_GRU_PAIR", "0")
-        got[flag] = (eng.polish(dev, want_acc=True), eng.chunk_forward(x, h), eng.chunk_forward(x[:33, :1], h[:33]),
-                     eng.polish(dev[:9], want_acc=True), eng.polish(big, want_acc=True))
+        got[name] = (eng.polish(dev, want_acc=True), eng.chunk_forward(x, h), eng.chunk_forward(x[:33, :1], h[:33]),
+                     eng.polish(dev[:9], want_acc=True), eng.polish(dev[:3], want_acc=True), eng.polish(big, want_acc=True))
         torch.cuda.synchronize()
-    for a, b in zip(got["0"], got["1"]):
-        for u, v_ in zip(a, b):
-            assert torch.equal(u, v_)
-    # the default takes it for this size
-    monkeypatch.delenv("HELEN_GRU_HALF8")
-    monkeypatch.delenv("HELEN_GRU_PAIR")
-    for u, v_ in zip(eng.polish(dev, want_acc=True), got["0"][0]):
+    for name in ("half", "quarter"):
+        for a, b in zip(got["whole"], got[name]):
+            for u, v_ in zip(a, b):
+                assert torch.equal(u, v_), name
+    # the defaults take them for these sizes: 1000 windows the half tiles, 500 the quarter tiles
+    for k in ("HELEN_GRU_HALF8", "HELEN_GRU_QUARTER4", "HELEN_GRU_PAIR"):
+        monkeypatch.delenv(k)
+    for u, v_ in zip(eng.polish(dev, want_acc=True), got["whole"][0]):
         assert torch.equal(u, v_)
+    for u, v_ in zip(eng.polish(dev[:500], want_acc=True), got["whole"][0]):
+        assert torch.equal(u, v_[:500])
     eng.close()
 
 
