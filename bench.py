@@ -96,6 +96,32 @@ def cpu_baseline(batch, seconds_target=12.0):
                       "8-window blocks, %d threads = usable CPUs under the cgroup quota), %.1f s" % (n, threads, dt)}
 
 
+def call_size_report(images, dev):
+    """Throughput of ONE fp32 device call of fewer windows than the headline's 4096 (inputs resident in HBM; 1 warm-up call,
+    then 6 timed ones): which kernels a call takes depends on how many tiles it has (quarter / half tiles on
+    v_mfma_f32_4x4x1_16b_f32 up to 32 / 64 tiles, one 8-wave workgroup per (tile, direction) up to 128, two tile groups on
+    two streams up to 239, tile pairs above: DESIGN.md 4 and 6).  All choices give the same bits (tests/test_gpu_scale.py)."""
+    import torch
+    from helen_amd.engine import HelenEngine
+    from helen_amd.weights import make_weights
+    out = {"unit": "windows/s", "what": call_size_report.__doc__.split(":")[0].replace("\n    ", " ")}
+    for n in (256, 512, 1024, 2048, 3072):
+        if images.shape[0] < n:
+            continue
+        e = HelenEngine(make_weights(input_scale=1.0 / 64.0), device=dev.index, max_windows=n)
+        try:
+            e.polish(images[:n])
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(6):
+                e.polish(images[:n])
+            torch.cuda.synchronize(dev)
+            out[str(n)] = round(6 * n / (time.perf_counter() - t0), 1)
+        finally:
+            e.close()
+    return out
+
+
 def margin_report(images, dev, precision):
     """Which labels can move: the top-1 / top-2 margin histogram of the fp32 path's accumulated softmax over up to
     4096 windows of the shard, for the bench's random-init network (heads x8) and for the `peaked` stand-in of a
@@ -568,7 +594,12 @@ def main():
         if args.precision != "fp32":
             out["precision_check"] = precision_check(eng, args.precision, images, dev)
         if not args.no_margins:
-            eng.close()            # the report builds engines of its own
+            eng.close()            # the reports build engines of their own
+            if args.precision == "fp32":
+                try:
+                    out["call_sizes"] = call_size_report(images, dev)
+                except Exception as e:      # noqa: BLE001 -- reported in the JSON line
+                    out["call_sizes"] = {"error": "%s: %s" % (type(e).__name__, e)}
             out["margins"] = margin_report(images, dev, args.precision)
         if host_error is not None:
             out["host_path"] = {"value": None, "error": host_error}
