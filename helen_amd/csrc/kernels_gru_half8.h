@@ -389,6 +389,8 @@ __global__ __launch_bounds__(256, 1) void gru_quarter4_kernel(const f32x4* __res
         }
         __builtin_amdgcn_sched_barrier(0);
         // r | z: the lower half holds r and receives z, the upper half holds z and receives r
+        // (four __shfl_xor: a loop of __builtin_amdgcn_ds_bpermute over the vector's elements came out of hipcc 7.2 with
+        // element 0 as the source of all four -- scripts/dev/ab_part_tiles.py showed rows 1-3 wrong)
         const f32x4 other = {__shfl_xor(arz.x, 32), __shfl_xor(arz.y, 32), __shfl_xor(arz.z, 32), __shfl_xor(arz.w, 32)};
         const f32x4 ar = upper ? other : arz, az = upper ? arz : other;
         const f32x4 hn = gru_cell4(ar, az, an, G[cur][0], G[cur][1], G[cur][2], hprev);
