@@ -162,25 +162,22 @@ __global__ __launch_bounds__(256, 1) void gru_half8_kernel(const f32x4* __restri
         if (DEC && has_prev) hd = hbuf[cur * 256 + (4 * (2 * w + slH) + pH) * 8 + 4 * wgH + j];
         half8_for<128>([&](auto TT) __attribute__((always_inline)) {
             constexpr int t = decltype(TT)::value;
-            if constexpr ((t & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 const f32x4 c = t ? acc[g] : g < 2 ? splat4(0.f) : bnv;
                 acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[t >> 5][(t >> 3) & 3], Wr[g][t >> 1], c, 3, t & 7, 1 + (t & 1));
             }
-            if constexpr (t == 15 && DEC) {
-                if (has_prev) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    hp = head_product(hd);
-                }
-            }
-            if constexpr (t == 31 && !DEC) {
-                if (has_prev) {
-                    *(f32x4*)(y_next + in_block(tile16)) = yv;
-                    y_next += kYStride * 4;
-                }
-            }
+
         });
+        // (no branch inside the MFMA stream: hipcc sinks the part of a chain that sits in front of one into the block
+        // behind it -- that chain's MFMAs then run back to back, two wait states each)
+        __builtin_amdgcn_sched_barrier(0);
+        if (DEC && has_prev) hp = head_product(hd);
+        if (!DEC && has_prev) {
+            *(f32x4*)(y_next + in_block(tile16)) = yv;
+            y_next += kYStride * 4;
+        }
         // DEC: the partials of slot s-2 were written in the gates of step s-1 and published by the barrier since
         if (DEC && has_prev2) {
             if (w == ((s - 2) & 3) && lane < 32) *(f32x4*)(pl_next + in_block(plo)) = sum_partials(s & 1);
@@ -242,7 +239,7 @@ namespace helen {
 //     MFMA 2: the n columns in both halves (BLGP: two k per W register; the second copy is idle work: 2 MFMAs per k
 //             where 1.5 would do, 256 per step = 2,222 cycles against gru_half8_kernel's 3,333).
 // Lane l < 32 then holds r and n of (4 windows, unit u), lane l + 32 holds z and n of the same unit: one exchange of
-// the r | z accumulator between the two halves (__shfl_xor 32), both halves do the same gate math, the lower one
+// the r | z accumulator between the two halves (v_permlane32_swap_b32), both halves do the same gate math, the lower one
 // writes.  Chains, gate cell and head sums as everywhere: the same bits.
 // Decoder heads: blocks (k-slice, class quad), four slices per instruction: waves 0 and 1 take slices 0-3 and 4-7.
 // grid (4 x tiles, 2 directions), 256 threads.
@@ -367,32 +364,34 @@ __global__ __launch_bounds__(256, 1) void gru_quarter4_kernel(const f32x4* __res
         if (DEC && has_prev && w < 2) hd = hbuf[cur * 128 + (4 * (4 * w + slH) + pH) * 4 + j];
         half8_for<128>([&](auto TT) __attribute__((always_inline)) {
             constexpr int t = decltype(TT)::value;
-            if constexpr ((t & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
             arz = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[t >> 6][(t >> 4) & 3], Wrz[t], arz, 4, t & 15, 0);
             an = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[t >> 6][(t >> 4) & 3], Wn[t >> 1], an, 4, t & 15, 1 + (t & 1));
-            if constexpr (t == 15 && DEC) {
-                if (has_prev && w < 2) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    hp = head_product(hd);
-                }
-            }
-            if constexpr (t == 31 && !DEC) {
-                if (has_prev) {
-                    if (mover) *(f32x4*)(y_next + in_block(tile16)) = yv;
-                    y_next += kYStride * 4;
-                }
-            }
         });
+        __builtin_amdgcn_sched_barrier(0);   // (no branch inside the MFMA stream: see gru_half8_kernel)
+        if (DEC && has_prev && w < 2) hp = head_product(hd);
+        if (!DEC && has_prev) {
+            if (mover) *(f32x4*)(y_next + in_block(tile16)) = yv;
+            y_next += kYStride * 4;
+        }
         if (DEC && has_prev2) {
             if (w == ((s - 2) & 3) && lane < 16) *(f32x4*)(pl_next + in_block(plo)) = sum_partials(s & 1);
             pl_next += 128 * 16;
         }
         __builtin_amdgcn_sched_barrier(0);
         // r | z: the lower half holds r and receives z, the upper half holds z and receives r
-        // (four __shfl_xor: a loop of __builtin_amdgcn_ds_bpermute over the vector's elements came out of hipcc 7.2 with
-        // element 0 as the source of all four -- scripts/dev/ab_part_tiles.py showed rows 1-3 wrong)
-        const f32x4 other = {__shfl_xor(arz.x, 32), __shfl_xor(arz.y, 32), __shfl_xor(arz.z, 32), __shfl_xor(arz.w, 32)};
-        const f32x4 ar = upper ? other : arz, az = upper ? arz : other;
+        // v_permlane32_swap_b32 with the accumulator as both operands: result 0 = the lower half's values in both halves
+        // (r), result 1 = the upper half's (z).  (__builtin_bit_cast applied directly to `arz[r]` in this unrolled loop came out
+        // of hipcc 7.2 reading element 0 for every r -- scripts/dev/ab_part_tiles.py showed rows 1-3 wrong --, hence the scalar.)
+        f32x4 ar, az;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float f = arz[r];      // (a scalar first: see above)
+            const unsigned x = __builtin_bit_cast(unsigned, f);
+            const auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+            ar[r] = __builtin_bit_cast(float, (unsigned)sw[0]);
+            az[r] = __builtin_bit_cast(float, (unsigned)sw[1]);
+        }
         const f32x4 hn = gru_cell4(ar, az, an, G[cur][0], G[cur][1], G[cur][2], hprev);
         float* aw = (float*)(abuf + (cur ^ 1) * 128);
         float* hw = (float*)(hbuf + (cur ^ 1) * 128);
