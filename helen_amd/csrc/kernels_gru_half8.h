@@ -159,7 +159,9 @@ __global__ __launch_bounds__(256, 1) void gru_half8_kernel(const f32x4* __restri
         f32x4 acc[3], yv = splat4(0.f), hd = splat4(0.f), hp = splat4(0.f);
         if (has_next) load_gi(cur ^ 1);
         if (!DEC && has_prev) yv = hbuf[cur * 256 + tid];
-        if (DEC && has_prev) hd = hbuf[cur * 256 + (4 * (2 * w + slH) + pH) * 8 + 4 * wgH + j];
+        // (DEC: the head product of h(s-1) rides in the stream, one MFMA per k of its sixteen; at s = 0 it multiplies the
+        // initial state and nobody takes the result)
+        if (DEC) hd = hbuf[cur * 256 + (4 * (2 * w + slH) + pH) * 8 + 4 * wgH + j];
         half8_for<128>([&](auto TT) __attribute__((always_inline)) {
             constexpr int t = decltype(TT)::value;
             __builtin_amdgcn_sched_barrier(0);
@@ -168,12 +170,13 @@ __global__ __launch_bounds__(256, 1) void gru_half8_kernel(const f32x4* __restri
                 const f32x4 c = t ? acc[g] : g < 2 ? splat4(0.f) : bnv;
                 acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[t >> 5][(t >> 3) & 3], Wr[g][t >> 1], c, 3, t & 7, 1 + (t & 1));
             }
+            if constexpr (DEC && t >= 16 && t < 32)
+                hp = __builtin_amdgcn_mfma_f32_4x4x1f32(hd[(t - 16) >> 2], HB[t - 16], hp, 2, (t - 16) & 3, 0);
 
         });
         // (no branch inside the MFMA stream: hipcc sinks the part of a chain that sits in front of one into the block
         // behind it -- that chain's MFMAs then run back to back, two wait states each)
         __builtin_amdgcn_sched_barrier(0);
-        if (DEC && has_prev) hp = head_product(hd);
         if (!DEC && has_prev) {
             *(f32x4*)(y_next + in_block(tile16)) = yv;
             y_next += kYStride * 4;
@@ -291,8 +294,8 @@ __global__ __launch_bounds__(256, 1) void gru_quarter4_kernel(const f32x4* __res
     // decoder heads (waves 0 and 1): blocks bH = (slice sl = bH >> 2, class quad pH = bH & 3)
     const int slH = b >> 2, pH = b & 3;
     float HB[16];
-    if (DEC && w < 2) {
-        const float* hw = (const float*)(Whd + (size_t)(dir * 8 + 4 * w + slH) * 64);
+    if (DEC) {   // (waves 2 and 3 repeat the products of waves 0 and 1 and drop them: no branch in the MFMA stream)
+        const float* hw = (const float*)(Whd + (size_t)(dir * 8 + 4 * (w & 1) + slH) * 64);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -361,15 +364,16 @@ __global__ __launch_bounds__(256, 1) void gru_quarter4_kernel(const f32x4* __res
         f32x4 arz = splat4(0.f), an = bnv, yv = splat4(0.f), hd = splat4(0.f), hp = splat4(0.f);
         if (has_next) load_gi(cur ^ 1);
         if (!DEC && has_prev && mover) yv = hbuf[cur * 128 + tid];
-        if (DEC && has_prev && w < 2) hd = hbuf[cur * 128 + (4 * (4 * w + slH) + pH) * 4 + j];
+        if (DEC) hd = hbuf[cur * 128 + (4 * (4 * (w & 1) + slH) + pH) * 4 + j];
         half8_for<128>([&](auto TT) __attribute__((always_inline)) {
             constexpr int t = decltype(TT)::value;
             __builtin_amdgcn_sched_barrier(0);
             arz = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[t >> 6][(t >> 4) & 3], Wrz[t], arz, 4, t & 15, 0);
             an = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[t >> 6][(t >> 4) & 3], Wn[t >> 1], an, 4, t & 15, 1 + (t & 1));
+            if constexpr (DEC && t >= 16 && t < 32)
+                hp = __builtin_amdgcn_mfma_f32_4x4x1f32(hd[(t - 16) >> 2], HB[t - 16], hp, 2, (t - 16) & 3, 0);
         });
         __builtin_amdgcn_sched_barrier(0);   // (no branch inside the MFMA stream: see gru_half8_kernel)
-        if (DEC && has_prev && w < 2) hp = head_product(hd);
         if (!DEC && has_prev) {
             if (mover) *(f32x4*)(y_next + in_block(tile16)) = yv;
             y_next += kYStride * 4;
@@ -426,7 +430,7 @@ __global__ __launch_bounds__(256, 1) void gru_quarter4_kernel(const f32x4* __res
             pl_next += 128 * 16;
         }
         if (w < 2) {
-            const f32x4 hp = head_product(hbuf[last * 128 + (4 * (4 * w + slH) + pH) * 4 + j]);
+            const f32x4 hp = head_product(hbuf[last * 128 + (4 * (4 * w + slH) + pH) * 4 + j]);   // (w < 2: w & 1 = w)
             part[(((T - 1) & 1) * 8 + 4 * w + slH) * 16 + 4 * pH + j] = hp;
         }
         __syncthreads();
