@@ -303,6 +303,22 @@ int check_launch(const char* what) {
     return HELEN_OK;
 }
 
+// Small calls (at most a quarter of the CUs in tiles): gemm_dec_wsp_kernel, the weight-stationary projection with a
+// (tile, direction)'s positions cut into runs so that there is about one workgroup per CU (same gi bit for bit).
+// (HELEN_DEC_WSP=0/1 forces it off / on; HELEN_DEC_WSP_PARTS=n the number of runs: A/B probes.)
+bool use_wsp_dec_projection(int tiles, int T, int cus, int* parts, int* run) {
+    const char* force = getenv("HELEN_DEC_WSP");
+    if (force && *force == '0') return false;
+    if (!(force && *force == '1') && 4 * tiles > cus) return false;
+    int want = cus / (2 * ((tiles + 7) / 8 * 8));
+    if (const char* n = getenv("HELEN_DEC_WSP_PARTS")) want = atoi(n);
+    want = want < 1 ? 1 : want;
+    const int per = (T + want - 1) / want;
+    *run = (per + HELEN_DWS_PB - 1) / HELEN_DWS_PB * HELEN_DWS_PB;   // whole stages
+    *parts = (T + *run - 1) / *run;
+    return true;
+}
+
 // One TransducerGRU.forward over `tiles` tiles whose encoder pre-activations are already in
 // gi_enc at positions [pos0, pos0+T): encoder recurrence -> decoder projection -> decoder
 // recurrence.  plogit then holds the decoder's partial logits, hid the returned hidden state.
@@ -472,9 +488,13 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
         LAUNCH(HELEN_K_GRU_ENC, gru_kernel<false>, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
                enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride, (const f32x4*)nullptr,
                (f32x4*)nullptr, kPlTileStride);
+    int dec_parts = 0, dec_run = 0;
     if (use_ws_dec_projection(tiles, m->cus))
         LAUNCH(HELEN_K_GEMM_DEC, gemm_dec_ws_kernel, dim3(2 * ((tiles + 7) / 8 * 8)), dim3(512), m->y1, kYTileStride,
                m->wp_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
+    else if (use_wsp_dec_projection(tiles, T, m->cus, &dec_parts, &dec_run))
+        LAUNCH(HELEN_K_GEMM_DEC, gemm_dec_wsp_kernel, dim3(2 * ((tiles + 7) / 8 * 8) * dec_parts), dim3(512), m->y1,
+               kYTileStride, m->wp_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles, dec_parts, dec_run);
     else
         LAUNCH(HELEN_K_GEMM_DEC, (gemm_gi_kernel<16, true>), ggrid, gblock, m->y1, kYTileStride, m->wp_dec,
                m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);

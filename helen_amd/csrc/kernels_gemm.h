@@ -234,7 +234,10 @@ __device__ __forceinline__ void gemm_dec_ws_body(f32x4* __restrict__ smem, const
                                                  const f32x4* __restrict__ A, long a_tile_stride,
                                                  const f32x4* __restrict__ Wp,
                                                  const float* __restrict__ bias,
-                                                 f32x4* __restrict__ gi, long gi_tile_stride, int npos) {
+                                                 f32x4* __restrict__ gi, long gi_tile_stride, int npos,
+                                                 int p0 = 0, int p1 = -1) {
+    // positions [p0, p1) of the npos (all of them by default): gemm_dec_wsp_kernel splits a small call's positions
+    if (p1 < 0) p1 = npos;
     constexpr int MG = 16, PB = HELEN_DWS_PB, N = 3;
     constexpr int ROWS = PB * MG;            // 1 KiB rows per stage
     constexpr int RPP = ROWS / 8 / PB;       // rows a wave brings in per position (2)
@@ -259,13 +262,13 @@ __device__ __forceinline__ void gemm_dec_ws_body(f32x4* __restrict__ smem, const
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
             const int r = v + 8 * i;
-            const int pc = min(PB * g + r / MG, npos - 1);
+            const int pc = min(p0 + PB * g + r / MG, p1 - 1);
             const int m = r % MG;
             const int slot = m < MG / 2 ? pc : npos - 1 - pc;   // forward half of slot p | backward half of slot npos-1-p
             dma_row_to_lds(lds0 + (unsigned)((b * ROWS + r) * 1024), a_tile + ((size_t)slot * MG + m) * 1024, lane16);
         }
     };
-    const int ng = (npos + PB - 1) / PB;
+    const int ng = (p1 - p0 + PB - 1) / PB;
     stage_rows(0, 0, 0, ROWS / 8);
     for (int g = 0; g < ng; ++g) {
         // VMEM queue, oldest first: ... the last DMA rows of stage g, then the N output stores of the last position
@@ -295,7 +298,7 @@ __device__ __forceinline__ void gemm_dec_ws_body(f32x4* __restrict__ smem, const
             }
             // exactly N stores per lane per position (counted above): positions past the end of the last stage
             // rewrite the last valid one with identical values
-            const int pos = min(PB * g + p, npos - 1);
+            const int pos = min(p0 + PB * g + p, p1 - 1);
             const int slot = dir ? (npos - 1 - pos) : pos;
             char* o = o_tile + (size_t)slot * (2 * kNTile * 64 * 16) + in_block(lane16);
 #pragma unroll
@@ -315,6 +318,28 @@ __global__ __launch_bounds__(512, 1) void gemm_dec_ws_kernel(const f32x4* __rest
     const int tile = (local >> 1) * 8 + (blockIdx.x & 7);
     if (tile >= ntiles) return;
     gemm_dec_ws_body(smem, tile, dir, A, a_tile_stride, Wp, bias, gi, gi_tile_stride, npos);
+}
+
+// The same for calls of fewer than half the CUs in (tile, direction) pairs: the positions of a (tile, direction) are cut
+// into `parts` runs of `run` positions (a multiple of the stage), one workgroup each, so that a small call still has
+// about one workgroup per CU instead of a few long ones -- or, before this kernel, gemm_gi_kernel's thousands of
+// single-wave workgroups, whose first loads and store tails are most of a small launch (256 windows: 0.123 ms for
+// 0.064 ms of MFMAs).  Each workgroup loads the direction's weights once more; same chains, same bits.
+// grid: 8 x ceil(tiles / 8) x 2 directions x parts, tile = 8 (group) + (blockIdx.x & 7) as above.
+__global__ __launch_bounds__(512, 1) void gemm_dec_wsp_kernel(const f32x4* __restrict__ A, long a_tile_stride,
+                                                              const f32x4* __restrict__ Wp,
+                                                              const float* __restrict__ bias,
+                                                              f32x4* __restrict__ gi, long gi_tile_stride,
+                                                              int npos, int ntiles, int parts, int run) {
+    __shared__ f32x4 smem[kDecWsLdsF4];
+    const int rest = blockIdx.x >> 3;
+    const int part = rest % parts;
+    const int local = rest / parts;
+    const int dir = local & 1;
+    const int tile = (local >> 1) * 8 + (blockIdx.x & 7);
+    if (tile >= ntiles) return;
+    const int p0 = part * run;
+    gemm_dec_ws_body(smem, tile, dir, A, a_tile_stride, Wp, bias, gi, gi_tile_stride, npos, p0, min(p0 + run, npos));
 }
 
 
