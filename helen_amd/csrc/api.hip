@@ -847,7 +847,10 @@ static bool use_split(const HelenModel* m, int tiles) {
     if (m->precision != HELEN_PRECISION_FP32) return false;   // (TileWindow shifts the fp32 scratch only)
     const char* force = getenv("HELEN_SPLIT");
     if (force && *force) return *force == '1' && tiles >= 2;
-    return 2 * tiles > m->cus && 16 * tiles < 15 * m->cus;
+    // ... and calls of a little more than a quarter of the CUs in tiles (65-85 tiles on 256 CUs), whose first group is the
+    // 64 tiles that fill the chip with half-tile recurrences and whose second the few left over (quarter tiles): 1,040
+    // windows 51.4 -> 59.4 k, 1,152: 56.0 -> 63.5 k, 1,280: 59.2 -> 65.4 k; from 88 tiles on it loses (1,408: 63.7 -> 63.2 k).
+    return (2 * tiles > m->cus && 16 * tiles < 15 * m->cus) || (4 * tiles > m->cus && 3 * tiles <= m->cus);
 }
 
 static int polish_batch_impl(HelenModel* m, const uint8_t* images, int n_windows, uint8_t* bases,
@@ -873,7 +876,11 @@ static int polish_batch_impl(HelenModel* m, const uint8_t* images, int n_windows
     // From 160 tiles on the first group is what fills the chip with one (tile, direction) per CU and the second takes
     // the rest (3,072 windows: 128 + 64 tiles 75.9 k windows/s, 96 + 96: 73.8 k, 112 + 80: 71.9 k; 2,560: 128 + 32
     // 72.3 k, 80 + 80 71.2 k); below, two equal halves (2,304 windows: 72 + 72 tiles 73.7 k, 128 + 16: 68.6 k).
-    int t0 = 8 * tiles >= 5 * m->cus ? m->cus / 2 : (tiles + 1) / 2;
+    // ... and between a quarter and a third of the CUs in tiles the first group is the quarter that fills the chip with
+    // half-tile recurrences (1,280 windows: 64 + 16 tiles 65.4 k windows/s, 32 + 48: 63.6 k).
+    int t0 = (4 * tiles > m->cus && 3 * tiles <= m->cus) ? m->cus / 4
+             : 8 * tiles >= 5 * m->cus              ? m->cus / 2
+                                                    : (tiles + 1) / 2;
     if (const char* at = getenv("HELEN_SPLIT_AT")) {      // (A/B probes: tiles of the first group)
         const int v = atoi(at);
         if (v > 0 && v < tiles) t0 = v;

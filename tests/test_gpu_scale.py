@@ -195,13 +195,13 @@ def test_a_timed_out_hand_off_is_reported_and_the_handle_falls_back(scale_case, 
 
 
 def test_split_calls_give_the_same_bits(scale_case, monkeypatch):
-    """Calls of 129-239 tiles run as two independent tile groups on two internal streams (helen_amd/csrc/api.hip:
+    """Calls of 129-239 and of 65-85 tiles run as two independent tile groups on two internal streams (helen_amd/csrc/api.hip:
     use_split); HELEN_SPLIT forces it on or off at any size.  Labels and accumulators must be EQUAL, for ragged sizes
     (a last tile that is not full, an odd tile count), repeated calls, and through helen_polish_host."""
     from helen_amd.engine import HelenEngine
     w, img, _ = scale_case
     names = ("bases", "rles", "acc_base", "acc_rle")
-    for n in (3072, 2309, 531, 17):
+    for n in (3072, 2309, 1141, 531, 17):
         dev = torch.from_numpy(img[7000:7000 + n]).cuda()
         eng = HelenEngine(w, device=0, max_windows=n)
         monkeypatch.setenv("HELEN_SPLIT", "0")
@@ -216,9 +216,9 @@ def test_split_calls_give_the_same_bits(scale_case, monkeypatch):
         hb, hr = eng.polish_host(img[7000:7000 + n])
         assert np.array_equal(hb, want[0].cpu().numpy()) and np.array_equal(hr, want[1].cpu().numpy())
         eng.close()
-    # the default: on at 192 tiles, off at 64 and at 256
+    # the default: on at 192 tiles and at 72 (64 tiles of half-tile recurrences + 8), off at 64, 96 and 256
     monkeypatch.delenv("HELEN_SPLIT", raising=False)
-    for n, launches in ((3072, 38), (1024, 19), (4096, 19)):
+    for n, launches in ((3072, 38), (1152, 38), (1024, 19), (1536, 19), (4096, 19)):
         eng = HelenEngine(w, device=0, max_windows=n)
         eng.set_profiling(["gru_enc"])
         eng.polish(torch.from_numpy(img[:n]).cuda())
