@@ -329,6 +329,21 @@ unsigned gemm_grid(int npos, int tiles, int positions_per_wave = HELEN_GEMM_P) {
     return (unsigned)((units + 7) / 8 * 8) * ((2 * kNTile / HELEN_GEMM_N) / HELEN_GEMM_WAVES);
 }
 
+// Small calls (at most a quarter of the CUs in tiles): gemm_enc_ws8p_kernel (same gi bit for bit).
+// (HELEN_ENC_WS8P=0/1 forces it off / on; HELEN_ENC_WS8P_PARTS=n the number of runs: A/B probes.)
+bool use_ws8p_enc_projection(int tiles, int npos, int cus, int* parts, int* run) {
+    const char* force = getenv("HELEN_ENC_WS8P");
+    if (force && *force == '0') return false;
+    if (!(force && *force == '1') && 4 * tiles > cus) return false;
+    int want = cus / tiles;
+    if (const char* n = getenv("HELEN_ENC_WS8P_PARTS")) want = atoi(n);
+    want = want < 1 ? 1 : want;
+    const int per = (npos + want - 1) / want;
+    *run = (per + HELEN_EWS8_PB - 1) / HELEN_EWS8_PB * HELEN_EWS8_PB;   // whole stages
+    *parts = (npos + *run - 1) / *run;
+    return true;
+}
+
 constexpr int kWsMinWorkgroups = 384;   // 1.5 workgroups per CU-slot pair: below this the position-parallel kernel wins
 
 void launch_enc_gemm(HelenModel* m, hipStream_t s, int tiles, int npos) {
@@ -339,10 +354,15 @@ void launch_enc_gemm(HelenModel* m, hipStream_t s, int tiles, int npos) {
     const int cus = m->cus, rounds = (tiles + cus - 1) / cus;
     const bool ws8 = (force8 && *force8) ? *force8 == '1'
                                          : (tiles > cus / 2 && rounds * cus - tiles <= cus / 8) || (rounds == 1 && 3 * tiles > 2 * cus);
+    int enc_parts = 0, enc_run = 0;
     if (ws8)
         // one long workgroup per tile, one per CU: wants whole rounds of 256 tiles
         LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_ws8_kernel, dim3(tiles), dim3(512), m->xa, kXaTileStride, m->wp_enc,
                m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles);
+    else if (use_ws8p_enc_projection(tiles, npos, cus, &enc_parts, &enc_run))
+        // a small call: the same kernel with a tile's positions cut into runs, about one workgroup per CU
+        LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_ws8p_kernel, dim3(tiles * enc_parts), dim3(512), m->xa, kXaTileStride, m->wp_enc,
+               m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles, enc_parts, enc_run);
     else if (3 * tiles >= kWsMinWorkgroups)
         // enough tiles to fill the chip with one workgroup per (tile, column set): weights stay in
         // registers, same MFMA order per accumulator as gemm_gi_kernel (bit-identical gi)

@@ -355,21 +355,19 @@ __global__ __launch_bounds__(512, 1) void gemm_dec_wsp_kernel(const f32x4* __res
 #ifndef HELEN_EWS8_PB
 #define HELEN_EWS8_PB 8
 #endif
-__global__ __launch_bounds__(512, 1) void gemm_enc_ws8_kernel(const f32x4* __restrict__ A, long a_tile_stride,
-                                                              const f32x4* __restrict__ Wp,
-                                                              const float* __restrict__ bias,
-                                                              f32x4* __restrict__ gi, long gi_tile_stride,
-                                                              int npos, int ntiles) {
+// (the body over one tile and positions [p0, p1): gemm_enc_ws8_kernel takes all of a tile's positions, gemm_enc_ws8p_kernel
+// cuts them into runs for small calls)
+__device__ __forceinline__ void gemm_enc_ws8_body(f32x4* __restrict__ smem, const int tile, const f32x4* __restrict__ A,
+                                                  long a_tile_stride, const f32x4* __restrict__ Wp,
+                                                  const float* __restrict__ bias, f32x4* __restrict__ gi,
+                                                  long gi_tile_stride, int npos, int p0, int p1) {
     constexpr int MG = kFPad / 16, PB = HELEN_EWS8_PB, N = 6;
     constexpr int ROWS = PB * MG;            // 1 KiB rows per stage
     constexpr int RPW = ROWS / 8;            // rows a wave brings in per stage
     static_assert(ROWS % 8 == 0, "stage rows must split over 8 waves");
-    __shared__ f32x4 smem[2 * ROWS * 64];    // 2 x PB x 6 KiB
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x;
-    if (tile >= ntiles) return;
     const int gt0 = N * v;                   // first of this wave's global column tiles (dir*24 + nt)
     const int dir = gt0 / kNTile;
     const int nt0 = gt0 % kNTile;
@@ -389,11 +387,11 @@ __global__ __launch_bounds__(512, 1) void gemm_enc_ws8_kernel(const f32x4* __res
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
             const int r = v + 8 * i;
-            const int pc = min(PB * g + r / MG, npos - 1);
+            const int pc = min(p0 + PB * g + r / MG, p1 - 1);
             dma_row_to_lds(lds0 + (unsigned)((b * ROWS + r) * 1024), a_tile + ((size_t)pc * MG + r % MG) * 1024, lane16);
         }
     };
-    const int ng = (npos + PB - 1) / PB;
+    const int ng = (p1 - p0 + PB - 1) / PB;
     stage_rows(0, 0, 0, RPW);
     for (int g = 0; g < ng; ++g) {
         // VMEM queue, oldest first: ... the DMA rows of stage g (issued before the last positions' MFMAs of stage
@@ -423,13 +421,41 @@ __global__ __launch_bounds__(512, 1) void gemm_enc_ws8_kernel(const f32x4* __res
             }
             // exactly N stores per lane per position (counted above): positions past the end of the last stage
             // rewrite the last valid one with identical values
-            const int pos = min(PB * g + p, npos - 1);
+            const int pos = min(p0 + PB * g + p, p1 - 1);
             const int slot = dir ? (npos - 1 - pos) : pos;
             char* o = o_tile + (size_t)slot * (2 * kNTile * 64 * 16) + in_block(lane16);
 #pragma unroll
             for (int n = 0; n < N; ++n) *(f32x4*)(o + n * 1024) = acc[n];
         }
     }
+}
+
+
+constexpr int kEncWs8LdsF4 = 2 * HELEN_EWS8_PB * (kFPad / 16) * 64;   // 2 x PB x 6 KiB
+
+__global__ __launch_bounds__(512, 1) void gemm_enc_ws8_kernel(const f32x4* __restrict__ A, long a_tile_stride,
+                                                              const f32x4* __restrict__ Wp,
+                                                              const float* __restrict__ bias,
+                                                              f32x4* __restrict__ gi, long gi_tile_stride,
+                                                              int npos, int ntiles) {
+    __shared__ f32x4 smem[kEncWs8LdsF4];
+    const int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    gemm_enc_ws8_body(smem, tile, A, a_tile_stride, Wp, bias, gi, gi_tile_stride, npos, 0, npos);
+}
+
+// For calls of fewer tiles than half the CUs: a tile's positions in `parts` runs of `run` positions (whole stages), one
+// workgroup each (see gemm_dec_wsp_kernel).  grid (tiles x parts), tile = blockIdx.x / parts.
+__global__ __launch_bounds__(512, 1) void gemm_enc_ws8p_kernel(const f32x4* __restrict__ A, long a_tile_stride,
+                                                               const f32x4* __restrict__ Wp,
+                                                               const float* __restrict__ bias,
+                                                               f32x4* __restrict__ gi, long gi_tile_stride,
+                                                               int npos, int ntiles, int parts, int run) {
+    __shared__ f32x4 smem[kEncWs8LdsF4];
+    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
+    if (tile >= ntiles) return;
+    const int p0 = part * run;
+    gemm_enc_ws8_body(smem, tile, A, a_tile_stride, Wp, bias, gi, gi_tile_stride, npos, p0, min(p0 + run, npos));
 }
 
 }  // namespace helen

@@ -262,13 +262,14 @@ def test_part_tile_recurrences_give_the_same_bits(scale_case, monkeypatch):
     h = torch.rand((700, 2, 128), device="cuda") - 0.5
     big = torch.from_numpy(img[8000:8000 + 1500]).cuda()
     got = {}
-    # (the decoder projection of such calls is gemm_dec_wsp_kernel -- a (tile, direction)'s positions cut into runs --
-    # unless HELEN_DEC_WSP=0 sends them to gemm_gi_kernel: the fourth configuration)
+    # (the projections of such calls are gemm_dec_wsp_kernel / gemm_enc_ws8p_kernel -- a tile's positions cut into runs --
+    # unless HELEN_DEC_WSP=0 / HELEN_ENC_WS8P=0 send them to gemm_gi_kernel: the fourth configuration)
     for name, half, quarter, wsp in (("whole", "0", "0", "1"), ("half", "1", "0", "1"), ("quarter", "0", "1", "1"),
                                      ("streaming projection", "0", "0", "0")):
         monkeypatch.setenv("HELEN_GRU_HALF8", half)
         monkeypatch.setenv("HELEN_GRU_QUARTER4", quarter)
         monkeypatch.setenv("HELEN_DEC_WSP", wsp)
+        monkeypatch.setenv("HELEN_ENC_WS8P", wsp)
         monkeypatch.setenv("HELEN_GRU_PAIR", "0")
         got[name] = (eng.polish(dev, want_acc=True), eng.chunk_forward(x, h), eng.chunk_forward(x[:33, :1], h[:33]),
                      eng.polish(dev[:9], want_acc=True), eng.polish(dev[:3], want_acc=True), eng.polish(big, want_acc=True))
@@ -278,7 +279,7 @@ def test_part_tile_recurrences_give_the_same_bits(scale_case, monkeypatch):
             for u, v_ in zip(a, b):
                 assert torch.equal(u, v_), name
     # the defaults take them for these sizes: 1000 windows the half tiles, 500 the quarter tiles
-    for k in ("HELEN_GRU_HALF8", "HELEN_GRU_QUARTER4", "HELEN_GRU_PAIR", "HELEN_DEC_WSP"):
+    for k in ("HELEN_GRU_HALF8", "HELEN_GRU_QUARTER4", "HELEN_GRU_PAIR", "HELEN_DEC_WSP", "HELEN_ENC_WS8P"):
         monkeypatch.delenv(k)
     for u, v_ in zip(eng.polish(dev, want_acc=True), got["whole"][0]):
         assert torch.equal(u, v_)
