@@ -11,6 +11,8 @@
     gemm_dec_ws_kernel, gemm_gi_kernel<6> | gemm_enc_ws_kernel -- gives the SAME bits: a 4096-window call
     (pair recurrence, weight-stationary projections) against four 1024-window calls (the fine-grained kernels).
 """
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -225,6 +227,28 @@ def test_split_calls_give_the_same_bits(scale_case, monkeypatch):
         torch.cuda.synchronize()
         assert eng.kernel_stats()["gru_enc"][1] == launches, (n, eng.kernel_stats())
         eng.close()
+
+
+def test_every_call_size_gives_the_plain_sequence_s_bits(monkeypatch):
+    """The boundaries of every size rule (32 / 64 / 85 / 128 / 239 tiles) and random sizes between 1 and 4096 windows: what
+    the library picks by itself against the plain one-tile-per-workgroup kernels, twice per size (scripts/dev/random_sizes.py
+    is the same check as a soak)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "random_sizes", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "dev",
+                                     "random_sizes.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for k in mod.PLAIN:                      # (the script sets and clears these itself: restore them afterwards)
+        monkeypatch.setenv(k, "x")
+        monkeypatch.delenv(k)
+    monkeypatch.setattr(sys, "argv", ["random_sizes.py", "12", "5"])
+    try:
+        assert mod.main() == 0
+    finally:
+        for k in mod.PLAIN:
+            os.environ.pop(k, None)
 
 
 def test_single_tile_recurrences_give_the_same_bits(scale_case, monkeypatch):
