@@ -74,6 +74,9 @@ class _DeviceStage(object):
         self.dev = torch.device("cuda", device)
         self.rt = torch.cuda.cudart()
         self.registered = []
+        # (page-locking a fresh shared mapping populates it: 0.09 s per 475 MB slot on the GPU box, 0.5 s for five.
+        # Locking the later slots from a helper thread while the first calls run was measured: the set-up shrinks
+        # by 0.26 s and the loop grows by as much -- the pages have to be brought in either way)
         for sl in slots:
             ptr, nbytes = sl.base_address()
             rc = self.rt.cudaHostRegister(ptr, nbytes, 0)
@@ -301,17 +304,24 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     through_library = 0
     t_setup = t_loop_end = start_time
     batch_iterator = 0
+    setup_took = {}
     try:
+        t_s = time.time()
         transducer_model, hidden_size, gru_layers, prev_ite = ModelHandler.load_simple_model(
             model_path, input_channels=ImageSizeOptions.IMAGE_CHANNELS,
             image_features=ImageSizeOptions.IMAGE_HEIGHT, seq_len=ImageSizeOptions.SEQ_LENGTH,
             num_base_classes=ImageSizeOptions.TOTAL_BASE_LABELS,
             num_rle_classes=ImageSizeOptions.TOTAL_RLE_LABELS)
         transducer_model.eval()
+        setup_took["MODEL FILE"] = time.time() - t_s
+        t_s = time.time()
         torch.cuda.set_device(device_id)
         transducer_model.to(device_id)
+        setup_took["DEVICE CONTEXT + WEIGHTS"] = time.time() - t_s
+        t_s = time.time()
         transducer_model.set_capacity(min(DEVICE_CALL_WINDOWS, cap))
         engine = transducer_model.engine
+        setup_took["ENGINE"] = time.time() - t_s
         if rank == 0:
             print(prediction_file_name(output_filename, rank))
             sys.stderr.write("INFO: MI355X HIP PATH, DEVICE " + str(device_id) + ", "
@@ -319,10 +329,12 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
             sys.stderr.write("Loading data\n")
         if os.environ.get("HELEN_DEVICE_STAGE", "async") != "sync" and hasattr(engine, "polish") \
                 and torch.cuda.is_available() and calls:
+            t_s = time.time()
             try:
                 stage = _DeviceStage(engine, slots, cap, device_id)
             except Exception as e:      # page-locking refused (ulimit -l, container policy): staged copies
                 sys.stderr.write("INFO: SLOTS NOT PAGE-LOCKED (" + str(e) + "), USING STAGED COPIES.\n")
+            setup_took["PAGE-LOCKS + STREAMS"] = time.time() - t_s
         t_setup = time.time()
         while True:
             t0 = time.time()
@@ -419,10 +431,11 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         "numa_node": None if plan is None else plan.numa_node})
     if rank == 0:
         sys.stderr.write("INFO: %d WINDOWS IN %.1f SECS (WAITING FOR READERS %.1f, DEVICE %.1f, WRITER BUSY %.1f; "
-                         "MODEL + ENGINE SET-UP %.1f, FLUSH + CLOSE %.1f = LAST SLOTS %.2f + FILE CLOSE %.2f + "
+                         "MODEL + ENGINE SET-UP %.1f [%s], FLUSH + CLOSE %.1f = LAST SLOTS %.2f + FILE CLOSE %.2f + "
                          "RELEASE %.2f [%s]).\n"
                          % (len(pairs), time.time() - start_time, STAGE_SECONDS["read_wait"],
                             STAGE_SECONDS["device"], STAGE_SECONDS["write"], t_setup - start_time,
+                            ", ".join("%s %.2f" % kv for kv in setup_took.items()),
                             time.time() - t_loop_end, t_drained - t_side, t_closed - t_drained,
                             time.time() - t_closed,
                             ", ".join("%s %.2f" % kv for kv in sorted(took.items()))))
