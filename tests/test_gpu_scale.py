@@ -251,6 +251,27 @@ def test_every_call_size_gives_the_plain_sequence_s_bits(monkeypatch):
             os.environ.pop(k, None)
 
 
+def test_host_path_on_label_arrays_that_share_pages(scale_case):
+    """helen_polish_host page-locks pageable caller memory only where a range owns its pages: label arrays of a few KiB from
+    the caller's heap, and two large label arrays that are neighbouring views of ONE buffer (they share the page the
+    boundary falls in), go through the pinned mirrors -- with the same labels as everything else."""
+    from helen_amd.engine import HelenEngine
+    w, img, _ = scale_case
+    n = 4300                                                     # 4.3 MB of label rows each: above the locking threshold
+    eng = HelenEngine(w, device=0, max_windows=4096)
+    want = [t.cpu().numpy() for t in eng.polish(torch.from_numpy(img[:n]).cuda())]
+    buf = np.empty(2 * n * 1000 + 1000, np.uint8)
+    for off in (0, 1, 777):                                      # the boundary between the two views at any offset in a page
+        b = buf[off:off + n * 1000].reshape(n, 1000)
+        r = buf[off + n * 1000:off + 2 * n * 1000].reshape(n, 1000)
+        eng.polish_host(img[:n], out=(b, r))
+        assert np.array_equal(b, want[0]) and np.array_equal(r, want[1]), off
+    for k in (1, 3, 17, 40):                                     # small arrays, fresh from the heap every time
+        hb, hr = eng.polish_host(img[:k])
+        assert np.array_equal(hb, want[0][:k]) and np.array_equal(hr, want[1][:k]), k
+    eng.close()
+
+
 def test_single_tile_recurrences_give_the_same_bits(scale_case, monkeypatch):
     """Calls of at most 128 tiles (one (tile, direction) per CU) take gru_single8_kernel (eight waves per tile), larger
     single-tile launches gru_kernel (four waves, two workgroups per CU); HELEN_GRU_SINGLE8 forces either.  Same bits,
