@@ -58,6 +58,7 @@ def build_parser():
     parser = argparse.ArgumentParser(
         prog="helen", formatter_class=argparse.RawTextHelpFormatter,
         description="HELEN inference path on MI355X (gfx950): MarginPolish images -> prediction HDF5.")
+    parser.add_argument("--version", default=False, action="store_true", help="Show version.")   # helen.py:261-266
     sub = parser.add_subparsers(dest="sub_command")
     add_polish_arguments(sub.add_parser("polish", help="call_consensus, then stitch"), 1)
     add_polish_arguments(sub.add_parser("call_consensus", help="generate the prediction HDF5 files"), 16)
@@ -99,7 +100,7 @@ def main(argv=None):
     elif flags.sub_command == "check_images":
         from .check_images import main as check_main
         return check_main(flags.image_dir, flags.images_per_file, flags.strict, flags.json)
-    elif flags.sub_command == "version":
+    elif flags.sub_command == "version" or (flags.sub_command is None and flags.version):
         print("HELEN-MI355X VERSION: " + __version__)
     elif flags.sub_command == "torch_stat":
         import torch
@@ -113,6 +114,42 @@ def main(argv=None):
         parser.print_help(sys.stderr)
         return 1
     return 0
+
+
+def build_train_parser():
+    """`helen_train` (helen/helen_train.py:196-223): of its sub-commands the evaluation one, `test`, is on this build's
+    path; `train` is accepted by the parser so that the refusal can say why."""
+    parser = argparse.ArgumentParser(
+        prog="helen_train", formatter_class=argparse.RawTextHelpFormatter,
+        description="Evaluation of a HELEN model on labeled MarginPolish images on MI355X (gfx950).")
+    parser.add_argument("--version", default=False, action="store_true", help="Show version.")
+    sub = parser.add_subparsers(dest="sub_command")
+    add_test_arguments(sub.add_parser("test", help="Test a model. Requires a set of labeled images"))
+    sub.add_parser("train", help="(not part of this build: training is outside the inference path)", add_help=False)
+    sub.add_parser("torch_stat", help="See PyTorch configuration.")
+    sub.add_parser("version", help="Show program version.")
+    return parser
+
+
+def train_main(argv=None):
+    """Console script `helen_train` (setup.py:155 of the reference)."""
+    parser = build_train_parser()
+    flags, unparsed = parser.parse_known_args(argv)
+    if flags.sub_command == "test":
+        args = list(sys.argv[1:] if argv is None else argv)
+        args.remove("test")
+        return main(["test"] + args)
+    if flags.sub_command == "train":
+        sys.stderr.write("ERROR: `helen_train train` IS NOT PART OF THIS BUILD (the MI355X inference path of `helen polish`; "
+                         "`helen_train test` evaluates a trained model).\n")
+        return 1
+    if flags.sub_command == "torch_stat":
+        return main(["torch_stat"])
+    if flags.sub_command == "version" or flags.version:
+        return main(["version"])
+    sys.stderr.write("ERROR: NO SUBCOMMAND PROVIDED. PLEASE USE --help TO SEE THE OPTIONS.\n")
+    parser.print_help(sys.stderr)
+    return 1
 
 
 if __name__ == "__main__":

@@ -321,11 +321,64 @@ def test_command_line_options_equal_the_reference_definition():
     spec.loader.exec_module(gen)
     want = json.load(open(os.path.join(root, "tests", "golden", "cli_ref.json")))["options"]
     subs = [a for a in build_parser()._actions if a.dest == "sub_command"][0].choices
-    for name in ("polish", "call_consensus", "stitch"):
-        got = {tuple(o["flags"]): o for o in gen.option_table(subs[name])}
+    from helen_amd.cli import build_train_parser
+    train_subs = [a for a in build_train_parser()._actions if a.dest == "sub_command"][0].choices
+    for name in ("polish", "call_consensus", "stitch", "helen_train test"):
+        got = {tuple(o["flags"]): o for o in gen.option_table(train_subs["test"] if name == "helen_train test" else subs[name])}
         for o in want[name]:
             mine = got.get(tuple(o["flags"]))
             assert mine is not None, (name, o["flags"])
             for key in ("dest", "default", "required", "type", "nargs", "const"):
                 assert mine[key] == o[key], (name, o["flags"], key, mine[key], o[key])
         assert len(got) == len(want[name]), (name, sorted(set(got) - {tuple(o["flags"]) for o in want[name]}))
+
+
+def test_helen_commands_run_through_their_entry_points(tmp_path):
+    """The reference installs console scripts `helen` and `helen_train` (setup.py:152-159) and pipelines call `helen polish ...`
+    (docker_test:37-45).  pyproject.toml declares the same two entry points; bin/helen and bin/helen_train are the same
+    functions for an uninstalled tree.  Both are run here as commands, from another directory: version, --version, --help
+    of every sub-command, the option table `helen polish --help` prints against the reference's definition, the missing
+    sub-command error, and `helen_train train` (not part of this build) refusing with a reason."""
+    import json
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        import tomllib as toml_reader
+    except ImportError:
+        import tomli as toml_reader
+    with open(os.path.join(root, "pyproject.toml"), "rb") as f:
+        scripts = toml_reader.load(f)["project"]["scripts"]
+    assert scripts == {"helen": "helen_amd.cli:main", "helen_train": "helen_amd.cli:train_main"}
+    import importlib
+    for target in scripts.values():                      # the declared entry points resolve to callables
+        mod, fn = target.split(":")
+        assert callable(getattr(importlib.import_module(mod), fn))
+
+    def run(*argv):
+        exe = os.path.join(root, "bin", argv[0])
+        assert os.access(exe, os.X_OK), exe
+        return subprocess.run([exe] + list(argv[1:]), cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+    for cmd in (("helen", "version"), ("helen", "--version"), ("helen_train", "version"), ("helen_train", "--version")):
+        r = run(*cmd)
+        assert r.returncode == 0 and re.match(r"HELEN-MI355X VERSION: \d+\.\d+", r.stdout), (cmd, r)
+    want = json.load(open(os.path.join(root, "tests", "golden", "cli_ref.json")))["options"]
+    for sub in ("polish", "call_consensus", "stitch"):
+        r = run("helen", sub, "--help")
+        assert r.returncode == 0, r
+        for o in want[sub]:
+            for flag in o["flags"]:
+                assert re.search(r"(^|[\s\[,])%s\b" % re.escape(flag), r.stdout, re.M), (sub, flag)
+    r = run("helen_train", "test", "--help")
+    assert r.returncode == 0
+    for o in want["helen_train test"]:
+        assert o["flags"][0] in r.stdout
+    r = run("helen")
+    assert r.returncode == 1 and "NO SUBCOMMAND" in r.stderr
+    r = run("helen", "polish")                          # argparse: the required options are named
+    assert r.returncode == 2 and "--image_dir" in r.stderr and "--model_path" in r.stderr
+    r = run("helen_train", "train", "--anything")
+    assert r.returncode == 1 and "NOT PART OF THIS BUILD" in r.stderr
+    # without -g the product refuses (it has no CPU mode, DESIGN.md 8) -- before touching any file
+    r = run("helen", "call_consensus", "-i", str(tmp_path), "-m", str(tmp_path / "none.pkl"), "-o", str(tmp_path / "o"))
+    assert r.returncode != 0
