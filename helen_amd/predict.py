@@ -491,30 +491,53 @@ def run_ranks(target, argsets, slot_prefixes=(), grace_seconds=10.0):
             except queue.Empty:
                 return
             results[r] = info
-    while alive:
-        for sentinel in wait(list(alive), timeout=0.5):
-            r, p = alive.pop(sentinel)
-            p.join()
-            if p.exitcode != 0:
-                failed.append((r, p.exitcode))
-        drain()
-        if failed and alive:
-            first = failed[0]
-            sys.stderr.write("ERROR: RANK %d EXITED WITH %s: TERMINATING THE OTHER %d RANK(S).\n"
-                             % (first[0], first[1], len(alive)))
-            for r, p in alive.values():
-                p.terminate()
-            deadline = time.time() + grace_seconds
-            for r, p in alive.values():
-                p.join(max(0.1, deadline - time.time()))
-                if p.is_alive():
-                    try:
-                        os.killpg(p.pid, 9)
-                    except OSError:
-                        p.kill()
-                    p.join()
-            alive = {}
-            sweep_slots(list(slot_prefixes))
+
+    def take_down(why):
+        """SIGTERM, the grace period, SIGKILL to the process group, the slot sweep -- for every rank still alive."""
+        if not alive:
+            return
+        sys.stderr.write("ERROR: %s: TERMINATING THE OTHER %d RANK(S).\n" % (why, len(alive)))
+        for r, p in alive.values():
+            p.terminate()
+        deadline = time.time() + grace_seconds
+        for r, p in alive.values():
+            p.join(max(0.1, deadline - time.time()))
+            if p.is_alive():
+                try:
+                    os.killpg(p.pid, 9)
+                except OSError:
+                    p.kill()
+                p.join()
+        alive.clear()
+        sweep_slots(list(slot_prefixes))
+
+    # The ranks sit in process groups of their own (_setup), so a Ctrl-C at the terminal or a scheduler's SIGTERM reaches
+    # only this process: it must pass the signal on, or the ranks would keep the GPUs while this process hangs in
+    # multiprocessing's exit handler (the reference's mp.spawn children share the parent's group and die with it,
+    # predict_gpu.py:223).  SIGTERM becomes SystemExit here for the duration of the wait.
+    import signal
+
+    def on_term(signum, frame):
+        raise SystemExit(128 + signum)
+    previous = None
+    if threading.current_thread() is threading.main_thread():
+        previous = signal.signal(signal.SIGTERM, on_term)
+    try:
+        while alive:
+            for sentinel in wait(list(alive), timeout=0.5):
+                r, p = alive.pop(sentinel)
+                p.join()
+                if p.exitcode != 0:
+                    failed.append((r, p.exitcode))
+            drain()
+            if failed and alive:
+                take_down("RANK %d EXITED WITH %s" % failed[0])
+    except BaseException as e:          # KeyboardInterrupt, SystemExit (SIGTERM), anything unexpected in the wait
+        take_down("INTERRUPTED (%s)" % type(e).__name__)
+        raise
+    finally:
+        if previous is not None:
+            signal.signal(signal.SIGTERM, previous)
     time.sleep(0.05)
     drain()
     return results, failed

@@ -45,3 +45,19 @@ def failing(rank, marker_dir, result_q, wait_for=(0,)):
 
 def quick(rank, marker_dir, result_q):
     result_q.put((rank, {"rank": rank, "pid": os.getpid()}))
+
+
+def sleeper_entry(rank, marker_dir, result_q):
+    sleeper(rank, marker_dir, result_q)
+
+
+def parent_main(marker_dir):
+    """A parent that runs two sleeping ranks through helen_amd.predict.run_ranks (the test signals THIS process)."""
+    from helen_amd.predict import run_ranks
+    open(os.path.join(marker_dir, "parent_%d" % os.getpid()), "w").close()
+    run_ranks(sleeper_entry, [(0, marker_dir), (1, marker_dir)], grace_seconds=5.0)
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    parent_main(sys.argv[1])

@@ -4,6 +4,8 @@ import os
 import sys
 import time
 
+import pytest
+
 from helen_amd import host_plan
 from helen_amd.host_plan import plan_host
 
@@ -144,3 +146,30 @@ def test_all_ranks_fine(tmp_path):
     from helen_amd.predict import run_ranks
     results, failed = _run_mixed(run_ranks, [rank_targets.quick] * 3, [(r, str(tmp_path)) for r in range(3)])
     assert failed == [] and sorted(results) == [0, 1, 2] and results[2]["rank"] == 2
+
+
+@pytest.mark.parametrize("signum", [2, 15])
+def test_an_interrupted_parent_takes_its_ranks_down(tmp_path, signum):
+    """The ranks live in process groups of their own, so Ctrl-C / a scheduler's SIGTERM reaches only the parent: run_ranks
+    passes it on (SIGTERM -> the ranks' own tear-down, the grace period, the group kill) and re-raises, instead of leaving
+    the ranks on the GPUs while the parent hangs in multiprocessing's exit handler."""
+    import signal
+    import subprocess
+    import sys
+    d = str(tmp_path)
+    tests = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, PYTHONPATH=tests + os.pathsep + os.path.dirname(tests) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    parent = subprocess.Popen([sys.executable, os.path.join(tests, "rank_targets.py"), d], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    deadline = time.time() + 60
+    while time.time() < deadline and not all(os.path.exists(os.path.join(d, "started_%d" % r)) for r in (0, 1)):
+        time.sleep(0.05)
+    assert os.path.exists(os.path.join(d, "started_1")), "the ranks did not start"
+    t0 = time.time()
+    parent.send_signal(signum)
+    out, err = parent.communicate(timeout=40)
+    took = time.time() - t0
+    assert took < 20, (took, err)
+    assert parent.returncode != 0
+    assert "INTERRUPTED" in err, err
+    assert os.path.exists(os.path.join(d, "unwound_0")) and os.path.exists(os.path.join(d, "unwound_1")), err
