@@ -50,11 +50,13 @@ def pmc_traffic(windows_per_launch, precision="fp32"):
     windows per launch.  fp32: the newest summary without a mode tag, kernels gru_kernel / gru_pair_kernel; bf16: the
     newest `*_bf16_pmc_summary.json`, the fused layer kernels.  None if no summary is committed."""
     import glob
+    tag = {"fp32": None, "bf16": "bf16", "fp32x3": "fp32x3"}[precision]
     files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))
-                   if ("bf16" in os.path.basename(f)) == (precision == "bf16"))
+                   if (tag in os.path.basename(f) if tag else not any(t in os.path.basename(f) for t in ("bf16", "fp32x3"))))
     if not files:
         return None, None
-    names = ("helen::gru_fused_bf16",) if precision == "bf16" else ("helen::gru_kernel", "helen::gru_pair_kernel")
+    names = {"bf16": ("helen::gru_fused_bf16",), "fp32x3": ("helen::gru_x3",),
+             "fp32": ("helen::gru_kernel", "helen::gru_pair_kernel")}[precision]
     try:
         # encoder and decoder launches of the recurrence, launch-weighted; the two-tile kernels where both were profiled
         ks = {k: v for k, v in json.load(open(files[-1]))["kernels"].items() if k.startswith(names)}
@@ -206,6 +208,118 @@ def precision_check(eng, precision, images, dev):
             "max_abs_logit": round(biggest, 3), "precision": precision}
 
 
+X3_MFMA_PEAK = BF16_MFMA_PEAK / 6.0    # fp32x3: six bf16 MFMAs per fp32 product group -> 416.7 TFLOP/s of fp32-class work
+
+
+def trained_identity(dev, precision):
+    """Labels of `precision` against the fp32 path on the reference model TRAINED on a synthetic polishing task
+    (tests/golden/trained_synth.npz, made by tests/golden/make_trained_synth.py): 512 fresh windows of that task."""
+    import numpy as np
+    import torch
+
+    from helen_amd.engine import HelenEngine
+    from helen_amd.synthetic import make_pileup_task
+    trained = os.path.join(ROOT, "tests", "golden", "trained_synth.npz")
+    if not os.path.exists(trained):
+        return None
+    z = np.load(trained)
+    w = {k: z[k] for k in z.files if not k.startswith("_")}
+    timg, tlb, tlr = make_pileup_task(512, seed=int(z["_task_seed"]) + 9000)
+    imgs = torch.from_numpy(timg).to(dev)
+    out = {"windows": 512}
+    labels = {}
+    for prec in ("fp32", precision):
+        e = HelenEngine(w, device=dev.index, max_windows=512, precision=prec)
+        b, r = e.polish(imgs)
+        labels[prec] = (b.cpu().numpy(), r.cpu().numpy())
+        e.close()
+        out["accuracy_vs_truth_" + prec] = {"base": round(float((labels[prec][0] == tlb).mean()), 5),
+                                            "rle": round(float((labels[prec][1] == tlr).mean()), 5)}
+    out["label_identity_vs_fp32"] = {"base": round(float((labels["fp32"][0] == labels[precision][0]).mean()), 6),
+                                     "rle": round(float((labels["fp32"][1] == labels[precision][1]).mean()), 6)}
+    return out
+
+
+def mode_report(precision, batch, coalesce, images, dev, fp32_labels, steps=8, warmup=2):
+    """One of the library's other arithmetic modes under the same clock as the headline: `steps` device calls of
+    `batch` x `coalesce` windows of the resident shard (inputs in HBM, wall clock between device syncs), the recurrence
+    launches timed by HIP events inside the timed region, its labels against the fp32 path's on the same windows, the
+    operator loop's logits against fp32's, and the trained-network identity.  bf16 at batch 512 is BASELINE.json
+    configs[3]; fp32x3 is the opt-in fp32-class mode on the bf16 matrix cores."""
+    import ctypes
+
+    import torch
+
+    from helen_amd import _lib
+    from helen_amd.engine import HelenEngine
+    from helen_amd.weights import make_weights
+    lib = _lib.load()
+    call_windows = batch * coalesce
+    n_calls_res = images.shape[0] // call_windows
+    if n_calls_res < 1:
+        return {"value": None, "skipped": "the resident shard holds fewer than %d windows" % call_windows}
+    eng = HelenEngine(make_weights(input_scale=1.0 / 64.0), device=dev.index, max_windows=call_windows, precision=precision)
+    try:
+        bases = torch.empty((n_calls_res * call_windows, 1000), dtype=torch.uint8, device=dev)
+        rles = torch.empty_like(bases)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+
+        def run(n):
+            for k in range(n):
+                s = (k % n_calls_res) * call_windows
+                e = s + call_windows
+                _lib.check(lib.helen_polish_batch(eng._handle, images[s:e].data_ptr(), call_windows, bases[s:e].data_ptr(),
+                                                  rles[s:e].data_ptr(), None, None, ctypes.c_void_p(stream)))
+        eng.set_profiling(["gru_enc", "gru_dec"])
+        run(max(warmup, steps))               # untimed; also creates the event pairs the timed steps recycle
+        torch.cuda.synchronize(dev)
+        eng.reset_kernel_stats()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        stats = eng.kernel_stats()
+        eng.set_profiling([])
+        value = steps * call_windows / elapsed
+        n_l = stats["gru_enc"][1] + stats["gru_dec"][1]
+        avg_ms = (stats["gru_enc"][0] + stats["gru_dec"][0]) / max(n_l, 1)
+        if precision == "bf16":
+            peak, flop = BF16_MFMA_PEAK, 100 * 2 * 384 * 2 * ((90 + 128) + (256 + 128) + 16) / 2.0
+            kernel = ("gru_fused_bf16_* (projection + recurrence per layer, bf16 MFMA, fp32 accumulate / state / gates); "
+                      "peak = dense bf16 MFMA")
+        else:
+            peak, flop = X3_MFMA_PEAK, GRU_FLOP_PER_WINDOW_LAUNCH
+            kernel = ("gru_x3_kernel (recurrence; every fp32 product group as 6 bf16 MFMAs, fp32 accumulate); peak = dense "
+                      "bf16 MFMA / 6")
+        achieved = flop * call_windows / (avg_ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(call_windows, precision)
+        k = min(steps, n_calls_res) * call_windows
+        k = min(k, fp32_labels[0].shape[0])
+        same_b = float((bases[:k] == fp32_labels[0][:k]).float().mean().item())
+        same_r = float((rles[:k] == fp32_labels[1][:k]).float().mean().item())
+        out = {"value": round(value, 1), "unit": "windows/s", "precision": precision, "batch": batch,
+               "batches_per_step": coalesce, "windows_per_step": call_windows, "steps": steps, "warmup": max(warmup, steps),
+               "ms_per_step": round(elapsed * 1e3 / steps, 4),
+               "roofline": {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": round(peak / 1e12, 1),
+                            "unit": "TFLOP/s", "frac": round(achieved * 1e12 / peak, 4), "avg_launch_ms": round(avg_ms, 4),
+                            "avg_launch_ms_encoder": round(stats["gru_enc"][0] / max(stats["gru_enc"][1], 1), 4),
+                            "avg_launch_ms_decoder": round(stats["gru_dec"][0] / max(stats["gru_dec"][1], 1), 4),
+                            "launches": n_l, "traffic": traffic, "traffic_source": traffic_src,
+                            "path_frac": round(value * FLOP_PER_WINDOW / peak, 4),
+                            "path_frac_of_fp32_mfma_peak": round(value * FLOP_PER_WINDOW / FP32_MFMA_PEAK, 4)},
+               "label_identity": {"base": round(same_b, 6), "rle": round(same_r, 6), "windows": k,
+                                  "against": "the fp32 path's labels of the same windows (the headline run above)"}}
+        chk = precision_check(eng, precision, images, dev)
+        out["max_abs_logit_diff"] = chk["max_abs_logit_diff"]
+        out["max_abs_logit"] = chk["max_abs_logit"]
+        out["windows_logits"] = chk["windows_logits"]
+    finally:
+        eng.close()
+    out["trained_network"] = trained_identity(dev, precision)
+    return out
+
+
 E2E_DEFAULT_WINDOWS = 49152        # per rank: 12 device calls of 4096 windows, ~0.6 s of device time
 E2E_FILES_PER_RANK = 16
 
@@ -352,6 +466,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-margins", action="store_true", help="skip the label-margin report (random-init and peaked weights)")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-memory -> host-memory leg")
+    ap.add_argument("--no-modes", action="store_true",
+                    help="skip the `modes` object (bf16 at batch 512 = BASELINE.json configs[3], and fp32x3, each under the "
+                         "same clock with its own roofline and its label / logit check against the fp32 path)")
     ap.add_argument("--e2e", type=int, default=None, metavar="WINDOWS",
                     help="windows PER RANK of the end-to-end leg: the product's call_consensus over a synthetic HDF5 "
                          "image directory, N ranks under --gpus N (default %d: a bounded leg in every line; 300000 = "
@@ -552,7 +669,7 @@ def main():
         avg_ms = gru_ms / max(gru_n, 1)
         win_per_launch = call_windows
         achieved = (CHUNKS_FLOP_PER_WINDOW_LAUNCH if one_launch else GRU_FLOP_PER_WINDOW_LAUNCH) * win_per_launch / (avg_ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(win_per_launch, args.precision) if args.precision != "fp32x3" else (None, None)
+        traffic, traffic_src = pmc_traffic(win_per_launch, args.precision)
         peak = BF16_MFMA_PEAK if args.precision == "bf16" else FP32_MFMA_PEAK
         bound, unit = "mfma", "TFLOP/s"
         if args.precision == "bf16":
@@ -591,7 +708,9 @@ def main():
                          "achieved": round(achieved, 2),
                          "peak": peak / (1e12 if bound == "mfma" else 1e9), "unit": unit,
                          "frac": round(achieved * (1e12 if bound == "mfma" else 1e9) / peak, 4),
-                         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "launches": gru_n,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_measured_in_this_run": False if traffic is not None else None,
+                         "avg_launch_ms": round(avg_ms, 4), "launches": gru_n,
                          "avg_launch_ms_encoder": None if one_launch else round(stats["gru_enc"][0] / max(stats["gru_enc"][1], 1), 4),
                          "avg_launch_ms_decoder": None if one_launch else round(stats["gru_dec"][0] / max(stats["gru_dec"][1], 1), 4),
                          "path_frac": round(value / world * FLOP_PER_WINDOW /
@@ -617,6 +736,14 @@ def main():
                         "call per rank over %d windows (sub-batches of %d: upload k+1 | kernels k | download k-1); "
                         "PCIe included; labels checked equal to the device path" % (hn, call_windows),
                 "h2d_GBps": round(hv / world * 90000 / 1e9, 2)}
+        if not args.no_modes and args.precision == "fp32" and world == 1:
+            eng.close()
+            out["modes"] = {}
+            for prec, mb in (("bf16", 512), ("fp32x3", B)):
+                try:
+                    out["modes"][prec] = mode_report(prec, mb, G, images, dev, (bases, rles))
+                except Exception as e:      # noqa: BLE001 -- a mode must not take the headline down with it
+                    out["modes"][prec] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B)
     eng.close()                # call_consensus builds its own engines (15.9 GB of scratch each)

@@ -61,6 +61,8 @@ struct HelenModel {
     int max_tiles = 0;
     int cus = 256;             // compute units of the device (hipDeviceProp_t::multiProcessorCount): what a "round" of workgroups is
     bool debug_hooks = false;  // $HELEN_DEBUG_HOOKS=1 when the model was created: helen_debug_inject_failure is armed-able
+    int host_lock = 1;         // helen_polish_host, pageable caller memory: 0 = never page-lock it (pinned mirrors), 1 = lock
+                               // ranges that own their pages, 2 = lock every range ($HELEN_HOST_LOCK = none | own | all)
     size_t device_bytes = 0;
     size_t ring_in_bytes = 0, ring_out_bytes = 0;   // what each dev_in / dev_out slot of the staging ring added to device_bytes
     // packed parameters (device)
@@ -596,6 +598,8 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
     {
         const char* hooks = getenv("HELEN_DEBUG_HOOKS");
         m->debug_hooks = hooks && hooks[0] == '1';
+        if (const char* hl = getenv("HELEN_HOST_LOCK"))
+            m->host_lock = !strcmp(hl, "none") ? 0 : !strcmp(hl, "all") ? 2 : 1;
     }
     m->precision = precision;
     m->max_windows = max_windows;
@@ -1077,13 +1081,14 @@ int helen_polish_host(HelenModel* m, const uint8_t* images, int n_windows, uint8
         *lo = (uintptr_t)q / kPage * kPage;
         *hi = ((uintptr_t)q + bytes + kPage - 1) / kPage * kPage;
     };
-    if (!in_pinned && (size_t)n_windows * img_bytes >= kLockMinBytes)
+    const size_t lock_min = m->host_lock == 2 ? 1 : kLockMinBytes;
+    if (m->host_lock && !in_pinned && (size_t)n_windows * img_bytes >= lock_min)
         in_pinned = registered.add(images, (size_t)n_windows * img_bytes);
-    if (!out_pinned && (size_t)n_windows * lab_bytes >= kLockMinBytes) {
+    if (m->host_lock && !out_pinned && (size_t)n_windows * lab_bytes >= lock_min) {
         uintptr_t b0, b1, r0, r1;
         pages(bases, (size_t)n_windows * lab_bytes, &b0, &b1);
         pages(rles, (size_t)n_windows * lab_bytes, &r0, &r1);
-        if ((b1 <= r0 || r1 <= b0) && registered.add(bases, (size_t)n_windows * lab_bytes)) {
+        if ((m->host_lock == 2 || b1 <= r0 || r1 <= b0) && registered.add(bases, (size_t)n_windows * lab_bytes)) {
             if (registered.add(rles, (size_t)n_windows * lab_bytes)) out_pinned = true;
         }
     }

@@ -110,16 +110,17 @@ class File {
     // old-style group over `kids` (any order; sorted here by name, bytewise like strcmp); returns the object
     // header address, and the B-tree / heap addresses for the root entry of the superblock
     uint64_t group(std::vector<Child>& kids, uint64_t* btree_out = nullptr, uint64_t* heap_out = nullptr) {
-        std::sort(kids.begin(), kids.end(), [](const Child& a, const Child& b) { return a.name < b.name; });
+        const auto by_name = [](const Child& a, const Child& b) { return a.name < b.name; };
+        if (!std::is_sorted(kids.begin(), kids.end(), by_name)) std::sort(kids.begin(), kids.end(), by_name);
         // local heap: "" at offset 0, then the names, each NUL-terminated and padded to 8
         std::vector<uint64_t> off(kids.size());
-        std::vector<uint8_t> heap(8, 0);
+        size_t heap_bytes = 8;
         for (size_t i = 0; i < kids.size(); ++i) {
-            off[i] = heap.size();
-            const size_t n = kids[i].name.size() + 1;
-            heap.insert(heap.end(), kids[i].name.begin(), kids[i].name.end());
-            heap.resize(heap.size() + 1 + ((8 - (n & 7)) & 7), 0);
+            off[i] = heap_bytes;
+            heap_bytes += (kids[i].name.size() + 1 + 7) & ~(size_t)7;
         }
+        std::vector<uint8_t> heap(heap_bytes, 0);
+        for (size_t i = 0; i < kids.size(); ++i) memcpy(heap.data() + off[i], kids[i].name.data(), kids[i].name.size());
         align8();
         const uint64_t heap_addr = tell();
         put("HEAP", 4); put8(0); pad(3);
@@ -133,11 +134,17 @@ class File {
         for (size_t i = 0; i < kids.size(); i += 2 * kLeafK) {
             const size_t n = std::min<size_t>(2 * kLeafK, kids.size() - i);
             const uint64_t a = tell();
-            put("SNOD", 4); put8(1); put8(0); put16((uint16_t)n);
+            uint8_t node[kSnodBytes];
+            memset(node, 0, sizeof(node));
+            memcpy(node, "SNOD", 4);
+            node[4] = 1;
+            const uint16_t n16 = (uint16_t)n;
+            memcpy(node + 6, &n16, 2);
             for (size_t k = 0; k < n; ++k) {
-                put64(off[i + k]); put64(kids[i + k].header); put32(0); put32(0); pad(16);
+                memcpy(node + 8 + 40 * k, &off[i + k], 8);
+                memcpy(node + 8 + 40 * k + 8, &kids[i + k].header, 8);
             }
-            pad((2 * kLeafK - n) * 40);
+            put(node, sizeof(node));
             level.push_back({a, off[i + n - 1]});
         }
         // B-tree levels, bottom up; an empty group is one empty leaf-level node

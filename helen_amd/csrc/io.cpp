@@ -15,6 +15,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -22,8 +23,10 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <set>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -46,6 +49,12 @@ constexpr int kName = 256;   // bytes reserved per contig name in the batch arra
 struct Quiet {
     Quiet() { H5Eset_auto2(H5E_DEFAULT, nullptr, nullptr); }
 };
+
+// The reader entry points may be called from several threads at once (helen_io_read_image_runs starts its own):
+// the caches below are guarded by g_cache_mutex; libhdf5 (not built thread-safe here) by g_library_mutex, one
+// caller at a time; the direct scanner only reads a read-only mapping and needs no lock.
+std::mutex g_cache_mutex;
+std::recursive_mutex g_library_mutex;
 
 // ---- reader side: per-process cache of open files -------------------------------------------
 // What a cached handle / mapping was opened on.  A path can be rewritten while this process lives (a second
@@ -197,7 +206,7 @@ int read_2d(hid_t loc, const char* name, hid_t memtype, int cols, int max_rows, 
 // file the scanner does not take (libhdf5 reads it instead).  $HELEN_IO_READER=libhdf5 turns the fast path off;
 // =direct turns the FALLBACK off (what the scanner declines is an error: the fuzz tests' way of exercising the
 // scanner alone on damaged files).
-long long g_fast_windows = 0, g_library_windows = 0;   // images read by the scanner / by libhdf5 in this process
+std::atomic<long long> g_fast_windows{0}, g_library_windows{0};   // images read by the scanner / by libhdf5 in this process
 struct Scanned {
     h5scan::File file;
     FileIdentity identity;
@@ -206,11 +215,15 @@ struct Scanned {
     uint64_t images = 0;
     uint64_t last_used = 0;
 };
-std::map<std::string, std::unique_ptr<Scanned>>& scanned_files() {
-    static std::map<std::string, std::unique_ptr<Scanned>> m;
+std::map<std::string, std::shared_ptr<Scanned>>& scanned_files() {
+    static std::map<std::string, std::shared_ptr<Scanned>> m;
     return m;
 }
+void forget_index(const char* path);
 void forget_path(const char* path) {
+    forget_index(path);
+    std::lock_guard<std::recursive_mutex> lib(g_library_mutex);
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
     auto& of = open_files();
     auto it = of.find(path);
     if (it != of.end()) {
@@ -223,9 +236,10 @@ bool reader_mode_is(const char* what) {
     const char* e = getenv("HELEN_IO_READER");
     return e && strcmp(e, what) == 0;
 }
-Scanned* scan_file(const char* path) {
+std::shared_ptr<Scanned> scan_file_shared(const char* path) {
     static const bool off = reader_mode_is("libhdf5");
     if (off) return nullptr;
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
     // A reader walks its files one after the other: only the newest few GIGABYTES stay mapped.  (A process that had
     // read a 27 GB image directory through eight mappings took up to 2 s to exit -- the kernel unmaps page by
     // page -- and predict waits for its readers; dropped when the reader moves on, that cost runs beside the device
@@ -240,7 +254,7 @@ Scanned* scan_file(const char* path) {
     if (it != m.end()) {
         if (present && it->second->identity == now) {
             it->second->last_used = ++tick;
-            return it->second->usable ? it->second.get() : nullptr;
+            return it->second->usable ? it->second : nullptr;
         }
         m.erase(it);     // rewritten, replaced or removed since it was mapped: never touch the old mapping again
     }
@@ -253,7 +267,7 @@ Scanned* scan_file(const char* path) {
             if (k->second->last_used < oldest->second->last_used) oldest = k;
         m.erase(oldest);
     }
-    std::unique_ptr<Scanned> sc(new Scanned());
+    std::shared_ptr<Scanned> sc(new Scanned());
     sc->identity = now;
     if (present && sc->file.open(path)) {
         std::vector<std::pair<std::string, uint64_t>> top;
@@ -268,9 +282,14 @@ Scanned* scan_file(const char* path) {
     }
     if (!sc->usable) sc->file.close();
     sc->last_used = ++tick;
-    Scanned* raw = sc.get();
-    m[path] = std::move(sc);
-    return raw->usable ? raw : nullptr;
+    m[path] = sc;
+    return sc->usable ? sc : nullptr;
+}
+// the mapping stays alive (whatever the cache evicts meanwhile) until this thread's next call
+Scanned* scan_file(const char* path) {
+    thread_local std::shared_ptr<Scanned> hold;
+    hold = scan_file_shared(path);
+    return hold.get();
 }
 
 // element 0 of an integer dataset as int64 (any width, signed or not); false: not a plain integer dataset
@@ -361,6 +380,37 @@ std::string reference_contig_text(const std::string& raw) {
 
 // helen_io_read_images through the scanner.  0: done; -1: the reader's error (message set); 1: something this
 // scanner does not take -- the caller reads the batch through libhdf5 instead.
+// One image group (object header `g`) into row 0 of the output arrays.  0: done; -1: the reader's error; 1: not for
+// the scanner.
+int fast_read_one(const h5scan::File& f, uint64_t g, const char* path, const char* name, uint8_t* img, int64_t* pos,
+                  int64_t* meta, char* c, std::string* contig) {
+    uint64_t h;
+    h5scan::Dataset dc, di, dp;
+    if (!f.lookup(g, "contig", &h) || !f.dataset(h, &dc) || !f.first_string(dc, contig)) return 1;
+    if (!scan_i64_first(f, g, "contig_start", meta + 0) || !scan_i64_first(f, g, "contig_end", meta + 1) ||
+        !scan_i64_first(f, g, "feature_chunk_idx", meta + 2))
+        return 1;
+    if (!f.lookup(g, "image", &h) || !f.dataset(h, &di)) return 1;
+    if (!f.lookup(g, "position", &h) || !f.dataset(h, &dp)) return 1;
+    if (di.cls > 1 || dp.cls != 0) return 1;
+    const int rows = di.rank == 2 && di.dims[0] <= (uint64_t)kSeq ? (int)di.dims[0] : -1;
+    if (di.rank != 2 || di.dims[1] != (uint64_t)kFeat || di.dims[0] > (uint64_t)kSeq || dp.rank != 2 || dp.dims[1] != 3 ||
+        dp.dims[0] != di.dims[0])
+        return fail("IMAGE SIZE ERROR: %s (%d, %d)", path, rows, kFeat);   // dataloader_predict.py:85-86
+    if (!scan_2d<uint8_t>(di, img) || !scan_2d<int64_t>(dp, pos)) return 1;
+    if (rows < kSeq) {                                                        // :74-82
+        memset(img + (size_t)rows * kFeat, 0, (size_t)(kSeq - rows) * kFeat);
+        for (int k = rows * 3; k < kSeq * 3; ++k) pos[k] = -1;
+    }
+    const std::string clean = reference_contig_text(*contig);
+    if (clean.size() > (size_t)kName - 1)
+        return fail("%s: image '%s': contig name longer than %d bytes", path, name, kName - 1);
+    memcpy(c, clean.c_str(), clean.size() + 1);
+    return 0;
+}
+
+// helen_io_read_images through the scanner.  0: done; -1: the reader's error (message set); 1: something this
+// scanner does not take -- the caller reads the batch through libhdf5 instead.
 int fast_read_images(Scanned* sc, const char* path, const char* names, int n, uint8_t* images, int64_t* positions,
                      int64_t* meta, char* contigs) {
     const h5scan::File& f = sc->file;
@@ -371,35 +421,35 @@ int fast_read_images(Scanned* sc, const char* path, const char* names, int n, ui
         const char* e = strchr(p, '\n');
         const std::string name = e ? std::string(p, e - p) : std::string(p);
         p = e ? e + 1 : p + name.size();
-        uint64_t g, h;
+        uint64_t g;
         if (!f.lookup(sc->images, name.c_str(), &g)) return 1;
-        h5scan::Dataset dc, di, dp;
-        if (!f.lookup(g, "contig", &h) || !f.dataset(h, &dc) || !f.first_string(dc, &contig)) return 1;
-        if (!scan_i64_first(f, g, "contig_start", meta + (size_t)i * 3 + 0) ||
-            !scan_i64_first(f, g, "contig_end", meta + (size_t)i * 3 + 1) ||
-            !scan_i64_first(f, g, "feature_chunk_idx", meta + (size_t)i * 3 + 2))
-            return 1;
-        if (!f.lookup(g, "image", &h) || !f.dataset(h, &di)) return 1;
-        if (!f.lookup(g, "position", &h) || !f.dataset(h, &dp)) return 1;
-        if (di.cls > 1 || dp.cls != 0) return 1;
-        const int rows = di.rank == 2 && di.dims[0] <= (uint64_t)kSeq ? (int)di.dims[0] : -1;
-        if (di.rank != 2 || di.dims[1] != (uint64_t)kFeat || di.dims[0] > (uint64_t)kSeq || dp.rank != 2 || dp.dims[1] != 3 ||
-            dp.dims[0] != di.dims[0])
-            return fail("IMAGE SIZE ERROR: %s (%d, %d)", path, rows, kFeat);   // dataloader_predict.py:85-86
-        uint8_t* img = images + (size_t)i * kSeq * kFeat;
-        int64_t* pos = positions + (size_t)i * kSeq * 3;
-        if (!scan_2d<uint8_t>(di, img) || !scan_2d<int64_t>(dp, pos)) return 1;
-        if (rows < kSeq) {                                                        // :74-82
-            memset(img + (size_t)rows * kFeat, 0, (size_t)(kSeq - rows) * kFeat);
-            for (int k = rows * 3; k < kSeq * 3; ++k) pos[k] = -1;
-        }
-        const std::string clean = reference_contig_text(contig);
-        if (clean.size() > (size_t)kName - 1)
-            return fail("%s: image '%s': contig name longer than %d bytes", path, name.c_str(), kName - 1);
-        char* c = contigs + (size_t)i * kName;
-        memcpy(c, clean.c_str(), clean.size() + 1);
+        const int rc = fast_read_one(f, g, path, name.c_str(), images + (size_t)i * kSeq * kFeat,
+                                     positions + (size_t)i * kSeq * 3, meta + (size_t)i * 3, contigs + (size_t)i * kName,
+                                     &contig);
+        if (rc) return rc;
     }
     return 0;
+}
+
+// ---- image index: the members of `images` of one file in name order, listed once -----------------------------------
+// The loader walks a file's images in name order (dataloader_predict.py:38-52); with the index a window is addressed by
+// (file, position in that order): no name travels between the languages and the scanner needs no B-tree descent per image.
+struct ImageIndex {
+    FileIdentity identity;
+    bool has_images = false;
+    bool through_library = false;                           // the scanner declined the file: names only
+    std::shared_ptr<Scanned> scanned;                       // keeps the mapping of `headers` alive
+    std::vector<std::string> names;
+    std::vector<uint64_t> headers;                          // object header of each image group (scanner)
+};
+std::map<std::string, std::shared_ptr<ImageIndex>>& image_indexes() {
+    static std::map<std::string, std::shared_ptr<ImageIndex>> m;
+    return m;
+}
+void forget_index(const char* path) {
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    if (path) image_indexes().erase(path);
+    else image_indexes().clear();
 }
 
 // ---- writer side ------------------------------------------------------------------------------
@@ -440,6 +490,52 @@ int write_ds(Writer* w, hid_t loc, const std::string& path, hid_t ftype, hid_t m
     return rc < 0 ? fail("cannot write dataset '%s'", path.c_str()) : 0;
 }
 
+// helen_io_read_images through libhdf5 (the caller holds g_library_mutex)
+int library_read_images(hid_t f, const char* path, const char* names, int n, uint8_t* images, int64_t* positions,
+                        int64_t* meta, char* contigs) {
+    const char* p = names;
+    for (int i = 0; i < n; ++i) {
+        const char* e = strchr(p, '\n');
+        std::string name = e ? std::string(p, e - p) : std::string(p);
+        p = e ? e + 1 : p + name.size();
+        const std::string gpath = "images/" + name;
+        hid_t g = H5Gopen2(f, gpath.c_str(), H5P_DEFAULT);
+        if (g < 0) return fail("%s: no image '%s'", path, name.c_str());
+        uint8_t* img = images + (size_t)i * kSeq * kFeat;
+        int64_t* pos = positions + (size_t)i * kSeq * 3;
+        int rows = 0, prow = 0;
+        int rc = read_str_first(g, "contig", contigs + (size_t)i * kName, kName);
+        if (rc == -2) {
+            H5Gclose(g);
+            return fail("%s: image '%s': contig name longer than %d bytes", path, name.c_str(), kName - 1);
+        }
+        rc |= read_i64_first(g, "contig_start", meta + (size_t)i * 3 + 0);
+        rc |= read_i64_first(g, "contig_end", meta + (size_t)i * 3 + 1);
+        rc |= read_i64_first(g, "feature_chunk_idx", meta + (size_t)i * 3 + 2);
+        if (rc) {
+            H5Gclose(g);
+            return fail("%s: image '%s' lacks contig / contig_start / contig_end / feature_chunk_idx", path,
+                        name.c_str());
+        }
+        const int r1 = read_2d(g, "image", H5T_NATIVE_UINT8, kFeat, kSeq, img, &rows);
+        const int r2 = read_2d(g, "position", H5T_NATIVE_INT64, 3, kSeq, pos, &prow);
+        H5Gclose(g);
+        if (r1 || r2 || prow != rows)
+            return fail("IMAGE SIZE ERROR: %s (%d, %d)", path, rows, kFeat);   // :85-86
+        if (rows < kSeq) {                                                        // :74-82
+            memset(img + (size_t)rows * kFeat, 0, (size_t)(kSeq - rows) * kFeat);
+            for (int k = rows * 3; k < kSeq * 3; ++k) pos[k] = -1;
+        }
+        char* c = contigs + (size_t)i * kName;
+        const std::string clean = reference_contig_text(c);
+        if (clean.size() > (size_t)kName - 1)
+            return fail("%s: image '%s': contig name longer than %d bytes", path, name.c_str(), kName - 1);
+        memcpy(c, clean.c_str(), clean.size() + 1);
+    }
+    return 0;
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -476,6 +572,7 @@ int helen_io_list_images(const char* path, char* out, size_t cap, long long* n_o
     }
     static const bool direct_only = reader_mode_is("direct");
     if (direct_only) return fail("%s: not a file the direct scanner takes", path);
+    std::lock_guard<std::recursive_mutex> lib(g_library_mutex);
     hid_t f = get_file(path);
     if (f < 0) return fail("cannot open '%s'", path);
     *n_out = 0;
@@ -529,47 +626,215 @@ int helen_io_read_images(const char* path, const char* names, int n, uint8_t* im
     static const bool direct_only = reader_mode_is("direct");
     if (direct_only) return fail("%s: not a file the direct scanner takes", path);
     g_library_windows += n;
+    std::lock_guard<std::recursive_mutex> lib(g_library_mutex);
     hid_t f = get_file(path);
     if (f < 0) return fail("cannot open '%s'", path);
-    const char* p = names;
-    for (int i = 0; i < n; ++i) {
-        const char* e = strchr(p, '\n');
-        std::string name = e ? std::string(p, e - p) : std::string(p);
-        p = e ? e + 1 : p + name.size();
-        const std::string gpath = "images/" + name;
-        hid_t g = H5Gopen2(f, gpath.c_str(), H5P_DEFAULT);
-        if (g < 0) return fail("%s: no image '%s'", path, name.c_str());
-        uint8_t* img = images + (size_t)i * kSeq * kFeat;
-        int64_t* pos = positions + (size_t)i * kSeq * 3;
-        int rows = 0, prow = 0;
-        int rc = read_str_first(g, "contig", contigs + (size_t)i * kName, kName);
-        if (rc == -2) {
-            H5Gclose(g);
-            return fail("%s: image '%s': contig name longer than %d bytes", path, name.c_str(), kName - 1);
+    return library_read_images(f, path, names, n, images, positions, meta, contigs);
+}
+
+/* ---- the same reader addressed by position: (file, first image, count) runs, several threads ------------------- */
+static std::shared_ptr<ImageIndex> image_index(const char* path) {
+    FileIdentity now;
+    const bool present = now.read(path);
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        auto it = image_indexes().find(path);
+        if (it != image_indexes().end()) {
+            if (present && it->second->identity == now) return it->second;
+            image_indexes().erase(it);
         }
-        rc |= read_i64_first(g, "contig_start", meta + (size_t)i * 3 + 0);
-        rc |= read_i64_first(g, "contig_end", meta + (size_t)i * 3 + 1);
-        rc |= read_i64_first(g, "feature_chunk_idx", meta + (size_t)i * 3 + 2);
-        if (rc) {
-            H5Gclose(g);
-            return fail("%s: image '%s' lacks contig / contig_start / contig_end / feature_chunk_idx", path,
-                        name.c_str());
-        }
-        const int r1 = read_2d(g, "image", H5T_NATIVE_UINT8, kFeat, kSeq, img, &rows);
-        const int r2 = read_2d(g, "position", H5T_NATIVE_INT64, 3, kSeq, pos, &prow);
-        H5Gclose(g);
-        if (r1 || r2 || prow != rows)
-            return fail("IMAGE SIZE ERROR: %s (%d, %d)", path, rows, kFeat);   // :85-86
-        if (rows < kSeq) {                                                        // :74-82
-            memset(img + (size_t)rows * kFeat, 0, (size_t)(kSeq - rows) * kFeat);
-            for (int k = rows * 3; k < kSeq * 3; ++k) pos[k] = -1;
-        }
-        char* c = contigs + (size_t)i * kName;
-        const std::string clean = reference_contig_text(c);
-        if (clean.size() > (size_t)kName - 1)
-            return fail("%s: image '%s': contig name longer than %d bytes", path, name.c_str(), kName - 1);
-        memcpy(c, clean.c_str(), clean.size() + 1);
     }
+    std::shared_ptr<ImageIndex> ix(new ImageIndex());
+    ix->identity = now;
+    bool listed = false;
+    if (std::shared_ptr<Scanned> sc = scan_file_shared(path)) {
+        if (!sc->has_images) {
+            listed = true;
+        } else {
+            std::vector<std::pair<std::string, uint64_t>> kids;
+            if (sc->file.children(sc->images, &kids)) {
+                listed = true;
+                ix->has_images = true;
+                ix->scanned = sc;
+                ix->names.reserve(kids.size());
+                ix->headers.reserve(kids.size());
+                for (auto& kv : kids) {
+                    ix->names.push_back(std::move(kv.first));
+                    ix->headers.push_back(kv.second);
+                }
+            }
+        }
+    }
+    if (!listed) {
+        static const bool direct_only = reader_mode_is("direct");
+        if (direct_only) {
+            fail("%s: not a file the direct scanner takes", path);
+            return nullptr;
+        }
+        std::vector<char> buf((size_t)1 << 20);
+        long long n = 0;
+        int rc;
+        while ((rc = helen_io_list_images(path, buf.data(), buf.size(), &n)) == -2) buf.resize((size_t)n + 16);
+        if (rc < 0) return nullptr;
+        ix->through_library = true;
+        ix->has_images = rc == 0;
+        const char* p = buf.data();
+        for (long long i = 0; i < n; ++i) {
+            const char* e = (const char*)memchr(p, '\n', buf.data() + buf.size() - p);
+            if (!e) break;
+            ix->names.emplace_back(p, e - p);
+            p = e + 1;
+        }
+    }
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    if (image_indexes().size() >= 4096) image_indexes().clear();
+    image_indexes()[path] = ix;
+    return ix;
+}
+
+/* Number of images of one file (*n_out) and whether libhdf5 has to read them (*through_library).  Returns 1 (and
+ * *n_out = 0) if the file has no `images` group. */
+int helen_io_index_images(const char* path, long long* n_out, int* through_library) {
+    *n_out = 0;
+    if (through_library) *through_library = 0;
+    const std::shared_ptr<ImageIndex> ix = image_index(path);
+    if (!ix) return -1;
+    if (through_library) *through_library = ix->through_library ? 1 : 0;
+    if (!ix->has_images) return 1;
+    *n_out = (long long)ix->names.size();
+    return 0;
+}
+
+/* Names of images [first, first + count) of the index, '\n'-separated; -2 if `cap` is too small (*needed = bytes). */
+int helen_io_image_names(const char* path, long long first, long long count, char* out, size_t cap, long long* needed) {
+    const std::shared_ptr<ImageIndex> ix = image_index(path);
+    if (!ix) return -1;
+    if (first < 0 || count < 0 || (size_t)(first + count) > ix->names.size()) return fail("%s: image range out of bounds", path);
+    size_t used = 0;
+    for (long long i = first; i < first + count; ++i) {
+        const std::string& nm = ix->names[(size_t)i];
+        if (used + nm.size() + 1 <= cap) {
+            memcpy(out + used, nm.data(), nm.size());
+            out[used + nm.size()] = '\n';
+        }
+        used += nm.size() + 1;
+    }
+    if (needed) *needed = (long long)used;
+    if (used + 1 > cap) return -2;
+    out[used] = 0;
+    return 0;
+}
+
+/* helen_io_read_images for images [first, first + count) of the file's index.  Thread-safe. */
+int helen_io_read_image_range(const char* path, long long first, int count, uint8_t* images, int64_t* positions,
+                              int64_t* meta, char* contigs, long long* through_library) {
+    const std::shared_ptr<ImageIndex> ix = image_index(path);
+    if (!ix) return -1;
+    if (first < 0 || count < 0 || (size_t)(first + count) > ix->names.size()) return fail("%s: image range out of bounds", path);
+    int done = 0;
+    if (!ix->through_library) {
+        const h5scan::File& f = ix->scanned->file;
+        std::string contig;
+        for (; done < count; ++done) {
+            const size_t k = (size_t)first + done;
+            const int rc = fast_read_one(f, ix->headers[k], path, ix->names[k].c_str(), images + (size_t)done * kSeq * kFeat,
+                                         positions + (size_t)done * kSeq * 3, meta + (size_t)done * 3,
+                                         contigs + (size_t)done * kName, &contig);
+            if (rc < 0) return rc;
+            if (rc > 0) break;          // this image is not for the scanner: the rest of the range goes to libhdf5
+        }
+        g_fast_windows += done;
+        if (done == count) return 0;
+        static const bool direct_only = reader_mode_is("direct");
+        if (direct_only) return fail("%s: not a file the direct scanner takes", path);
+    }
+    std::string names;
+    for (int i = done; i < count; ++i) {
+        names += ix->names[(size_t)first + i];
+        names += '\n';
+    }
+    if (through_library) *through_library += count - done;
+    // (helen_io_read_images tries the scanner first: switched off for this call by going to the library code directly)
+    std::lock_guard<std::recursive_mutex> lib(g_library_mutex);
+    g_library_windows += count - done;
+    hid_t f = get_file(path);
+    if (f < 0) return fail("cannot open '%s'", path);
+    return library_read_images(f, path, names.c_str(), count - done, images + (size_t)done * kSeq * kFeat,
+                               positions + (size_t)done * kSeq * 3, meta + (size_t)done * 3, contigs + (size_t)done * kName);
+}
+
+/* A reader that has moved past a file lets go of its index and its mapping (unmapping gigabytes of touched pages takes
+ * the kernel tenths of a second: call this from a thread that has nothing better to do). */
+void helen_io_forget_images(const char* path) {
+    std::shared_ptr<ImageIndex> ix;
+    std::shared_ptr<Scanned> sc;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        auto it = image_indexes().find(path);
+        if (it != image_indexes().end()) {
+            ix = it->second;
+            image_indexes().erase(it);
+        }
+        auto js = scanned_files().find(path);
+        if (js != scanned_files().end()) {
+            sc = js->second;
+            scanned_files().erase(js);
+        }
+    }
+    ix.reset();
+    sc.reset();      // the last reference unmaps here, outside the lock
+}
+
+/* `n_runs` ranges (paths[i], firsts[i], counts[i]) read into consecutive rows of the output arrays by `threads`
+ * threads of this call (pieces of at most 32 images, taken in order).  *through_library = images libhdf5 read (those are
+ * serialised: the library is not thread-safe).  The first failing piece's error is this call's. */
+int helen_io_read_image_runs(int n_runs, const char* const* paths, const long long* firsts, const int* counts, int threads,
+                             uint8_t* images, int64_t* positions, int64_t* meta, char* contigs,
+                             long long* through_library) {
+    struct Piece {
+        int run;
+        long long first;
+        int count;
+        size_t row;
+    };
+    std::vector<Piece> pieces;
+    size_t row = 0;
+    for (int r = 0; r < n_runs; ++r)
+        for (int o = 0; o < counts[r]; o += 32) {
+            const int c = std::min(32, counts[r] - o);
+            pieces.push_back({r, firsts[r] + o, c, row});
+            row += (size_t)c;
+        }
+    if (through_library) *through_library = 0;
+    std::atomic<size_t> next{0};
+    std::atomic<bool> failed{false};
+    std::atomic<long long> lib_total{0};
+    std::mutex err_mutex;
+    std::string first_error;
+    auto work = [&]() {
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= pieces.size() || failed.load()) return;
+            const Piece& p = pieces[k];
+            long long lib = 0;
+            const int rc = helen_io_read_image_range(paths[p.run], p.first, p.count, images + p.row * kSeq * kFeat,
+                                                     positions + p.row * kSeq * 3, meta + p.row * 3,
+                                                     contigs + p.row * kName, &lib);
+            lib_total += lib;
+            if (rc != 0) {
+                std::lock_guard<std::mutex> lock(err_mutex);
+                if (!failed.exchange(true)) first_error = g_err;
+                return;
+            }
+        }
+    };
+    const int nt = std::max(1, std::min<int>(threads, (int)pieces.size()));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    if (through_library) *through_library = lib_total.load();
+    if (failed.load()) return fail("%s", first_error.c_str());
     return 0;
 }
 
@@ -611,6 +876,7 @@ int helen_io_read_labeled(const char* path, const char* names, int n, uint8_t* i
         }
         static const bool direct_only = reader_mode_is("direct");
         if (direct_only) return fail("%s: not a file the direct scanner takes", path);
+        std::lock_guard<std::recursive_mutex> lib(g_library_mutex);
         if (f < 0) f = get_file(path);
         if (f < 0) return fail("cannot open '%s'", path);
         const std::string gpath = "images/" + name;
@@ -685,6 +951,9 @@ void helen_io_reader_counts(long long* out) {
 
 /* Drop every cached read handle of this process. */
 void helen_io_close_readers(void) {
+    forget_index(nullptr);
+    std::lock_guard<std::recursive_mutex> lib(g_library_mutex);
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
     for (auto& kv : open_files()) H5Fclose(kv.second.id);
     open_files().clear();
     scanned_files().clear();
@@ -708,6 +977,7 @@ void* helen_io_writer_open(const char* path) {
         }
         return w;
     }
+    std::lock_guard<std::recursive_mutex> lib(g_library_mutex);
     hid_t fapl = H5Pcreate(H5P_FILE_ACCESS);
     // thousands of tiny objects: allocate metadata in 1 MiB blocks (+10 % writes/s, same format)
     H5Pset_meta_block_size(fapl, (hsize_t)1 << 20);
@@ -774,6 +1044,7 @@ int helen_io_write_predictions_sel(void* handle, int n_sel, const int32_t* sel, 
             if (!w->fast->ok()) return fail("write failed (disk full?)");
             continue;
         }
+        std::lock_guard<std::recursive_mutex> lib(g_library_mutex);
         const std::string root = "predictions/" + contig + "/" + prefix;
         if (w->regions.insert(prefix).second) {
             if (write_ds(w, w->file, root + "/contig_start", H5T_STD_I64LE, H5T_NATIVE_INT64, w->space_scalar, &cs)) return -1;
@@ -898,6 +1169,7 @@ int helen_io_list_regions(const char* path, const char* contig, long long* sizes
         region.clear();
         st.clear();
         en.clear();
+        std::lock_guard<std::recursive_mutex> lib(g_library_mutex);
         hid_t f = get_file(path);
         if (f < 0) return fail("cannot open '%s'", path);
         const std::string gpath = std::string("predictions/") + contig;
@@ -953,6 +1225,7 @@ long long helen_io_region_sequence(const char* path, const char* contig, const c
     }
     static const bool direct_only = reader_mode_is("direct");
     if (direct_only) return fail("%s: not a file the direct scanner takes", path);
+    std::lock_guard<std::recursive_mutex> lib(g_library_mutex);
     hid_t f = get_file(path);
     if (f < 0) return fail("cannot open '%s'", path);
     const std::string gpath = std::string("predictions/") + contig + "/" + region;
@@ -1061,11 +1334,21 @@ int helen_io_writer_close(void* handle) {
             std::vector<h5emit::Child> regions;
         };
         Node rootn;
+        std::vector<std::string> parts;
         for (auto& c : w->tree) {
+            // (the ordinary contig name -- no '/', not empty, not '.' -- is one component: its regions go straight under it,
+            // already in name order because the map is)
+            const bool plain = !c.first.empty() && c.first != "." && c.first.find('/') == std::string::npos;
+            Node* direct = plain ? &rootn.sub[c.first] : nullptr;
+            if (direct) direct->regions.reserve(direct->regions.size() + c.second.size());
             for (auto& r : c.second) {
                 settle_region(w, &r.second);
+                if (direct && !r.first.empty() && r.first != "." && r.first.find('/') == std::string::npos) {
+                    direct->regions.push_back({r.first, r.second.header});
+                    continue;
+                }
                 const std::string full = c.first + "/" + r.first;
-                std::vector<std::string> parts;
+                parts.clear();
                 for (size_t b = 0; b <= full.size();) {
                     size_t e = full.find('/', b);
                     if (e == std::string::npos) e = full.size();
@@ -1080,12 +1363,16 @@ int helen_io_writer_close(void* handle) {
         }
         bool clash = false;
         std::function<uint64_t(Node&)> emit = [&](Node& n) -> uint64_t {
-            std::vector<h5emit::Child> kids = n.regions;
-            std::set<std::string> names;
-            for (auto& k : kids) names.insert(k.name);
-            for (auto& kv : n.sub) {
-                if (!names.insert(kv.first).second) clash = true;   // a region and a contig component of one name
-                kids.push_back({kv.first, emit(kv.second)});
+            std::vector<h5emit::Child> kids;
+            kids.swap(n.regions);
+            if (!n.sub.empty()) {
+                std::set<std::string> names;
+                if (!kids.empty())
+                    for (auto& k : kids) names.insert(k.name);
+                for (auto& kv : n.sub) {
+                    if (!names.insert(kv.first).second) clash = true;   // a region and a contig component of one name
+                    kids.push_back({kv.first, emit(kv.second)});
+                }
             }
             return w->fast->group(kids);
         };

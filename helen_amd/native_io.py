@@ -46,6 +46,20 @@ def load():
     lib.helen_io_close_readers.argtypes = []
     lib.helen_io_read_images.restype = ctypes.c_int
     lib.helen_io_read_images.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, vp, vp, vp, vp]
+    lib.helen_io_index_images.restype = ctypes.c_int
+    lib.helen_io_index_images.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_int)]
+    lib.helen_io_image_names.restype = ctypes.c_int
+    lib.helen_io_image_names.argtypes = [ctypes.c_char_p, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_char_p,
+                                         ctypes.c_size_t, ctypes.POINTER(ctypes.c_longlong)]
+    lib.helen_io_read_image_range.restype = ctypes.c_int
+    lib.helen_io_read_image_range.argtypes = [ctypes.c_char_p, ctypes.c_longlong, ctypes.c_int, vp, vp, vp, vp,
+                                              ctypes.POINTER(ctypes.c_longlong)]
+    lib.helen_io_read_image_runs.restype = ctypes.c_int
+    lib.helen_io_read_image_runs.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_longlong),
+                                             ctypes.POINTER(ctypes.c_int), ctypes.c_int, vp, vp, vp, vp,
+                                             ctypes.POINTER(ctypes.c_longlong)]
+    lib.helen_io_forget_images.restype = None
+    lib.helen_io_forget_images.argtypes = [ctypes.c_char_p]
     lib.helen_io_writer_open.restype = vp
     lib.helen_io_writer_open.argtypes = [ctypes.c_char_p]
     lib.helen_io_write_predictions.restype = ctypes.c_int
@@ -92,6 +106,65 @@ def list_images(path):
         if rc != 0:
             raise IOError(_err(lib))
         return buf.raw.split(b"\0", 1)[0].decode().split("\n")[:n.value] if n.value else []
+
+
+def index_images(path):
+    """(number of images, read through libhdf5?) of one file, or None if it has no `images` group: the file's images in
+    name order are addressed by position from here on (read_image_runs)."""
+    lib = load()
+    n, through = ctypes.c_longlong(), ctypes.c_int()
+    rc = lib.helen_io_index_images(os.fsencode(path), ctypes.byref(n), ctypes.byref(through))
+    if rc == 1:
+        return None
+    if rc != 0:
+        raise IOError(_err(lib))
+    return int(n.value), bool(through.value)
+
+
+def image_names(path, first, count):
+    """Names of images [first, first + count) of the file's index."""
+    lib = load()
+    cap = 64 * max(1, count) + 64
+    while True:
+        buf = ctypes.create_string_buffer(cap)
+        need = ctypes.c_longlong()
+        rc = lib.helen_io_image_names(os.fsencode(path), first, count, buf, cap, ctypes.byref(need))
+        if rc == -2:
+            cap = int(need.value) + 16
+            continue
+        if rc != 0:
+            raise IOError(_err(lib))
+        return buf.value.decode().split("\n")[:count] if count else []
+
+
+def _raise_reader_error(lib):
+    msg = _err(lib)
+    if msg.startswith("IMAGE SIZE ERROR") or "contig name longer than" in msg:
+        raise ValueError(msg)
+    raise IOError(msg)
+
+
+def read_image_runs(runs, threads, images, positions, meta, contigs):
+    """runs = [(path, first, count), ...] read into consecutive rows of the arrays (as read_images) by `threads` native
+    threads; the GIL is released for the duration.  Returns how many of the images libhdf5 had to read."""
+    lib = load()
+    n = len(runs)
+    paths = (ctypes.c_char_p * n)(*[os.fsencode(r[0]) for r in runs])
+    firsts = (ctypes.c_longlong * n)(*[int(r[1]) for r in runs])
+    counts = (ctypes.c_int * n)(*[int(r[2]) for r in runs])
+    through = ctypes.c_longlong()
+    rc = lib.helen_io_read_image_runs(n, paths, firsts, counts, int(threads), images.ctypes.data, positions.ctypes.data,
+                                      meta.ctypes.data, contigs.ctypes.data, ctypes.byref(through))
+    if rc != 0:
+        _raise_reader_error(lib)
+    return int(through.value)
+
+
+def forget_images(path):
+    """The reader has moved past `path`: drop its index and mapping (the unmap runs in the calling thread)."""
+    lib = load()
+    if lib is not None:
+        lib.helen_io_forget_images(os.fsencode(path))
 
 
 def emit_images(path, contig, starts, chunks, lengths, images):

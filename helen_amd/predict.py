@@ -78,6 +78,8 @@ class _DeviceStage(object):
         # Locking the later slots from a helper thread while the first calls run was measured: the set-up shrinks
         # by 0.26 s and the loop grows by as much -- the pages have to be brought in either way)
         for sl in slots:
+            if not hasattr(sl, "base_address"):      # a PinnedSlot: page-locked memory of the runtime already
+                continue
             ptr, nbytes = sl.base_address()
             rc = self.rt.cudaHostRegister(ptr, nbytes, 0)
             if int(rc) != 0:
@@ -99,7 +101,8 @@ class _DeviceStage(object):
         with torch.cuda.stream(self.s_in):
             if self.busy[i] is not None:
                 self.s_in.wait_event(self.busy[i])
-            self.img[i][:n].copy_(torch.from_numpy(slot.images[:n]), non_blocking=True)
+            src = slot.images_t[:n] if hasattr(slot, "images_t") else torch.from_numpy(slot.images[:n])
+            self.img[i][:n].copy_(src, non_blocking=True)
             ev_in = self.s_in.record_event()
         compute.wait_event(ev_in)
         bases, rles = self.engine.polish(self.img[i][:n])
@@ -107,8 +110,9 @@ class _DeviceStage(object):
         self.busy[i] = ev_c
         with torch.cuda.stream(self.s_out):
             self.s_out.wait_event(ev_c)
-            torch.from_numpy(slot.bases[:n]).copy_(bases, non_blocking=True)
-            torch.from_numpy(slot.rles[:n]).copy_(rles, non_blocking=True)
+            pinned = hasattr(slot, "bases_t")
+            (slot.bases_t[:n] if pinned else torch.from_numpy(slot.bases[:n])).copy_(bases, non_blocking=True)
+            (slot.rles_t[:n] if pinned else torch.from_numpy(slot.rles[:n])).copy_(rles, non_blocking=True)
             ev_out = self.s_out.record_event()
         self.inflight.append((slot, n, ev_out, (bases, rles)))     # keep the device labels alive
 
@@ -216,6 +220,84 @@ def _feeder_loop(calls, free_slots, ready_q, pool, cap, err, num_workers=0):
         ready_q.put(None)           # whatever happened, the consumer gets its end-of-stream
 
 
+def reader_mode(runs, num_workers, writers):
+    """"threads" (the default): the readers are native threads of this process (helen_io_read_image_runs: the direct
+    scanner walks the files' mappings in parallel, no interpreter involved) filling page-locked slots -- no reader
+    processes to start, no shared-memory files to reserve, page-lock and tear down.  "processes" (round 2's pool over
+    shared-memory slots) when libhdf5 has to read some of the files and more than one worker was asked for (the library is
+    serialised inside a process), when a writer pool needs slots other processes can attach, or on request
+    ($HELEN_READERS=processes)."""
+    from . import native_io
+    want = os.environ.get("HELEN_READERS", "")
+    if want in ("threads", "processes"):
+        return want if native_io.available() else "processes"
+    if not native_io.available() or writers > 1:
+        return "processes"
+    if num_workers > 1 and any(lib for _, _, lib in runs):
+        return "processes"
+    return "threads"
+
+
+def _thread_feeder_loop(calls, free_slots, ready_q, make_slot, n_slots, threads, batch_size, err, device_id, reap_q):
+    """Feeder of the "threads" mode: per device call a free slot (the first `n_slots` are made here, one at a time, as
+    the pipeline asks for them: page-locked allocations cost ~0.1 s each and only the first one is waited for), the
+    call's (file, first, count) runs read by `threads` native threads, files the reader has left handed to the reaper."""
+    from . import native_io
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.set_device(device_id)      # the page-locked allocations below belong to this rank's device
+        made = 0
+        last_path = None
+        for runs in calls:
+            slot = None
+            if made < n_slots:
+                try:
+                    slot = free_slots.get_nowait()
+                except queue.Empty:
+                    slot = make_slot()
+                    made += 1
+            if slot is None:
+                slot = free_slots.get()
+            if slot is None:        # a writer failed: the main loop must not wait for more slots
+                return
+            n = sum(c for _, _, c in runs)
+            lib = native_io.read_image_runs(runs, threads, slot.images[:n], slot.positions[:n], slot.meta[:n],
+                                            slot.contigs[:n])
+            done = _ReadDone(lib)
+            ready_q.put((slot, n, [done], -(-n // batch_size)))
+            for path, _, _ in runs:
+                if last_path is not None and path != last_path:
+                    reap_q.put(last_path)
+                last_path = path
+    except Exception as e:
+        err.append(e)
+    finally:
+        ready_q.put(None)           # whatever happened, the consumer gets its end-of-stream
+        reap_q.put(None)
+
+
+class _ReadDone(object):
+    """What a finished read hands the main loop in place of the pool's futures."""
+
+    def __init__(self, through_library):
+        self.through_library = through_library
+
+    def result(self):
+        return self
+
+
+def _reaper_loop(reap_q):
+    """Lets go of the mappings of files the reader has moved past (unmapping gigabytes of touched pages is tenths of a
+    second of kernel time: here it runs beside the device, not at the end of the run)."""
+    from . import native_io
+    while True:
+        path = reap_q.get()
+        if path is None:
+            return
+        native_io.forget_images(path)
+
+
 def _get_or_error(q, *error_lists):
     """q.get() that gives up (returns None, like the end-of-stream sentinel) as soon as a pipeline stage has
     reported an error: a failed writer must fail the run, not leave it waiting for a slot that never comes."""
@@ -250,6 +332,7 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
 
     from . import native_io
     from .model_handler import ModelHandler
+    start_time = time.time()
     if plan is not None:
         num_workers = min(num_workers, plan.reader_workers) if num_workers > 0 else 0
     native_io.close_readers()          # a long-lived process may have these paths mapped from an earlier run
@@ -263,24 +346,44 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     # Readers and writers first: their processes start (and the first slots fill) while the model is
     # loaded and the device context is created below.
     test_data = SequenceDataset(image_directory=None, file_list=test_file)
-    pairs = test_data.all_images
-    batches = [pairs[i:i + batch_size] for i in range(0, len(pairs), batch_size)]   # sequential,
-    calls = [batches[i:i + group] for i in range(0, len(batches), group)]           # short last batch
-    total_batches = len(batches)
-
-    # reader filling | H2D | kernels | D2H | writer: five slots keep every stage busy
-    n_slots = min(plan.slots if plan is not None else 5, max(1, len(calls)))
-    slots = [SharedSlot(cap, prefix=plan.slot_prefix if plan is not None else "helen_slot_") for _ in range(n_slots)]
+    total_windows = len(test_data)
+    total_batches = -(-total_windows // batch_size)
+    mode = reader_mode(test_data.runs, num_workers, writers)
     free_slots, ready_q, wq = queue.Queue(), queue.Queue(maxsize=2), queue.Queue()
-    for sl in slots:
-        free_slots.put(sl)
     pool = None
-    if num_workers > 0 and calls:
-        import concurrent.futures as cf
-        pool = cf.ProcessPoolExecutor(num_workers, mp_context=mp.get_context("spawn"))
+    if mode == "threads":
+        calls = test_data.call_runs(cap)
+        # reader filling | H2D | kernels | D2H | writer: five slots keep every stage busy
+        n_slots = min(plan.slots if plan is not None else 5, max(1, len(calls)))
+        slots = []
+
+        def make_slot():
+            from .sequence_dataset import PinnedSlot
+            slots.append(PinnedSlot(cap))
+            return slots[-1]
+    else:
+        pairs = test_data.all_images
+        batches = [pairs[i:i + batch_size] for i in range(0, len(pairs), batch_size)]   # sequential,
+        calls = [batches[i:i + group] for i in range(0, len(batches), group)]           # short last batch
+        n_slots = min(plan.slots if plan is not None else 5, max(1, len(calls)))
+        slots = [SharedSlot(cap, prefix=plan.slot_prefix if plan is not None else "helen_slot_") for _ in range(n_slots)]
+        for sl in slots:
+            free_slots.put(sl)
+        if num_workers > 0 and calls:
+            import concurrent.futures as cf
+            pool = cf.ProcessPoolExecutor(num_workers, mp_context=mp.get_context("spawn"))
     ferr, werr = [], []
-    feeder = threading.Thread(target=_feeder_loop, args=(calls, free_slots, ready_q, pool, cap, ferr, num_workers),
-                              daemon=True)
+    reaper = None
+    if mode == "threads":
+        reap_q = queue.Queue()
+        reaper = threading.Thread(target=_reaper_loop, args=(reap_q,), daemon=True)
+        reaper.start()
+        feeder = threading.Thread(target=_thread_feeder_loop, daemon=True,
+                                  args=(calls, free_slots, ready_q, make_slot, n_slots, max(1, num_workers), batch_size,
+                                        ferr, device_id, reap_q))
+    else:
+        feeder = threading.Thread(target=_feeder_loop, args=(calls, free_slots, ready_q, pool, cap, ferr, num_workers),
+                                  daemon=True)
     for k in STAGE_SECONDS:
         STAGE_SECONDS[k] = 0.0
     if writers == 1:
@@ -300,7 +403,6 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         else:
             writer_pool.submit(slot, n)
 
-    start_time = time.time()
     through_library = 0
     t_setup = t_loop_end = start_time
     batch_iterator = 0
@@ -423,17 +525,17 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         raise close_error
     LAST_PREDICT.clear()
     LAST_PREDICT.update({
-        "rank": rank, "device": device_id, "windows": len(pairs), "seconds": round(time.time() - start_time, 3),
+        "rank": rank, "device": device_id, "windows": total_windows, "seconds": round(time.time() - start_time, 3),
         "stage_seconds": {k: round(v, 3) for k, v in STAGE_SECONDS.items()},
         "setup_seconds": round(t_setup - start_time, 3), "close_seconds": round(time.time() - t_loop_end, 3),
-        "reader_workers": num_workers, "slots": n_slots, "device_calls": len(calls),
+        "reader_workers": num_workers, "reader_mode": mode, "slots": n_slots, "device_calls": len(calls),
         "cpus_pinned": None if plan is None or not plan.cpus else len(plan.cpus),
         "numa_node": None if plan is None else plan.numa_node})
     if rank == 0:
         sys.stderr.write("INFO: %d WINDOWS IN %.1f SECS (WAITING FOR READERS %.1f, DEVICE %.1f, WRITER BUSY %.1f; "
                          "MODEL + ENGINE SET-UP %.1f [%s], FLUSH + CLOSE %.1f = LAST SLOTS %.2f + FILE CLOSE %.2f + "
                          "RELEASE %.2f [%s]).\n"
-                         % (len(pairs), time.time() - start_time, STAGE_SECONDS["read_wait"],
+                         % (total_windows, time.time() - start_time, STAGE_SECONDS["read_wait"],
                             STAGE_SECONDS["device"], STAGE_SECONDS["write"], t_setup - start_time,
                             ", ".join("%s %.2f" % kv for kv in setup_took.items()),
                             time.time() - t_loop_end, t_drained - t_side, t_closed - t_drained,

@@ -176,6 +176,31 @@ class SharedSlot(object):
             os.unlink(self.path)
 
 
+class PinnedSlot(object):
+    """`cap` windows of reader output for reader THREADS of this process: the images and the label rows -- what the copy
+    engines touch -- in page-locked host memory of the runtime (hipHostMalloc through torch; nothing to register, nothing
+    to unregister, handed back to torch's host allocator at the end), positions / bounds / names in ordinary memory."""
+
+    path = None          # (no file behind it: writer PROCESSES cannot attach)
+
+    def __init__(self, cap):
+        import torch
+        self.cap = int(cap)
+        L, H = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT
+        pin = torch.cuda.is_available()
+        self.images_t = torch.empty((self.cap, L, H), dtype=torch.uint8, pin_memory=pin)
+        self.bases_t = torch.empty((self.cap, L), dtype=torch.uint8, pin_memory=pin)
+        self.rles_t = torch.empty((self.cap, L), dtype=torch.uint8, pin_memory=pin)
+        self.images, self.bases, self.rles = self.images_t.numpy(), self.bases_t.numpy(), self.rles_t.numpy()
+        self.positions = np.empty((self.cap, L, 3), np.int64)
+        self.meta = np.empty((self.cap, 3), np.int64)
+        self.contigs = np.zeros((self.cap, native_io.NAME_BYTES), np.uint8)
+
+    def close(self):
+        self.images = self.positions = self.meta = self.contigs = self.bases = self.rles = None
+        self.images_t = self.bases_t = self.rles_t = None
+
+
 def _unlink_quietly(path):
     import os
     try:
@@ -217,26 +242,69 @@ def fill_shared(path, cap, offset, pairs):
 
 
 class SequenceDataset(object):
+    """dataloader_predict.py:18-52: every image of every file, files in the given order, a file's images in name order.
+    `runs` = [(path, number of images, read through libhdf5?)] is that index by position (the native reader addresses an
+    image as (file, position): helen_io_read_image_runs); `all_images` = the reference's list of (path, name) pairs,
+    materialised when somebody asks for it."""
+
     def __init__(self, image_directory, file_list=None):
         if file_list is not None:
             hdf_files = list(file_list)
         else:
             hdf_files = get_file_paths_from_directory(image_directory)
+        self.runs = []
+        self._pairs = None
+        if native_io.available():
+            for path in hdf_files:
+                got = native_io.index_images(path)
+                if got is None:
+                    sys.stderr.write("WARN: NO IMAGES FOUND IN FILE: " + path + "\n")
+                    continue
+                self.runs.append((path, got[0], got[1]))
+            return
         pairs = []
         for path in hdf_files:
-            if native_io.available():
-                names = native_io.list_images(path)
-            else:
-                with hdf5.File(path, "r") as f:
-                    names = f.keys("images") if "images" in f else None
+            with hdf5.File(path, "r") as f:
+                names = f.keys("images") if "images" in f else None
             if names is None:
                 sys.stderr.write("WARN: NO IMAGES FOUND IN FILE: " + path + "\n")
                 continue
+            self.runs.append((path, len(names), True))
             pairs.extend((path, name) for name in names)
-        self.all_images = pairs
+        self._pairs = pairs
+
+    @property
+    def all_images(self):
+        if self._pairs is None:
+            pairs = []
+            for path, n, _ in self.runs:
+                pairs.extend((path, name) for name in native_io.image_names(path, 0, n))
+            self._pairs = pairs
+        return self._pairs
+
+    @all_images.setter
+    def all_images(self, pairs):
+        self._pairs = pairs
+
+    def call_runs(self, windows_per_call):
+        """The index cut into device calls of `windows_per_call` consecutive images: [[(path, first, count), ...], ...]."""
+        calls, cur, room = [], [], windows_per_call
+        for path, n, _ in self.runs:
+            first = 0
+            while first < n:
+                take = min(room, n - first)
+                cur.append((path, first, take))
+                first += take
+                room -= take
+                if room == 0:
+                    calls.append(cur)
+                    cur, room = [], windows_per_call
+        if cur:
+            calls.append(cur)
+        return calls
 
     def __len__(self):
-        return len(self.all_images)
+        return sum(n for _, n, _ in self.runs) if self._pairs is None else len(self._pairs)
 
     def __getitem__(self, index):
         path, name = self.all_images[index]

@@ -11,9 +11,10 @@
  *   - functions returning int give 0 on success, -1 on error (helen_io_last_error() then describes it; the string
  *     is thread-local), and the small positive codes documented per function; nothing throws across the ABI;
  *   - all buffers are the caller's, C-contiguous; strings are NUL-terminated UTF-8;
- *   - the file functions (helen_io_*) keep per-process caches of open files and mappings and are NOT thread-safe:
- *     call them from one thread per process (this package parallelises with processes); helen_ssw_align is
- *     re-entrant and may be called from any number of threads;
+ *   - the file functions (helen_io_*) keep per-process caches of open files and mappings behind a lock; the READER
+ *     functions may be called from any number of threads (the direct scanner runs in parallel, whatever goes through
+ *     libhdf5 -- not built thread-safe -- is serialised; helen_io_read_image_runs starts its own threads); a WRITER handle
+ *     belongs to one thread at a time; helen_ssw_align is re-entrant;
  *   - HELEN_IO_SEQ (1000) positions and HELEN_IO_FEATURES (90) features per window (`Options.py:13-21`);
  *     HELEN_IO_NAME (256) bytes per contig name slot.
  */
@@ -49,6 +50,25 @@ int helen_io_list_images(const char* path, char* out, size_t cap, long long* n_o
  *   meta      [n, 3] int64 = contig_start, contig_end, feature_chunk_idx        contigs [n, 256] char */
 int helen_io_read_images(const char* path, const char* names, int n, uint8_t* images, int64_t* positions,
                          int64_t* meta, char* contigs);
+
+/* The same reader addressed by POSITION in the file's name-ordered image list (what the loader's index is,
+ * `dataloader_predict.py:38-52`): no names cross the boundary and the scanner needs no look-up per image.
+ *   helen_io_index_images     *n_out = images of the file, *through_library = 1 if libhdf5 has to read them (the direct
+ *                             scanner does not take the file's storage); returns 1 if there is no `images` group
+ *   helen_io_image_names      names of images [first, first + count), '\n'-separated; -2: cap too small (*needed)
+ *   helen_io_read_image_range helen_io_read_images for images [first, first + count); *through_library += images
+ *                             libhdf5 read
+ *   helen_io_read_image_runs  n_runs ranges (paths[i], firsts[i], counts[i]) into consecutive rows of the arrays, read
+ *                             by `threads` threads of this call
+ *   helen_io_forget_images    drop the index and the mapping of one file (the reader has moved on) */
+int helen_io_index_images(const char* path, long long* n_out, int* through_library);
+int helen_io_image_names(const char* path, long long first, long long count, char* out, size_t cap, long long* needed);
+int helen_io_read_image_range(const char* path, long long first, int count, uint8_t* images, int64_t* positions,
+                              int64_t* meta, char* contigs, long long* through_library);
+int helen_io_read_image_runs(int n_runs, const char* const* paths, const long long* firsts, const int* counts,
+                             int threads, uint8_t* images, int64_t* positions, int64_t* meta, char* contigs,
+                             long long* through_library);
+void helen_io_forget_images(const char* path);
 
 /* The loader of `helen_train test` (`models/dataloader.py:48-61`): image uint8 [1000, 90], label_base and
  * label_run_length uint8 [1000] of `n` images of one file, exactly as stored (that loader does not pad: any other

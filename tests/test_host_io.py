@@ -563,3 +563,77 @@ def test_check_images_strict_on_the_gpu_box(tmp_path):
     r = subprocess.run([sys.executable, "-m", "helen_amd", "check_images", "-i", str(tmp_path / "plain"), "--strict",
                         "--json", str(tmp_path / "cli.json")], cwd=root, capture_output=True, text=True)
     assert r.returncode == 0 and "ready" in r.stdout, r.stdout + r.stderr
+
+
+def test_reader_threads_equal_the_per_name_reader(tmp_path):
+    """helen_io_read_image_runs -- images addressed by (file, position in name order), read by several native threads --
+    against the per-name batch reader (which the reference's own reader pins, test_*_equals_the_reference_*): runs that
+    start and end inside files, a file with short images, 1 / 3 / 8 threads, a piece boundary (32 images) inside a run."""
+    from helen_amd import native_io
+    from helen_amd.sequence_dataset import SequenceDataset, _load_batch
+    from helen_amd.synthetic import write_image_dir
+    if not native_io.available():
+        pytest.skip("libhelen_io.so not built")
+    files = write_image_dir(str(tmp_path / "img"), 150, n_files=3, short_every=7)
+    ds = SequenceDataset(None, file_list=files)
+    assert [(p, n) for p, n, _ in ds.runs] == [(f, 50) for f in files] and not any(lib for _, _, lib in ds.runs)
+    assert len(ds) == 150
+    pairs = ds.all_images
+    assert [n for _, n in pairs[:50]] == native_io.image_names(files[0], 0, 50) == native_io.list_images(files[0])
+    runs = [(files[0], 13, 37), (files[1], 0, 50), (files[2], 0, 41)]
+    want = _load_batch(pairs[13:141])
+    for threads in (1, 3, 8):
+        n = 128
+        images = np.full((n, 1000, 90), 7, np.uint8)
+        positions = np.full((n, 1000, 3), 7, np.int64)
+        meta = np.full((n, 3), 7, np.int64)
+        contigs = np.full((n, native_io.NAME_BYTES), 7, np.uint8)
+        assert native_io.read_image_runs(runs, threads, images, positions, meta, contigs) == 0
+        assert np.array_equal(images, want.images) and np.array_equal(positions, want.positions)
+        assert np.array_equal(meta[:, 0], want.contig_start) and np.array_equal(meta[:, 2], want.chunk_id)
+        assert native_io.contig_names(contigs) == want.contig
+    assert ds.call_runs(64) == [[(files[0], 0, 50), (files[1], 0, 14)], [(files[1], 14, 36), (files[2], 0, 28)],
+                                [(files[2], 28, 22)]]
+    with pytest.raises(IOError, match="out of bounds"):
+        native_io.read_image_runs([(files[0], 40, 11)], 2, images, positions, meta, contigs)
+    # a rewritten file is noticed (identity check), a forgotten one is indexed again
+    native_io.forget_images(files[0])
+    assert native_io.index_images(files[0]) == (50, False)
+    write_image_dir(str(tmp_path / "img"), 30, n_files=3)
+    assert native_io.index_images(files[0]) == (10, False)
+
+
+def test_reader_threads_take_library_files_too(tmp_path, monkeypatch):
+    """A file the direct scanner does not take is read through libhdf5 by the same entry point (serialised), the count of
+    such images is returned, and the values are the per-name reader's."""
+    from helen_amd import native_io
+    from helen_amd.sequence_dataset import SequenceDataset, _load_batch
+    from helen_amd.synthetic import write_image_file
+    from helen_amd.weights import make_images
+    if not native_io.available():
+        pytest.skip("libhelen_io.so not built")
+    monkeypatch.setenv("HELEN_IO_READER", "libhdf5")         # (read once per process: this test runs in a child)
+    import subprocess
+    import sys
+    img = make_images(40, seed=11)
+    a, b = str(tmp_path / "a.h5"), str(tmp_path / "b.h5")
+    write_image_file(a, img[:24], first_window=0)
+    write_image_file(b, img[24:], first_window=24)
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from helen_amd import native_io
+from helen_amd.sequence_dataset import SequenceDataset, _load_batch
+ds = SequenceDataset(None, file_list=[%r, %r])
+assert [(n, lib) for _, n, lib in ds.runs] == [(24, True), (16, True)], ds.runs
+want = _load_batch(ds.all_images)
+n = 40
+images = np.zeros((n, 1000, 90), np.uint8); positions = np.zeros((n, 1000, 3), np.int64)
+meta = np.zeros((n, 3), np.int64); contigs = np.zeros((n, native_io.NAME_BYTES), np.uint8)
+assert native_io.read_image_runs([(%r, 0, 24), (%r, 0, 16)], 4, images, positions, meta, contigs) == 40
+assert np.array_equal(images, want.images) and np.array_equal(positions, want.positions)
+assert native_io.reader_counts()[1] >= 40
+print("ok")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), a, b, a, b)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr

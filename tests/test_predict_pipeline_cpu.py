@@ -26,8 +26,10 @@ class _StandInEngine(object):
         pass
 
 
-@pytest.mark.parametrize("workers", [0, 2])
-def test_pipeline_with_stand_in_device(tmp_path, monkeypatch, workers):
+@pytest.mark.parametrize("workers,readers", [(0, "threads"), (2, "threads"), (0, "processes"), (2, "processes")])
+def test_pipeline_with_stand_in_device(tmp_path, monkeypatch, workers, readers):
+    """Both reader modes of predict() (helen_amd.predict.reader_mode): native threads filling page-locked slots, and the
+    pool of reader processes over shared-memory slots."""
     import torch
 
     import helen_amd.predict as P
@@ -41,12 +43,14 @@ def test_pipeline_with_stand_in_device(tmp_path, monkeypatch, workers):
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
     monkeypatch.setattr(P, "DEVICE_CALL_WINDOWS", 64)       # 4 loader batches per "device call"
     monkeypatch.setenv("HELEN_WRITERS", "1")                # the reference's single file per rank
+    monkeypatch.setenv("HELEN_READERS", readers)
     img_dir = str(tmp_path / "img")
     write_image_dir(img_dir, 150, n_files=3, short_every=7)   # 150 = 9 batches of 16 + one of 6
     model = str(tmp_path / "m.pkl")
     ModelHandler.save_model(make_weights(), None, 128, 1, 0, model)
     files = sorted(glob.glob(os.path.join(img_dir, "*.h5")))
     P.predict(files, str(tmp_path / "out"), model, 16, workers, 0, 0)
+    assert P.LAST_PREDICT["reader_mode"] == readers and P.LAST_PREDICT["windows"] == 150
     ds = SequenceDataset(None, file_list=files)
     seen = 0
     with hdf5.File(str(tmp_path / "out_0.hdf")) as f:
