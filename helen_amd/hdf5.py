@@ -67,6 +67,8 @@ def _load():
         "H5Fopen": (H, [ctypes.c_char_p, ctypes.c_uint, H]),
         "H5Fcreate": (H, [ctypes.c_char_p, ctypes.c_uint, H, H]),
         "H5Fclose": (I, [H]), "H5Fflush": (I, [H, I]),
+        "H5Pset_libver_bounds": (I, [H, I, I]), "H5Pset_fletcher32": (I, [H]),
+        "H5get_libversion": (I, [ctypes.POINTER(ctypes.c_uint)] * 3),
         "H5Gopen2": (H, [H, ctypes.c_char_p, H]), "H5Gclose": (I, [H]),
         "H5Gget_info": (I, [H, ctypes.POINTER(_GInfo)]),
         "H5Lget_name_by_idx": (ctypes.c_ssize_t, [H, ctypes.c_char_p, I, I, _hsize, ctypes.c_char_p,
@@ -126,7 +128,9 @@ _STD = {
 class File(object):
     """An open HDF5 file.  mode 'r' (read-only) or 'w' (create/truncate)."""
 
-    def __init__(self, path, mode="r"):
+    def __init__(self, path, mode="r", libver=None):
+        """libver="latest" (mode 'w' only) writes the newest file format the library knows, as h5py's libver="latest"
+        does: superblock 3, version 2 object headers, link-message / dense groups, version 4 layout messages."""
         self._lib = _load()
         self.path = path
         self.mode = mode
@@ -134,7 +138,19 @@ class File(object):
         if mode == "r":
             self._fid = self._lib.H5Fopen(bpath, H5F_ACC_RDONLY, 0)
         elif mode == "w":
-            self._fid = self._lib.H5Fcreate(bpath, H5F_ACC_TRUNC, 0, 0)
+            fapl = 0
+            if libver == "latest":
+                fapl = self._lib.H5Pcreate(_gid("H5P_CLS_FILE_ACCESS_ID_g"))
+                ver = [ctypes.c_uint() for _ in range(3)]
+                self._lib.H5get_libversion(*[ctypes.byref(v) for v in ver])
+                # H5F_LIBVER_LATEST: 1 in 1.8, 2 (V110) in 1.10, 3 (V112) in 1.12, 4 (V114) in 1.14
+                latest = {8: 1, 10: 2, 12: 3, 14: 4}.get(ver[1].value, 2)
+                self._lib.H5Pset_libver_bounds(fapl, latest, latest)
+            elif libver is not None:
+                raise ValueError("libver must be None or 'latest'")
+            self._fid = self._lib.H5Fcreate(bpath, H5F_ACC_TRUNC, 0, fapl)
+            if fapl:
+                self._lib.H5Pclose(fapl)
             self._lcpl = self._lib.H5Pcreate(_gid("H5P_CLS_LINK_CREATE_ID_g"))
             self._lib.H5Pset_create_intermediate_group(self._lcpl, 1)
         else:
@@ -305,7 +321,7 @@ class File(object):
             L.H5Sclose(sid)
             L.H5Dclose(did)
 
-    def write(self, path, value, dtype=None, chunks=None, gzip=None, shuffle=False, string="fixed"):
+    def write(self, path, value, dtype=None, chunks=None, gzip=None, shuffle=False, string="fixed", fletcher32=False):
         """Create dataset `path` (intermediate groups are created) from a Python int (scalar
         int64 dataset, what `h5py_file[path] = int` makes), a str / bytes (see `string`) or an ndarray
         (a 0-d array makes a scalar dataset).  `chunks` (a shape) makes it chunked, `gzip` (1..9) adds the
@@ -330,7 +346,7 @@ class File(object):
             dims = (_hsize * arr.ndim)(*arr.shape)
             sid = L.H5Screate_simple(arr.ndim, dims, None)
         dcpl = 0
-        if (chunks is not None or gzip or shuffle) and arr.ndim > 0 and arr.size:
+        if (chunks is not None or gzip or shuffle or fletcher32) and arr.ndim > 0 and arr.size:
             dcpl = L.H5Pcreate(_gid("H5P_CLS_DATASET_CREATE_ID_g"))
             ch = tuple(chunks) if chunks is not None else arr.shape
             L.H5Pset_chunk(dcpl, arr.ndim, (_hsize * arr.ndim)(*[max(1, min(int(c), int(d))) for c, d in zip(ch, arr.shape)]))
@@ -338,6 +354,8 @@ class File(object):
                 L.H5Pset_shuffle(dcpl)
             if gzip:
                 L.H5Pset_deflate(dcpl, int(gzip))
+            if fletcher32:
+                L.H5Pset_fletcher32(dcpl)
         did = L.H5Dcreate2(self._fid, path.encode(), _gid(_STD[dt]), sid, self._lcpl, dcpl, 0)
         if dcpl:
             L.H5Pclose(dcpl)

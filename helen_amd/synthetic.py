@@ -14,14 +14,19 @@ from .weights import make_images
 
 
 def write_image_file(path, images, contig="chr20_synth", first_window=0, lengths=None,
-                     chunks_per_region=1, labels=None, gzip=None):
+                     chunks_per_region=1, labels=None, gzip=None, chunks=None, shuffle=False, fletcher32=False, libver=None,
+                     string="fixed"):
     """Write `images` (uint8 [n, 1000, 90]) as n images of one file.  Window k covers
     contig_start = 800*k .. +1000 (SEQ_OVERLAP 200, Options.py:17); `lengths[i] < 1000` stores a
     short image (the reader pads it).  labels = (label_base, label_run_length) uint8 [n, 1000] makes
     it a labeled file as the evaluation loader reads it (models/dataloader.py:59-61); gzip = 1..9 stores
-    image and position chunked + deflated (as an h5py writer with compression="gzip" would)."""
+    image and position chunked + deflated (as an h5py writer with compression="gzip" would); chunks = (rows, 90) stores them
+    chunked (position in chunks of the same number of rows); shuffle / fletcher32 add those filters; libver="latest"
+    writes the newest file format (superblock 3, version 2 object headers, dense groups, version 4 layouts)."""
     n = images.shape[0]
-    with hdf5.File(path, "w") as f:
+    packed = bool(gzip or shuffle or fletcher32)
+    ich = tuple(chunks) if chunks is not None else ((256, 90) if packed else None)
+    with hdf5.File(path, "w", libver=libver) as f:
         for i in range(n):
             k = first_window + i
             region = k // chunks_per_region
@@ -30,14 +35,15 @@ def write_image_file(path, images, contig="chr20_synth", first_window=0, lengths
             L = int(lengths[i]) if lengths is not None else ImageSizeOptions.SEQ_LENGTH
             name = "%s-%d-%d-%d" % (contig, start, start + 1000, chunk)
             base = "images/" + name + "/"
-            f.write(base + "contig", contig)
+            f.write(base + "contig", contig, string=string)
             f.write(base + "contig_start", np.array([start], np.int64))
             f.write(base + "contig_end", np.array([start + 1000], np.int64))
             f.write(base + "feature_chunk_idx", np.array([chunk], np.int64))
-            f.write(base + "image", images[i, :L], np.uint8, chunks=(256, 90) if gzip else None, gzip=gzip)
+            f.write(base + "image", images[i, :L], np.uint8, chunks=ich, gzip=gzip, shuffle=shuffle, fletcher32=fletcher32)
             pos = np.zeros((L, 3), np.int64)
             pos[:, 0] = start + np.arange(L)
-            f.write(base + "position", pos, np.int64, chunks=(L, 3) if gzip else None, gzip=gzip)
+            pch = (ich[0], 3) if chunks is not None else ((L, 3) if packed else None)
+            f.write(base + "position", pos, np.int64, chunks=pch, gzip=gzip, shuffle=shuffle, fletcher32=fletcher32)
             if labels is not None:
                 f.write(base + "label_base", labels[0][i, :L], np.uint8)
                 f.write(base + "label_run_length", labels[1][i, :L], np.uint8)

@@ -1,7 +1,8 @@
 """The direct scanner of MarginPolish image files (helen_amd/csrc/h5scan.h) against libhdf5: the same batch read
 through the scanner and through the library (HELEN_IO_READER=libhdf5, in a child process) must be byte-identical
-for plain files and for every storage variant; files the scanner does not take (chunked / filtered datasets) and
-damaged files must end up with libhdf5's answer or libhdf5's error, never with a guess."""
+for plain files and for every storage variant -- contiguous, chunked, deflated, shuffled, checksummed, old and new file
+format; what the scanner still declines (a paged chunk index) and damaged files must end up with libhdf5's answer or
+libhdf5's error, never with a guess."""
 import os
 import subprocess
 import sys
@@ -57,7 +58,7 @@ def test_scanner_equals_libhdf5_on_plain_files(tmp_path):
     assert first == sorted(first)
 
 
-def test_scanner_takes_the_variants_it_can_and_leaves_the_rest_to_libhdf5(tmp_path):
+def test_scanner_reads_mixed_types_contiguous_and_packed(tmp_path):
     img = make_images(6, seed=5)
     rng = np.random.default_rng(2)
     plain, packed = str(tmp_path / "plain.h5"), str(tmp_path / "packed.h5")
@@ -81,7 +82,88 @@ def test_scanner_takes_the_variants_it_can_and_leaves_the_rest_to_libhdf5(tmp_pa
     # np.array2string(...).replace("'", '') of the reference's reader: a name with single quotes is printed in double
     # quotes, which stay (pinned against the reference's own reader in tests/test_host_io.py)
     assert list(fast["contig"][:2]) == ['"chr0quoted"', '"chr1quoted"']
-    assert tuple(fast["counts"]) == (6, 6)          # contiguous file: scanner; chunked + deflated file: libhdf5
+    assert tuple(fast["counts"]) == (12, 0)         # both through the scanner (round 4: chunked + shuffled + deflated too)
+    assert tuple(lib["counts"]) == (0, 12)
+
+
+VARIANTS = {
+    "chunked_rows": dict(chunks=(100, 90)),
+    "chunked_one": dict(chunks=(1000, 90)),
+    "chunked_ragged": dict(chunks=(384, 90)),
+    "gzip1": dict(gzip=1),
+    "gzip9": dict(gzip=9),
+    "shuffle_gzip": dict(gzip=4, shuffle=True),
+    "shuffle_only": dict(shuffle=True),
+    "fletcher32": dict(fletcher32=True),
+    "gzip_fletcher32": dict(gzip=4, shuffle=True, fletcher32=True),
+    "vlen_names": dict(string="vlen"),
+    "latest": dict(libver="latest"),
+    "latest_vlen": dict(libver="latest", string="vlen"),
+    "latest_chunked": dict(libver="latest", chunks=(100, 90)),          # fixed-array chunk index
+    "latest_single_chunk": dict(libver="latest", chunks=(1000, 90)),    # single-chunk index (short images: one chunk too)
+    "latest_gzip": dict(libver="latest", gzip=4, shuffle=True),         # filtered fixed array / filtered single chunk
+    "latest_gzip_fletcher32": dict(libver="latest", gzip=6, fletcher32=True),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_scanner_equals_libhdf5_on_storage_variants(tmp_path, variant):
+    """Every way of storing an image file that libhdf5 / h5py offer short of unlimited dimensions: the scanner reads all of
+    them itself (no image goes through libhdf5) and returns what libhdf5 returns.  40 images, so that a new-style
+    `images` group is DENSE (fractal heap + version 2 B-tree) while each image's own group keeps its links in its header;
+    short images (613, 1 row) make ragged and single chunks."""
+    from helen_amd.synthetic import write_image_file
+    n = 40
+    img = make_images(n, seed=9, mode="pileup")
+    lengths = np.full(n, 1000)
+    lengths[5::7] = 613
+    lengths[3] = 1
+    path = str(tmp_path / (variant + ".h5"))
+    write_image_file(path, img, lengths=lengths, **VARIANTS[variant])
+    fast = _read([path], str(tmp_path / "fast.npz"), None)
+    lib = _read([path], str(tmp_path / "lib.npz"), "libhdf5")
+    _same(fast, lib)
+    assert tuple(fast["counts"]) == (n, 0) and tuple(lib["counts"]) == (0, n)
+    assert list(fast["names"]) == sorted(fast["names"])
+    # the direct scanner ALONE (the fallback switched off): listing, per-name reads and positional reads
+    alone = _read([path], str(tmp_path / "alone.npz"), "direct")
+    _same(alone, lib)
+
+
+def test_a_large_new_style_group(tmp_path):
+    """3,000 images in a libver=latest file: a fractal heap with indirect blocks and a version 2 B-tree with internal
+    nodes.  Names in libhdf5's order, every image read."""
+    from helen_amd.synthetic import write_image_file
+    n = 3000
+    img = make_images(n, seed=4, mode="pileup")
+    path = str(tmp_path / "many.h5")
+    write_image_file(path, img, lengths=np.full(n, 2), libver="latest")
+    fast = _read([path], str(tmp_path / "fast.npz"), "direct")
+    lib = _read([path], str(tmp_path / "lib.npz"), "libhdf5")
+    _same(fast, lib)
+    assert tuple(fast["counts"]) == (n, 0)
+
+
+def test_what_the_scanner_declines_goes_to_libhdf5(tmp_path):
+    """A chunk index the scanner does not walk (libver=latest, 2,000 chunks per image: a PAGED fixed array): those images
+    are read by libhdf5, the others of the same run by the scanner, the batch is libhdf5's."""
+    from helen_amd.synthetic import write_image_file
+    img = make_images(4, seed=2, mode="pileup")
+    paged, plain = str(tmp_path / "a_paged.h5"), str(tmp_path / "b_plain.h5")
+    write_image_file(paged, img[:2], libver="latest", chunks=(1, 45))
+    write_image_file(plain, img[2:], first_window=2)
+    fast = _read([paged, plain], str(tmp_path / "fast.npz"), None)
+    lib = _read([paged, plain], str(tmp_path / "lib.npz"), "libhdf5")
+    _same(fast, lib)
+    assert tuple(fast["counts"]) == (2, 2)
+    assert native_io.index_images(paged) == (2, False)       # the file is the scanner's (its groups are); its datasets are not
+    n = 4
+    images = np.zeros((n, 1000, 90), np.uint8)
+    positions = np.zeros((n, 1000, 3), np.int64)
+    meta = np.zeros((n, 3), np.int64)
+    contigs = np.zeros((n, native_io.NAME_BYTES), np.uint8)
+    assert native_io.read_image_runs([(paged, 0, 2), (plain, 0, 2)], 3, images, positions, meta, contigs) == 2
+    assert np.array_equal(images, lib["images"]) and np.array_equal(positions, lib["positions"])
 
 
 def test_damaged_files_are_libhdf5s_business(tmp_path):
