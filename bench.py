@@ -320,7 +320,8 @@ def mode_report(precision, batch, coalesce, images, dev, fp32_labels, steps=8, w
     return out
 
 
-E2E_DEFAULT_WINDOWS = 49152        # per rank: 12 device calls of 4096 windows, ~0.6 s of device time
+E2E_DEFAULT_WINDOWS = 300000       # per rank: BASELINE.json configs[1]'s chr20-scale image set (27 GB of images in /dev/shm,
+                                   # written in ~25 s; the leg shrinks to what /dev/shm holds)
 E2E_FILES_PER_RANK = 16
 
 

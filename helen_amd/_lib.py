@@ -24,8 +24,11 @@ EXPORTS = (
     "helen_model_device_bytes", "helen_polish_batch", "helen_polish_host",
     "helen_gru_chunk_forward", "helen_evaluate_batch", "helen_debug_inject_failure", "helen_set_profiling",
     "helen_reset_kernel_stats",
-    "helen_get_kernel_stats",
+    "helen_get_kernel_stats", "helen_reload_overrides", "helen_describe_dispatch", "helen_plan_call", "helen_has_persistent",
 )
+RECURRENCE_KERNELS = ("gru_kernel", "gru_single8_kernel", "gru_half8_kernel", "gru_quarter4_kernel", "gru_pair_kernel")
+DECODER_PROJECTIONS = ("gemm_gi_kernel<16>", "gemm_dec_ws_kernel", "gemm_dec_wsp_kernel")
+ENCODER_PROJECTIONS = ("gemm_gi_kernel<6>", "gemm_enc_ws_kernel", "gemm_enc_ws8_kernel", "gemm_enc_ws8p_kernel")
 
 _f32p = ctypes.POINTER(ctypes.c_float)
 
@@ -109,11 +112,36 @@ def load():
     lib.helen_get_kernel_stats.restype = ci
     lib.helen_get_kernel_stats.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double),
                                            ctypes.POINTER(ctypes.c_longlong)]
+    lib.helen_reload_overrides.restype = ci
+    lib.helen_reload_overrides.argtypes = [vp]
+    lib.helen_describe_dispatch.restype = ci
+    lib.helen_describe_dispatch.argtypes = [ci, ctypes.c_char_p, ctypes.c_size_t]
+    lib.helen_plan_call.restype = ci
+    lib.helen_plan_call.argtypes = [ci, ci, ctypes.POINTER(ci)]
+    lib.helen_has_persistent.restype = ci
+    lib.helen_has_persistent.argtypes = []
     got = lib.helen_abi_version()
     if got != HELEN_ABI_VERSION:
         raise ImportError("libhelen_hip.so ABI %d != binding ABI %d; rebuild" % (got, HELEN_ABI_VERSION))
     _lib = lib
     return lib
+
+
+def describe_dispatch(cus):
+    """The kernel table of a device with `cus` compute units (helen_amd/csrc/dispatch.h), as text: a dry run."""
+    buf = ctypes.create_string_buffer(1 << 16)
+    check(load().helen_describe_dispatch(int(cus), buf, len(buf)))
+    return buf.value.decode()
+
+
+def plan_call(cus, tiles):
+    """What a call of `tiles` tiles takes on `cus` CUs: dict(split, first_group, recurrence, decoder, decoder_runs, encoder,
+    encoder_runs, bf16_two_tiles) with the kernels by name."""
+    out = (ctypes.c_int * 8)()
+    check(load().helen_plan_call(int(cus), int(tiles), out))
+    return {"split": bool(out[0]), "first_group": int(out[1]), "recurrence": RECURRENCE_KERNELS[out[2]],
+            "decoder": DECODER_PROJECTIONS[out[3]], "decoder_runs": int(out[4]), "encoder": ENCODER_PROJECTIONS[out[5]],
+            "encoder_runs": int(out[6]), "bf16_two_tiles": bool(out[7])}
 
 
 def check(rc):

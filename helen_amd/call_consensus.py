@@ -84,15 +84,37 @@ def call_consensus(image_dir, model_path, batch_size, num_workers, threads, outp
     sys.stderr.write("INFO: AVAILABLE GPU DEVICES: " + str(device_ids) + "\n")
 
     input_files = file_manager.get_file_paths_from_directory(image_dir)
-    if input_files and os.environ.get("HELEN_SKIP_IMAGE_CHECK", "") != "1":
-        vet_image_directory(image_dir)
     file_chunks = file_manager.shard_round_robin(input_files, callers)
     callers = len(file_chunks)
     if callers == 0:
         _err("NO IMAGE FILES (*.h5) FOUND IN " + image_dir)
         sys.exit(1)
-    predict_gpu(file_chunks, output_filename, model_path, batch_size, callers, device_ids,
-                num_workers)
+    vet = None
+    if os.environ.get("HELEN_SKIP_IMAGE_CHECK", "") != "1":
+        if callers > 1:
+            vet_image_directory(image_dir)          # before any process is started
+        else:
+            # one rank runs in this process: the schema check of a few images per file runs BESIDE its start-up (the
+            # reader raises the same IMAGE SIZE ERROR itself when it meets such an image; the check's findings are
+            # reported either way)
+            import threading
+            vet = {"error": None}
+
+            def run_vet():
+                try:
+                    vet_image_directory(image_dir)
+                except BaseException as e:          # noqa: BLE001 -- re-raised below
+                    vet["error"] = e
+            vet["thread"] = threading.Thread(target=run_vet, daemon=True)
+            vet["thread"].start()
+    try:
+        predict_gpu(file_chunks, output_filename, model_path, batch_size, callers, device_ids,
+                    num_workers)
+    finally:
+        if vet is not None:
+            vet["thread"].join()
+    if vet is not None and vet["error"] is not None:
+        raise vet["error"]
     sys.stderr.write("INFO: PREDICTION GENERATED SUCCESSFULLY.\n")
 
 

@@ -211,6 +211,11 @@ def image_directory_report(image_dir, images_per_file=8, strict=False):
                 continue
             names = native_io.list_images(path) if native_io.available() else f.keys("images")
             entry["images"] = len(names)
+            if native_io.available() and names:
+                # what the host plan of a run will price this file with (helen_amd.host_plan.READER_RATE)
+                from .host_plan import READER_RATE
+                entry["storage_class"] = native_io.image_storage(path)
+                entry["predicted_windows_per_s_per_reader"] = READER_RATE.get(entry["storage_class"])
             report["images"] += len(names)
             step = 1 if strict else max(1, len(names) // max(1, images_per_file))
             chosen = names if strict else names[::step][:images_per_file]
@@ -254,8 +259,11 @@ def main(image_dir, images_per_file=8, strict=False, json_path=None, out=sys.std
         return 1 if check_image_directory(image_dir, images_per_file, out=out) else 0
     rep = image_directory_report(image_dir, images_per_file, strict)
     for e in rep["files"]:
-        out.write("%s: %d images%s\n" % (e["path"], e["images"],
-                                         (", read through the " + e["reader_path"]) if e.get("reader_path") else ""))
+        out.write("%s: %d images%s%s\n" % (e["path"], e["images"],
+                                           (", read through the " + e["reader_path"]) if e.get("reader_path") else "",
+                                           (", stored %s: ~%d windows/s per reader" % (e["storage_class"],
+                                                                                    e["predicted_windows_per_s_per_reader"]))
+                                           if e.get("storage_class") else ""))
         for ds in REQUIRED + LABELS:
             if ds in e["datasets"]:
                 d = e["datasets"][ds]

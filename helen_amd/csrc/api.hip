@@ -13,14 +13,18 @@
 #include <new>
 #include <vector>
 
+#include <unistd.h>
+
 #include "../../include/helen_hip.h"
 #include "kernels.h"
+#include "dispatch.h"
 
 using namespace helen;
 
-#ifndef HELEN_PERSISTENT_DEFAULT      // the chunk loop as one launch where it applies (see use_persistent)
-#define HELEN_PERSISTENT_DEFAULT false
-#endif
+static_assert(kDecStagePositions == HELEN_DWS_PB && kEncStagePositions == HELEN_EWS8_PB, "dispatch.h's stage sizes are the kernels'");
+// polish_persistent_kernel (the 19-chunk loop as ONE launch, kernels_persistent.h) is measured 0.6-0.8 % SLOWER than the
+// per-phase launches: it is compiled in only with -DHELEN_WITH_PERSISTENT (make PERSISTENT=1) and then
+// still opt-in per model ($HELEN_PERSISTENT=1 at helen_model_create).
 #ifndef HELEN_BF16_ENC_DEFAULT
 #define HELEN_BF16_ENC_DEFAULT '1'
 #endif
@@ -61,8 +65,9 @@ struct HelenModel {
     int max_tiles = 0;
     int cus = 256;             // compute units of the device (hipDeviceProp_t::multiProcessorCount): what a "round" of workgroups is
     bool debug_hooks = false;  // $HELEN_DEBUG_HOOKS=1 when the model was created: helen_debug_inject_failure is armed-able
-    int host_lock = 1;         // helen_polish_host, pageable caller memory: 0 = never page-lock it (pinned mirrors), 1 = lock
-                               // ranges that own their pages, 2 = lock every range ($HELEN_HOST_LOCK = none | own | all)
+    int host_lock = 0;         // helen_polish_host, pageable caller memory: 0 = never page-lock it (pinned mirrors: the
+                               // default), 1 = lock ranges that own their pages, 2 = every range ($HELEN_HOST_LOCK = none | own | all)
+    Overrides overrides;       // the environment's A/B switches as read at helen_model_create (dispatch.h)
     size_t device_bytes = 0;
     size_t ring_in_bytes = 0, ring_out_bytes = 0;   // what each dev_in / dev_out slot of the staging ring added to device_bytes
     // packed parameters (device)
@@ -305,136 +310,34 @@ int check_launch(const char* what) {
     return HELEN_OK;
 }
 
-// Small calls (at most a quarter of the CUs in tiles): gemm_dec_wsp_kernel, the weight-stationary projection with a
-// (tile, direction)'s positions cut into runs so that there is about one workgroup per CU (same gi bit for bit).
-// (HELEN_DEC_WSP=0/1 forces it off / on; HELEN_DEC_WSP_PARTS=n the number of runs: A/B probes.)
-bool use_wsp_dec_projection(int tiles, int T, int cus, int* parts, int* run) {
-    const char* force = getenv("HELEN_DEC_WSP");
-    if (force && *force == '0') return false;
-    if (!(force && *force == '1') && 4 * tiles > cus) return false;
-    int want = cus / (2 * ((tiles + 7) / 8 * 8));
-    if (const char* n = getenv("HELEN_DEC_WSP_PARTS")) want = atoi(n);
-    want = want < 1 ? 1 : want;
-    const int per = (T + want - 1) / want;
-    *run = (per + HELEN_DWS_PB - 1) / HELEN_DWS_PB * HELEN_DWS_PB;   // whole stages
-    *parts = (T + *run - 1) / *run;
-    return true;
-}
-
-// One TransducerGRU.forward over `tiles` tiles whose encoder pre-activations are already in
-// gi_enc at positions [pos0, pos0+T): encoder recurrence -> decoder projection -> decoder
-// recurrence.  plogit then holds the decoder's partial logits, hid the returned hidden state.
-// 1-D grid of the projection kernels: units = tiles x position groups, padded to a multiple of 8
+// 1-D grid of the streaming projection kernels: units = tiles x position groups, padded to a multiple of 8
 // (the XCD count), times 8 / HELEN_GEMM_WAVES column-group workgroups per unit.
 unsigned gemm_grid(int npos, int tiles, int positions_per_wave = HELEN_GEMM_P) {
     const int units = tiles * ((npos + positions_per_wave - 1) / positions_per_wave);
     return (unsigned)((units + 7) / 8 * 8) * ((2 * kNTile / HELEN_GEMM_N) / HELEN_GEMM_WAVES);
 }
 
-// Small calls (at most a quarter of the CUs in tiles): gemm_enc_ws8p_kernel (same gi bit for bit).
-// (HELEN_ENC_WS8P=0/1 forces it off / on; HELEN_ENC_WS8P_PARTS=n the number of runs: A/B probes.)
-bool use_ws8p_enc_projection(int tiles, int npos, int cus, int* parts, int* run) {
-    const char* force = getenv("HELEN_ENC_WS8P");
-    if (force && *force == '0') return false;
-    if (!(force && *force == '1') && 4 * tiles > cus) return false;
-    int want = cus / tiles;
-    if (const char* n = getenv("HELEN_ENC_WS8P_PARTS")) want = atoi(n);
-    want = want < 1 ? 1 : want;
-    const int per = (npos + want - 1) / want;
-    *run = (per + HELEN_EWS8_PB - 1) / HELEN_EWS8_PB * HELEN_EWS8_PB;   // whole stages
-    *parts = (npos + *run - 1) / *run;
-    return true;
-}
-
-constexpr int kWsMinWorkgroups = 384;   // 1.5 workgroups per CU-slot pair: below this the position-parallel kernel wins
-
+// Encoder input projection: which of the four kernels (all the same gi bit for bit) is dispatch.h's plan_encoder.
 void launch_enc_gemm(HelenModel* m, hipStream_t s, int tiles, int npos) {
-    const dim3 grid(gemm_grid(npos, tiles)), block(HELEN_GEMM_WAVES * 64);
-    // All three give the same gi bit for bit (same MFMA order per accumulator); HELEN_ENC_WS8=0/1 forces the
-    // one-workgroup-per-tile kernel off / on (A/B probes).
-    static const char* force8 = getenv("HELEN_ENC_WS8");
-    const int cus = m->cus, rounds = (tiles + cus - 1) / cus;
-    const bool ws8 = (force8 && *force8) ? *force8 == '1'
-                                         : (tiles > cus / 2 && rounds * cus - tiles <= cus / 8) || (rounds == 1 && 3 * tiles > 2 * cus);
-    int enc_parts = 0, enc_run = 0;
-    if (ws8)
-        // one long workgroup per tile, one per CU: wants whole rounds of 256 tiles
-        LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_ws8_kernel, dim3(tiles), dim3(512), m->xa, kXaTileStride, m->wp_enc,
-               m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles);
-    else if (use_ws8p_enc_projection(tiles, npos, cus, &enc_parts, &enc_run))
-        // a small call: the same kernel with a tile's positions cut into runs, about one workgroup per CU
-        LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_ws8p_kernel, dim3(tiles * enc_parts), dim3(512), m->xa, kXaTileStride, m->wp_enc,
-               m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles, enc_parts, enc_run);
-    else if (3 * tiles >= kWsMinWorkgroups)
-        // enough tiles to fill the chip with one workgroup per (tile, column set): weights stay in
-        // registers, same MFMA order per accumulator as gemm_gi_kernel (bit-identical gi)
-        LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_ws_kernel, dim3(3 * ((tiles + 7) / 8 * 8)), dim3(256), m->xa,
-               kXaTileStride, m->wp_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles);
-    else
-        LAUNCH(HELEN_K_GEMM_ENC, (gemm_gi_kernel<kFPad / 16, false>), grid, block, m->xa,
-               kXaTileStride, m->wp_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles);
-}
-
-// Which fp32 recurrence kernel: gru_kernel puts one tile per workgroup, two workgroups per CU; gru_pair_kernel
-// two tiles per workgroup, one workgroup per CU (same results bit for bit).  A launch of either lasts as long
-// as its longest CU queue: `rounds` x the time of one resident set.  (HELEN_GRU_PAIR=0/1 forces one: A/B probes.)
-// The per-set times below were measured at 100 steps; both kernels' time is proportional to the step count (6 us
-// per step, scripts/dev/step_slope.py), so the comparison holds for the operator entry's shorter T as well.
-bool use_pair_recurrence(int tiles, int cus) {
-    static const char* force = getenv("HELEN_GRU_PAIR");
-    if (force && *force) return *force == '1';
-    const int wg_single = 2 * tiles, wg_pair = 2 * ((tiles + 1) / 2);
-    // measured per resident set at 100 steps: one workgroup per CU alone 0.36 ms (gru_kernel; gru_single8_kernel 0.30),
-    // two per CU 0.635 ms, a pair workgroup 0.617 ms
-    auto t_single = [&](int wgs) {
-        const int full = wgs / (2 * cus), rest = wgs % (2 * cus);
-        return full * 0.635 + (rest == 0 ? 0.0 : rest <= cus ? 0.31 : 0.635);
-    };
-    const double t_pair = ((wg_pair + cus - 1) / cus) * 0.617;
-    return t_pair < t_single(wg_single);
-}
-
-// bf16 mode: gru_fused_bf16_kernel (one tile per workgroup, one workgroup per CU) or gru_fused_bf16_pair_kernel
-// (two tiles per workgroup; same results bit for bit).  The pair needs more than one round of single workgroups to
-// pay: below that every tile has a CU of its own anyway.  (HELEN_BF16_PAIR=0/1 forces one: A/B probes.)
-// One (tile, direction) per CU at most: the 8-wave single-tile recurrence instead of gru_kernel's four waves (same
-// results bit for bit).  (HELEN_GRU_SINGLE8=0/1 forces one: A/B probes.)
-bool use_single8_recurrence(int tiles, int cus) {
-    const char* force = getenv("HELEN_GRU_SINGLE8");
-    if (force && *force) return *force == '1';
-    return 2 * tiles <= cus;
-}
-
-// At most a quarter of the CUs in tiles: half tiles of 8 windows on v_mfma_f32_4x4x1_16b_f32, 4 x tiles workgroups (same
-// results bit for bit).  (HELEN_GRU_HALF8=0/1 forces one: A/B probes.)
-bool use_half8_recurrence(int tiles, int cus) {
-    const char* force = getenv("HELEN_GRU_HALF8");
-    if (force && *force) return *force == '1';
-    return 4 * tiles <= cus;
-}
-
-// ... and at most an eighth: quarter tiles of 4 windows, 8 x tiles workgroups.  (HELEN_GRU_QUARTER4=0/1 forces one.)
-bool use_quarter4_recurrence(int tiles, int cus) {
-    const char* force = getenv("HELEN_GRU_QUARTER4");
-    if (force && *force) return *force == '1';
-    return 8 * tiles <= cus;
-}
-
-bool use_bf16_pair(int tiles, int cus) {
-    static const char* force = getenv("HELEN_BF16_PAIR");
-    if (force && *force) return *force == '1';
-    return 2 * tiles > cus;
-}
-
-// Which decoder projection: gemm_dec_ws_kernel has one long workgroup per (tile, direction) and one workgroup per
-// CU, so it wants whole rounds of 256; gemm_gi_kernel is fine-grained (same gi bit for bit).
-// (HELEN_DEC_WS=0/1 forces one: A/B probes.)
-bool use_ws_dec_projection(int tiles, int cus) {
-    static const char* force = getenv("HELEN_DEC_WS");
-    if (force && *force) return *force == '1';
-    const int wgs = 2 * tiles;
-    const int rounds = (wgs + cus - 1) / cus;
-    return wgs >= cus && rounds * cus - wgs <= cus / 8;   // at most an eighth of the last round idle
+    const EncoderPlan e = plan_encoder(tiles, npos, m->cus, m->overrides);
+    switch (e.kind) {
+        case kEncTile:          // one long workgroup per tile, one per CU: wants whole rounds of tiles
+            LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_ws8_kernel, dim3(tiles), dim3(512), m->xa, kXaTileStride, m->wp_enc,
+                   m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles);
+            break;
+        case kEncTileRuns:      // a small call: a tile's positions cut into runs, about one workgroup per CU
+            LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_ws8p_kernel, dim3(tiles * e.parts), dim3(512), m->xa, kXaTileStride, m->wp_enc,
+                   m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles, e.parts, e.run);
+            break;
+        case kEncSets:          // one workgroup per (tile, column set)
+            LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_ws_kernel, dim3(3 * ((tiles + 7) / 8 * 8)), dim3(256), m->xa,
+                   kXaTileStride, m->wp_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles);
+            break;
+        default:
+            LAUNCH(HELEN_K_GEMM_ENC, (gemm_gi_kernel<kFPad / 16, false>), dim3(gemm_grid(npos, tiles)),
+                   dim3(HELEN_GEMM_WAVES * 64), m->xa, kXaTileStride, m->wp_enc, m->bias_enc, m->gi_enc, kGiEncTileStride,
+                   npos, tiles);
+    }
 }
 
 // One TransducerGRU.forward over `tiles` tiles whose encoder pre-activations are already in
@@ -451,10 +354,9 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
         // windows (profiles/r03_bf16_probes.txt): encoder 0.157 against 0.162 ms, decoder 0.254 against 0.241 (no
         // registers for its LDS prefetch): interleaved encoder, pair decoder.  HELEN_BF16_IL = two digits, encoder
         // then decoder: 0 = pair, 1 = interleaved, 2 = pair with waves 4-7 skewed by a phase (A/B probes).
-        const char* il = getenv("HELEN_BF16_IL");      // (read per call: the tests flip it within one process)
-        const char il_enc = il && il[0] ? il[0] : HELEN_BF16_ENC_DEFAULT;
-        const char il_dec = il && il[0] && il[1] ? il[1] : HELEN_BF16_DEC_DEFAULT;
-        if (use_bf16_pair(tiles, m->cus)) {
+        const char il_enc = m->overrides.bf16_il_enc ? m->overrides.bf16_il_enc : HELEN_BF16_ENC_DEFAULT;
+        const char il_dec = m->overrides.bf16_il_dec ? m->overrides.bf16_il_dec : HELEN_BF16_DEC_DEFAULT;
+        if (bf16_pair_pays(tiles, m->cus, m->overrides)) {
             const dim3 grid((tiles + 1) / 2, 2), block(512);
 #define HELEN_ENC_ARGS m->xb, (long)kSeq * 192, pos0, T, m->w3i_enc, m->w3h_enc, m->bias_enc, m->bhn_enc, m->hid, m->y1p, \
                        kY1bTileStride, (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride, tiles
@@ -489,53 +391,41 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
                m->w3h_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kY1pTileStride, m->whd, m->plogit, kPlTileStride);
         return;
     }
-    const bool pair = use_pair_recurrence(tiles, m->cus);
-    if (pair)
-        LAUNCH(HELEN_K_GRU_ENC, gru_pair_kernel<false>, dim3((tiles + 1) / 2, 2), dim3(512), m->gi_enc,
-               kGiEncTileStride, pos0, enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride,
-               (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride, tiles);
-    else if (use_quarter4_recurrence(tiles, m->cus))
-        LAUNCH(HELEN_K_GRU_ENC, gru_quarter4_kernel<false>, dim3(4 * tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
-               enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride, (const f32x4*)nullptr,
-               (f32x4*)nullptr, kPlTileStride);
-    else if (use_half8_recurrence(tiles, m->cus))
-        LAUNCH(HELEN_K_GRU_ENC, gru_half8_kernel<false>, dim3(2 * tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
-               enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride, (const f32x4*)nullptr,
-               (f32x4*)nullptr, kPlTileStride);
-    else if (use_single8_recurrence(tiles, m->cus))
-        LAUNCH(HELEN_K_GRU_ENC, gru_single8_kernel<false>, dim3(tiles, 2), dim3(512), m->gi_enc, kGiEncTileStride, pos0,
-               enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride, (const f32x4*)nullptr,
-               (f32x4*)nullptr, kPlTileStride);
-    else
-        LAUNCH(HELEN_K_GRU_ENC, gru_kernel<false>, dim3(tiles, 2), dim3(256), m->gi_enc, kGiEncTileStride, pos0,
-               enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, kYTileStride, (const f32x4*)nullptr,
-               (f32x4*)nullptr, kPlTileStride);
-    int dec_parts = 0, dec_run = 0;
-    if (use_ws_dec_projection(tiles, m->cus))
-        LAUNCH(HELEN_K_GEMM_DEC, gemm_dec_ws_kernel, dim3(2 * ((tiles + 7) / 8 * 8)), dim3(512), m->y1, kYTileStride,
-               m->wp_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
-    else if (use_wsp_dec_projection(tiles, T, m->cus, &dec_parts, &dec_run))
-        LAUNCH(HELEN_K_GEMM_DEC, gemm_dec_wsp_kernel, dim3(2 * ((tiles + 7) / 8 * 8) * dec_parts), dim3(512), m->y1,
-               kYTileStride, m->wp_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles, dec_parts, dec_run);
-    else
-        LAUNCH(HELEN_K_GEMM_DEC, (gemm_gi_kernel<16, true>), ggrid, gblock, m->y1, kYTileStride, m->wp_dec,
-               m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
-    if (pair)
-        LAUNCH(HELEN_K_GRU_DEC, gru_pair_kernel<true>, dim3((tiles + 1) / 2, 2), dim3(512), m->gi_dec,
-               kGiDecTileStride, 0, 0, T, m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd,
-               m->plogit, kPlTileStride, tiles);
-    else if (use_quarter4_recurrence(tiles, m->cus))
-        LAUNCH(HELEN_K_GRU_DEC, gru_quarter4_kernel<true>, dim3(4 * tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, 0, T,
-               m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd, m->plogit, kPlTileStride);
-    else if (use_half8_recurrence(tiles, m->cus))
-        LAUNCH(HELEN_K_GRU_DEC, gru_half8_kernel<true>, dim3(2 * tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, 0, T,
-               m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd, m->plogit, kPlTileStride);
-    else if (use_single8_recurrence(tiles, m->cus))
-        LAUNCH(HELEN_K_GRU_DEC, gru_single8_kernel<true>, dim3(tiles, 2), dim3(512), m->gi_dec, kGiDecTileStride, 0, 0, T,
-               m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd, m->plogit, kPlTileStride);
-    else
-        LAUNCH(HELEN_K_GRU_DEC, gru_kernel<true>, dim3(tiles, 2), dim3(256), m->gi_dec, kGiDecTileStride, 0, 0, T,
-               m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, m->whd, m->plogit, kPlTileStride);
+    // fp32: which recurrence and which decoder projection is dispatch.h's plan_chunk (all the same bits)
+    const ChunkPlan plan = plan_chunk(tiles, T, m->cus, m->overrides);
+#define HELEN_REC_ENC_ARGS m->gi_enc, kGiEncTileStride, pos0, enc_npos - pos0 - T, T, m->whp_enc, m->bhn_enc, m->hid, m->y1, \
+                           kYTileStride, (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride
+#define HELEN_REC_DEC_ARGS m->gi_dec, kGiDecTileStride, 0, 0, T, m->whp_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kYTileStride, \
+                           m->whd, m->plogit, kPlTileStride
+    switch (plan.recurrence) {
+        case kRecPair: LAUNCH(HELEN_K_GRU_ENC, gru_pair_kernel<false>, dim3((tiles + 1) / 2, 2), dim3(512), HELEN_REC_ENC_ARGS, tiles); break;
+        case kRecQuarter4: LAUNCH(HELEN_K_GRU_ENC, gru_quarter4_kernel<false>, dim3(4 * tiles, 2), dim3(256), HELEN_REC_ENC_ARGS); break;
+        case kRecHalf8: LAUNCH(HELEN_K_GRU_ENC, gru_half8_kernel<false>, dim3(2 * tiles, 2), dim3(256), HELEN_REC_ENC_ARGS); break;
+        case kRecSingle8: LAUNCH(HELEN_K_GRU_ENC, gru_single8_kernel<false>, dim3(tiles, 2), dim3(512), HELEN_REC_ENC_ARGS); break;
+        default: LAUNCH(HELEN_K_GRU_ENC, gru_kernel<false>, dim3(tiles, 2), dim3(256), HELEN_REC_ENC_ARGS);
+    }
+    switch (plan.decoder) {
+        case kDecStationary:
+            LAUNCH(HELEN_K_GEMM_DEC, gemm_dec_ws_kernel, dim3(2 * ((tiles + 7) / 8 * 8)), dim3(512), m->y1, kYTileStride,
+                   m->wp_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
+            break;
+        case kDecStationaryRuns:
+            LAUNCH(HELEN_K_GEMM_DEC, gemm_dec_wsp_kernel, dim3(2 * ((tiles + 7) / 8 * 8) * plan.dec_parts), dim3(512), m->y1,
+                   kYTileStride, m->wp_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles, plan.dec_parts, plan.dec_run);
+            break;
+        default:
+            LAUNCH(HELEN_K_GEMM_DEC, (gemm_gi_kernel<16, true>), ggrid, gblock, m->y1, kYTileStride, m->wp_dec,
+                   m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
+    }
+    switch (plan.recurrence) {
+        case kRecPair: LAUNCH(HELEN_K_GRU_DEC, gru_pair_kernel<true>, dim3((tiles + 1) / 2, 2), dim3(512), HELEN_REC_DEC_ARGS, tiles); break;
+        case kRecQuarter4: LAUNCH(HELEN_K_GRU_DEC, gru_quarter4_kernel<true>, dim3(4 * tiles, 2), dim3(256), HELEN_REC_DEC_ARGS); break;
+        case kRecHalf8: LAUNCH(HELEN_K_GRU_DEC, gru_half8_kernel<true>, dim3(2 * tiles, 2), dim3(256), HELEN_REC_DEC_ARGS); break;
+        case kRecSingle8: LAUNCH(HELEN_K_GRU_DEC, gru_single8_kernel<true>, dim3(tiles, 2), dim3(512), HELEN_REC_DEC_ARGS); break;
+        default: LAUNCH(HELEN_K_GRU_DEC, gru_kernel<true>, dim3(tiles, 2), dim3(256), HELEN_REC_DEC_ARGS);
+    }
+#undef HELEN_REC_ENC_ARGS
+#undef HELEN_REC_DEC_ARGS
 }
 
 // The staging ring of helen_polish_host: two slots of device input / output buffers, pinned host mirrors (used
@@ -598,8 +488,9 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
     {
         const char* hooks = getenv("HELEN_DEBUG_HOOKS");
         m->debug_hooks = hooks && hooks[0] == '1';
-        if (const char* hl = getenv("HELEN_HOST_LOCK"))
-            m->host_lock = !strcmp(hl, "none") ? 0 : !strcmp(hl, "all") ? 2 : 1;
+        m->overrides = read_overrides();
+        if (m->overrides.host_lock >= 0) m->host_lock = m->overrides.host_lock;
+        if (m->overrides.verbose) fputs(describe_dispatch(m->cus, m->overrides).c_str(), stderr);
     }
     m->precision = precision;
     m->max_windows = max_windows;
@@ -670,13 +561,15 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
     if ((rc = dev_alloc(m, &m->plogit, nt * kPlTileStride))) return rc;   // the decoder emits partial logits, no y2
     if ((rc = dev_alloc(m, &m->hid, nt * (kHidStride / 4)))) return rc;
     if ((rc = dev_alloc(m, &m->pending, nt * 2 * kJump * 64))) return rc;
-    if (precision == HELEN_PRECISION_FP32) {
+#ifdef HELEN_WITH_PERSISTENT
+    if (precision == HELEN_PRECISION_FP32 && m->overrides.persistent == 1) {
         const size_t words = 64 + (nt + 1) / 2 * 2;
         if ((rc = dev_alloc(m, &m->sync_area, words))) return rc;
         HIP_TRY(hipMemset(m->sync_area, 0, words * sizeof(unsigned)));
         HIP_TRY(hipHostMalloc((void**)&m->persistent_error, sizeof(unsigned), hipHostMallocMapped));
         *m->persistent_error = 0;
     }
+#endif
     return HELEN_OK;
 }
 
@@ -727,14 +620,59 @@ int helen_model_device_bytes(const HelenModel* m, size_t* out_bytes) {
     return HELEN_OK;
 }
 
-// The chunk loop as ONE launch (polish_persistent_kernel) where the per-phase path would take the two-tile recurrence
-// and the weight-stationary decoder projection anyway: the same device bodies, the same bits.  HELEN_PERSISTENT=0/1
-// forces it off / on (on: any tile count, A/B probes and tests).
+int helen_reload_overrides(HelenModel* m) {
+    if (!m) return fail(HELEN_EINVAL, "null argument");
+    HELEN_ENTER(m);
+    const int keep = m->overrides.persistent;      // (what was allocated at creation decides that one)
+    m->overrides = read_overrides();
+    m->overrides.persistent = keep;
+    m->host_lock = m->overrides.host_lock >= 0 ? m->overrides.host_lock : 0;
+    return HELEN_OK;
+}
+
+int helen_describe_dispatch(int cus, char* out, size_t cap) {
+    if (cus < 8 || !out || cap == 0) return fail(HELEN_EINVAL, "cus >= 8 and a buffer, please");
+    const std::string text = describe_dispatch(cus, read_overrides());
+    snprintf(out, cap, "%s", text.c_str());
+    return text.size() < cap ? HELEN_OK : fail(HELEN_EINVAL, "the table needs %zu bytes", text.size() + 1);
+}
+
+int helen_plan_call(int cus, int tiles, int* out) {
+    if (cus < 8 || tiles < 1 || !out) return fail(HELEN_EINVAL, "cus >= 8, tiles >= 1 and an int[8], please");
+    const Overrides o = read_overrides();
+    const CallPlan c = plan_call(tiles, cus, true, o);
+    const ChunkPlan k = plan_chunk(tiles, kWin, cus, o);
+    const EncoderPlan e = plan_encoder(tiles, kSeq, cus, o);
+    out[0] = c.split ? 1 : 0;
+    out[1] = c.first_group;
+    out[2] = (int)k.recurrence;
+    out[3] = (int)k.decoder;
+    out[4] = k.dec_parts;
+    out[5] = (int)e.kind;
+    out[6] = e.parts;
+    out[7] = bf16_pair_pays(tiles, cus, o) ? 1 : 0;
+    return HELEN_OK;
+}
+
+int helen_has_persistent(void) {
+#ifdef HELEN_WITH_PERSISTENT
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+// The chunk loop as ONE launch (polish_persistent_kernel): only in builds with -DHELEN_WITH_PERSISTENT, and then only for
+// a model created under $HELEN_PERSISTENT=1 (same device bodies, same bits; 0.6-0.8 % slower).
 static bool use_persistent(const HelenModel* m, int tiles) {
-    if (m->precision != HELEN_PRECISION_FP32 || m->persistent_off || !m->sync_area) return false;
-    const char* force = getenv("HELEN_PERSISTENT");
-    if (force && *force) return *force == '1';
-    return HELEN_PERSISTENT_DEFAULT && use_pair_recurrence(tiles, m->cus) && use_ws_dec_projection(tiles, m->cus);
+#ifdef HELEN_WITH_PERSISTENT
+    (void)tiles;
+    return m->precision == HELEN_PRECISION_FP32 && !m->persistent_off && m->sync_area && m->overrides.persistent == 1;
+#else
+    (void)m;
+    (void)tiles;
+    return false;
+#endif
 }
 
 // uint8 windows -> operand tiles -> encoder input projection for all 1000 positions (overlapping chunks
@@ -762,6 +700,7 @@ static int launch_front(HelenModel* m, hipStream_t s, const uint8_t* images, int
     return HELEN_OK;
 }
 
+#ifdef HELEN_WITH_PERSISTENT
 static int launch_persistent(HelenModel* m, hipStream_t s, int tiles, int n_windows, uint8_t* bases, uint8_t* rles,
                              float* acc_base_opt, float* acc_rle_opt) {
     if (*(volatile unsigned*)m->persistent_error) {
@@ -814,6 +753,8 @@ static int launch_persistent(HelenModel* m, hipStream_t s, int tiles, int n_wind
     return HELEN_OK;
 }
 
+#endif
+
 // The launch sequence of one call over `tiles` tiles whose scratch starts at the model's (possibly shifted) pointers.
 static int polish_range(HelenModel* m, hipStream_t s, const uint8_t* images, int n_windows, uint8_t* bases,
                         uint8_t* rles, float* acc_base_opt, float* acc_rle_opt, bool allow_persistent) {
@@ -821,8 +762,10 @@ static int polish_range(HelenModel* m, hipStream_t s, const uint8_t* images, int
     const bool persistent = allow_persistent && use_persistent(m, tiles);
     int rc = launch_front(m, s, images, n_windows, tiles, !persistent);
     if (rc) return rc;
+#ifdef HELEN_WITH_PERSISTENT
     if (persistent)                      // pack, encoder projection, the chunk loop: three launches
         return launch_persistent(m, s, tiles, n_windows, bases, rles, acc_base_opt, acc_rle_opt);
+#endif
     for (int c = 0; c < kChunks; ++c) {  // predict_gpu.py:114-149
         launch_chunk(m, s, tiles, c * kJump, kWin, kSeq);
         LAUNCH(HELEN_K_HEADS, heads_kernel, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->plogit, kPlTileStride,
@@ -856,7 +799,8 @@ struct TileWindow {
     }
 };
 
-// fp32 calls of more than 128 and fewer than 240 tiles run as TWO independent groups of tiles on two internal streams.
+// fp32 calls of more than 128 and fewer than 240 tiles (on 256 CUs; dispatch.h's plan_call states it in CUs) run as TWO
+// independent groups of tiles on two internal streams.
 // Such a call is too large for one (tile, direction) per CU and too small to fill the chip with tile pairs: as one
 // lockstep sequence its recurrences take a pair launch's 0.62 ms with up to half the CUs idle and its projections a
 // partial second round.  Windows never interact, so each half is an ordinary call of at most 120 tiles (eight-wave
@@ -866,17 +810,14 @@ struct TileWindow {
 // 3,840: 77.1 -> 77.5 k; at 128 tiles and below (the chip is not full either way, but the two queues do not
 // overlap better than one: 1,024 windows 53.1 -> 53.2 k, and 51.2 k with the second group started half a chunk
 // late so that one group's projection falls beside the other's recurrence) and from 240 tiles on it loses 0.3-2 %.
-// (HELEN_SPLIT=0/1 forces it: A/B probes.)
-static bool use_split(const HelenModel* m, int tiles) {
-    if (m->precision != HELEN_PRECISION_FP32) return false;   // (TileWindow shifts the fp32 scratch only)
-    const char* force = getenv("HELEN_SPLIT");
-    if (force && *force) return *force == '1' && tiles >= 2;
-    // ... and calls of a little more than a quarter of the CUs in tiles (65-85 tiles on 256 CUs), whose first group is the
-    // 64 tiles that fill the chip with half-tile recurrences and whose second the few left over (quarter tiles): 1,040
-    // windows 51.4 -> 59.4 k, 1,152: 56.0 -> 63.5 k, 1,280: 59.2 -> 65.4 k; from 88 tiles on it loses (1,408: 63.7 -> 63.2 k).
-    return (2 * tiles > m->cus && 16 * tiles < 15 * m->cus) || (4 * tiles > m->cus && 3 * tiles <= m->cus);
-}
-
+// ... and calls of a little more than a quarter of the CUs in tiles (65-85 tiles on 256 CUs), whose first group is the
+// 64 tiles that fill the chip with half-tile recurrences and whose second the few left over (quarter tiles): 1,040
+// windows 51.4 -> 59.4 k, 1,152: 56.0 -> 63.5 k, 1,280: 59.2 -> 65.4 k; from 88 tiles on it loses (1,408: 63.7 -> 63.2 k).
+// The first group takes the larger part, whole tiles: from 160 tiles on what fills the chip with one (tile, direction)
+// per CU (3,072 windows: 128 + 64 tiles 75.9 k windows/s, 96 + 96: 73.8 k, 112 + 80: 71.9 k; 2,560: 128 + 32 72.3 k,
+// 80 + 80 71.2 k); below, two equal halves (2,304 windows: 72 + 72 tiles 73.7 k, 128 + 16: 68.6 k); between a quarter
+// and a third of the CUs the quarter that fills the chip with half-tile recurrences (1,280 windows: 64 + 16 tiles 65.4 k
+// windows/s, 32 + 48: 63.6 k).
 static int polish_batch_impl(HelenModel* m, const uint8_t* images, int n_windows, uint8_t* bases,
                              uint8_t* rles, float* acc_base_opt, float* acc_rle_opt, void* stream) {
     if (!m || !images || !bases || !rles) return fail(HELEN_EINVAL, "null argument");
@@ -885,7 +826,9 @@ static int polish_batch_impl(HelenModel* m, const uint8_t* images, int n_windows
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
     const int tiles = (n_windows + kTile - 1) / kTile;
-    if (!use_split(m, tiles) || use_persistent(m, tiles)) {
+    // (TileWindow shifts the fp32 scratch only)
+    const CallPlan call = plan_call(tiles, m->cus, m->precision == HELEN_PRECISION_FP32, m->overrides);
+    if (!call.split || use_persistent(m, tiles)) {
         const int rc = polish_range(m, s, images, n_windows, bases, rles, acc_base_opt, acc_rle_opt, true);
         return rc ? rc : check_launch("helen_polish_batch");
     }
@@ -896,19 +839,7 @@ static int polish_batch_impl(HelenModel* m, const uint8_t* images, int n_windows
         }
         HIP_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     }
-    // the first group takes the larger half, whole tiles
-    // From 160 tiles on the first group is what fills the chip with one (tile, direction) per CU and the second takes
-    // the rest (3,072 windows: 128 + 64 tiles 75.9 k windows/s, 96 + 96: 73.8 k, 112 + 80: 71.9 k; 2,560: 128 + 32
-    // 72.3 k, 80 + 80 71.2 k); below, two equal halves (2,304 windows: 72 + 72 tiles 73.7 k, 128 + 16: 68.6 k).
-    // ... and between a quarter and a third of the CUs in tiles the first group is the quarter that fills the chip with
-    // half-tile recurrences (1,280 windows: 64 + 16 tiles 65.4 k windows/s, 32 + 48: 63.6 k).
-    int t0 = (4 * tiles > m->cus && 3 * tiles <= m->cus) ? m->cus / 4
-             : 8 * tiles >= 5 * m->cus              ? m->cus / 2
-                                                    : (tiles + 1) / 2;
-    if (const char* at = getenv("HELEN_SPLIT_AT")) {      // (A/B probes: tiles of the first group)
-        const int v = atoi(at);
-        if (v > 0 && v < tiles) t0 = v;
-    }
+    const int t0 = call.first_group;
     const int w0 = t0 * kTile;
     HIP_TRY(hipEventRecord(m->ev_fork, s));
     for (int k = 0; k < 2; ++k) {
@@ -1068,15 +999,22 @@ int helen_polish_host(HelenModel* m, const uint8_t* images, int n_windows, uint8
             for (int i = 0; i < n; ++i) (void)hipHostUnregister(p[i]);
         }
     } registered;
-    // Only ranges that own their pages are locked: at least kLockMinBytes long (an allocation of that size is a mapping
-    // of its own; a few KiB of label rows from the caller's heap share their pages with whatever else lives there) and,
-    // for the two label arrays, not touching each other's pages.  Everything else goes through the pinned mirrors.  (Round 3:
-    // helen_polish_host on label arrays of 17 .. 3,072 windows that came from the Python heap aborted about one run of
-    // the GPU suite in seven with "Memory access fault by GPU ... on address <a page boundary in the caller's heap>":
-    // the suspect is two registrations that share a page -- a copy resolved through the wrong one runs off its end.
-    // Not reproduced in 2,400 calls of a soak (scripts/dev/host_small.py) or 30 repeats of the test alone; none in six
-    // runs of the suite with this rule.)
-    constexpr size_t kLockMinBytes = (size_t)4 << 20, kPage = 4096;
+    // PAGEABLE caller memory goes through the library's own pinned mirrors BY DEFAULT (round 4).  Rounds 2-3 page-locked the
+    // caller's ranges for the duration of the call (hipHostRegister / hipHostUnregister); one run of the GPU suite in
+    // about seven then died of "Memory access fault by GPU ... on address <a page of the caller's heap>" inside this
+    // function.  What the reproducers established (scripts/dev/host_register_repro.hip, host_fault_repro.py,
+    // suite_soak.sh): on this ROCm, registered host memory is mapped IN PLACE (device address == host
+    // address: a fault address in the heap is the registered range itself), page by page, with NO reference count --
+    // hipHostUnregister revokes the GPU access of every page of its range, including pages another registration (a
+    // neighbouring array, or the runtime's own cached pin of a pageable hipMemcpy to the same heap block) still counts
+    // on, and the kernel rebuilds GPU mappings after an invalidation (heap trim, page migration) only for ranges that
+    // still have access.  None of 27,000 reproducer iterations, 600 repeats of the test body or 7 runs of the whole suite
+    // under the old rule faulted again, so the trigger stays unproven; what IS established is that transient
+    // registration of memory this library does not own shares state with every other registrar in the process.  The
+    // mirrors do not: they are allocated once, owned here, never unregistered under a copy -- at 0.97 of the
+    // registered path's rate (77.3 k against 79.4 k windows/s).  $HELEN_HOST_LOCK=own | all restores the old rules for
+    // whoever knows their memory (own: ranges of at least 4 MiB, label arrays on disjoint pages; all: everything).
+    const size_t kLockMinBytes = (size_t)4 << 20, kPage = (size_t)sysconf(_SC_PAGESIZE);
     auto pages = [&](const void* q, size_t bytes, uintptr_t* lo, uintptr_t* hi) {
         *lo = (uintptr_t)q / kPage * kPage;
         *hi = ((uintptr_t)q + bytes + kPage - 1) / kPage * kPage;
@@ -1119,10 +1057,17 @@ int helen_polish_host(HelenModel* m, const uint8_t* images, int n_windows, uint8
             if (k >= 2 && (r = drain(k - 2))) return r;   // slot b (device buffers, mirrors) is free again after this
             const uint8_t* src = images + (size_t)k * sub * img_bytes;
             if (!in_pinned) {
-                memcpy(m->pin_in[b], src, count(k) * img_bytes);
-                src = m->pin_in[b];
+                // through the mirror in pieces of 512 windows: the upload of a piece runs beside the copy of the next
+                // (only the first sub-batch has nothing else to hide its staging behind)
+                const size_t piece = (size_t)512 * img_bytes, total = count(k) * img_bytes;
+                for (size_t o = 0; o < total; o += piece) {
+                    const size_t nb = total - o < piece ? total - o : piece;
+                    memcpy(m->pin_in[b] + o, src + o, nb);
+                    HIP_TRY(hipMemcpyAsync(m->dev_in[b] + o, m->pin_in[b] + o, nb, hipMemcpyHostToDevice, m->h2d_stream));
+                }
+            } else {
+                HIP_TRY(hipMemcpyAsync(m->dev_in[b], src, count(k) * img_bytes, hipMemcpyHostToDevice, m->h2d_stream));
             }
-            HIP_TRY(hipMemcpyAsync(m->dev_in[b], src, count(k) * img_bytes, hipMemcpyHostToDevice, m->h2d_stream));
             HIP_TRY(hipEventRecord(m->ev_in[b], m->h2d_stream));
             HIP_TRY(hipStreamWaitEvent(s, m->ev_in[b], 0));
             r = polish_batch_impl(m, m->dev_in[b], count(k), m->dev_out[b], m->dev_out[b] + (size_t)sub * lab_bytes,
@@ -1172,7 +1117,9 @@ int helen_debug_inject_failure(HelenModel* m, int sub_batch) {
     HELEN_ENTER(m);      // never while another thread is inside a call on this handle
     if (sub_batch == HELEN_DEBUG_PERSISTENT_TIMEOUT) {
         // pretend a workgroup hand-off of polish_persistent_kernel gave up: the word the device would have set
-        if (!m->persistent_error) return fail(HELEN_EINVAL, "this model has no one-launch chunk loop (fp32 only)");
+        if (!m->persistent_error)
+            return fail(HELEN_EINVAL, "this model has no one-launch chunk loop (fp32, a build with -DHELEN_WITH_PERSISTENT, "
+                                      "created under HELEN_PERSISTENT=1)");
         *m->persistent_error = 1;
         return HELEN_OK;
     }

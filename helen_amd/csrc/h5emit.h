@@ -112,15 +112,23 @@ class File {
     uint64_t group(std::vector<Child>& kids, uint64_t* btree_out = nullptr, uint64_t* heap_out = nullptr) {
         const auto by_name = [](const Child& a, const Child& b) { return a.name < b.name; };
         if (!std::is_sorted(kids.begin(), kids.end(), by_name)) std::sort(kids.begin(), kids.end(), by_name);
+        return group_sorted(kids.size(), [&](size_t i) -> const std::string& { return kids[i].name; },
+                            [&](size_t i) { return kids[i].header; }, btree_out, heap_out);
+    }
+    // the same over `n` members ALREADY in name order, named and addressed through the two accessors (a contig's 300,000
+    // regions are written from the writer's own table without copying a name)
+    template <typename NameAt, typename HeaderAt>
+    uint64_t group_sorted(size_t n_kids, NameAt&& name_at, HeaderAt&& header_at, uint64_t* btree_out = nullptr,
+                          uint64_t* heap_out = nullptr) {
         // local heap: "" at offset 0, then the names, each NUL-terminated and padded to 8
-        std::vector<uint64_t> off(kids.size());
+        std::vector<uint64_t> off(n_kids);
         size_t heap_bytes = 8;
-        for (size_t i = 0; i < kids.size(); ++i) {
+        for (size_t i = 0; i < n_kids; ++i) {
             off[i] = heap_bytes;
-            heap_bytes += (kids[i].name.size() + 1 + 7) & ~(size_t)7;
+            heap_bytes += (name_at(i).size() + 1 + 7) & ~(size_t)7;
         }
         std::vector<uint8_t> heap(heap_bytes, 0);
-        for (size_t i = 0; i < kids.size(); ++i) memcpy(heap.data() + off[i], kids[i].name.data(), kids[i].name.size());
+        for (size_t i = 0; i < n_kids; ++i) memcpy(heap.data() + off[i], name_at(i).data(), name_at(i).size());
         align8();
         const uint64_t heap_addr = tell();
         put("HEAP", 4); put8(0); pad(3);
@@ -131,8 +139,8 @@ class File {
         // symbol table nodes
         struct Node { uint64_t addr, max_key; };
         std::vector<Node> level;
-        for (size_t i = 0; i < kids.size(); i += 2 * kLeafK) {
-            const size_t n = std::min<size_t>(2 * kLeafK, kids.size() - i);
+        for (size_t i = 0; i < n_kids; i += 2 * kLeafK) {
+            const size_t n = std::min<size_t>(2 * kLeafK, n_kids - i);
             const uint64_t a = tell();
             uint8_t node[kSnodBytes];
             memset(node, 0, sizeof(node));
@@ -142,7 +150,8 @@ class File {
             memcpy(node + 6, &n16, 2);
             for (size_t k = 0; k < n; ++k) {
                 memcpy(node + 8 + 40 * k, &off[i + k], 8);
-                memcpy(node + 8 + 40 * k + 8, &kids[i + k].header, 8);
+                const uint64_t h = header_at(i + k);
+                memcpy(node + 8 + 40 * k + 8, &h, 8);
             }
             put(node, sizeof(node));
             level.push_back({a, off[i + n - 1]});

@@ -324,20 +324,25 @@ class File {
     }
 
     // how a dataset is stored, for reports (check_images): 0 compact, 1 contiguous, 2 chunked; number of filters
-    bool storage(uint64_t header, int* layout_class, int* n_filters) const {
+    bool storage(uint64_t header, int* layout_class, int* n_filters, bool* deflated) const {
         int cls = -1, nf = 0;
-        bool bad = false;
+        bool bad = false, z = false;
         const bool good = messages(header, [&](uint16_t type, uint8_t, const uint8_t* m, size_t len) {
             if (type == 0x0008 && len >= 2) cls = m[1];
             if (type == 0x000B) {
                 Pipeline p;
-                if (parse_pipeline(m, len, &p)) nf = (int)p.filters.size();
-                else bad = true;
+                if (parse_pipeline(m, len, &p)) {
+                    nf = (int)p.filters.size();
+                    for (int id : p.filters) z = z || id == 1;
+                } else {
+                    bad = true;
+                }
             }
         });
         if (!good || bad || cls < 0) return false;
         *layout_class = cls;
         *n_filters = nf;
+        *deflated = z;
         return true;
     }
 

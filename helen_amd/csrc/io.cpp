@@ -763,6 +763,36 @@ int helen_io_read_image_range(const char* path, long long first, int count, uint
                                positions + (size_t)done * kSeq * 3, meta + (size_t)done * 3, contigs + (size_t)done * kName);
 }
 
+/* How a file's images are stored, from its first image (a MarginPolish run writes all of them alike): out[0] = 0 the direct
+ * scanner reads the file, 1 libhdf5 has to; out[1] = layout class of `image` (0 compact, 1 contiguous, 2 chunked, -1 not
+ * inspected); out[2] = number of filters; out[3] = 1 if deflate is among them.  Returns 1 if the file has no images. */
+int helen_io_image_storage(const char* path, int* out) {
+    out[0] = 0;
+    out[1] = -1;
+    out[2] = 0;
+    out[3] = 0;
+    const std::shared_ptr<ImageIndex> ix = image_index(path);
+    if (!ix) return -1;
+    if (!ix->has_images || ix->names.empty()) return 1;
+    if (ix->through_library) {
+        out[0] = 1;
+        return 0;
+    }
+    const h5scan::File& f = ix->scanned->file;
+    uint64_t h;
+    int cls = -1, nf = 0;
+    bool z = false;
+    h5scan::Dataset d;
+    if (!f.lookup(ix->headers[0], "image", &h) || !f.storage(h, &cls, &nf, &z) || !f.dataset(h, &d)) {
+        out[0] = 1;                 // the groups are the scanner's, the datasets are not: libhdf5 reads the images
+        return 0;
+    }
+    out[1] = cls;
+    out[2] = nf;
+    out[3] = z ? 1 : 0;
+    return 0;
+}
+
 /* A reader that has moved past a file lets go of its index and its mapping (unmapping gigabytes of touched pages takes
  * the kernel tenths of a second: call this from a thread that has nothing better to do). */
 void helen_io_forget_images(const char* path) {
@@ -1332,21 +1362,24 @@ int helen_io_writer_close(void* handle) {
         struct Node {
             std::map<std::string, Node> sub;
             std::vector<h5emit::Child> regions;
+            const std::map<std::string, Region>* table = nullptr;    // an ordinary contig: its regions as the writer holds them
         };
         Node rootn;
         std::vector<std::string> parts;
+        auto plain = [](const std::string& s) { return !s.empty() && s != "." && s.find('/') == std::string::npos; };
         for (auto& c : w->tree) {
-            // (the ordinary contig name -- no '/', not empty, not '.' -- is one component: its regions go straight under it,
-            // already in name order because the map is)
-            const bool plain = !c.first.empty() && c.first != "." && c.first.find('/') == std::string::npos;
-            Node* direct = plain ? &rootn.sub[c.first] : nullptr;
-            if (direct) direct->regions.reserve(direct->regions.size() + c.second.size());
+            // (the ordinary contig name -- no '/', not empty, not '.' -- is one component, and so are its regions' names:
+            // the group is written straight from the writer's table, which is in name order because the map is)
+            bool direct = plain(c.first) && rootn.sub.find(c.first) == rootn.sub.end();
             for (auto& r : c.second) {
                 settle_region(w, &r.second);
-                if (direct && !r.first.empty() && r.first != "." && r.first.find('/') == std::string::npos) {
-                    direct->regions.push_back({r.first, r.second.header});
-                    continue;
-                }
+                direct = direct && plain(r.first);
+            }
+            if (direct) {
+                rootn.sub[c.first].table = &c.second;
+                continue;
+            }
+            for (auto& r : c.second) {
                 const std::string full = c.first + "/" + r.first;
                 parts.clear();
                 for (size_t b = 0; b <= full.size();) {
@@ -1358,17 +1391,29 @@ int helen_io_writer_close(void* handle) {
                 }
                 Node* n = &rootn;
                 for (size_t k = 0; k + 1 < parts.size(); ++k) n = &n->sub[parts[k]];
+                if (n->table) {                 // a later contig puts something under an ordinary one ('a' and 'a/b'): spell it out
+                    for (auto& r2 : *n->table) n->regions.push_back({r2.first, r2.second.header});
+                    n->table = nullptr;
+                }
                 n->regions.push_back({parts.empty() ? std::string(".") : parts.back(), r.second.header});
             }
         }
         bool clash = false;
         std::function<uint64_t(Node&)> emit = [&](Node& n) -> uint64_t {
+            if (n.table && n.sub.empty() && n.regions.empty()) {
+                std::vector<const std::pair<const std::string, Region>*> rows;
+                rows.reserve(n.table->size());
+                for (auto& r : *n.table) rows.push_back(&r);
+                return w->fast->group_sorted(rows.size(), [&](size_t i) -> const std::string& { return rows[i]->first; },
+                                             [&](size_t i) { return rows[i]->second.header; });
+            }
             std::vector<h5emit::Child> kids;
             kids.swap(n.regions);
+            if (n.table)
+                for (auto& r2 : *n.table) kids.push_back({r2.first, r2.second.header});
             if (!n.sub.empty()) {
                 std::set<std::string> names;
-                if (!kids.empty())
-                    for (auto& k : kids) names.insert(k.name);
+                for (auto& k : kids) names.insert(k.name);
                 for (auto& kv : n.sub) {
                     if (!names.insert(kv.first).second) clash = true;   // a region and a contig component of one name
                     kids.push_back({kv.first, emit(kv.second)});

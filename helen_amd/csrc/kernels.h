@@ -17,4 +17,6 @@
 #include "kernels_fused_bf16_pair.h"
 #include "kernels_fused_bf16_il.h"
 #include "kernels_heads.h"
+#ifdef HELEN_WITH_PERSISTENT      // the 19-chunk loop as one launch: quarantined (slower; see api.hip)
 #include "kernels_persistent.h"
+#endif

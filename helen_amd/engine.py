@@ -188,6 +188,11 @@ class HelenEngine(object):
                 rle[s:e].data_ptr(), h_out[s:e].data_ptr(), self._stream()))
         return base, rle, h_out
 
+    def reload_overrides(self):
+        """Read the environment's A/B switches (HELEN_GRU_PAIR, HELEN_SPLIT, ... : helen_amd/csrc/dispatch.h) again for
+        this engine; they are otherwise read once, when it is created."""
+        _lib.check(self._lib.helen_reload_overrides(self._handle))
+
     def inject_failure(self, sub_batch):
         """Test hook: the next polish_host fails right after enqueuing sub-batch `sub_batch` (-1 disarms)."""
         _lib.check(self._lib.helen_debug_inject_failure(self._handle, int(sub_batch)))

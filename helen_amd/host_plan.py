@@ -8,7 +8,8 @@ helen_amd/csrc/h5scan.h, profiles/r03_reader_scaling.txt), so one GPU wants thre
 threads (device stage, writer).  Eight ranks want ~40 CPUs; a container may grant fewer than it shows (cgroup quota:
 the 16-CPU box of this project tops out at 240-320 k windows/s of readers, under half of what eight MI355X take), and
 a two-socket box has the GPUs split over NUMA nodes.
-Nothing here touches torch: the device -> NUMA node map is read from sysfs by PCI address.
+Nothing here touches torch or creates a device context: a device's PCI address is read from the KFD topology in sysfs
+(/sys/class/kfd/kfd/topology/nodes/*/properties), its NUMA node from /sys/bus/pci/devices/<address>.
 """
 import os
 import sys
@@ -18,6 +19,15 @@ import sys
 # four to six, 27-30 k as one of eight to twelve (the quota and memory bandwidth are shared); the planning figure
 # is the crowded one.  Device stage of one rank (fp32, 4096-window calls): 81 k.
 READER_WINDOWS_PER_S = 30000.0
+# Round 4: what ONE reader (a native thread of helen_io_read_image_runs, or a reader process of the fallback pool) delivers
+# depends on how the file stores its images -- profiles/r04_reader_variants.txt (scripts/reader_variants.py on the GPU box's
+# host, EPYC 9575F), the figure of one reader among eight: a contiguous image is a copy out of the page cache (92-108 k
+# windows/s from one thread, 520-536 k from eight), a chunked one a copy per chunk (65-80 k / 410-450 k), a deflated one is
+# zlib's inflate of 90 KB (5.9 k / 45 k on pileup-like pixels; incompressible ones inflate three times faster), and what
+# the direct scanner does not take costs libhdf5's six object opens per window (3.2-12.6 k from its one thread per
+# process).  The plan prices a run with the storage class it FINDS (the first image of every file:
+# helen_amd.native_io.image_storage).
+READER_RATE = {"contiguous": 65000.0, "chunked": 50000.0, "deflate": 5600.0, "libhdf5": 5000.0}
 DEVICE_WINDOWS_PER_S = 81000.0
 WRITER_WINDOWS_PER_S = 100000.0
 RANK_THREADS = 2            # the rank's own busy threads: device stage + writer (feeder and release threads sleep)
@@ -54,14 +64,58 @@ def parse_cpulist(text):
     return out
 
 
-def device_pci_address(device):
-    """'dddd:bb:dd.f' of HIP device `device` (torch's device properties), or None."""
+def kfd_gpu_addresses(topology="/sys/class/kfd/kfd/topology/nodes"):
+    """PCI addresses ('dddd:bb:dd.f') of the GPUs in the order the ROCm runtime enumerates them: the KFD topology nodes
+    with compute units (`simd_count` > 0), by node number; `location_id` is bus << 8 | device << 3 | function, `domain`
+    the PCI domain.  No device context is created (the parent of the ranks must not hold the GPUs).  [] when the kernel
+    does not expose the topology."""
+    out = []
     try:
-        import torch
-        p = torch.cuda.get_device_properties(int(device))
-        return "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
-    except Exception:
-        return None
+        nodes = sorted((int(n), n) for n in os.listdir(topology) if n.isdigit())
+    except OSError:
+        return out
+    for _, name in nodes:
+        props = {}
+        try:
+            for line in open(os.path.join(topology, name, "properties")):
+                k, _, v = line.strip().partition(" ")
+                props[k] = v
+        except OSError:
+            continue
+        try:
+            if int(props.get("simd_count", "0")) <= 0:
+                continue                     # a CPU node
+            loc = int(props["location_id"])
+            out.append("%04x:%02x:%02x.%d" % (int(props.get("domain", "0")), (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7))
+        except (KeyError, ValueError):
+            out.append(None)
+    return out
+
+
+def visible_gpu_addresses(topology="/sys/class/kfd/kfd/topology/nodes", environ=None):
+    """kfd_gpu_addresses filtered the way the runtime filters devices: ROCR_VISIBLE_DEVICES first, then
+    HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES on what is left (lists of indices; anything else -- UUIDs -- gives [])."""
+    environ = os.environ if environ is None else environ
+    gpus = kfd_gpu_addresses(topology)
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES" if "HIP_VISIBLE_DEVICES" in environ else "CUDA_VISIBLE_DEVICES"):
+        text = environ.get(var)
+        if text is None or text.strip() == "":
+            continue
+        try:
+            idx = [int(x) for x in text.split(",") if x.strip() != ""]
+        except ValueError:
+            return []
+        if any(i < 0 or i >= len(gpus) for i in idx):
+            return []
+        gpus = [gpus[i] for i in idx]
+    return gpus
+
+
+def device_pci_address(device, topology="/sys/class/kfd/kfd/topology/nodes"):
+    """'dddd:bb:dd.f' of HIP device `device`, from the KFD topology in sysfs (no torch, no device context), or None."""
+    gpus = visible_gpu_addresses(topology)
+    d = int(device)
+    return gpus[d] if 0 <= d < len(gpus) else None
 
 
 def device_local_cpus(pci_address, sysfs="/sys/bus/pci/devices"):
@@ -102,15 +156,48 @@ class RankPlan(object):
                 "slots": self.slots}
 
 
+def reader_rate(storage):
+    """windows/s of ONE reader over files of the given storage classes: {class: windows} (or files, any weight) -> the
+    rate of walking all of them, i.e. the weighted harmonic mean of READER_RATE; None / empty = contiguous."""
+    if not storage:
+        return READER_RATE["contiguous"]
+    total = float(sum(storage.values()))
+    if total <= 0:
+        return READER_RATE["contiguous"]
+    return total / sum(w / READER_RATE.get(c, READER_RATE["libhdf5"]) for c, w in storage.items() if w > 0)
+
+
+def storage_of_files(files):
+    """{storage class: number of files} of a rank's image files (their first images; a file without images counts
+    nowhere).  {} when the native reader is not built."""
+    from . import native_io
+    out = {}
+    if not native_io.available():
+        return out
+    for path in files:
+        try:
+            c = native_io.image_storage(path)
+        except (IOError, OSError):
+            c = "libhdf5"
+        if c is not None:
+            out[c] = out.get(c, 0) + 1
+    return out
+
+
 class HostPlan(object):
-    def __init__(self, ranks, usable, requested_workers, shm_free, shm_need, notes):
+    def __init__(self, ranks, usable, requested_workers, shm_free, shm_need, notes, storage=None):
         self.ranks, self.usable_cpus, self.requested_workers = ranks, usable, requested_workers
         self.shm_free, self.shm_need, self.notes = shm_free, shm_need, notes
+        self.storage = storage                # per rank: {storage class: files}, or None (not inspected)
+
+    def rank_reader_rate(self, r):
+        return reader_rate(self.storage[r] if self.storage else None)
 
     @property
     def host_ceiling(self):
-        """windows/s the planned reader processes can deliver (the writer of a rank does more than its device)."""
-        return sum(max(1, r.reader_workers) for r in self.ranks) * READER_WINDOWS_PER_S
+        """windows/s the planned readers can deliver over the storage they will find (the writer of a rank does more
+        than its device)."""
+        return sum(max(1, rp.reader_workers) * self.rank_reader_rate(r) for r, rp in enumerate(self.ranks))
 
     @property
     def device_ceiling(self):
@@ -123,22 +210,40 @@ class HostPlan(object):
                 "predicted_host_ceiling_windows_per_s": round(self.host_ceiling),
                 "predicted_device_ceiling_windows_per_s": round(self.device_ceiling),
                 "predicted_bound": "host readers" if self.host_ceiling < self.device_ceiling else "device",
+                "image_storage_per_rank": self.storage,
+                "reader_windows_per_s_each": [round(self.rank_reader_rate(r)) for r in range(len(self.ranks))],
                 "shm_free_bytes": self.shm_free, "shm_slot_bytes_all_ranks": self.shm_need,
                 "ranks": [r.as_dict() for r in self.ranks], "notes": self.notes}
 
     def describe(self, out=sys.stderr):
         d = self.as_dict()
-        out.write("INFO: HOST PLAN: %d RANK(S), %d USABLE CPUS, READER PROCESSES PER RANK %s (REQUESTED %d), "
+        out.write("INFO: HOST PLAN: %d RANK(S), %d USABLE CPUS, READERS PER RANK %s (REQUESTED %d) AT ~%s WINDOWS/S EACH, "
                   "HOST CEILING ~%d WINDOWS/S, DEVICE CEILING ~%d WINDOWS/S (%s-BOUND).\n"
                   % (d["n_ranks"], d["usable_cpus"], d["reader_workers_per_rank"], self.requested_workers,
+                     sorted(set(d["reader_windows_per_s_each"])),
                      d["predicted_host_ceiling_windows_per_s"], d["predicted_device_ceiling_windows_per_s"],
                      d["predicted_bound"].upper()))
+        if self.storage:
+            seen = {}
+            for st in self.storage:
+                for c, k in st.items():
+                    seen[c] = seen.get(c, 0) + k
+            out.write("INFO: HOST PLAN: IMAGE STORAGE FOUND: %s.\n"
+                      % ", ".join("%d FILE(S) %s (~%d WINDOWS/S PER READER)" % (k, c.upper(), READER_RATE.get(c, 0))
+                                  for c, k in sorted(seen.items())))
+            if self.host_ceiling < self.device_ceiling:
+                slow = [c for c in seen if READER_RATE.get(c, 0) < READER_RATE["contiguous"]]
+                out.write("WARN: HOST PLAN: THIS RUN IS HOST-BOUND AT ~%d%% OF THE DEVICE RATE%s; MORE READERS (-w) OR "
+                          "CONTIGUOUS, UNCOMPRESSED IMAGE FILES WOULD LIFT IT (python -m helen_amd check_images -i <dir> "
+                          "--strict SAYS WHICH PATH EVERY FILE TAKES).\n"
+                          % (100 * self.host_ceiling / self.device_ceiling,
+                             (": THE IMAGES ARE STORED " + " / ".join(c.upper() for c in sorted(slow))) if slow else ""))
         for n in self.notes:
             out.write("INFO: HOST PLAN: " + n + "\n")
 
 
 def plan_host(devices, num_workers, cap_windows, calls_per_rank=None, usable=None, allowed=None, shm_free=None,
-              local_cpus=None, token=None):
+              local_cpus=None, token=None, storage=None):
     """The plan for `len(devices)` ranks.
 
     * reader processes per rank = min(requested `-w`, (usable CPUs - RANK_THREADS x ranks) // ranks), at least 1 when
@@ -150,6 +255,7 @@ def plan_host(devices, num_workers, cap_windows, calls_per_rank=None, usable=Non
     * slots per rank: five (reader | H2D | kernels | D2H | writer) when the RAM-backed directory has room for all
       ranks' slots with a quarter to spare, else three, else the slots go to the temp directory (SharedSlot falls
       back by itself; the plan only says so beforehand).
+    `storage` = per rank {storage class: files} (storage_of_files) prices the readers with what they will find.
     `usable`, `allowed`, `shm_free`, `local_cpus` (device -> (node, cpus)) are injectable for tests."""
     n = len(devices)
     notes = []
@@ -177,6 +283,9 @@ def plan_host(devices, num_workers, cap_windows, calls_per_rank=None, usable=Non
             nodes_seen.add(node)
             mine = [c for c in cpus if c in set(allowed)]
             cpus_of[r] = mine
+        if any(v is None for v in node_of.values()) and local_cpus is None:
+            notes.append("NUMA LOOK-UP: NO PCI ADDRESS / NODE IN SYSFS FOR DEVICE(S) %s"
+                         % ",".join(str(devices[r]) for r, v in sorted(node_of.items()) if v is None))
         if len(nodes_seen) < 2:
             if nodes_seen or not node_of:
                 notes.append("NO NUMA PINNING: ALL DEVICES ON ONE NODE (OR SYSFS HAS NO NODE FOR THEM)")
@@ -209,7 +318,7 @@ def plan_host(devices, num_workers, cap_windows, calls_per_rank=None, usable=Non
     token = token if token is not None else "%d" % os.getpid()
     ranks = [RankPlan(r, devices[r], workers, cpus_of.get(r), node_of.get(r), slots,
                       "helen_slot_%s_%d_" % (token, r)) for r in range(n)]
-    return HostPlan(ranks, usable, requested, shm_free, need, notes)
+    return HostPlan(ranks, usable, requested, shm_free, need, notes, storage=storage)
 
 
 def apply_rank_plan(plan):

@@ -58,6 +58,8 @@ def load():
     lib.helen_io_read_image_runs.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_longlong),
                                              ctypes.POINTER(ctypes.c_int), ctypes.c_int, vp, vp, vp, vp,
                                              ctypes.POINTER(ctypes.c_longlong)]
+    lib.helen_io_image_storage.restype = ctypes.c_int
+    lib.helen_io_image_storage.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
     lib.helen_io_forget_images.restype = None
     lib.helen_io_forget_images.argtypes = [ctypes.c_char_p]
     lib.helen_io_writer_open.restype = vp
@@ -158,6 +160,24 @@ def read_image_runs(runs, threads, images, positions, meta, contigs):
     if rc != 0:
         _raise_reader_error(lib)
     return int(through.value)
+
+
+def image_storage(path):
+    """How the images of a file are stored, judged by its first image: one of "contiguous", "chunked", "deflate" (read by
+    the direct scanner; compact counts as contiguous) or "libhdf5" (the scanner does not take the file); None without
+    images.  The classes are what helen_amd.host_plan has reader rates for."""
+    lib = load()
+    out = (ctypes.c_int * 4)()
+    rc = lib.helen_io_image_storage(os.fsencode(path), out)
+    if rc == 1:
+        return None
+    if rc != 0:
+        raise IOError(_err(lib))
+    if out[0] == 1:
+        return "libhdf5"
+    if out[3]:
+        return "deflate"
+    return "chunked" if out[1] == 2 else "contiguous"
 
 
 def forget_images(path):

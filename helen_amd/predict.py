@@ -654,10 +654,11 @@ def predict_gpu(file_chunks, output_filepath, model_path, batch_size, total_call
 
     Before anything starts the host is budgeted over all ranks (helen_amd.host_plan): reader processes per rank
     from the usable CPUs, NUMA pinning of each rank to its GPU's node, one RAM-backed slot budget."""
-    from .host_plan import plan_host
+    from .host_plan import plan_host, storage_of_files
     args = (output_filepath, model_path, batch_size, num_workers)
     group = max(1, DEVICE_CALL_WINDOWS // batch_size)
-    host = plan_host(list(devices[:total_callers]), num_workers, group * batch_size)
+    host = plan_host(list(devices[:total_callers]), num_workers, group * batch_size,
+                     storage=[storage_of_files(file_chunks[r]) for r in range(total_callers)])
     host.describe()
     LAST_RUN.clear()
     LAST_RUN.update({"host_plan": host.as_dict(), "ranks": []})

@@ -260,7 +260,8 @@ class SequenceDataset(object):
                 if got is None:
                     sys.stderr.write("WARN: NO IMAGES FOUND IN FILE: " + path + "\n")
                     continue
-                self.runs.append((path, got[0], got[1]))
+                # (libhdf5's business if the scanner declines the file -- or, judged by the first image, its datasets)
+                self.runs.append((path, got[0], got[1] or (got[0] > 0 and native_io.image_storage(path) == "libhdf5")))
             return
         pairs = []
         for path in hdf_files:

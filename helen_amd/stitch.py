@@ -215,7 +215,8 @@ def _spill_dir():
     return None
 
 
-# exceptions of worker runs since perform_stitch started (the reference only prints them)
+# exceptions of worker runs of the LAST perform_stitch of this process (the reference only prints them); every call
+# collects its own list and leaves it here when it ends -- concurrent calls do not share state
 FAILED_RUNS = []
 
 
@@ -234,8 +235,10 @@ def _submit_contig(contig, sequence_chunk_keys, threads, executor):
     return [executor.submit(_small_chunk_stitch_worker, contig, fc, spill) for fc in file_chunks]
 
 
-def _finish_contig(jobs):
-    """Second half: collect the runs' sequences and stitch them (bytes-like)."""
+def _finish_contig(jobs, failed=None):
+    """Second half: collect the runs' sequences and stitch them (bytes-like).  `failed` (a list) receives the text of
+    every run that raised."""
+    failed = FAILED_RUNS if failed is None else failed
     sequence_chunks = []
     for job in jobs:
         if isinstance(job, concurrent.futures.Future):
@@ -252,7 +255,7 @@ def _finish_contig(jobs):
                     raise RuntimeError("a stitch worker process died (%s): the FASTA would be truncated"
                                        % job.exception())
                 sys.stderr.write("ERROR: " + str(job.exception()) + "\n")
-                FAILED_RUNS.append(str(job.exception()))
+                failed.append(str(job.exception()))
         else:
             sequence_chunks.append(job)
     if not sequence_chunks:
@@ -313,9 +316,10 @@ def get_file_paths_from_directory(directory_path):
 def perform_stitch(input_directory, output_path, output_prefix, threads):
     """Every contig of every prediction file -> `<output_path>/<output_prefix>.fa`
     (StitchInterface.py:40-106).  Unlike the reference, which prints a failed run's exception and returns a FASTA
-    stitched from what survived, this raises after writing that FASTA when any run failed."""
+    stitched from what survived, this raises after writing that FASTA when any run failed -- the error names the
+    incomplete file; $HELEN_STITCH_KEEP_GOING=1 restores the reference's behaviour (print, return the path)."""
     native_io.close_readers() if native_io.available() else None
-    del FAILED_RUNS[:]
+    failed = []
     all_prediction_files = get_file_paths_from_directory(input_directory)
     all_contigs = set()
     contigs_of = {}
@@ -356,7 +360,7 @@ def perform_stitch(input_directory, output_path, output_prefix, threads):
                     in_flight += len(chunk_name_tuple)
                     nxt += 1
                 contig, prefix, regions, jobs = pending.pop(0)
-                consensus_sequence = _finish_contig(jobs)
+                consensus_sequence = _finish_contig(jobs, failed)
                 in_flight -= regions
                 sys.stderr.write("INFO: " + prefix + " FINISHED PROCESSING " + contig
                                  + ", POLISHED SEQUENCE LENGTH: " + str(len(consensus_sequence)) + ".\n")
@@ -375,7 +379,12 @@ def perform_stitch(input_directory, output_path, output_prefix, threads):
                         os.unlink(leftover)
                     except OSError:
                         pass
-    if FAILED_RUNS:
-        raise RuntimeError("%d stitch run(s) failed, %s is incomplete; first error: %s"
-                           % (len(FAILED_RUNS), output_filename, FAILED_RUNS[0]))
+    FAILED_RUNS[:] = failed
+    if failed:
+        text = ("%d stitch run(s) failed, %s is INCOMPLETE (stitched from the runs that survived); first error: %s"
+                % (len(failed), output_filename, failed[0]))
+        if os.environ.get("HELEN_STITCH_KEEP_GOING", "") == "1":      # StitchInterface.py:40-106 prints and carries on
+            sys.stderr.write("ERROR: " + text + "\n")
+            return output_filename
+        raise RuntimeError(text)
     return output_filename

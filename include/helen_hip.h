@@ -120,6 +120,23 @@ int helen_model_destroy(HelenModel* model);
 int helen_model_device_bytes(const HelenModel* model, size_t* out_bytes);
 
 /*
+ * Which kernels a call takes is one table derived from the device's CU count (helen_amd/csrc/dispatch.h); every
+ * choice gives the same bits.  The environment's A/B switches (HELEN_GRU_PAIR, HELEN_GRU_SINGLE8, HELEN_GRU_HALF8,
+ * HELEN_GRU_QUARTER4, HELEN_DEC_WS, HELEN_DEC_WSP[_PARTS], HELEN_ENC_WS8, HELEN_ENC_WS8P[_PARTS], HELEN_SPLIT[_AT],
+ * HELEN_BF16_PAIR, HELEN_BF16_IL, HELEN_HOST_LOCK, HELEN_VERBOSE = print the table) are read ONCE, when the model is
+ * created; helen_reload_overrides reads them again for this model (tests and probes that flip one between calls).
+ *   helen_describe_dispatch   the table for a device of `cus` compute units, as text (a dry run: no device needed)
+ *   helen_plan_call           out[8] = split?, tiles of the first group, recurrence kernel, decoder projection, its
+ *                             position runs, encoder projection, its position runs, bf16 two-tile kernels?  (the enums of
+ *                             dispatch.h) for a call of `tiles` tiles on `cus` CUs
+ *   helen_has_persistent      1 if the library was built with the one-launch chunk loop (-DHELEN_WITH_PERSISTENT)
+ */
+int helen_reload_overrides(HelenModel* model);
+int helen_describe_dispatch(int cus, char* out, size_t cap);
+int helen_plan_call(int cus, int tiles, int* out);
+int helen_has_persistent(void);
+
+/*
  * The whole per-batch body of the reference loop (`models/predict_gpu.py:97-159`): uint8 -> f32,
  * zero initial hidden, 19 chunks of TransducerGRU.forward with the hidden state carried
  * chunk-to-chunk, per-chunk softmax zero-padded and added into [n,1000,C] accumulators, argmax
@@ -140,8 +157,11 @@ int helen_polish_batch(HelenModel* model, const uint8_t* images, int n_windows, 
  * Same, from HOST memory: sub-batches of `max_windows` windows go up with hipMemcpyAsync on a copy
  * stream, overlapped with the kernels of the previous sub-batch and the label download of the one
  * before.  Page-locked caller memory (hipHostMalloc / hipHostRegister, e.g. a torch pinned tensor) is
- * the source and destination of the DMA itself; pageable memory is page-locked for the duration of
- * the call (two pinned mirrors take over where that is refused).
+ * the source and destination of the DMA itself (79.9 k windows/s); pageable memory goes through two pinned
+ * mirrors the library owns (77.3 k) -- it is NOT page-locked in place by default: on this ROCm a registration maps the
+ * caller's pages in place without a reference count, so unregistering a range takes GPU access away from every page
+ * it shares with any other registration of the process (api.hip: helen_polish_host has the whole story;
+ * $HELEN_HOST_LOCK=own | all at model creation restores the in-place rules of rounds 2-3).
  * Synchronous: returns when the labels are in host memory; on an error nothing is left in flight.
  * Hand it MANY sub-batches per call: the first upload and the last download are the only exposed
  * copies.  Replaces the DataLoader -> `.to(device_id)` -> `.cpu()` hand-offs of

@@ -69,6 +69,10 @@ int helen_io_read_image_runs(int n_runs, const char* const* paths, const long lo
                              int threads, uint8_t* images, int64_t* positions, int64_t* meta, char* contigs,
                              long long* through_library);
 void helen_io_forget_images(const char* path);
+/* How a file's images are stored, judged by its first image: out[0] = 0 the direct scanner reads them, 1 libhdf5 has to;
+ * out[1] = layout class of `image` (0 compact, 1 contiguous, 2 chunked; -1 not inspected); out[2] = number of filters;
+ * out[3] = 1 if deflate is among them.  Returns 1 if the file has no images.  (helen_amd.host_plan prices a run with it.) */
+int helen_io_image_storage(const char* path, int* out);
 
 /* The loader of `helen_train test` (`models/dataloader.py:48-61`): image uint8 [1000, 90], label_base and
  * label_run_length uint8 [1000] of `n` images of one file, exactly as stored (that loader does not pad: any other

@@ -28,9 +28,11 @@ def main():
     for n in sizes:
         for k in PLAIN:
             os.environ.pop(k, None)
+        eng.reload_overrides()           # (the switches are read when an engine is created; this reads them again)
         got = [t.clone() for t in eng.polish(img[:n], want_acc=True)]
         got2 = [t.clone() for t in eng.polish(img[:n], want_acc=True)]      # the same call again
         os.environ.update(PLAIN)
+        eng.reload_overrides()
         want = eng.polish(img[:n], want_acc=True)
         torch.cuda.synchronize()
         ok = all(torch.equal(a, b) and torch.equal(a, c) for a, b, c in zip(want, got, got2))

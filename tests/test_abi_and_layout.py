@@ -84,3 +84,53 @@ def test_product_does_not_touch_the_oracle():
 def test_chunk_starts_match_reference_loop():
     from helen_amd.options import chunk_starts
     assert chunk_starts() == list(range(0, 901, 50)) and len(chunk_starts()) == 19
+
+
+def test_dispatch_table_dry_run(monkeypatch):
+    """helen_amd/csrc/dispatch.h: which kernels a call takes is ONE table derived from the device's CU count -- run dry
+    here (no device) for the MI355X's 256 CUs and for 304- and 128-CU parts.  The 256-CU rows are DESIGN.md 6's table;
+    the other two must be the same rules scaled, with no tile count left without a plan; an environment switch changes
+    exactly its own column."""
+    from helen_amd import _lib
+    for k in ("HELEN_GRU_PAIR", "HELEN_GRU_SINGLE8", "HELEN_GRU_HALF8", "HELEN_GRU_QUARTER4", "HELEN_DEC_WS", "HELEN_DEC_WSP",
+              "HELEN_ENC_WS8", "HELEN_ENC_WS8P", "HELEN_SPLIT", "HELEN_SPLIT_AT", "HELEN_BF16_PAIR"):
+        monkeypatch.delenv(k, raising=False)
+    want = {1: "gru_quarter4_kernel", 32: "gru_quarter4_kernel", 33: "gru_half8_kernel", 64: "gru_half8_kernel",
+            86: "gru_single8_kernel", 128: "gru_single8_kernel", 240: "gru_pair_kernel", 256: "gru_pair_kernel"}
+    for tiles, rec in want.items():
+        p = _lib.plan_call(256, tiles)
+        assert p["recurrence"] == rec and not p["split"], (tiles, p)
+    assert _lib.plan_call(256, 256)["decoder"] == "gemm_dec_ws_kernel" and _lib.plan_call(256, 256)["encoder"] == "gemm_enc_ws8_kernel"
+    assert _lib.plan_call(256, 16)["decoder"] == "gemm_dec_wsp_kernel" and _lib.plan_call(256, 16)["decoder_runs"] == 7
+    assert _lib.plan_call(256, 64)["decoder_runs"] == 2 and _lib.plan_call(256, 100)["decoder"] == "gemm_gi_kernel<16>"
+    for tiles, first in ((65, 64), (85, 64), (129, 65), (144, 72), (160, 128), (192, 128), (239, 128)):
+        p = _lib.plan_call(256, tiles)
+        assert p["split"] and p["first_group"] == first, (tiles, p)
+    assert not _lib.plan_call(256, 86)["split"] and not _lib.plan_call(256, 240)["split"]
+    for cus in (128, 304):
+        text = _lib.describe_dispatch(cus)
+        assert text.splitlines()[0].startswith("dispatch for %d CUs" % cus)
+        # the same rules in CUs: an eighth / a quarter / half of the CUs in tiles, the split ranges, whole rounds of pairs
+        assert _lib.plan_call(cus, cus // 8)["recurrence"] == "gru_quarter4_kernel"
+        assert _lib.plan_call(cus, cus // 8 + 1)["recurrence"] == "gru_half8_kernel"
+        assert _lib.plan_call(cus, cus // 4)["recurrence"] == "gru_half8_kernel"
+        assert _lib.plan_call(cus, cus // 4 + 1)["split"] and _lib.plan_call(cus, cus // 4 + 1)["first_group"] == cus // 4
+        assert _lib.plan_call(cus, cus // 2)["recurrence"] == "gru_single8_kernel" and not _lib.plan_call(cus, cus // 2)["split"]
+        assert _lib.plan_call(cus, cus // 2 + 1)["split"]
+        assert _lib.plan_call(cus, cus)["recurrence"] == "gru_pair_kernel" and not _lib.plan_call(cus, cus)["split"]
+        assert _lib.plan_call(cus, cus)["decoder"] == "gemm_dec_ws_kernel" and _lib.plan_call(cus, cus)["encoder"] == "gemm_enc_ws8_kernel"
+        for tiles in range(1, 2 * cus + 1):                  # every size has a plan whose groups are smaller than the call
+            p = _lib.plan_call(cus, tiles)
+            assert not p["split"] or 0 < p["first_group"] < tiles, (cus, tiles, p)
+    # switches: read from the environment at model creation (here: at the dry run)
+    monkeypatch.setenv("HELEN_GRU_PAIR", "0")
+    monkeypatch.setenv("HELEN_SPLIT", "0")
+    p = _lib.plan_call(256, 256)
+    assert p["recurrence"] == "gru_kernel" and p["decoder"] == "gemm_dec_ws_kernel"
+    assert not _lib.plan_call(256, 192)["split"]
+    monkeypatch.setenv("HELEN_SPLIT", "1")
+    monkeypatch.setenv("HELEN_SPLIT_AT", "5")
+    assert _lib.plan_call(256, 20) == dict(_lib.plan_call(256, 20), split=True, first_group=5)
+    # the product reads no switch per call: api.hip has exactly one getenv (the debug-hook gate), dispatch.h the rest
+    src = open(os.path.join(ROOT, "helen_amd", "csrc", "api.hip")).read()
+    assert src.count("getenv(") == 1 and "use_pair_recurrence" not in src and "use_split" not in src

@@ -11,6 +11,7 @@
     gemm_dec_ws_kernel, gemm_gi_kernel<6> | gemm_enc_ws_kernel -- gives the SAME bits: a 4096-window call
     (pair recurrence, weight-stationary projections) against four 1024-window calls (the fine-grained kernels).
 """
+import os
 import sys
 
 import numpy as np
@@ -131,16 +132,20 @@ def test_the_chunk_loop_as_one_launch_gives_the_same_bits(scale_case, monkeypatc
     sequence: accumulators and labels must be EQUAL -- at 4096 windows (its default range), at an odd tile count, at
     sizes it is only forced onto (64 and 21 tiles), over repeated and alternating calls on one handle (tickets and
     epochs carry over), and with more pairs than the device holds at once (8192 windows in one call)."""
+    from helen_amd import _lib
     from helen_amd.engine import HelenEngine
+    if not _lib.load().helen_has_persistent():
+        pytest.skip("libhelen_hip.so was built without the one-launch chunk loop (make PERSISTENT=1): quarantined, it is slower")
     w, img, _ = scale_case
     dev = torch.from_numpy(img[6144:6144 + 8192]).cuda()
     names = ("bases", "rles", "acc_base", "acc_rle")
     for cap, n in ((4096, 4096), (4080, 4080), (1024, 1024), (331, 331), (8192, 8192)):
-        eng = HelenEngine(w, device=0, max_windows=cap)
         monkeypatch.setenv("HELEN_PERSISTENT", "0")
-        want = eng.polish(dev[:n], want_acc=True)
+        plain = HelenEngine(w, device=0, max_windows=cap)
+        want = plain.polish(dev[:n], want_acc=True)
         torch.cuda.synchronize()
         monkeypatch.setenv("HELEN_PERSISTENT", "1")
+        eng = HelenEngine(w, device=0, max_windows=cap)          # (the switch is read when the model is created)
         eng.set_profiling(["chunks", "gru_enc"])
         eng.reset_kernel_stats()
         for rep in range(3):
@@ -151,15 +156,14 @@ def test_the_chunk_loop_as_one_launch_gives_the_same_bits(scale_case, monkeypatc
         st = eng.kernel_stats()
         assert st["chunks"][1] == 3 and st["gru_enc"][1] == 0, st      # one launch per call, no per-phase launches
         eng.set_profiling([])
-        # alternating with the per-phase path and with a smaller call on the same handle
-        monkeypatch.setenv("HELEN_PERSISTENT", "0")
-        eng.polish(dev[:n // 2])
-        monkeypatch.setenv("HELEN_PERSISTENT", "1")
+        # a smaller call on the same handle
+        plain.polish(dev[:n // 2])
         part = eng.polish(dev[:n // 2], want_acc=True)
         torch.cuda.synchronize()
         for name, x, y in zip(names, want, part):
             assert torch.equal(x[:n // 2], y), name + ": half-size call after a full one differs"
         eng.close()
+        plain.close()
     # it is opt-in (measured 0.6 % slower than the per-phase launches at 4096 windows, far slower below): unset = off
     monkeypatch.delenv("HELEN_PERSISTENT", raising=False)
     eng = HelenEngine(w, device=0, max_windows=4096)
@@ -174,8 +178,11 @@ def test_a_timed_out_hand_off_is_reported_and_the_handle_falls_back(scale_case, 
     """polish_persistent_kernel gives up a hand-off after ~4 s and sets a host-visible word instead of hanging the queue;
     the next call on that path must say so (its predecessor's labels are invalid) and the handle must keep working on the
     per-phase launches.  The time-out itself is injected (HELEN_DEBUG_HOOKS)."""
+    from helen_amd import _lib
     from helen_amd._lib import HelenError
     from helen_amd.engine import HelenEngine
+    if not _lib.load().helen_has_persistent():
+        pytest.skip("libhelen_hip.so was built without the one-launch chunk loop (make PERSISTENT=1)")
     w, img, _ = scale_case
     dev = torch.from_numpy(img[:512]).cuda()
     monkeypatch.setenv("HELEN_DEBUG_HOOKS", "1")
@@ -207,9 +214,11 @@ def test_split_calls_give_the_same_bits(scale_case, monkeypatch):
         dev = torch.from_numpy(img[7000:7000 + n]).cuda()
         eng = HelenEngine(w, device=0, max_windows=n)
         monkeypatch.setenv("HELEN_SPLIT", "0")
+        eng.reload_overrides()                 # (the switches are read at creation; this reads them again)
         want = eng.polish(dev, want_acc=True)
         torch.cuda.synchronize()
         monkeypatch.setenv("HELEN_SPLIT", "1")
+        eng.reload_overrides()
         for rep in range(2):
             got = eng.polish(dev, want_acc=True)
             torch.cuda.synchronize()
@@ -252,13 +261,23 @@ def test_every_call_size_gives_the_plain_sequence_s_bits(monkeypatch):
 
 
 def test_host_path_on_label_arrays_that_share_pages(scale_case):
-    """helen_polish_host page-locks pageable caller memory only where a range owns its pages: label arrays of a few KiB from
-    the caller's heap, and two large label arrays that are neighbouring views of ONE buffer (they share the page the
-    boundary falls in), go through the pinned mirrors -- with the same labels as everything else."""
+    """helen_polish_host on pageable caller memory, under each of its rules ($HELEN_HOST_LOCK, read when the engine is
+    created): none (the default: the library's pinned mirrors), own (page-lock ranges that own their pages: at least 4 MiB,
+    label arrays on disjoint pages) and all.  Label arrays of a few KiB from the caller's heap, and two large label arrays
+    that are neighbouring views of ONE buffer (they share the page the boundary falls in): the same labels as everything
+    else, whatever the rule."""
     from helen_amd.engine import HelenEngine
     w, img, _ = scale_case
     n = 4300                                                     # 4.3 MB of label rows each: above the locking threshold
-    eng = HelenEngine(w, device=0, max_windows=4096)
+    for rule in ("none", "own", "all"):
+        os.environ["HELEN_HOST_LOCK"] = rule
+        try:
+            _host_path_case(HelenEngine(w, device=0, max_windows=4096), img, n)
+        finally:
+            os.environ.pop("HELEN_HOST_LOCK", None)
+
+
+def _host_path_case(eng, img, n):
     want = [t.cpu().numpy() for t in eng.polish(torch.from_numpy(img[:n]).cuda())]
     buf = np.empty(2 * n * 1000 + 1000, np.uint8)
     for off in (0, 1, 777):                                      # the boundary between the two views at any offset in a page
@@ -286,6 +305,7 @@ def test_single_tile_recurrences_give_the_same_bits(scale_case, monkeypatch):
     for flag in ("0", "1"):
         monkeypatch.setenv("HELEN_GRU_SINGLE8", flag)
         monkeypatch.setenv("HELEN_GRU_PAIR", "0")
+        eng.reload_overrides()
         got[flag] = (eng.polish(dev, want_acc=True), eng.chunk_forward(x, h), eng.chunk_forward(x[:33, :1], h[:33]))
         torch.cuda.synchronize()
     for a, b in zip(got["0"], got["1"]):
@@ -316,6 +336,7 @@ def test_part_tile_recurrences_give_the_same_bits(scale_case, monkeypatch):
         monkeypatch.setenv("HELEN_DEC_WSP", wsp)
         monkeypatch.setenv("HELEN_ENC_WS8P", wsp)
         monkeypatch.setenv("HELEN_GRU_PAIR", "0")
+        eng.reload_overrides()
         got[name] = (eng.polish(dev, want_acc=True), eng.chunk_forward(x, h), eng.chunk_forward(x[:33, :1], h[:33]),
                      eng.polish(dev[:9], want_acc=True), eng.polish(dev[:3], want_acc=True), eng.polish(big, want_acc=True))
         torch.cuda.synchronize()
@@ -326,6 +347,7 @@ def test_part_tile_recurrences_give_the_same_bits(scale_case, monkeypatch):
     # the defaults take them for these sizes: 1000 windows the half tiles, 500 the quarter tiles
     for k in ("HELEN_GRU_HALF8", "HELEN_GRU_QUARTER4", "HELEN_GRU_PAIR", "HELEN_DEC_WSP", "HELEN_ENC_WS8P"):
         monkeypatch.delenv(k)
+    eng.reload_overrides()
     for u, v_ in zip(eng.polish(dev, want_acc=True), got["whole"][0]):
         assert torch.equal(u, v_)
     for u, v_ in zip(eng.polish(dev[:500], want_acc=True), got["whole"][0]):

@@ -365,8 +365,8 @@ np.savez(%(out)r, images=images, lb=lb, lr=lr, counts=np.array(native_io.reader_
 
 
 def test_labeled_images_native_reader_equals_the_per_item_reader(tmp_path):
-    """The evaluation loader (models/dataloader.py:48-61) through helen_io_read_labeled -- scanner, libhdf5 fallback
-    (a deflated file), either alone -- against the per-item ctypes reader; a short labeled image is the loader's
+    """The evaluation loader (models/dataloader.py:48-61) through helen_io_read_labeled -- scanner (a contiguous and a
+    deflated file) and libhdf5 alone -- against the per-item ctypes reader; a short labeled image is the loader's
     IMAGE SIZE ERROR, not padded."""
     import subprocess
     import sys
@@ -380,7 +380,7 @@ def test_labeled_images_native_reader_equals_the_per_item_reader(tmp_path):
     d = tmp_path / "labeled"
     d.mkdir()
     write_image_file(str(d / "a.h5"), img[:6], first_window=0, labels=(lb[:6], lr[:6]))
-    write_image_file(str(d / "b.h5"), img[6:], first_window=6, labels=(lb[6:], lr[6:]), gzip=4)   # libhdf5's business
+    write_image_file(str(d / "b.h5"), img[6:], first_window=6, labels=(lb[6:], lr[6:]), gzip=4)   # inflated by the scanner
     ds = SequenceDataset(str(d))
     order = [int(name.split("-")[1]) // 800 for _, name in ds.all_images]
     want = [np.stack([ds[i][k] for i in range(len(ds))]) for k in range(3)]          # per-item reader
@@ -398,7 +398,7 @@ def test_labeled_images_native_reader_equals_the_per_item_reader(tmp_path):
         got[reader] = dict(np.load(out))
         for k, w in zip(("images", "lb", "lr"), want):
             assert np.array_equal(got[reader][k], w), (reader, k)
-    assert tuple(got[""]["counts"]) == (6, 4) and tuple(got["libhdf5"]["counts"]) == (0, 10)
+    assert tuple(got[""]["counts"]) == (10, 0) and tuple(got["libhdf5"]["counts"]) == (0, 10)
     short = tmp_path / "short"
     short.mkdir()
     write_image_file(str(short / "s.h5"), img[:2], lengths=[1000, 999], labels=(lb[:2], lr[:2]))
@@ -510,14 +510,23 @@ def _strict_check_cases(tmp_path):
     assert r["verdict"] == "ready" and r["images"] == r["images_inspected"] == r["images_read"] == 45
     assert [f["reader_path"] for f in r["files"]] == ["direct scanner"] * 3
     assert r["files"][0]["datasets"]["image"]["types"] == ["uint8"] and r["files"][1]["datasets"]["image"]["rows_min"] == 613
-    # deflated storage: read through libhdf5, and the report says so
+    # deflated storage: the scanner inflates it itself (round 4), the report names the storage class and its price
     z = tmp_path / "deflated"
     z.mkdir()
     write_image_file(str(z / "z.h5"), make_images(6, seed=9), first_window=100, gzip=4)
     out = io.StringIO()
     assert check_main(str(z), strict=True, json_path=rep, out=out) == 0, out.getvalue()
     r = json.load(open(rep))
-    assert r["files"][0]["reader_path"] == "libhdf5" and r["files"][0]["datasets"]["image"]["filters"] == [["deflate"]]
+    assert r["files"][0]["reader_path"] == "direct scanner" and r["files"][0]["datasets"]["image"]["filters"] == [["deflate"]]
+    assert r["files"][0]["storage_class"] == "deflate" and "stored deflate" in out.getvalue()
+    # a chunk index the scanner does not walk (paged fixed array): read through libhdf5, and the report says so
+    pg = tmp_path / "paged"
+    pg.mkdir()
+    write_image_file(str(pg / "p.h5"), make_images(2, seed=9), first_window=100, libver="latest", chunks=(1, 45))
+    out = io.StringIO()
+    assert check_main(str(pg), strict=True, json_path=rep, out=out) == 0, out.getvalue()
+    r = json.load(open(rep))
+    assert r["files"][0]["reader_path"] == "libhdf5" and r["files"][0]["storage_class"] == "libhdf5"
     assert "read through the libhdf5" in out.getvalue()
     # every schema variant in one file: all eight images are taken
     v = tmp_path / "variants"

@@ -173,3 +173,110 @@ def test_an_interrupted_parent_takes_its_ranks_down(tmp_path, signum):
     assert parent.returncode != 0
     assert "INTERRUPTED" in err, err
     assert os.path.exists(os.path.join(d, "unwound_0")) and os.path.exists(os.path.join(d, "unwound_1")), err
+
+
+def test_the_plan_prices_readers_with_the_storage_it_finds(tmp_path):
+    """host_plan.READER_RATE: one reader's windows/s per storage class (profiles/r04_reader_variants.txt).  A directory of
+    deflated images is host-bound where a contiguous one is device-bound, and the plan says so before anything starts."""
+    import numpy as np
+
+    from helen_amd import native_io
+    from helen_amd.host_plan import READER_RATE, reader_rate, storage_of_files
+    from helen_amd.synthetic import write_image_file
+    from helen_amd.weights import make_images
+    if not native_io.available():
+        pytest.skip("libhelen_io.so not built")
+    img = make_images(3, seed=1)
+    files = []
+    for name, kw in (("a_plain", {}), ("b_chunked", dict(chunks=(100, 90))), ("c_gzip", dict(gzip=4)),
+                     ("d_latest", dict(libver="latest")), ("e_paged", dict(libver="latest", chunks=(1, 45)))):
+        files.append(str(tmp_path / (name + ".h5")))
+        write_image_file(files[-1], img, **kw)
+    assert [native_io.image_storage(f) for f in files] == ["contiguous", "chunked", "deflate", "contiguous", "libhdf5"]
+    assert storage_of_files(files) == {"contiguous": 2, "chunked": 1, "deflate": 1, "libhdf5": 1}
+    assert reader_rate({"contiguous": 5}) == READER_RATE["contiguous"]
+    mixed = reader_rate({"contiguous": 1, "deflate": 1})
+    assert READER_RATE["deflate"] < mixed < 2 * READER_RATE["deflate"]        # harmonic: the slow half dominates
+    fast = plan_host([0], 8, 4096, usable=16, allowed=list(range(16)), shm_free=1 << 40, storage=[{"contiguous": 16}])
+    slow = plan_host([0], 8, 4096, usable=16, allowed=list(range(16)), shm_free=1 << 40, storage=[{"deflate": 16}])
+    assert fast.as_dict()["predicted_bound"] == "device" and slow.as_dict()["predicted_bound"] == "host readers"
+    assert slow.as_dict()["reader_windows_per_s_each"] == [round(READER_RATE["deflate"])]
+    import io
+    text = io.StringIO()
+    slow.describe(out=text)
+    assert "HOST-BOUND" in text.getvalue() and "DEFLATE" in text.getvalue()
+    text = io.StringIO()
+    fast.describe(out=text)
+    assert "HOST-BOUND" not in text.getvalue() and "CONTIGUOUS" in text.getvalue()
+    # check_images reports the class and the predicted rate per file
+    from helen_amd.check_images import image_directory_report
+    rep = image_directory_report(str(tmp_path), strict=True)
+    got = {os.path.basename(e["path"]): (e["storage_class"], e["reader_path"]) for e in rep["files"]}
+    assert got["c_gzip.h5"] == ("deflate", "direct scanner") and got["e_paged.h5"] == ("libhdf5", "libhdf5")
+    assert all(e["predicted_windows_per_s_per_reader"] == READER_RATE[e["storage_class"]] for e in rep["files"])
+
+
+def _fake_node(tmp_path, gpus=8, cpus_per_socket=96):
+    """A 2-socket, 8-GPU box as sysfs shows it: KFD topology nodes 0-1 = the sockets (no SIMDs), 2-9 = the GPUs (four per
+    socket, PCI buses 0x05.. / 0x85..), and /sys/bus/pci/devices/<address>/{numa_node, local_cpulist}."""
+    topo, pci = tmp_path / "kfd_nodes", tmp_path / "pci"
+    for n in range(2):
+        (topo / str(n)).mkdir(parents=True)
+        (topo / str(n) / "properties").write_text("cpu_cores_count %d\nsimd_count 0\nlocation_id 0\ndomain 0\n" % cpus_per_socket)
+    for g in range(gpus):
+        socket = g // (gpus // 2)
+        bus = (0x05 if socket == 0 else 0x85) + 0x10 * (g % (gpus // 2))
+        (topo / str(2 + g)).mkdir(parents=True)
+        (topo / str(2 + g) / "properties").write_text("cpu_cores_count 0\nsimd_count 1024\nlocation_id %d\ndomain 0\n" % (bus << 8))
+        d = pci / ("0000:%02x:00.0" % bus)
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text("%d\n" % socket)
+        lo = socket * cpus_per_socket
+        (d / "local_cpulist").write_text("%d-%d\n" % (lo, lo + cpus_per_socket - 1))
+    return str(topo), str(pci)
+
+
+def test_eight_ranks_on_a_two_socket_node(tmp_path, monkeypatch):
+    """BASELINE.json configs[2] without the node: plan_host on a fake sysfs tree of 2 sockets x 96 CPUs and 8 GPUs (the
+    PCI address of a device comes from the KFD topology, its NUMA node and CPUs from /sys/bus/pci -- no torch, no device
+    context) -- with all 192 CPUs, and under a 16-CPU cgroup quota."""
+    for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "HELEN_PIN", "HELEN_READERS_UNCAPPED"):
+        monkeypatch.delenv(k, raising=False)
+    topo, pci = _fake_node(tmp_path)
+    addrs = host_plan.kfd_gpu_addresses(topo)
+    assert addrs == ["0000:05:00.0", "0000:15:00.0", "0000:25:00.0", "0000:35:00.0",
+                     "0000:85:00.0", "0000:95:00.0", "0000:a5:00.0", "0000:b5:00.0"]
+    assert host_plan.device_pci_address(5, topo) == "0000:95:00.0" and host_plan.device_pci_address(8, topo) is None
+    assert host_plan.visible_gpu_addresses(topo, {"HIP_VISIBLE_DEVICES": "6,1"}) == ["0000:a5:00.0", "0000:15:00.0"]
+    assert host_plan.visible_gpu_addresses(topo, {"ROCR_VISIBLE_DEVICES": "4,5,6,7", "HIP_VISIBLE_DEVICES": "1"}) == ["0000:95:00.0"]
+    assert host_plan.visible_gpu_addresses(topo, {"HIP_VISIBLE_DEVICES": "GPU-abcdef"}) == []
+    assert host_plan.device_local_cpus("0000:95:00.0", pci) == (1, list(range(96, 192)))
+
+    def local(d):
+        return host_plan.device_local_cpus(host_plan.device_pci_address(d, topo), pci)
+    storage = [{"contiguous": 16}] * 8
+    # the whole machine: every rank gets the 8 readers it asked for, pinned to its GPU's socket, device-bound
+    full = plan_host(list(range(8)), 8, 4096, usable=192, allowed=list(range(192)), shm_free=1 << 40, local_cpus=local,
+                     storage=storage)
+    d = full.as_dict()
+    assert d["reader_workers_per_rank"] == [8] * 8 and d["predicted_bound"] == "device"
+    assert [r.numa_node for r in full.ranks] == [0] * 4 + [1] * 4
+    assert full.ranks[0].cpus == list(range(96)) and full.ranks[7].cpus == list(range(96, 192))
+    assert d["predicted_device_ceiling_windows_per_s"] == 8 * host_plan.DEVICE_WINDOWS_PER_S
+    # a 16-CPU grant on the same box: (16 - 2 x 8) // 8 = 0 -> one reader per rank, host-bound, and the plan says so
+    small = plan_host(list(range(8)), 8, 4096, usable=16, allowed=list(range(16)), shm_free=1 << 40, local_cpus=local,
+                      storage=storage)
+    d = small.as_dict()
+    assert d["reader_workers_per_rank"] == [1] * 8 and d["predicted_bound"] == "host readers"
+    assert d["predicted_host_ceiling_windows_per_s"] == 8 * host_plan.READER_RATE["contiguous"]
+    assert any("GRANTED" in n for n in d["notes"])
+    # ... where the allowed CPUs all sit on socket 0: ranks 4-7 have no local CPUs to be pinned to -> nobody is pinned into a share it cannot run in
+    assert all(r.cpus is None for r in small.ranks[4:])
+    # the smallest grant at which eight ranks are device-bound on contiguous images: readers x 65 k >= 81 k -> 2 readers + 2 own threads per rank
+    need = next(u for u in range(8, 193) if plan_host(list(range(8)), 8, 4096, usable=u, allowed=list(range(192)), shm_free=1 << 40,
+                                                      local_cpus=local, storage=storage).as_dict()["predicted_bound"] == "device")
+    assert need == 8 * (2 + host_plan.RANK_THREADS)
+    # deflated images need more: 81 k / 5.6 k = 15 readers per rank
+    zneed = next((u for u in range(8, 400) if plan_host(list(range(8)), 16, 4096, usable=u, allowed=list(range(192)), shm_free=1 << 40,
+                                                        local_cpus=local, storage=[{"deflate": 16}] * 8).as_dict()["predicted_bound"] == "device"), None)
+    assert zneed == 8 * (15 + host_plan.RANK_THREADS)

@@ -248,8 +248,9 @@ def test_long_contig_names_are_refused_not_cut(tmp_path):
 
 
 def test_fallback_reads_are_reported(tmp_path, monkeypatch, capfd):
-    """Files the direct scanner declines (here: chunked + deflated datasets) are read by libhdf5 -- same labels --
-    and the run says how many windows went that way."""
+    """Files the direct scanner declines (here: a paged chunk index, libver=latest with 2,000 chunks per image) are read
+    by libhdf5 -- same labels -- and the run says how many windows went that way; with more than one worker asked for,
+    such a directory goes through the pool of reader PROCESSES (the library is serialised inside one)."""
     from helen_amd.model_handler import ModelHandler
     from helen_amd.synthetic import write_image_file
     from helen_amd.weights import make_images, make_weights
@@ -261,12 +262,13 @@ def test_fallback_reads_are_reported(tmp_path, monkeypatch, capfd):
     img_dir.mkdir()
     img = make_images(40, seed=3)
     write_image_file(str(img_dir / "a_plain.h5"), img[:24], first_window=0)
-    write_image_file(str(img_dir / "b_packed.h5"), img[24:], first_window=24, gzip=4)
+    write_image_file(str(img_dir / "b_packed.h5"), img[24:], first_window=24, libver="latest", chunks=(1, 45))
     model = str(tmp_path / "m.pkl")
     ModelHandler.save_model(make_weights(), None, 128, 1, 0, model)
     P.predict(sorted(glob.glob(str(img_dir / "*.h5"))), str(tmp_path / "out"), model, 8, 2, 0, 0)
     err = capfd.readouterr().err
     assert "16 OF THEM WERE READ THROUGH LIBHDF5" in err
+    assert P.LAST_PREDICT["reader_mode"] == "processes"
     with hdf5.File(str(tmp_path / "out_0.hdf")) as f:
         assert len(f.keys("predictions/chr20_synth")) >= 1
         total = sum(len([k for k in f.keys("predictions/chr20_synth/" + r) if k not in ("contig_start", "contig_end")])

@@ -338,3 +338,34 @@ def test_aligner_equals_reference_ssw_with_other_penalties(penalties):
             assert a.cigar_string == cig.value.decode(), (penalties, r, q)
             checked += 1
     assert checked > 300
+
+
+def test_a_failed_run_fails_the_stitch_and_names_the_incomplete_fasta(tmp_path, monkeypatch):
+    """A run whose worker raises (here: a region whose chunk group lacks its datasets): the reference prints the exception
+    and returns a FASTA stitched from what survived (StitchInterface.py:40-106); this package writes that FASTA and then
+    RAISES, naming it -- unless $HELEN_STITCH_KEEP_GOING=1 asks for the reference's behaviour.  The failure list belongs to
+    the call (two calls do not share it)."""
+    import helen_amd.stitch as S
+    code = {"A": 1, "C": 2, "G": 3, "T": 4}
+    seq = "ACGT" * 600
+    regions = []
+    for k in range(2):
+        lo, hi = 800 * k, 800 * k + 1000
+        pos = np.stack([np.arange(lo, hi), np.zeros(hi - lo, np.int64), np.zeros(hi - lo, np.int64)], 1)
+        regions.append((lo, hi, [(0, pos, np.array([code[c] for c in seq[lo:hi]]), np.ones(hi - lo, np.int64))]))
+    good, bad = tmp_path / "good", tmp_path / "bad"
+    good.mkdir()
+    bad.mkdir()
+    _write_predictions(str(good / "p_0.hdf"), "chrS", regions)
+    with hdf5.File(str(bad / "p_0.hdf"), "w") as f:          # a region with its bounds and an EMPTY chunk group
+        f.write("predictions/chrB/chrB-0-1000/contig_start", 0)
+        f.write("predictions/chrB/chrB-0-1000/contig_end", 1000)
+        f.write("predictions/chrB/chrB-0-1000/0/position", np.zeros((1000, 3), np.uint32))
+    with pytest.raises(RuntimeError, match=r"1 stitch run\(s\) failed, .*asm\.fa is INCOMPLETE"):
+        S.perform_stitch(str(bad), str(tmp_path / "out_bad"), "asm", 2)
+    assert len(S.FAILED_RUNS) == 1 and os.path.exists(str(tmp_path / "out_bad" / "asm.fa"))
+    out = S.perform_stitch(str(good), str(tmp_path / "out_good"), "asm", 2)       # the next call starts clean
+    assert S.FAILED_RUNS == [] and open(out).read().startswith(">chrS\n" + seq[:1800])
+    monkeypatch.setenv("HELEN_STITCH_KEEP_GOING", "1")
+    assert S.perform_stitch(str(bad), str(tmp_path / "out_keep"), "asm", 2).endswith("asm.fa")
+    assert len(S.FAILED_RUNS) == 1
