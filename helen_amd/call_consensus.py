@@ -67,21 +67,26 @@ def call_consensus(image_dir, model_path, batch_size, num_workers, threads, outp
     output_filename = os.path.join(output_dir, output_prefix)
     sys.stderr.write("INFO: OUTPUT FILE: " + output_filename + "\n")
 
-    if not gpu_mode:
-        # The reference's CPU mode is an ONNX Runtime session (models/predict_cpu.py); this build
-        # is the MI355X path only and refuses rather than silently running something else.
-        _err("THIS BUILD HAS NO CPU INFERENCE PATH; RUN WITH --gpu_mode (-g).")
-        sys.exit(1)
-    import torch
-    if not torch.cuda.is_available():
-        _err("NO MI355X VISIBLE (torch.cuda.is_available() IS FALSE).")
-        sys.exit(1)
-    try:
-        device_ids, callers = plan_devices(device_ids, torch.cuda.device_count())
-    except ValueError as e:
-        _err(str(e))
-        sys.exit(1)
-    sys.stderr.write("INFO: AVAILABLE GPU DEVICES: " + str(device_ids) + "\n")
+    if gpu_mode:
+        import torch
+        if not torch.cuda.is_available():
+            # (never a silent switch to the host path: --gpu_mode means the MI355X)
+            _err("NO MI355X VISIBLE (torch.cuda.is_available() IS FALSE).")
+            sys.exit(1)
+        try:
+            device_ids, callers = plan_devices(device_ids, torch.cuda.device_count())
+        except ValueError as e:
+            _err(str(e))
+            sys.exit(1)
+        sys.stderr.write("INFO: AVAILABLE GPU DEVICES: " + str(device_ids) + "\n")
+    else:
+        # the reference's CPU mode (CallConsensusInterface.py:128-131,150-153): `callers` processes of threads // callers
+        # threads each -- here around libhelen_cpu.so (helen_amd/csrc/cpu_path.cpp) instead of an ONNX Runtime session
+        if callers <= 0:
+            _err("callers NEEDS TO BE >0.")
+            sys.exit(1)
+        threads_per_caller = max(1, int(threads / callers))
+        sys.stderr.write("INFO: HOST PATH: %d CALLER(S) OF %d THREAD(S).\n" % (callers, threads_per_caller))
 
     input_files = file_manager.get_file_paths_from_directory(image_dir)
     file_chunks = file_manager.shard_round_robin(input_files, callers)
@@ -108,8 +113,12 @@ def call_consensus(image_dir, model_path, batch_size, num_workers, threads, outp
             vet["thread"] = threading.Thread(target=run_vet, daemon=True)
             vet["thread"].start()
     try:
-        predict_gpu(file_chunks, output_filename, model_path, batch_size, callers, device_ids,
-                    num_workers)
+        if gpu_mode:
+            predict_gpu(file_chunks, output_filename, model_path, batch_size, callers, device_ids,
+                        num_workers)
+        else:
+            from .predict import predict_cpu
+            predict_cpu(file_chunks, output_filename, model_path, batch_size, callers, threads_per_caller, num_workers)
     finally:
         if vet is not None:
             vet["thread"].join()

@@ -245,7 +245,7 @@ def _thread_feeder_loop(calls, free_slots, ready_q, make_slot, n_slots, threads,
     from . import native_io
     try:
         import torch
-        if torch.cuda.is_available():
+        if device_id is not None and torch.cuda.is_available():
             torch.cuda.set_device(device_id)      # the page-locked allocations below belong to this rank's device
         made = 0
         last_path = None
@@ -321,10 +321,12 @@ def _remove_stale_outputs(output_filename, rank):
             os.unlink(path)
 
 
-def predict(test_file, output_filename, model_path, batch_size, num_workers, rank, device_id, plan=None):
+def predict(test_file, output_filename, model_path, batch_size, num_workers, rank, device_id, plan=None, cpu_threads=None):
     """Run inference over the image files `test_file` (a list) on device `device_id` and write
     `<output_filename>_<rank>.hdf` (predict_gpu.py:38-179).  `plan` (helen_amd.host_plan.RankPlan, from
     predict_gpu) caps the reader processes at what the host grants this rank and names its slots.
+    `cpu_threads` (an int) makes it the predict of a run WITHOUT --gpu_mode (models/predict_cpu.py:39-170): the same
+    pipeline around the host engine (helen_amd.cpu_engine, `cpu_threads` OpenMP threads), one loader batch per call.
 
     Pipeline over shared-memory slots of one device call each:
       reader processes fill slot k+2 | H2D k+1 | kernels k | D2H k-1 | writer(s) store slot k-2."""
@@ -340,7 +342,8 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     writers = writer_count(num_workers)
     prediction_data_file = DataStore(prediction_file_name(output_filename, rank), mode="w") \
         if writers == 1 else None
-    group = max(1, DEVICE_CALL_WINDOWS // batch_size)       # loader batches per device call
+    on_host = cpu_threads is not None
+    group = 1 if on_host else max(1, DEVICE_CALL_WINDOWS // batch_size)       # loader batches per engine call
     cap = group * batch_size
 
     # Readers and writers first: their processes start (and the first slots fill) while the model is
@@ -359,7 +362,7 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
 
         def make_slot():
             from .sequence_dataset import PinnedSlot
-            slots.append(PinnedSlot(cap))
+            slots.append(PinnedSlot(cap, pin=not on_host))
             return slots[-1]
     else:
         pairs = test_data.all_images
@@ -380,7 +383,7 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         reaper.start()
         feeder = threading.Thread(target=_thread_feeder_loop, daemon=True,
                                   args=(calls, free_slots, ready_q, make_slot, n_slots, max(1, num_workers), batch_size,
-                                        ferr, device_id, reap_q))
+                                        ferr, None if on_host else device_id, reap_q))
     else:
         feeder = threading.Thread(target=_feeder_loop, args=(calls, free_slots, ready_q, pool, cap, ferr, num_workers),
                                   daemon=True)
@@ -417,8 +420,11 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         transducer_model.eval()
         setup_took["MODEL FILE"] = time.time() - t_s
         t_s = time.time()
-        torch.cuda.set_device(device_id)
-        transducer_model.to(device_id)
+        if on_host:
+            transducer_model.use_cpu(cpu_threads)
+        else:
+            torch.cuda.set_device(device_id)
+            transducer_model.to(device_id)
         setup_took["DEVICE CONTEXT + WEIGHTS"] = time.time() - t_s
         t_s = time.time()
         transducer_model.set_capacity(min(DEVICE_CALL_WINDOWS, cap))
@@ -426,10 +432,13 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         setup_took["ENGINE"] = time.time() - t_s
         if rank == 0:
             print(prediction_file_name(output_filename, rank))
-            sys.stderr.write("INFO: MI355X HIP PATH, DEVICE " + str(device_id) + ", "
-                             + str(engine.device_bytes >> 20) + " MiB OF DEVICE MEMORY HELD.\n")
+            if on_host:
+                sys.stderr.write("INFO: HOST PATH (NO --gpu_mode), %d THREAD(S) PER CALLER.\n" % max(1, cpu_threads))
+            else:
+                sys.stderr.write("INFO: MI355X HIP PATH, DEVICE " + str(device_id) + ", "
+                                 + str(engine.device_bytes >> 20) + " MiB OF DEVICE MEMORY HELD.\n")
             sys.stderr.write("Loading data\n")
-        if os.environ.get("HELEN_DEVICE_STAGE", "async") != "sync" and hasattr(engine, "polish") \
+        if os.environ.get("HELEN_DEVICE_STAGE", "async") != "sync" and hasattr(engine, "polish") and not on_host \
                 and torch.cuda.is_available() and calls:
             t_s = time.time()
             try:
@@ -545,6 +554,45 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
             sys.stderr.write("INFO: %d OF THEM WERE READ THROUGH LIBHDF5: THE DIRECT IMAGE SCANNER DOES NOT TAKE THEIR "
                              "STORAGE (CHUNKED / FILTERED / NEW-STYLE FILE); SEE python -m helen_amd check_images.\n"
                              % through_library)
+
+
+def _setup_cpu(rank, total_callers, args, all_input_files, result_q=None):
+    """One caller of a run without --gpu_mode (predict_cpu.py:177-195; no process group is created: it was never used)."""
+    output_filepath, model_path, batch_size, num_workers, threads = args
+    if result_q is not None:
+        import signal
+
+        def on_term(signum, frame):
+            raise SystemExit(143)
+        signal.signal(signal.SIGTERM, on_term)
+        try:
+            os.setpgid(0, 0)
+        except OSError:
+            pass
+    predict(all_input_files[rank], output_filepath, model_path, batch_size, num_workers, rank, None, cpu_threads=threads)
+    if result_q is not None:
+        result_q.put((rank, dict(LAST_PREDICT)))
+
+
+def predict_cpu(file_chunks, output_filepath, model_path, batch_size, total_callers, threads, num_workers):
+    """`callers` processes, each over its own file list with `threads` threads, each writing `<output>_<rank>.hdf`
+    (models/predict_cpu.py:198-248).  The engine is libhelen_cpu.so (no ONNX export: the .pkl is all it needs); a failing
+    caller takes the others down, as mp.spawn(join=True) does (:245-248)."""
+    args = (output_filepath, model_path, batch_size, num_workers, max(1, int(threads)))
+    LAST_RUN.clear()
+    LAST_RUN.update({"host_plan": None, "ranks": []})
+    t0 = time.time()
+    if total_callers == 1:
+        _setup_cpu(0, 1, args, file_chunks)
+        LAST_RUN["ranks"] = [dict(LAST_PREDICT)]
+        LAST_RUN["seconds"] = round(time.time() - t0, 3)
+        return
+    results, failed = run_ranks(_setup_cpu, [(r, total_callers, args, file_chunks) for r in range(total_callers)])
+    LAST_RUN["ranks"] = [results[r] for r in sorted(results)]
+    LAST_RUN["seconds"] = round(time.time() - t0, 3)
+    if failed:
+        raise RuntimeError("prediction process(es) failed: " + ", ".join(
+            "rank %d exit %s" % f for f in failed) + "; the other callers were terminated")
 
 
 def _setup(rank, total_callers, args, all_input_files, all_devices, plans=None, result_q=None):

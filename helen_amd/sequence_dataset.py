@@ -183,11 +183,11 @@ class PinnedSlot(object):
 
     path = None          # (no file behind it: writer PROCESSES cannot attach)
 
-    def __init__(self, cap):
+    def __init__(self, cap, pin=True):
         import torch
         self.cap = int(cap)
         L, H = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT
-        pin = torch.cuda.is_available()
+        pin = pin and torch.cuda.is_available()
         self.images_t = torch.empty((self.cap, L, H), dtype=torch.uint8, pin_memory=pin)
         self.bases_t = torch.empty((self.cap, L), dtype=torch.uint8, pin_memory=pin)
         self.rles_t = torch.empty((self.cap, L), dtype=torch.uint8, pin_memory=pin)

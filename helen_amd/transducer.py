@@ -1,7 +1,9 @@
 """TransducerGRU: drop-in for the reference's model object at the operator boundary
 (helen/modules/python/models/TransducerModel.py:20-93): same constructor, `forward(x, hidden)`,
 `init_hidden`, `eval`, `to`, `state_dict` / `load_state_dict` -- but the forward is
-libhelen_hip.so's helen_gru_chunk_forward on an MI355X.  There is no CPU execution path.
+libhelen_hip.so's helen_gru_chunk_forward on an MI355X.  The host executes it only on request: `use_cpu(threads)`
+(what a run WITHOUT --gpu_mode does, like the reference's ONNX Runtime session, models/predict_cpu.py:39-170) binds the
+model to libhelen_cpu.so; nothing ever falls back to it -- a model that was not told so needs a GPU.
 """
 from collections import OrderedDict
 
@@ -37,6 +39,14 @@ class TransducerGRU(object):
         import os
         self.precision = os.environ.get("HELEN_PRECISION", "fp32")
         self.training = False
+        self._cpu_threads = None        # set by use_cpu(): the host engine, explicitly
+
+    def use_cpu(self, threads=0):
+        """Bind this model to the host path (libhelen_cpu.so) with `threads` OpenMP threads per call: the engine of a run
+        without --gpu_mode (CallConsensusInterface.py:131,152).  Explicit: no other call ever selects it."""
+        self._drop_engine()
+        self._cpu_threads = int(threads)
+        return self
 
     # ---- nn.Module-like surface used by the reference's callers ----
     def state_dict(self):
@@ -91,6 +101,9 @@ class TransducerGRU(object):
     @property
     def engine(self):
         """The device-resident replica (created on first use)."""
+        if self._engine is None and self._cpu_threads is not None:
+            from .cpu_engine import CpuEngine
+            self._engine = CpuEngine(self._params, threads=self._cpu_threads)
         if self._engine is None:
             from .engine import HelenEngine
             dev = self._device if self._device is not None else torch.device("cuda", 0)
@@ -102,6 +115,9 @@ class TransducerGRU(object):
     def forward(self, x, hidden):
         """x [B, T, 90] f32, hidden [B, 2, 128] -> (base [B,T,5], rle [B,T,11], hidden [B,2,128])
         (TransducerModel.py:60-79).  Inputs are moved to the model's device if needed."""
+        if self._cpu_threads is not None:
+            base, rle, h = self.engine.chunk_forward(x.detach().cpu().numpy(), hidden.detach().cpu().numpy())
+            return torch.from_numpy(base), torch.from_numpy(rle), torch.from_numpy(h)
         dev = self._device if self._device is not None else torch.device("cuda", 0)
         if x.shape[0] > self._max_windows:
             self.set_capacity(x.shape[0])

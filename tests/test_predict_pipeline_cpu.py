@@ -385,6 +385,6 @@ def test_helen_commands_run_through_their_entry_points(tmp_path):
     assert r.returncode == 2 and "--image_dir" in r.stderr and "--model_path" in r.stderr
     r = run("helen_train", "train", "--anything")
     assert r.returncode == 1 and "NOT PART OF THIS BUILD" in r.stderr
-    # without -g the product refuses (it has no CPU mode) -- before touching any file
+    # a model file that does not exist is refused before anything is touched
     r = run("helen", "call_consensus", "-i", str(tmp_path), "-m", str(tmp_path / "none.pkl"), "-o", str(tmp_path / "o"))
     assert r.returncode != 0
