@@ -76,6 +76,25 @@ __device__ __forceinline__ f32x4 gru_cell4(f32x4 ar, f32x4 az, f32x4 an, f32x4 g
     return f32x4{lo.x, lo.y, hi.x, hi.y};
 }
 
+// The same four cells on SCALAR instructions (the same IEEE operations per component: same bits).  Beside bf16 MFMAs a
+// packed fp32 instruction costs a SIMD 16 cycles where two scalar ones cost 2 x 4.7 (scripts/ubench/bf16_mfma_valu_overlap.hip):
+// probe form for the bf16 layer kernels (-DHELEN_BP_SCALAR_GATES).  The empty asm keeps the SLP vectoriser from packing them again.
+__device__ __forceinline__ float gru_cell1_scalar(float sr, float sz, float an, float gn, float hp) {
+    float er = __builtin_amdgcn_exp2f(sr * -1.4426950408889634f);
+    float ez = __builtin_amdgcn_exp2f(sz * -1.4426950408889634f);
+    asm volatile("" : "+v"(er), "+v"(ez));
+    const float rg = __builtin_amdgcn_rcpf(1.0f + er);
+    const float zg = __builtin_amdgcn_rcpf(1.0f + ez);
+    float pre = __builtin_fmaf(rg, an, gn);
+    asm volatile("" : "+v"(pre));
+    const float ng = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre * 2.8853900817779268f)), 1.0f);
+    return __builtin_fmaf(zg, hp - ng, ng);
+}
+__device__ __forceinline__ f32x4 gru_cell4_scalar(f32x4 sr, f32x4 sz, f32x4 an, f32x4 gn, const float (&hp)[4]) {
+    return f32x4{gru_cell1_scalar(sr.x, sz.x, an.x, gn.x, hp[0]), gru_cell1_scalar(sr.y, sz.y, an.y, gn.y, hp[1]),
+                 gru_cell1_scalar(sr.z, sz.z, an.z, gn.z, hp[2]), gru_cell1_scalar(sr.w, sz.w, an.w, gn.w, hp[3])};
+}
+
 constexpr int kGruLdsF4 = 2 * 512 + 4 * 384 + 4 * 512;  // h[2] | gi[4 waves] | W tile 5[4 waves]
 
 template <bool DEC>

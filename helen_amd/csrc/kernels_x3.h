@@ -179,7 +179,11 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (s + 1 < T) dma_gi(slot0 + s + 1);
         {   // four cells as two packed pairs (gru_cell4)
+#ifdef HELEN_BP_SCALAR_GATES
+            const f32x4 hn4 = gru_cell4_scalar(acc[0] + G[0], acc[1] + G[1], acc[2], G[2], hprev);
+#else
             const f32x4 hn4 = gru_cell4(acc[0], acc[1], acc[2], G[0], G[1], G[2], hprev);
+#endif
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 hprev[r] = hn4[r];

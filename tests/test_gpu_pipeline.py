@@ -346,6 +346,26 @@ def test_bench_two_ranks_end_to_end_line():
     print(json.dumps(e))
 
 
+def test_bench_eight_ranks_end_to_end_line():
+    """BASELINE.json configs[2] without the node: `bench.py --gpus 8 --single-device --e2e 8192` -- eight bench ranks,
+    then the product's call_consensus over eight spawned ranks (all on cuda:0), each with the readers the host plan grants,
+    each writing its own prediction file; the line carries all eight ranks and every window."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--single-device", "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline", "--no-host-path", "--no-margins", "--e2e", "8192",
+                        "--e2e-workers", "8"], cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    e = line["end_to_end"]
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and len(line["per_rank_windows_per_s"]) == 8
+    assert e["n_ranks"] == 8 and e["windows"] == 8 * 8192 and e["regions_stored"] == 8 * 8192, e
+    assert e["output_files"] == ["p_%d.hdf" % k for k in range(8)] and len(e["per_rank"]) == 8
+    assert all(r_["windows"] == 8192 and r_["reader_workers"] >= 1 for r_ in e["per_rank"])
+    assert sum(e["reader_workers_per_rank"]) + 2 * 8 <= max(e["usable_cpus"], 3 * 8)       # the host budget holds
+    assert e["predicted_bound"] in ("device", "host readers")
+    print(json.dumps({k: e[k] for k in ("value", "usable_cpus", "reader_workers_per_rank", "predicted_bound")}))
+
+
 def test_bench_survives_an_rccl_that_does_not_come_up():
     """The barrier of `bench.py --gpus N` crosses RCCL AND gloo; the times travel over gloo.  Two ranks on ONE device
     is a configuration RCCL refuses: the line must still come out, say so, and have used the gloo barrier (on a node
