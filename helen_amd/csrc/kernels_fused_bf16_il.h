@@ -5,8 +5,11 @@
 
 #include "kernels_fused_bf16_pair.h"
 
-#ifndef HELEN_BF16_IL_PARKED
-#define HELEN_BF16_IL_PARKED 2      // K32 groups of the decoder's W_ih kept in LDS instead of registers
+#ifndef HELEN_BF16_IL_SINGLE
+#define HELEN_BF16_IL_SINGLE 1      // decoder: ONE fp32 h buffer and ONE bf16 plane per tile (reader and writer are a barrier apart)
+#endif
+#ifndef HELEN_BF16_IL_PARKED        // K32 groups of the decoder's W_ih kept in LDS instead of registers (24 KiB each)
+#define HELEN_BF16_IL_PARKED (HELEN_BF16_IL_SINGLE ? 3 : 2)
 #endif
 
 #define HELEN_PIN(x) asm volatile("" : "+v"(x))
@@ -14,7 +17,7 @@
 #define HELEN_BF16_IL_LEAD 6
 #endif
 #ifndef HELEN_BF16_IL_ADEPTH      // A fragments in flight (registers: 4 each): all seven of the encoder's, three of the decoder's
-#define HELEN_BF16_IL_ADEPTH(dec) ((dec) ? 3 : 7)
+#define HELEN_BF16_IL_ADEPTH(dec) ((dec) ? (HELEN_BF16_IL_SINGLE ? 5 : 3) : 7)
 #endif
 
 namespace helen {
@@ -58,8 +61,15 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
     // deep: the row of step s+2 is DMA'd at the start of M(x,s) into the slot whose row (step s) the whole workgroup
     // finished reading before the previous barrier (input part of step s, computed in the other tile's M phase).
     // Decoder: 2 x 56 KiB + 48 KiB of parked weights = 160 KiB, all of a CU's LDS.
+    // Round 4 (HELEN_BF16_IL_SINGLE): the decoder keeps ONE fp32 h buffer and ONE plane per tile -- a tile's h is read in its
+    // M regions (MFMA operands, head slice) and by its own lanes' gate slots, and written at the end of its G regions, and
+    // M(x,.) and G(x,.) regions alternate with a barrier in between: 2 x 44 KiB + three parked groups (72 KiB) = 160 KiB,
+    // which moves a third K32 group of W_ih (12 registers) out of the register file.
     constexpr int RD = 2;
-    constexpr int kRing = 1024 + 512, kPart = kRing + RD * MI * 64, kPerTile = kPart + (DEC ? 2 * 8 * 64 : 0);
+    constexpr int NB = (DEC && HELEN_BF16_IL_SINGLE) ? 1 : 2;      // h buffers per tile
+    constexpr int kPlane = NB * 512, kRing = kPlane + NB * 256, kPart = kRing + RD * MI * 64, kPerTile = kPart + (DEC ? 2 * 8 * 64 : 0);
+    auto hsel = [](int b) __attribute__((always_inline)) { return NB == 2 ? b * 512 : 0; };                 // fp32 h buffer b (f4 offset)
+    auto psel = [=](int b) __attribute__((always_inline)) { return kPlane + (NB == 2 ? b * 256 : 0); };     // bf16 plane b
     constexpr int kParked = DEC ? HELEN_BF16_IL_PARKED : 0, MR = MI - kParked;
     __shared__ f32x4 smem[2 * kPerTile + kParked * 8 * 3 * 64];
     const int tid = threadIdx.x;
@@ -154,7 +164,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            ((unsigned short*)(smem + x * kPerTile + 1024))[poff + 8 * r] =
+            ((unsigned short*)(smem + x * kPerTile + kPlane))[poff + 8 * r] =
                 bf16_bits(((const float*)(smem + x * kPerTile))[hoff + 4 * r]);
     // input part x . W_ih^T + b of a tile's next step (three accumulators), kept until that step's M phase
     f32x4 gin[2][3];
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
         ring_rd[0] = MI * 1024u;
     }
     __syncthreads();
-    bf16x8 a_pref = ((const bf16x8*)(smem + 1024))[lane];   // group 0 of tile 0's h plane
+    bf16x8 a_pref = ((const bf16x8*)(smem + kPlane))[lane];   // group 0 of tile 0's h plane
 
     // Pending gate math of each tile: the finished accumulators of its newest step.
     f32x4 Pr[2], Pz[2], Pn[2], Pg[2];
@@ -202,8 +212,8 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
         const bool has_next2 = steady || s + 2 < T;
         f32x4* const base = smem + x * kPerTile;
         f32x4* const obase = smem + o * kPerTile;
-        const f32x4* hx = base + cur * 512;
-        const bf16x8* pa = (const bf16x8*)(base + 1024 + cur * 256) + lane;
+        const f32x4* hx = base + hsel(cur);
+        const bf16x8* pa = (const bf16x8*)(base + psel(cur)) + lane;
         const bf16x8* L = (const bf16x8*)((const char*)(obase + kRing) + ring_rd[o]) + lane;
         int issued = 0;
         if (has_next2) {
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
         // gate state of tile o: four cells (rows 4q + c of unit u)
         const f32x4 gr = Pr[o], gz = Pz[o], gnn = Pn[o], ggn = Pg[o];
         float t1[4], t2[4], e1[4], e2[4], rg[4], zg[4], t3[4], e3[4], u3[4], qq[4], ng[4], dd[4], hn[4], hp[4];
-        const float* hpo = (const float*)(obase + (ow ^ 1) * 512) + hoff;   // h_o(so - 1): fp32 buffer so & 1
+        const float* hpo = (const float*)(obase + hsel(ow ^ 1)) + hoff;   // h_o(so - 1): fp32 buffer so & 1
         const bool do_in = x == 0 || has_next;
         // A fragments (K32 groups of h_x(s-1), then of the other tile's input rows), fetched AD - 1 groups ahead of the
         // MFMAs that use them: an LDS read takes ~130 cycles here, a group of three MFMAs covers 51 (measured with
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
         constexpr bool kAsmLoads = AD == NF;            // every fragment fetched at the top of the region
         bf16x8 aq[AD];
         // LDS byte addresses of this lane's 16 bytes of group 0 of h_x(s-1) and of the other tile's ring slot
-        const unsigned pa_lds = lds0 + (unsigned)((x * kPerTile + 1024 + cur * 256) * 16) + lane16;
+        const unsigned pa_lds = lds0 + (unsigned)((x * kPerTile + psel(cur)) * 16) + lane16;
         const unsigned in_lds = lds0 + (unsigned)((o * kPerTile + kRing) * 16) + ring_rd[o] + lane16;
         auto fetch_a = [&](auto F) __attribute__((always_inline)) {
             constexpr int f = decltype(F)::value;
@@ -371,8 +381,8 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
         if constexpr (gates) {     // new h of tile o -> LDS (fp32 state / layer output, bf16 plane), head partial of its previous h
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                ((float*)(obase + ow * 512))[hoff + 4 * r] = hn[r];
-                ((unsigned short*)(obase + 1024 + ow * 256))[poff + 8 * r] = bf16_bits(hn[r]);
+                ((float*)(obase + hsel(ow)))[hoff + 4 * r] = hn[r];
+                ((unsigned short*)(obase + psel(ow)))[poff + 8 * r] = bf16_bits(hn[r]);
             }
         }
         // this phase's results become tile x's pending gate math
@@ -381,7 +391,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
         Pn[x] = ahn;
         Pg[x] = gnx;
         if (!DEC && has_prev) {                                  // h_x(s-1) as a bf16 plane = the layer output of slot s-1
-            *(uint2*)(y_next[x] + in_block((unsigned)tid * 8u)) = ((const uint2*)(base + 1024 + cur * 256))[tid];
+            *(uint2*)(y_next[x] + in_block((unsigned)tid * 8u)) = ((const uint2*)(base + psel(cur)))[tid];
             y_next[x] += 512 * 16;
             issued += 1;
         }
@@ -402,7 +412,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
         asm volatile("" ::: "memory");
         HELEN_BIL_TICK(2)
         // next region: M(o, .) starts on h_o in buffer ow (just published), gates of tile x
-        if constexpr (HELEN_BF16_IL_ADEPTH(DEC) < 4 + MI) a_pref = ((const bf16x8*)(obase + 1024 + ow * 256))[lane];
+        if constexpr (HELEN_BF16_IL_ADEPTH(DEC) < 4 + MI) a_pref = ((const bf16x8*)(obase + psel(ow)))[lane];
         __builtin_amdgcn_sched_barrier(0);
     };
     using I0 = std::integral_constant<int, 0>;
@@ -445,12 +455,12 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
         f32x4* const obase = smem + kPerTile;
         float hp[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hp[r] = ((const float*)(obase + (last ^ 1) * 512))[hoff + 4 * r];
+        for (int r = 0; r < 4; ++r) hp[r] = ((const float*)(obase + hsel(last ^ 1)))[hoff + 4 * r];
         const f32x4 hn4 = gru_cell4(Pr[1], Pz[1], Pn[1], Pg[1], hp);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            ((float*)(obase + last * 512))[hoff + 4 * r] = hn4[r];
-            ((unsigned short*)(obase + 1024 + last * 256))[poff + 8 * r] = bf16_bits(hn4[r]);
+            ((float*)(obase + hsel(last)))[hoff + 4 * r] = hn4[r];
+            ((unsigned short*)(obase + psel(last)))[poff + 8 * r] = bf16_bits(hn4[r]);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -463,7 +473,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
                 if (v < 4) store_logits(x, (T - 2) & 1, (unsigned)tid * 4u);
                 y_next[x] += 128 * 16;
             }
-            const f32x4 a = (smem + x * kPerTile + last * 512)[v * 64 + lane];
+            const f32x4 a = (smem + x * kPerTile + hsel(last))[v * 64 + lane];
             f32x4 pl = splat4(0.f);
 #pragma unroll
             for (int e = 0; e < 4; ++e) pl = mfma4(a[e], Bh[e], pl);
@@ -477,10 +487,10 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
     } else {
 #pragma unroll
         for (int x = 0; x < 2; ++x)
-            *(uint2*)(y_next[x] + (unsigned)tid * 8u) = ((const uint2*)(smem + x * kPerTile + 1024 + last * 256))[tid];
+            *(uint2*)(y_next[x] + (unsigned)tid * 8u) = ((const uint2*)(smem + x * kPerTile + psel(last)))[tid];
     }
 #pragma unroll
-    for (int x = 0; x < 2; ++x) hid_p[x][tid] = (smem + x * kPerTile + last * 512)[tid];
+    for (int x = 0; x < 2; ++x) hid_p[x][tid] = (smem + x * kPerTile + hsel(last))[tid];
 }
 
 }  // namespace helen
