@@ -336,7 +336,9 @@ class File(object):
         elif isinstance(value, (str, bytes)):
             return self._write_string(path, value, string)
         else:
-            arr = np.ascontiguousarray(value, dtype=dtype)
+            arr = np.asarray(value, dtype=dtype)        # (np.ascontiguousarray would turn a 0-d array into a [1] array)
+            if not arr.flags.c_contiguous:
+                arr = np.ascontiguousarray(arr)
         dt = arr.dtype
         if dt not in _STD:
             raise Hdf5Error("unsupported dtype %s" % dt)

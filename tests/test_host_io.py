@@ -646,3 +646,120 @@ print("ok")
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), a, b, a, b)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr
+
+
+H5DUMP = "/opt/conda/bin/h5dump"
+
+
+def _h5dump_dataset(path, name):
+    """(type text, shape or None for a scalar, values) of one dataset as libhdf5's own `h5dump` prints it: a reader that
+    shares no code with helen_amd/hdf5.py or the scanner."""
+    import re
+    import subprocess
+    r = subprocess.run([H5DUMP, "-w", "0", "-d", name, path], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    text = r.stdout
+    m = re.search(r"DATATYPE\s+(H5T_STRING\s*\{[^}]*\}|\S+)", text)
+    dtype = re.sub(r"\s+", " ", m.group(1))
+    m = re.search(r"DATASPACE\s+SIMPLE\s*\{\s*\(([^)]*)\)", text)
+    shape = tuple(int(v) for v in m.group(1).split(",")) if m else None
+    body = text[text.index("DATA {") + 6:text.rindex("}")]
+    body = body[:body.rindex("}")] if body.strip().endswith("}") else body
+    values = []
+    for line in body.splitlines():
+        line = line.strip()
+        if not line or line == "}":
+            continue
+        line = re.sub(r"^\([\d,]*\):\s*", "", line).rstrip(",")
+        if line.startswith('"'):
+            values.extend(re.findall(r'"((?:[^"\\]|\\.)*)"', line))
+        else:
+            values.extend(float(v) if ("." in v or "e" in v.lower() or "inf" in v or "nan" in v) else int(v)
+                          for v in (t.strip() for t in line.split(",")) if v)
+    return dtype, shape, values
+
+
+@pytest.mark.skipif(not os.path.exists(H5DUMP), reason="h5dump not installed")
+def test_hdf5_layer_against_libhdf5s_own_tool(tmp_path):
+    """The golden generators run the reference's reader / writer / stitch over an h5py stand-in built on helen_amd/hdf5.py
+    (tests/golden/reference_env.py), so that binding is on both sides of those comparisons.  Here it -- and the direct
+    scanner and emitter -- are put against `h5dump`, libhdf5's own command-line reader, which shares no code with any of
+    them: (a) an image file with every schema variant the reference's reader takes, written through hdf5.py: types, shapes
+    and values as h5dump prints them = what hdf5.py reads back = what the scanner reads; (b) a prediction file from the
+    direct emitter and one from the libhdf5 writer: names, types (uint32 positions with the -1 wrap, uint8 labels, int64
+    bounds) and values as h5dump prints them."""
+    from helen_amd.data_store import DataStore
+    from helen_amd.sequence_dataset import SequenceDataset, _load_batch
+    img = make_images(3, seed=13, mode="pileup")
+    path = str(tmp_path / "variants.h5")
+    rng = np.random.default_rng(3)
+    want = {}
+    with hdf5.File(path, "w") as f:
+        for i in range(3):
+            base = "images/w%d/" % i
+            L = [1000, 37, 1][i]
+            contig = ["chr1", "chr2'q", "c3"][i]
+            f.write(base + "contig", contig, string=["fixed", "vlen", "scalar"][i])
+            ints = [np.int64, np.int32, np.uint16][i]
+            for name, val in (("contig_start", 800 * i), ("contig_end", 800 * i + 1000), ("feature_chunk_idx", i)):
+                f.write(base + name, np.array(val if i == 1 else [val], ints))
+            it = [np.uint8, np.uint16, np.int32][i]
+            f.write(base + "image", img[i, :L].astype(it), it, chunks=(64, 90) if i == 1 else None, gzip=4 if i == 1 else None)
+            pt = [np.int64, np.int32, np.uint32][i]
+            pos = np.stack([100 + np.arange(L), rng.integers(0, 3, L), rng.integers(0, 2, L)], 1).astype(pt)
+            f.write(base + "position", pos, pt)
+            want[i] = (contig, ints, it, pt, L, pos)
+    names = {np.int64: "H5T_STD_I64LE", np.int32: "H5T_STD_I32LE", np.uint16: "H5T_STD_U16LE", np.uint8: "H5T_STD_U8LE",
+             np.uint32: "H5T_STD_U32LE"}
+    with hdf5.File(path) as f:
+        for i in range(3):
+            contig, ints, it, pt, L, pos = want[i]
+            base = "/images/w%d/" % i
+            t, shape, vals = _h5dump_dataset(path, base + "contig")
+            assert t.startswith("H5T_STRING") and vals == [contig]
+            assert ("H5T_VARIABLE" in t) == (i == 1) and shape == (None if i == 2 else (1,))
+            assert str(np.asarray(f.read(base + "contig")).reshape(-1)[0]) in (contig, "b'%s'" % contig) or \
+                np.asarray(f.read(base + "contig")).reshape(-1)[0] in (contig, contig.encode())
+            t, shape, vals = _h5dump_dataset(path, base + "contig_start")
+            assert t == names[ints] and vals == [800 * i] and shape == (None if i == 1 else (1,))
+            assert int(np.asarray(f.read(base + "contig_start")).reshape(-1)[0]) == 800 * i
+            t, shape, vals = _h5dump_dataset(path, base + "image")
+            assert t == names[it] and shape == (L, 90)
+            assert np.array_equal(np.array(vals).reshape(L, 90), img[i, :L]) and np.array_equal(f.read(base + "image"), img[i, :L])
+            t, shape, vals = _h5dump_dataset(path, base + "position")
+            assert t == names[pt] and shape == (L, 3) and np.array_equal(np.array(vals).reshape(L, 3), pos)
+            assert np.array_equal(f.read(base + "position"), pos)
+    # the product's reader (direct scanner) on the same file returns what h5dump printed
+    b = _load_batch(SequenceDataset(None, file_list=[path]).all_images)
+    for i in range(3):
+        contig, ints, it, pt, L, pos = want[i]
+        assert np.array_equal(b.images[i, :L], img[i, :L]) and not b.images[i, L:].any()
+        assert np.array_equal(b.positions[i, :L], pos.astype(np.int64)) and (b.positions[i, L:] == -1).all()
+        assert (int(b.contig_start[i]), int(b.contig_end[i]), int(b.chunk_id[i])) == (800 * i, 800 * i + 1000, i)
+    assert b.contig == ["chr1", '"chr2q"', "c3"]          # (the reference's array2string quirk: tests above)
+    # prediction files of both writers
+    P = np.full((1000, 3), -1, np.int64)
+    P[:700, 0] = 5000 + np.arange(700)
+    P[:700, 1:] = rng.integers(0, 3, (700, 2))
+    B = rng.integers(0, 5, 1000).astype(np.uint8)
+    R = rng.integers(0, 11, 1000).astype(np.uint8)
+    for writer in ("", "libhdf5"):
+        out = str(tmp_path / ("pred_%s.hdf" % (writer or "direct")))
+        if writer:
+            os.environ["HELEN_IO_WRITER"] = writer
+        try:
+            with DataStore(out, "w") as s:
+                s.write_prediction("chrP", 5000, 6000, 2, P, B, R)
+        finally:
+            os.environ.pop("HELEN_IO_WRITER", None)
+        root = "/predictions/chrP/chrP-5000-6000"
+        assert _h5dump_dataset(out, root + "/contig_start") == ("H5T_STD_I64LE", None, [5000])
+        assert _h5dump_dataset(out, root + "/contig_end") == ("H5T_STD_I64LE", None, [6000])
+        t, shape, vals = _h5dump_dataset(out, root + "/2/position")
+        assert t == "H5T_STD_U32LE" and shape == (1000, 3)
+        got = np.array(vals, dtype=np.uint64).reshape(1000, 3)
+        assert np.array_equal(got[:700], P[:700]) and (got[700:] == 4294967295).all()       # -1 wraps (DataStore.py:126)
+        t, shape, vals = _h5dump_dataset(out, root + "/2/bases")
+        assert t == "H5T_STD_U8LE" and shape == (1000,) and np.array_equal(np.array(vals), B)
+        t, shape, vals = _h5dump_dataset(out, root + "/2/rles")
+        assert t == "H5T_STD_U8LE" and np.array_equal(np.array(vals), R)
