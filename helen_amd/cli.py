@@ -22,7 +22,7 @@ def add_polish_arguments(parser, threads_default):
     parser.add_argument("-p", "--output_prefix", type=str, required=False, default="HELEN_prediction",
                         help="Prefix for the output file. Default is: HELEN_prediction")
     parser.add_argument("-g", "--gpu_mode", default=False, action="store_true",
-                        help="If set then the MI355X HIP path is used (required: this build has no CPU path).")
+                        help="If set then the MI355X HIP path is used; without it the host path runs (callers x threads, like the reference).")
     parser.add_argument("-d_ids", "--device_ids", type=str, required=False, default=None,
                         help="List of gpu device ids to use for inference, e.g. 0,1,2. Default: all.")
     parser.add_argument("-c", "--callers", type=int, required=False, default=8,
@@ -47,7 +47,7 @@ def add_test_arguments(parser):
                         help="Path to directory containing labeled images for testing the models.")
     parser.add_argument("--batch_size", type=int, required=False, default=100, help="Batch size, default is 100.")
     parser.add_argument("--model_path", type=str, required=False, default="./model", help="Path of the model to load")
-    parser.add_argument("--gpu_mode", action="store_true", help="Run on the MI355X HIP path (required).")
+    parser.add_argument("--gpu_mode", action="store_true", help="Run on the MI355X HIP path (without it: the host path).")
     parser.add_argument("--print_details", action="store_true", help="Accepted for compatibility.")
     parser.add_argument("--output_dir", type=str, required=False, default="./debug_output", help="Output directory.")
     parser.add_argument("--num_workers", type=int, required=False, default=40, help="Accepted for compatibility.")

@@ -110,7 +110,7 @@ def test(data_filepath, batch_size, gpu_mode, transducer_model, num_workers, gru
     device); returns {'loss', 'accuracy', 'base_confusion_matrix', 'rle_confusion_matrix'}."""
     import torch
     if not gpu_mode:
-        raise RuntimeError("helen_amd evaluates on the MI355X only: pass gpu_mode=True (there is no CPU path)")
+        return _test_on_host(data_filepath, batch_size, transducer_model, num_workers, num_base_classes, num_rle_classes)
     test_data = SequenceDataset(data_filepath)
     transducer_model.eval()
     class_weights = np.array(TrainOptions.CLASS_WEIGHTS, np.float32)
@@ -150,6 +150,66 @@ def test(data_filepath, batch_size, gpu_mode, transducer_model, num_workers, gru
         sys.stderr.write("".join("{:9d} ".format(int(e)) for e in row) + "\n")
     return {"loss": avg_loss, "accuracy": accuracy, "base_confusion_matrix": bc,
             "rle_confusion_matrix": rc, "total_loss_rle": total_loss_rle, "total_images": total_images}
+
+
+def host_batch_losses(engine, images, label_base, label_rle, class_weights, base_cm, rle_cm):
+    """models/test.py:78-126 for ONE loader batch on the host engine (helen_amd.cpu_engine.CpuEngine): hidden = 0, then per
+    chunk the logits of TransducerGRU.forward, nn.CrossEntropyLoss (mean) on the base logits and the class-weighted one
+    (weighted mean, Options.py:29) on the run-length logits -- in float64 from fp32 logits -- and the confusion counts
+    [target][argmax].  -> (loss_base [19], loss_rle [19])."""
+    n = images.shape[0]
+    x = images.astype(np.float32)
+    h = np.zeros((n, 2, TrainOptions.HIDDEN_SIZE), np.float32)
+    w = np.asarray(class_weights, np.float64)
+    lb_out, lr_out = [], []
+    rows = np.arange(n)[:, None]
+    for c in range(19):
+        lo = c * TrainOptions.WINDOW_JUMP
+        base, rle, h = engine.chunk_forward(x[:, lo:lo + TrainOptions.TRAIN_WINDOW], h)
+        tb = label_base[:, lo:lo + TrainOptions.TRAIN_WINDOW].astype(np.int64)
+        tr = label_rle[:, lo:lo + TrainOptions.TRAIN_WINDOW].astype(np.int64)
+        cols = np.arange(tb.shape[1])[None, :]
+
+        def nll(logits, target):
+            z = logits.astype(np.float64)
+            z = z - z.max(-1, keepdims=True)
+            return -(z[rows, cols, target] - np.log(np.exp(z).sum(-1)))
+        lb_out.append(nll(base, tb).mean())
+        wr = w[tr]
+        lr_out.append((nll(rle, tr) * wr).sum() / wr.sum())
+        np.add.at(base_cm, (tb.ravel(), base.argmax(-1).ravel()), 1)
+        np.add.at(rle_cm, (tr.ravel(), rle.argmax(-1).ravel()), 1)
+    return np.array(lb_out), np.array(lr_out)
+
+
+def _test_on_host(data_filepath, batch_size, transducer_model, num_workers, num_base_classes, num_rle_classes):
+    """`helen_train test` WITHOUT --gpu_mode (the reference evaluates on the CPU then, models/test.py:56-60): the same
+    loop on the host engine, `num_workers` threads at most."""
+    import os
+    test_data = SequenceDataset(data_filepath)
+    transducer_model.eval()
+    threads = max(1, min(int(num_workers) if num_workers else 1, os.cpu_count() or 1))
+    engine = transducer_model.use_cpu(threads).engine
+    base_cm = np.zeros((num_base_classes, num_base_classes), np.int64)
+    rle_cm = np.zeros((num_rle_classes, num_rle_classes), np.int64)
+    sys.stderr.write("Test starting (host path, %d threads)\n" % threads)
+    total_loss = total_loss_rle = 0.0
+    total_images = 0
+    n = len(test_data)
+    for lo in range(0, n, batch_size):
+        hi = min(n, lo + batch_size)
+        images, lb, lr = test_data.read_range(lo, hi)
+        loss_b, loss_r = host_batch_losses(engine, images, lb, lr, TrainOptions.CLASS_WEIGHTS, base_cm, rle_cm)
+        total_loss += float((loss_b + loss_r).sum())
+        total_loss_rle += float(loss_r.sum())
+        total_images += (hi - lo) * len(loss_b)
+        sys.stderr.write("Base acc: %s, RLE acc: %s, RLE loss: %s\n" % (
+            round(100.0 * np.trace(base_cm) / max(1.0, base_cm.sum()), 4),
+            round(100.0 * np.trace(rle_cm) / max(1.0, rle_cm.sum()), 4), round(total_loss_rle, 4)))
+    avg_loss = total_loss / total_images if total_images else 0
+    sys.stderr.write("\nTest Loss: " + str(avg_loss) + "\n")
+    return {"loss": avg_loss, "accuracy": 0, "base_confusion_matrix": base_cm, "rle_confusion_matrix": rle_cm,
+            "total_loss_rle": total_loss_rle, "total_images": total_images}
 
 
 def test_interface(test_file, batch_size, gpu_mode, num_workers, model_path, output_directory,

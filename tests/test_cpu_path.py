@@ -124,3 +124,54 @@ def test_config0_through_the_helen_command_without_a_gpu(tmp_path):
                             "-o", str(tmp_path / "o2")], capture_output=True, text=True, timeout=300)
         assert r.returncode == 1 and "NO MI355X VISIBLE" in r.stderr
         assert not glob.glob(str(tmp_path / "o2" / "*.hdf"))
+
+
+def test_evaluation_on_the_host_matches_the_reference_golden(tmp_path):
+    """`helen_train test` WITHOUT --gpu_mode: the loop of models/test.py:78-126 on the host engine against
+    tests/golden/eval10.npz (the reference model with torch's own CrossEntropyLoss, loader batch 4 -> batches 4 / 4 / 2):
+    per-(batch, chunk) losses, loss sums, both confusion matrices -- the bar the device path's evaluation is held to --
+    and the whole command through its entry point on a labeled image directory."""
+    from golden_cases import EVAL_BATCH, EVAL_LOSS_RTOL
+    from helen_amd.evaluate import host_batch_losses
+    from helen_amd.options import TrainOptions
+    w, img, g = load_case("eval10")
+    e = _engine(w, threads=4)
+    cm_b, cm_r = np.zeros((5, 5), np.int64), np.zeros((11, 11), np.int64)
+    lb, lr = [], []
+    for lo in range(0, 10, EVAL_BATCH):
+        a, b = host_batch_losses(e, img[lo:lo + EVAL_BATCH], g["label_base"][lo:lo + EVAL_BATCH],
+                                 g["label_rle"][lo:lo + EVAL_BATCH], TrainOptions.CLASS_WEIGHTS, cm_b, cm_r)
+        lb.append(a)
+        lr.append(b)
+    loss_b, loss_r = np.array(lb), np.array(lr)
+    np.testing.assert_allclose(np.stack([loss_b.ravel(), loss_r.ravel()], axis=1), g["chunk_losses"], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(float((loss_b + loss_r).sum()), g["total_loss"][0], rtol=EVAL_LOSS_RTOL)
+    np.testing.assert_allclose(float(loss_r.sum()), g["total_loss_rle"][0], rtol=EVAL_LOSS_RTOL)
+    assert np.array_equal(cm_b, g["base_confusion_matrix"]) and np.array_equal(cm_r, g["rle_confusion_matrix"])
+    # the command: labeled image directory -> loss and confusion matrices (.tsv)
+    from helen_amd.model_handler import ModelHandler
+    from helen_amd.synthetic import write_image_file
+    d = tmp_path / "labeled"
+    d.mkdir()
+    write_image_file(str(d / "a.h5"), img, labels=(g["label_base"], g["label_rle"]))
+    model = str(tmp_path / "m.pkl")
+    ModelHandler.save_model(w, None, 128, 1, 0, model)
+    r = subprocess.run([os.path.join(ROOT, "bin", "helen_train"), "test", "--test_image_dir", str(d), "--model_path", model,
+                        "--batch_size", "4", "--num_workers", "4", "--output_dir", str(tmp_path / "ev")],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # (the loader walks the images in NAME order, so its batches hold other windows than the golden's: the expectation is
+    # the pinned per-batch function over the loader's own batches; the confusion matrices do not depend on the order)
+    from helen_amd.evaluate import SequenceDataset as Labeled
+    order = [int(name.split("-")[1]) // 800 for _, name in Labeled(str(d)).all_images]
+    assert sorted(order) == list(range(10)) and order != list(range(10))
+    want_loss, scratch_b, scratch_r = 0.0, np.zeros((5, 5), np.int64), np.zeros((11, 11), np.int64)
+    for lo in range(0, 10, 4):
+        k = order[lo:lo + 4]
+        a, b = host_batch_losses(e, img[k], g["label_base"][k], g["label_rle"][k], TrainOptions.CLASS_WEIGHTS, scratch_b, scratch_r)
+        want_loss += float((a + b).sum())
+    want_loss /= 10 * 19
+    got = float(re.search(r"Test Loss: ([0-9.eE+-]+)", r.stderr).group(1))
+    assert abs(got - want_loss) <= 1e-9 * want_loss, (got, want_loss)
+    assert np.array_equal(np.loadtxt(str(tmp_path / "ev" / "BASE_CONFUSION_MATRIX.tsv"), dtype=np.int64), g["base_confusion_matrix"])
+    assert np.array_equal(np.loadtxt(str(tmp_path / "ev" / "RLE_CONFUSION_MATRIX.tsv"), dtype=np.int64), g["rle_confusion_matrix"])
