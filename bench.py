@@ -341,8 +341,8 @@ def gather_strings(dist, world, text):
 
 def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_device, dist, may_shrink=False):
     """The whole `call_consensus` of the product over `world` ranks -- synthetic MarginPolish image directory (HDF5,
-    16 files per rank, sharded round-robin by file as CallConsensusInterface.py:138-145) -> per rank: reader processes
-    -> device -> ONE prediction HDF5 -- wall-clocked from the call to its return: host budgeting, process start-up,
+    16 files per rank, sharded round-robin by file as CallConsensusInterface.py:138-145) -> per rank: reader threads
+    (page-locked slots) -> device -> ONE prediction HDF5 -- wall-clocked from the call to its return: host budgeting, process start-up,
     model load and the final close included (SURVEY.md 8d "end-to-end").  Every bench rank writes its share of the
     inputs (direct emitter of libhelen_io.so, RAM-backed directory); rank 0 then runs call_consensus, which starts
     its OWN process per device exactly as the CLI does, while the other bench ranks sleep on a file (not in a
@@ -474,7 +474,7 @@ def main():
                     help="windows PER RANK of the end-to-end leg: the product's call_consensus over a synthetic HDF5 "
                          "image directory, N ranks under --gpus N (default %d: a bounded leg in every line; 300000 = "
                          "chr20 scale, needs ~120 KB of /dev/shm per window; 0 = off)" % E2E_DEFAULT_WINDOWS)
-    ap.add_argument("--e2e-workers", type=int, default=8, help="reader processes of the --e2e leg")
+    ap.add_argument("--e2e-workers", type=int, default=8, help="readers per rank of the --e2e leg (-w of call_consensus)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp32x3"],
                     help="gate-matmul arithmetic; fp32 (true fp32 MFMA) is BASELINE.json configs[1], the "
                          "headline; fp32x3 = fp32-class via three-term bf16 splits (opt-in experiment)")

@@ -158,7 +158,7 @@ int helen_polish_batch(HelenModel* model, const uint8_t* images, int n_windows, 
  * stream, overlapped with the kernels of the previous sub-batch and the label download of the one
  * before.  Page-locked caller memory (hipHostMalloc / hipHostRegister, e.g. a torch pinned tensor) is
  * the source and destination of the DMA itself (79.9 k windows/s); pageable memory goes through two pinned
- * mirrors the library owns (77.3 k) -- it is NOT page-locked in place by default: on this ROCm a registration maps the
+ * mirrors the library owns (78.9 k) -- it is NOT page-locked in place by default: on this ROCm a registration maps the
  * caller's pages in place without a reference count, so unregistering a range takes GPU access away from every page
  * it shares with any other registration of the process (api.hip: helen_polish_host has the whole story;
  * $HELEN_HOST_LOCK=own | all at model creation restores the in-place rules of rounds 2-3).

@@ -25,7 +25,7 @@ try:
     print("inputs written in %.1f s" % (time.time() - t0), flush=True)
     t0 = time.time()
     root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, "-m", "helen_amd", "polish", "-i", os.path.join(d, "img"), "-m", model, "-b", "256",
+    r = subprocess.run([os.path.join(root, "bin", "helen"), "polish", "-i", os.path.join(d, "img"), "-m", model, "-b", "256",
                         "-w", "8", "-t", threads, "-o", os.path.join(d, "out"), "-p", "asm", "-g"], cwd=root,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     dt = time.time() - t0
