@@ -21,7 +21,7 @@ KERNEL_CLASSES = ("pack", "gemm_enc", "gru_enc", "gemm_dec", "gru_dec", "heads",
 # every symbol include/helen_hip.h declares
 EXPORTS = (
     "helen_abi_version", "helen_last_error", "helen_model_create", "helen_model_destroy",
-    "helen_model_device_bytes", "helen_polish_batch", "helen_polish_host",
+    "helen_model_device_bytes", "helen_polish_batch", "helen_polish_host", "helen_polish_submit", "helen_polish_flush",
     "helen_gru_chunk_forward", "helen_evaluate_batch", "helen_debug_inject_failure", "helen_set_profiling",
     "helen_reset_kernel_stats",
     "helen_get_kernel_stats", "helen_reload_overrides", "helen_describe_dispatch", "helen_plan_call", "helen_has_persistent",
@@ -99,6 +99,10 @@ def load():
     lib.helen_polish_batch.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp]
     lib.helen_polish_host.restype = ci
     lib.helen_polish_host.argtypes = [vp, vp, ci, vp, vp, vp]
+    lib.helen_polish_submit.restype = ci
+    lib.helen_polish_submit.argtypes = [vp, vp, ci, vp, vp, vp]
+    lib.helen_polish_flush.restype = ci
+    lib.helen_polish_flush.argtypes = [vp]
     lib.helen_gru_chunk_forward.restype = ci
     lib.helen_gru_chunk_forward.argtypes = [vp, vp, vp, ci, ci, vp, vp, vp, vp]
     lib.helen_evaluate_batch.restype = ci

@@ -115,6 +115,16 @@ struct HelenModel {
     hipStream_t d2h_stream = nullptr;
     bool ring_ready = false;   // set only when every piece of the staging ring exists
     int fail_at_sub = -1;      // helen_debug_inject_failure: sub-batch of the next helen_polish_host that fails
+    // queueing entry (helen_polish_submit / helen_polish_flush): small submissions are gathered in the pinned mirrors
+    // until a device call's worth (max_windows) is there; the ring above is shared with helen_polish_host
+    struct QueuedRows {
+        uint8_t *bases, *rles;
+        int count;
+    };
+    std::vector<QueuedRows> q_rows[2];   // whose labels the windows of mirror b are, in order
+    int q_fill = 0, q_cur = 0;           // windows gathered in mirror q_cur
+    int q_count[2] = {0, 0};             // windows of the device call in flight on ring slot b (0 = none)
+    void* q_stream = nullptr;            // the compute stream of the queue's calls (the first submit's)
     std::atomic<bool> busy{false};   // a handle serves one host thread at a time (include/helen_hip.h): enforced
     hipEvent_t ev_in[2] = {nullptr, nullptr};
     hipEvent_t ev_done[2] = {nullptr, nullptr};
@@ -996,6 +1006,8 @@ int helen_polish_host(HelenModel* m, const uint8_t* images, int n_windows, uint8
     if (!m || !images || !bases || !rles) return fail(HELEN_EINVAL, "null argument");
     if (n_windows <= 0) return fail(HELEN_EINVAL, "n_windows must be > 0");
     HELEN_ENTER(m);
+    if (m->q_fill || m->q_count[0] || m->q_count[1])
+        return fail(HELEN_EINVAL, "submitted windows are pending: helen_polish_flush first (the staging ring is shared)");
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
     const int sub = m->max_windows;
@@ -1135,6 +1147,129 @@ int helen_polish_host(HelenModel* m, const uint8_t* images, int n_windows, uint8
         memcpy(g_err, keep, sizeof(keep));
         (void)issued;
     }
+    return rc;
+}
+
+// ---- queueing entry: many small submissions, device calls of max_windows ------------------------------------------
+// A caller that owns one loader batch at a time (the reference's loop, predict_gpu.py:94-159) cannot hand
+// helen_polish_host 4,096 windows, and a call of 256 runs at 0.40 of the rate (3,800 dependent steps whatever the
+// batch).  submit() copies the batch's images into the pinned mirror and returns; whenever max_windows have gathered,
+// a device call goes out (upload, kernels and label download all asynchronous, two ring slots); flush() sends what is
+// left and returns when every submitted batch's labels are in the arrays that were named for it.
+static int queue_prepare(HelenModel* m) {
+    int rc;
+    if (!m->ring_ready && (rc = build_ring(m))) return rc;
+    const size_t sub = (size_t)m->max_windows, img_bytes = (size_t)kSeq * kF, lab_bytes = (size_t)kSeq;
+    for (int i = 0; i < 2; ++i) {
+        if (!m->pin_in[i]) HIP_TRY(hipHostMalloc((void**)&m->pin_in[i], sub * img_bytes, hipHostMallocDefault));
+        if (!m->pin_out[i]) HIP_TRY(hipHostMalloc((void**)&m->pin_out[i], sub * 2 * lab_bytes, hipHostMallocDefault));
+    }
+    return HELEN_OK;
+}
+static int queue_launch(HelenModel* m, int b, int count) {          // the windows gathered in mirror b -> ring slot b
+    const size_t img_bytes = (size_t)kSeq * kF, lab_bytes = (size_t)kSeq, sub = (size_t)m->max_windows;
+    hipStream_t s = (hipStream_t)m->q_stream;
+    HIP_TRY(hipMemcpyAsync(m->dev_in[b], m->pin_in[b], (size_t)count * img_bytes, hipMemcpyHostToDevice, m->h2d_stream));
+    HIP_TRY(hipEventRecord(m->ev_in[b], m->h2d_stream));
+    HIP_TRY(hipStreamWaitEvent(s, m->ev_in[b], 0));
+    const int rc = polish_batch_impl(m, m->dev_in[b], count, m->dev_out[b], m->dev_out[b] + sub * lab_bytes, nullptr, nullptr, s);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(m->ev_done[b], s));
+    HIP_TRY(hipStreamWaitEvent(m->d2h_stream, m->ev_done[b], 0));
+    HIP_TRY(hipMemcpyAsync(m->pin_out[b], m->dev_out[b], sub * 2 * lab_bytes, hipMemcpyDeviceToHost, m->d2h_stream));
+    HIP_TRY(hipEventRecord(m->ev_out[b], m->d2h_stream));
+    m->q_count[b] = count;
+    return HELEN_OK;
+}
+static int queue_retire(HelenModel* m, int b) {                     // labels of ring slot b -> the callers' arrays
+    if (m->q_count[b] == 0) return HELEN_OK;
+    HIP_TRY(hipEventSynchronize(m->ev_out[b]));
+    const size_t lab_bytes = (size_t)kSeq, sub = (size_t)m->max_windows;
+    size_t row = 0;
+    for (const HelenModel::QueuedRows& q : m->q_rows[b]) {
+        memcpy(q.bases, m->pin_out[b] + row * lab_bytes, (size_t)q.count * lab_bytes);
+        memcpy(q.rles, m->pin_out[b] + (sub + row) * lab_bytes, (size_t)q.count * lab_bytes);
+        row += (size_t)q.count;
+    }
+    m->q_rows[b].clear();
+    m->q_count[b] = 0;
+    return HELEN_OK;
+}
+static void queue_abandon(HelenModel* m) {                          // after an error: nothing in flight, nothing pending
+    char keep[sizeof(g_err)];
+    memcpy(keep, g_err, sizeof(keep));
+    if (m->h2d_stream) (void)hipStreamSynchronize(m->h2d_stream);
+    (void)hipStreamSynchronize((hipStream_t)m->q_stream);
+    if (m->d2h_stream) (void)hipStreamSynchronize(m->d2h_stream);
+    (void)hipGetLastError();
+    for (int b = 0; b < 2; ++b) {
+        m->q_rows[b].clear();
+        m->q_count[b] = 0;
+    }
+    m->q_fill = 0;
+    memcpy(g_err, keep, sizeof(keep));
+}
+
+int helen_polish_submit(HelenModel* m, const uint8_t* images, int n_windows, uint8_t* bases, uint8_t* rles, void* stream) {
+    if (!m || !images || !bases || !rles) return fail(HELEN_EINVAL, "null argument");
+    if (n_windows <= 0) return fail(HELEN_EINVAL, "n_windows must be > 0");
+    HELEN_ENTER(m);
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = queue_prepare(m);
+    if (rc) return rc;
+    const bool empty = m->q_fill == 0 && m->q_count[0] == 0 && m->q_count[1] == 0;
+    if (empty) m->q_stream = stream;
+    else if (m->q_stream != stream) return fail(HELEN_EINVAL, "one stream per queue: flush before submitting on another stream");
+    const size_t img_bytes = (size_t)kSeq * kF, lab_bytes = (size_t)kSeq;
+    const int cap = m->max_windows;
+    auto body = [&]() -> int {
+        while (n_windows > 0) {
+            const int b = m->q_cur;
+            if (m->q_fill == 0) {                  // mirror b is about to be refilled: its previous call must be through
+                const int r = queue_retire(m, b);
+                if (r) return r;
+            }
+            const int take = n_windows < cap - m->q_fill ? n_windows : cap - m->q_fill;
+            copy_with_threads(m->pin_in[b] + (size_t)m->q_fill * img_bytes, images, (size_t)take * img_bytes);
+            m->q_rows[b].push_back({bases, rles, take});
+            m->q_fill += take;
+            images += (size_t)take * img_bytes;
+            bases += (size_t)take * lab_bytes;
+            rles += (size_t)take * lab_bytes;
+            n_windows -= take;
+            if (m->q_fill == cap) {
+                const int r = queue_launch(m, b, cap);
+                if (r) return r;
+                m->q_fill = 0;
+                m->q_cur = b ^ 1;
+            }
+        }
+        return HELEN_OK;
+    };
+    rc = body();
+    if (rc) queue_abandon(m);
+    return rc;
+}
+
+int helen_polish_flush(HelenModel* m) {
+    if (!m) return fail(HELEN_EINVAL, "null argument");
+    HELEN_ENTER(m);
+    HIP_TRY(hipSetDevice(m->device));
+    if (m->q_fill == 0 && m->q_count[0] == 0 && m->q_count[1] == 0) return HELEN_OK;
+    auto body = [&]() -> int {
+        int r;
+        const int b = m->q_cur;
+        if (m->q_fill > 0) {
+            // (mirror b was retired when its first window arrived)
+            if ((r = queue_launch(m, b, m->q_fill))) return r;
+            m->q_fill = 0;
+            m->q_cur = b ^ 1;
+        }
+        if ((r = queue_retire(m, m->q_cur))) return r;          // the older call first
+        return queue_retire(m, m->q_cur ^ 1);
+    };
+    const int rc = body();
+    if (rc) queue_abandon(m);
     return rc;
 }
 

@@ -146,6 +146,27 @@ class HelenEngine(object):
                 self._stream()))
         return bases, rles
 
+    def submit(self, images, out):
+        """The queueing form of polish_host (helen_polish_submit): images uint8 [n,1000,90] (copied before this returns),
+        out = (bases, rles) C-contiguous uint8 [n,1000] that receive the labels by the time flush() returns -- keep them
+        alive until then.  Device calls go out whenever max_windows windows have gathered."""
+        images = np.ascontiguousarray(images.numpy() if isinstance(images, torch.Tensor) else images, dtype=np.uint8)
+        n = images.shape[0]
+        bases, rles = out
+        for a in (bases, rles):
+            if a.dtype != np.uint8 or a.shape != (n, ImageSizeOptions.SEQ_LENGTH) or not a.flags.c_contiguous:
+                raise ValueError("out arrays must be C-contiguous uint8 [n,1000]")
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.helen_polish_submit(self._handle, images.ctypes.data, n, bases.ctypes.data,
+                                                     rles.ctypes.data, self._stream()))
+        self._queued = getattr(self, "_queued", [])
+        self._queued.append((bases, rles))           # (referenced until the flush)
+
+    def flush(self):
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.helen_polish_flush(self._handle))
+        self._queued = []
+
     def evaluate(self, images, label_base, label_rle, class_weights, base_confusion, rle_confusion):
         """The per-batch body of the reference's evaluation loop (models/test.py:78-126) for uint8 CUDA
         tensors images [n,1000,90], label_base / label_rle [n,1000].  Returns chunk_stats f32 CUDA

@@ -171,6 +171,23 @@ int helen_polish_host(HelenModel* model, const uint8_t* images, int n_windows, u
                       uint8_t* rles, void* stream);
 
 /*
+ * The queueing form of helen_polish_host, for a caller that holds ONE loader batch at a time (the reference's loop,
+ * `models/predict_gpu.py:94-159`): a device call of 256 windows runs at 0.40 of the rate of one of 4,096 (a window is
+ * 3,800 dependent GRU steps however few windows there are), so the library gathers.
+ *   helen_polish_submit  copies the batch's images (host memory, pageable or not) into the library's pinned mirror and
+ *                        returns; whenever `max_windows` windows have gathered, a device call goes out asynchronously
+ *                        (upload, kernels on `stream`, label download; two in flight at most).  `bases` / `rles`
+ *                        (host, uint8 [n_windows, 1000]) must stay valid until the flush: labels are written into them
+ *                        by a LATER submit or by the flush, never before.  One stream per queue.
+ *   helen_polish_flush   sends what is left and returns when the labels of every submitted batch are in place.
+ * After an error nothing is in flight and nothing is pending (the queue is empty again).  helen_polish_host refuses
+ * while submissions are pending (the staging ring is shared).
+ */
+int helen_polish_submit(HelenModel* model, const uint8_t* images, int n_windows, uint8_t* bases, uint8_t* rles,
+                        void* stream);
+int helen_polish_flush(HelenModel* model);
+
+/*
  * Test hook for the error path of helen_polish_host: the NEXT call fails with HELEN_EHIP right after it has
  * enqueued sub-batch `sub_batch` (copies and kernels of that and earlier sub-batches are in flight at that
  * moment).  The call must still return with nothing in flight and the handle usable.  -1 disarms.

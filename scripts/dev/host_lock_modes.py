@@ -35,3 +35,25 @@ for mode in ("none", "own", "all", "pinned"):
     same = np.array_equal(hb, ref[0]) and np.array_equal(hr, ref[1])
     print("%-6s: %s windows/s  (labels equal: %s)" % (mode, ", ".join("%.0f" % r for r in rates), same), flush=True)
     eng.close()
+
+# the queueing entry: the same windows handed over as loader batches of 256 (helen_polish_submit / helen_polish_flush)
+os.environ.pop("HELEN_HOST_LOCK", None)
+eng = HelenEngine(w, device=0, max_windows=4096)
+ob, orr = np.empty((n, 1000), np.uint8), np.empty((n, 1000), np.uint8)
+for lo in range(0, 4096, 256):
+    eng.submit(img[lo:lo + 256], (ob[lo:lo + 256], orr[lo:lo + 256]))
+eng.flush()
+rates = []
+for rep in range(3):
+    t0 = time.time()
+    for lo in range(0, n, 256):
+        eng.submit(img[lo:lo + 256], (ob[lo:lo + 256], orr[lo:lo + 256]))
+    eng.flush()
+    rates.append(n / (time.time() - t0))
+print("queued: %s windows/s  (128 submissions of 256 windows + flush; labels equal: %s)"
+      % (", ".join("%.0f" % r for r in rates), np.array_equal(ob, ref[0]) and np.array_equal(orr, ref[1])), flush=True)
+t0 = time.time()
+for lo in range(0, 4096, 256):
+    eng.polish_host(img[lo:lo + 256])
+print("for comparison, helen_polish_host per batch of 256: %.0f windows/s" % (4096 / (time.time() - t0)))
+eng.close()

@@ -1,5 +1,6 @@
 """Parity of the HIP path (through the C ABI) against the golden vectors of the reference model
 and against the CPU oracle.  Run on the GPU box: pytest -m gpu."""
+import ctypes
 import os
 import sys
 
@@ -130,6 +131,46 @@ def test_polish_host_matches_device():
     bh, rh = eng.polish_host(img)
     bd, rd = eng.polish(torch.from_numpy(img).cuda())
     assert np.array_equal(bh, bd.cpu().numpy()) and np.array_equal(rh, rd.cpu().numpy())
+    eng.close()
+
+
+def test_queued_submissions_give_the_labels_of_one_call():
+    """helen_polish_submit / helen_polish_flush: loader batches of any size handed over one at a time are gathered into
+    device calls of max_windows; after the flush every batch's label arrays hold what one big call gives.  Ragged batch
+    sizes (a batch that spans two device calls, single windows), more than two device calls, a second round on the same
+    handle, a flush with nothing pending, helen_polish_host refused while submissions are pending, a change of stream
+    refused."""
+    from helen_amd import _lib
+    from helen_amd._lib import HelenError
+    from helen_amd.engine import HelenEngine
+    w = make_weights(seed=3, input_scale=1.0 / 64.0)
+    img = make_images(230, seed=19)
+    eng = HelenEngine(w, device=0, max_windows=48)
+    want_b, want_r = [t.cpu().numpy() for t in eng.polish(torch.from_numpy(img[:48]).cuda())]
+    ref = HelenEngine(w, device=0, max_windows=256)
+    want_b, want_r = [t.cpu().numpy() for t in ref.polish(torch.from_numpy(img).cuda())]
+    ref.close()
+    eng.flush()                                              # nothing pending: fine
+    for rnd in range(2):
+        sizes = [7, 1, 40, 16, 48, 3, 60, 1, 30, 24] if rnd == 0 else [230]
+        outs, lo = [], 0
+        for n in sizes:
+            out = (np.full((n, 1000), 255, np.uint8), np.full((n, 1000), 255, np.uint8))
+            eng.submit(img[lo:lo + n], out)
+            outs.append((lo, n, out))
+            lo += n
+        assert lo == 230
+        if rnd == 0:
+            with pytest.raises(HelenError, match="pending"):
+                eng.polish_host(img[:4])
+            rc = eng._lib.helen_polish_submit(eng._handle, img.ctypes.data, 1, outs[0][2][0].ctypes.data,
+                                              outs[0][2][1].ctypes.data, ctypes.c_void_p(12345))
+            assert rc < 0 and b"one stream per queue" in eng._lib.helen_last_error()
+        eng.flush()
+        for lo, n, (b, r) in outs:
+            assert np.array_equal(b, want_b[lo:lo + n]) and np.array_equal(r, want_r[lo:lo + n]), (rnd, lo, n)
+    hb, hr = eng.polish_host(img[:50])                       # the ring is the host path's again
+    assert np.array_equal(hb, want_b[:50]) and np.array_equal(hr, want_r[:50])
     eng.close()
 
 
