@@ -188,9 +188,18 @@ class PinnedSlot(object):
         self.cap = int(cap)
         L, H = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT
         pin = pin and torch.cuda.is_available()
-        self.images_t = torch.empty((self.cap, L, H), dtype=torch.uint8, pin_memory=pin)
-        self.bases_t = torch.empty((self.cap, L), dtype=torch.uint8, pin_memory=pin)
-        self.rles_t = torch.empty((self.cap, L), dtype=torch.uint8, pin_memory=pin)
+        try:
+            self.images_t = torch.empty((self.cap, L, H), dtype=torch.uint8, pin_memory=pin)
+            self.bases_t = torch.empty((self.cap, L), dtype=torch.uint8, pin_memory=pin)
+            self.rles_t = torch.empty((self.cap, L), dtype=torch.uint8, pin_memory=pin)
+        except RuntimeError as e:       # page-locking refused (ulimit -l, container policy): ordinary memory, staged copies
+            if not pin:
+                raise
+            import sys
+            sys.stderr.write("INFO: SLOT NOT PAGE-LOCKED (" + str(e).splitlines()[0][:120] + "), USING STAGED COPIES.\n")
+            self.images_t = torch.empty((self.cap, L, H), dtype=torch.uint8)
+            self.bases_t = torch.empty((self.cap, L), dtype=torch.uint8)
+            self.rles_t = torch.empty((self.cap, L), dtype=torch.uint8)
         self.images, self.bases, self.rles = self.images_t.numpy(), self.bases_t.numpy(), self.rles_t.numpy()
         self.positions = np.empty((self.cap, L, 3), np.int64)
         self.meta = np.empty((self.cap, 3), np.int64)
