@@ -697,6 +697,14 @@ int helen_has_persistent(void) {
 #endif
 }
 
+int helen_has_w4(void) {
+#ifdef HELEN_WITH_W4
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 // The chunk loop as ONE launch (polish_persistent_kernel): only in builds with -DHELEN_WITH_PERSISTENT, and then only for
 // a model created under $HELEN_PERSISTENT=1 (same device bodies, same bits; 0.6-0.8 % slower).
 static bool use_persistent(const HelenModel* m, int tiles) {

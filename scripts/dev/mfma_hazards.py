@@ -69,9 +69,11 @@ def scan(lines):
             parts = m.split(None, 1)
             if m.startswith("s_nop"):
                 waited += int(parts[1], 0) + 1
-                continue
-            if len(parts) < 2 or m.startswith("s_"):
+            elif len(parts) < 2 or m.startswith("s_"):
                 waited += 1
+            if m.startswith("s_nop") or len(parts) < 2 or m.startswith("s_"):
+                if waited >= NEED:
+                    break
                 continue
             ops = parts[1].split(", ")
             if m.startswith("v_mfma"):
