@@ -30,7 +30,7 @@ static_assert(kDecStagePositions == HELEN_DWS_PB && kEncStagePositions == HELEN_
 #define HELEN_BF16_ENC_DEFAULT '1'
 #endif
 #ifndef HELEN_BF16_DEC_DEFAULT
-#define HELEN_BF16_DEC_DEFAULT '0'
+#define HELEN_BF16_DEC_DEFAULT '1'
 #endif
 
 namespace {
@@ -361,9 +361,9 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
         // projection fused into the recurrence: no gi at all; the encoder reads the packed pileup counts,
         // the decoder the encoder's bf16 output plane
         // Two tiles per workgroup: gru_fused_bf16_il_kernel interleaves the gate math with the other tile's MFMAs,
-        // gru_fused_bf16_pair_kernel runs them one after the other (all bit-identical).  Measured per launch of 4096
-        // windows (profiles/r03_bf16_probes.txt): encoder 0.157 against 0.162 ms, decoder 0.254 against 0.241 (no
-        // registers for its LDS prefetch): interleaved encoder, pair decoder.  HELEN_BF16_IL = two digits, encoder
+        // gru_fused_bf16_pair_kernel runs them one after the other (all bit-identical).  Measured per launch of 8192
+        // windows (profiles/r04_bf16_own.txt): encoder 0.322 against 0.319-0.335 ms, decoder 0.485 against 0.500 since
+        // round 4's form of the kernel (a step's input part in its own region): both interleaved.  HELEN_BF16_IL = two digits, encoder
         // then decoder: 0 = pair, 1 = interleaved, 2 = pair with waves 4-7 skewed by a phase, 3 = four waves (make W4=1)
         // (A/B probes).
         const char il_enc = m->overrides.bf16_il_enc ? m->overrides.bf16_il_enc : HELEN_BF16_ENC_DEFAULT;

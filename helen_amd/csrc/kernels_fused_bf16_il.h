@@ -5,20 +5,17 @@
 
 #include "kernels_fused_bf16_pair.h"
 
-#ifndef HELEN_BF16_IL_SINGLE
-#define HELEN_BF16_IL_SINGLE 1      // decoder: ONE fp32 h buffer and ONE bf16 plane per tile (reader and writer are a barrier apart)
+#ifndef HELEN_BF16_IL_PARKED       // K32 groups of the decoder's W_ih kept in LDS instead of registers (24 KiB each): none needed
+#define HELEN_BF16_IL_PARKED 0
 #endif
-#ifndef HELEN_BF16_IL_PARKED        // K32 groups of the decoder's W_ih kept in LDS instead of registers (24 KiB each)
-#define HELEN_BF16_IL_PARKED (HELEN_BF16_IL_SINGLE ? 3 : 2)
+#ifndef HELEN_BF16_IL_ADEPTH       // A fragments in flight (4 registers each)
+#define HELEN_BF16_IL_ADEPTH(dec) ((dec) ? 5 : 7)
+#endif
+#ifndef HELEN_BF16_IL_LEAD         // gate slots ahead of the first MFMA of a region
+#define HELEN_BF16_IL_LEAD 6
 #endif
 
 #define HELEN_PIN(x) asm volatile("" : "+v"(x))
-#ifndef HELEN_BF16_IL_LEAD        // gate slots ahead of the first MFMA of a region (asm-load variant)
-#define HELEN_BF16_IL_LEAD 6
-#endif
-#ifndef HELEN_BF16_IL_ADEPTH      // A fragments in flight (registers: 4 each): all seven of the encoder's, three of the decoder's
-#define HELEN_BF16_IL_ADEPTH(dec) ((dec) ? (HELEN_BF16_IL_SINGLE ? 5 : 3) : 7)
-#endif
 
 namespace helen {
 
@@ -50,6 +47,18 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 4: a step's input part is computed in the step's OWN region.  Until then the input part x(s+1) . W_ih^T + b of a
+// tile's NEXT step was computed in the other tile's MFMA phase and carried (three accumulators, plus the three being
+// filled: 36 registers a lane) to the region that adds the recurrent part.  At 256 registers that forced the decoder to
+// park K32 groups of W_ih in LDS -- three of eight: nine more fragment reads per wave and region (72 KiB per workgroup
+// beside the 96 KiB of A fragments) -- and kept it slower than the pair kernel.  Now region (x, s) runs tile x's WHOLE
+// step: bias -> input part -> recurrent part in one accumulator chain per gate (the same order of MFMAs per accumulator
+// as every other bf16 kernel: bit-identical), the n gate's input part in its own chain.  Nothing is carried but the
+// finished accumulators awaiting their gate math, all 36 weight fragments of a decoder wave are resident, and the row a
+// region needs was DMA'd a whole step earlier (lookahead one step, ring of two).  Decoder launch of 8,192 windows:
+// 0.485 ms against the pair kernel's 0.500 (profiles/r04_bf16_own.txt); encoder as before.
+// ------------------------------------------------------------------------------------------------
 template <int MI, bool DEC>
 __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
     const f32x4* __restrict__ in, long in_tile_stride, int pos0, int T, const bf16x8* __restrict__ Wi3,
@@ -57,19 +66,11 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
     f32x4* __restrict__ hid, f32x4* __restrict__ yplane_out, long yp_tile_stride,
     const f32x4* __restrict__ Whd, f32x4* __restrict__ plogit, long pl_tile_stride, int ntiles) {
     // LDS per tile: fp32 h [2][512 f4] | bf16 h plane [2][256] | input ring [RD][MI * 64] | (DEC) head partials [2][8][64]
-    // (DEC) after both tiles: the last kParked K32 groups of W_ih of every wave [8][kParked][3][64].  The ring is two
-    // deep: the row of step s+2 is DMA'd at the start of M(x,s) into the slot whose row (step s) the whole workgroup
-    // finished reading before the previous barrier (input part of step s, computed in the other tile's M phase).
-    // Decoder: 2 x 56 KiB + 48 KiB of parked weights = 160 KiB, all of a CU's LDS.
-    // Round 4 (HELEN_BF16_IL_SINGLE): the decoder keeps ONE fp32 h buffer and ONE plane per tile -- a tile's h is read in its
-    // M regions (MFMA operands, head slice) and by its own lanes' gate slots, and written at the end of its G regions, and
-    // M(x,.) and G(x,.) regions alternate with a barrier in between: 2 x 44 KiB + three parked groups (72 KiB) = 160 KiB,
-    // which moves a third K32 group of W_ih (12 registers) out of the register file.
+    // (DEC) after both tiles: the parked K32 groups of W_ih of every wave [8][kParked][3][64] (none by default).
     constexpr int RD = 2;
-    constexpr int NB = (DEC && HELEN_BF16_IL_SINGLE) ? 1 : 2;      // h buffers per tile
-    constexpr int kPlane = NB * 512, kRing = kPlane + NB * 256, kPart = kRing + RD * MI * 64, kPerTile = kPart + (DEC ? 2 * 8 * 64 : 0);
-    auto hsel = [](int b) __attribute__((always_inline)) { return NB == 2 ? b * 512 : 0; };                 // fp32 h buffer b (f4 offset)
-    auto psel = [=](int b) __attribute__((always_inline)) { return kPlane + (NB == 2 ? b * 256 : 0); };     // bf16 plane b
+    constexpr int kPlane = 2 * 512, kRing = kPlane + 2 * 256, kPart = kRing + RD * MI * 64, kPerTile = kPart + (DEC ? 2 * 8 * 64 : 0);
+    auto hsel = [](int b) __attribute__((always_inline)) { return b * 512; };                 // fp32 h buffer b (f4 offset)
+    auto psel = [=](int b) __attribute__((always_inline)) { return kPlane + b * 256; };       // bf16 plane b
     constexpr int kParked = DEC ? HELEN_BF16_IL_PARKED : 0, MR = MI - kParked;
     __shared__ f32x4 smem[2 * kPerTile + kParked * 8 * 3 * 64];
     const int tid = threadIdx.x;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
     const int u = 16 * v + j;
     const int tile_of[2] = {min(2 * (int)blockIdx.x, ntiles - 1), min(2 * (int)blockIdx.x + 1, ntiles - 1)};
 
-    bf16x8 Wh[3][4], Wi[3][MR];
+    bf16x8 Wh[3][4], Wi[3][MR > 0 ? MR : 1];
     bf16x8* const wpark = (bf16x8*)(smem + 2 * kPerTile) + v * (kParked * 3 * 64) + lane;
     {
         const bf16x8* wh = Wh3 + (size_t)((dir * 8 + v) * 36) * 64 + lane;
@@ -147,43 +148,23 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
         *(float*)(y_next[x] + voff) = sum;
     };
 
-    // ---- prologue: initial h, the rows of steps 0 and 1 -- for both tiles
+    // ---- prologue: initial h and the row of step 0 -- for both tiles
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
         smem[x * kPerTile + tid] = hid_p[x][tid];
         ring_dma[x] = 0;
         ring_rd[x] = 0;
         dma_in(x);
-        if (T > 1) dma_in(x);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // (the previous h of a lane's four cells is re-read from the fp32 buffer by the gate slots: registers are what
-    // this kernel is short of)
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             ((unsigned short*)(smem + x * kPerTile + kPlane))[poff + 8 * r] =
                 bf16_bits(((const float*)(smem + x * kPerTile))[hoff + 4 * r]);
-    // input part x . W_ih^T + b of a tile's next step (three accumulators), kept until that step's M phase
-    f32x4 gin[2][3];
-    {   // tile 0's first input part (tile 1's is computed in M(0,0))
-        const bf16x8* L = (const bf16x8*)(smem + kRing) + lane;
-#pragma unroll
-        for (int g = 0; g < 3; ++g) gin[0][g] = splat4(bi[g]);
-#pragma unroll
-        for (int M = 0; M < MI; ++M) {
-            const bf16x8 a = L[M * 64];
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-                gin[0][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    a, M < MR ? Wi[g][M < MR ? M : 0] : wpark[((M < MR ? 0 : M - MR) * 3 + g) * 64], gin[0][g], 0, 0, 0);
-        }
-        ring_rd[0] = MI * 1024u;
-    }
     __syncthreads();
-    bf16x8 a_pref = ((const bf16x8*)(smem + kPlane))[lane];   // group 0 of tile 0's h plane
 
     // Pending gate math of each tile: the finished accumulators of its newest step.
     f32x4 Pr[2], Pz[2], Pn[2], Pg[2];
@@ -192,84 +173,63 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
 
 #ifdef HELEN_BIL_TIMING   // developer probe: where a wave's cycles go
     long long tk[3] = {0, 0, 0};
-#define HELEN_BIL_TICK(i) { __builtin_amdgcn_sched_barrier(0); long long now_ = __builtin_readcyclecounter(); tk[i] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
     long long tlast = __builtin_readcyclecounter();
-#else
-#define HELEN_BIL_TICK(i)
 #endif
-    constexpr int NM = 12 + (DEC ? 4 : 0) + 3 * MI;   // MFMAs of one M phase: recurrent, head slice, the other tile's input part
-    constexpr int NS = 44;                            // gate slots (below)
+    constexpr int NIN = 3 * MI, NHEAD = DEC ? 4 : 0, NREC = 12;
+    constexpr int NM = NIN + NHEAD + NREC;            // MFMAs of one M phase: the step's input part, head slice of h(s-1), recurrent part
+    constexpr int NS = 44;                            // gate slots (the il kernel's program)
 
-    // One region between two barriers: the MFMA phase of tile X at step s, and -- if `gates` -- the gate math of
-    // tile O = 1 - X at its newest step so (whose accumulators are in P*[O]), slot by slot behind the MFMAs.
-    // CUR = s & 1; OW = the h buffer of tile O that its gates write ((so + 1) & 1).  The flags as in the pair kernel.
+    // One region between two barriers: the MFMA phase of tile X at step s, and -- if `gates` -- the gate math of tile
+    // O = 1 - X at its newest step so (whose accumulators are in P*[O]), slot by slot behind the MFMAs.
+    // CUR = s & 1; OW = the h buffer of tile O that its gates write ((so + 1) & 1).  STEADY: s >= 2 and s + 1 < T.
     auto region = [&](auto X, auto CUR, auto OW, auto STEADY, auto GATES, int s, int so) __attribute__((always_inline)) {
         constexpr int x = decltype(X)::value, o = 1 - x, cur = decltype(CUR)::value, ow = decltype(OW)::value;
         constexpr bool steady = decltype(STEADY)::value, gates = decltype(GATES)::value;
         const bool has_prev = steady || s > 0;
         const bool has_prev2 = steady || s > 1;
-        const bool has_next = steady || s + 1 < T;      // tile o has a step after so: its input part is needed
-        const bool has_next2 = steady || s + 2 < T;
+        const bool has_next = steady || s + 1 < T;
         f32x4* const base = smem + x * kPerTile;
         f32x4* const obase = smem + o * kPerTile;
         const f32x4* hx = base + hsel(cur);
-        const bf16x8* pa = (const bf16x8*)(base + psel(cur)) + lane;
-        const bf16x8* L = (const bf16x8*)((const char*)(obase + kRing) + ring_rd[o]) + lane;
         int issued = 0;
-        if (has_next2) {
+        if (has_next) {           // the row of step s+1 into the ring slot whose row (step s-1) was read a whole step ago
             dma_in(x);
             issued += v < MI;
         }
-        f32x4 ar = gin[x][0], az = gin[x][1], ahn = splat4(bn), pl = splat4(0.f);
-        const f32x4 gnx = gin[x][2];
-        f32x4 ain[3];
+        f32x4 ar = splat4(bi[0]), az = splat4(bi[1]), gnx = splat4(bi[2]), ahn = splat4(bn), pl = splat4(0.f);
         // gate state of tile o: four cells (rows 4q + c of unit u)
         const f32x4 gr = Pr[o], gz = Pz[o], gnn = Pn[o], ggn = Pg[o];
         float t1[4], t2[4], e1[4], e2[4], rg[4], zg[4], t3[4], e3[4], u3[4], qq[4], ng[4], dd[4], hn[4], hp[4];
         const float* hpo = (const float*)(obase + hsel(ow ^ 1)) + hoff;   // h_o(so - 1): fp32 buffer so & 1
-        const bool do_in = x == 0 || has_next;
-        // A fragments (K32 groups of h_x(s-1), then of the other tile's input rows), fetched AD - 1 groups ahead of the
-        // MFMAs that use them: an LDS read takes ~130 cycles here, a group of three MFMAs covers 51 (measured with
-        // one group of lookahead: 914 cycles for the encoder's 21 MFMAs, gate slots removed)
-        constexpr int NF = 4 + MI, AD = HELEN_BF16_IL_ADEPTH(DEC) < NF ? HELEN_BF16_IL_ADEPTH(DEC) : NF;
-        constexpr bool kAsmLoads = AD == NF;            // every fragment fetched at the top of the region
+        // A fragments: the MI K32 groups of tile x's input row of step s, then the four of h_x(s-1).  AD in flight, fragment
+        // f + AD fetched behind the last MFMA of group f.  Inline asm loads (an ordinary LDS load is free to sink below the
+        // sched_barriers), waited for by position in the in-order LDS queue: hipcc's own LDS accesses in between only make
+        // a wait stricter than it has to be.
+        constexpr int NF = MI + 4, AD = HELEN_BF16_IL_ADEPTH(DEC) < NF ? HELEN_BF16_IL_ADEPTH(DEC) : NF;
         bf16x8 aq[AD];
-        // LDS byte addresses of this lane's 16 bytes of group 0 of h_x(s-1) and of the other tile's ring slot
         const unsigned pa_lds = lds0 + (unsigned)((x * kPerTile + psel(cur)) * 16) + lane16;
-        const unsigned in_lds = lds0 + (unsigned)((o * kPerTile + kRing) * 16) + ring_rd[o] + lane16;
+        const unsigned in_lds = lds0 + (unsigned)((x * kPerTile + kRing) * 16) + ring_rd[x] + lane16;
         auto fetch_a = [&](auto F) __attribute__((always_inline)) {
             constexpr int f = decltype(F)::value;
-            if constexpr (kAsmLoads) {
-                // Inline asm: an ordinary LDS load is as free to sink below the sched_barriers as the MFMAs were
-                // (and a volatile one turns into a flat load with a full wait).  hipcc's waitcnt pass does not see
-                // these: fragment f is waited for explicitly below, by position in the in-order LDS queue.
+            if constexpr (f < NF) {
                 f32x4 t;
-                if constexpr (f < 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"(pa_lds), "n"(f * 1024));
-                else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"(in_lds), "n"((f - 4) * 1024));
+                if constexpr (f < MI) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"(in_lds), "n"(f * 1024));
+                else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"(pa_lds), "n"((f - MI) * 1024));
                 aq[f % AD] = __builtin_bit_cast(bf16x8, t);
-            } else {
-                if constexpr (f < 4) aq[f % AD] = pa[f * 64];
-                else if constexpr (f < NF) { if (do_in) aq[f % AD] = L[(f - 4) * 64]; }
             }
         };
-        if constexpr (kAsmLoads) {
-            static_for<AD>([&](auto F) __attribute__((always_inline)) { fetch_a(F); });
-        } else {
-            aq[0] = a_pref;
-            static_for<AD - 1>([&](auto F) __attribute__((always_inline)) { fetch_a(std::integral_constant<int, decltype(F)::value + 1>{}); });
-        }
-        // fragment f has arrived when at most NF - 1 - f of the younger fetches are outstanding
+        f32x4 hd = splat4(0.f);             // (before the fragments in the in-order LDS queue)
+        if (DEC && has_prev) hd = hx[v * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<AD>([&](auto F) __attribute__((always_inline)) { fetch_a(F); });
+        // fragment f has arrived when at most min(NF - 1 - f, AD - 1) younger fetches are outstanding
         auto wait_a = [&](auto F) __attribute__((always_inline)) {
             constexpr int f = decltype(F)::value;
-            if constexpr (kAsmLoads) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NF - 1 - f) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NF - 1 - f < AD - 1 ? NF - 1 - f : AD - 1) : "memory");
         };
-        bf16x8 b_nxt = a_pref;                          // (DEC) the parked W_ih fragment of the next MFMA that needs one
-        f32x4 hd = splat4(0.f);
-        if (DEC && has_prev) hd = hx[v * 64 + lane];
-
         auto gate_slot = [&](auto K) __attribute__((always_inline)) {
             constexpr int k = decltype(K)::value;
-            if constexpr (!gates) {
+            if constexpr (!gates || k >= NS) {
                 return;
             } else if constexpr (k < 4) {                 // P1
                 t1[k] = gr[k] * -1.4426950408889634f;
@@ -310,51 +270,54 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
                 hn[c + 1] = __builtin_fmaf(zg[c + 1], dd[c + 1], ng[c + 1]);
             }
         };
-        // MFMA i of the phase, its operand loads one group ahead
+        // The head slice: four fp32 MFMAs (v_mfma_f32_16x16x4_f32) between the input and the recurrent part.  They cost the
+        // two waves of a SIMD 493 cycles of a 2,530-cycle region (compiled out: MFMA stream 2,027 -> 1,534); spread over the
+        // input part or put first in the region they cost more (profiles/r04_bf16_own.txt).
+        auto head_item = [&](auto E) __attribute__((always_inline)) {
+            constexpr int e = decltype(E)::value;
+#ifndef HELEN_BIL_NOHEAD
+            if (has_prev) { pl = mfma4(hd[e], Bh[e], pl); HELEN_PIN(pl); }
+#endif
+        };
         auto mfma_item = [&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
-            if constexpr (i < 12) {
+            if constexpr (i < NIN) {                                  // input part: fragments 0 .. MI-1
                 constexpr int M = i / 3, g = i % 3;
                 if constexpr (g == 0) wait_a(std::integral_constant<int, M>{});
                 const bf16x8 a_cur = aq[M % AD];
+                bf16x8 b;
+                if constexpr (M < MR) b = Wi[g][M < MR ? M : 0];
+                else b = wpark[((M < MR ? 0 : M - MR) * 3 + g) * 64];
                 // (PIN: LLVM sinks a pure MFMA chain whose result is only needed at the end of the block below every
-                // sched_barrier in between -- at IR level, where sched_barrier orders nothing; an empty volatile asm
-                // that "modifies" the accumulator keeps each MFMA in its slot)
+                // sched_barrier in between; an empty volatile asm that "modifies" the accumulator keeps each MFMA in its slot)
+                if constexpr (g == 0) { ar = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, b, ar, 0, 0, 0); HELEN_PIN(ar); }
+                if constexpr (g == 1) { az = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, b, az, 0, 0, 0); HELEN_PIN(az); }
+                if constexpr (g == 2) {
+                    gnx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, b, gnx, 0, 0, 0);
+                    HELEN_PIN(gnx);
+                    fetch_a(std::integral_constant<int, M + AD>{});      // the slot of group M is free again
+                }
+            } else if constexpr (i < NIN + NHEAD) {
+                head_item(std::integral_constant<int, i - NIN>{});
+            } else {                                                  // recurrent part: fragments MI .. MI+3
+                constexpr int ii = i - NIN - NHEAD, M = ii / 3, g = ii % 3;
+                // the head slice of h_x(s-1) (slot s-1) is parked while the partials of slot s-2 (the other parity) are
+                // still to be read at the end of this region
+                if constexpr (DEC && ii == 6)
+                    if (has_prev) (base + kPart + (((s - 1) & 1) * 8 + v) * 64)[lane] = pl;
+                if constexpr (g == 0) wait_a(std::integral_constant<int, MI + M>{});
+                const bf16x8 a_cur = aq[(MI + M) % AD];
                 if constexpr (g == 0) { ar = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, Wh[0][M], ar, 0, 0, 0); HELEN_PIN(ar); }
                 if constexpr (g == 1) { az = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, Wh[1][M], az, 0, 0, 0); HELEN_PIN(az); }
                 if constexpr (g == 2) {
                     ahn = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, Wh[2][M], ahn, 0, 0, 0);
                     HELEN_PIN(ahn);
-                    if constexpr (!kAsmLoads) fetch_a(std::integral_constant<int, M + AD>{});      // the slot of group M is free again
-                }
-            } else if constexpr (DEC && i < 16) {
-                constexpr int e = i - 12;
-                if (has_prev) { pl = mfma4(hd[e], Bh[e], pl); HELEN_PIN(pl); }
-            } else {
-                constexpr int ii = i - 12 - (DEC ? 4 : 0), M = ii / 3, g = ii % 3;
-                // the head slice of h_x(s-1) (slot s-1) is parked while the partials of slot s-2 (the other parity) are
-                // still to be read at the end of this region
-                if constexpr (DEC && ii == 6)
-                    if (has_prev) (base + kPart + (((s - 1) & 1) * 8 + v) * 64)[lane] = pl;
-                if (do_in) {
-                    if constexpr (g == 0) wait_a(std::integral_constant<int, 4 + M>{});
-                    const bf16x8 a_cur = aq[(4 + M) % AD];
-                    if constexpr (M == 0) ain[g] = splat4(bi[g]);
-                    // a parked W_ih fragment is fetched behind the MFMA before the one that needs it
-                    if constexpr (M < MR)
-                        ain[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, Wi[g][M < MR ? M : 0], ain[g], 0, 0, 0);
-                    else
-                        ain[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, b_nxt, ain[g], 0, 0, 0);
-                    if constexpr (kParked > 0 && ii + 1 < 3 * MI && (ii + 1) / 3 >= MR)
-                        b_nxt = wpark[(((ii + 1) / 3 - MR) * 3 + (ii + 1) % 3) * 64];
-                    HELEN_PIN(ain[g]);
-                    if constexpr (g == 2 && !kAsmLoads) fetch_a(std::integral_constant<int, 4 + M + AD>{});
+                    fetch_a(std::integral_constant<int, MI + M + AD>{});
                 }
             }
         };
-        // kLead gate slots go first: they cover the LDS latency of the first A fragment (fetched at the top of the region
-        // when kAsmLoads; the decoder's comes from before the barrier)
-        constexpr int kLead = kAsmLoads ? HELEN_BF16_IL_LEAD : 0;
+        // kLead gate slots go first: they cover the LDS latency of the first A fragment
+        constexpr int kLead = HELEN_BF16_IL_LEAD;
         static_for<(NM + kLead > NS ? NM + kLead : NS)>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
             __builtin_amdgcn_sched_barrier(0);
@@ -367,18 +330,14 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
 #endif
         });
         __builtin_amdgcn_sched_barrier(0);
-        if (do_in) {
-#pragma unroll
-            for (int g = 0; g < 3; ++g) gin[o][g] = ain[g];
-            ring_rd[o] = ring_rd[o] == (RD - 1u) * MI * 1024u ? 0u : ring_rd[o] + MI * 1024u;
-        }
+        ring_rd[x] = ring_rd[x] == (RD - 1u) * MI * 1024u ? 0u : ring_rd[x] + MI * 1024u;
 #ifdef HELEN_BIL_NOGATES
         static_for<4>([&](auto C) { hn[decltype(C)::value] = gr[decltype(C)::value] + gz[decltype(C)::value] + gnn[decltype(C)::value] + ggn[decltype(C)::value]; });
 #endif
 #ifdef HELEN_BIL_NOMFMA
-        ain[0] = ain[1] = ain[2] = splat4(bn);
+        ar = az = gnx = ahn = splat4(bn);
 #endif
-        if constexpr (gates) {     // new h of tile o -> LDS (fp32 state / layer output, bf16 plane), head partial of its previous h
+        if constexpr (gates) {     // new h of tile o -> LDS (fp32 state / layer output, bf16 plane)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 ((float*)(obase + hsel(ow)))[hoff + 4 * r] = hn[r];
@@ -395,24 +354,28 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
             y_next[x] += 512 * 16;
             issued += 1;
         }
-        if (DEC && has_prev2) {                                  // slot s-2: partials parked by tile x's gates of step s-1
+        if (DEC && has_prev2) {                                  // slot s-2: partials parked in tile x's region of step s-1
             if (v < 4) {
                 store_logits(x, s & 1, in_block((unsigned)tid * 4u));
                 issued += 1;
             }
             y_next[x] += 128 * 16;
         }
-        HELEN_BIL_TICK(0)
+#ifdef HELEN_BIL_TIMING
+        { __builtin_amdgcn_sched_barrier(0); long long now_ = __builtin_readcyclecounter(); tk[0] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
+#endif
         if (issued == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (issued == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        HELEN_BIL_TICK(1)
+#ifdef HELEN_BIL_TIMING
+        { __builtin_amdgcn_sched_barrier(0); long long now_ = __builtin_readcyclecounter(); tk[1] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
+#endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        HELEN_BIL_TICK(2)
-        // next region: M(o, .) starts on h_o in buffer ow (just published), gates of tile x
-        if constexpr (HELEN_BF16_IL_ADEPTH(DEC) < 4 + MI) a_pref = ((const bf16x8*)(obase + psel(ow)))[lane];
+#ifdef HELEN_BIL_TIMING
+        { __builtin_amdgcn_sched_barrier(0); long long now_ = __builtin_readcyclecounter(); tk[2] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
+#endif
         __builtin_amdgcn_sched_barrier(0);
     };
     using I0 = std::integral_constant<int, 0>;
@@ -432,12 +395,9 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
             region(I1{}, I0{}, I1{}, STEADY, Yes{}, s_, s_);
         }
     };
-#ifdef HELEN_BF16_STATIC_PRIO   // probe: static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-    if (v >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
     int s = 0;
     for (; s < T && s < 2; ++s) step(No{}, s);
-    for (; s + 3 < T; s += 2) {                           // steady state: s >= 2 and (s + 1) + 2 < T
+    for (; s + 2 < T; s += 2) {                           // steady state: s >= 2 and (s + 1) + 1 < T
         region(I0{}, I0{}, I0{}, Yes{}, Yes{}, s, s - 1);
         region(I1{}, I0{}, I1{}, Yes{}, Yes{}, s, s);
         region(I0{}, I1{}, I1{}, Yes{}, Yes{}, s + 1, s);

@@ -60,12 +60,20 @@ static const char* kFill[] = {"", " + 1 v_exp", " + 2 v_fma", " + 2 v_exp"};
 template <int MODE, int NACC, int THREADS, int FILL = 0>
 void run(const float* in, float* out, long long* cyc) {
     const int trips = 2000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
     hipLaunchKernelGGL((stream<MODE, NACC, THREADS, FILL>), dim3(256), dim3(THREADS), 0, 0, in, out, trips, cyc);
+    hipEventRecord(e0, 0);
     hipLaunchKernelGGL((stream<MODE, NACC, THREADS, FILL>), dim3(256), dim3(THREADS), 0, 0, in, out, trips, cyc);
+    hipEventRecord(e1, 0);
     hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double tflops = 256.0 * (THREADS / 64) * trips * 24.0 * 16384.0 / (ms * 1e-3) / 1e12;
     long long c;
     hipMemcpy(&c, cyc, sizeof(c), hipMemcpyDeviceToHost);
-    printf("%-34s%-11s %2d accumulators  %d wave(s)/SIMD: %6.2f cycles per MFMA per wave\n", kName[MODE], kFill[FILL], NACC, THREADS / 256, (double)c / (trips * 24.0));
+    printf("%-34s%-11s %2d accumulators  %d wave(s)/SIMD: %6.2f cycles per MFMA per wave  %.3f ms = %.0f TFLOP/s on 256 CUs\n", kName[MODE], kFill[FILL], NACC, THREADS / 256, (double)c / (trips * 24.0), ms, tflops);
 }
 
 int main() {
