@@ -24,7 +24,7 @@ EXPORTS = (
     "helen_model_device_bytes", "helen_polish_batch", "helen_polish_host", "helen_polish_submit", "helen_polish_flush",
     "helen_gru_chunk_forward", "helen_evaluate_batch", "helen_debug_inject_failure", "helen_set_profiling",
     "helen_reset_kernel_stats",
-    "helen_get_kernel_stats", "helen_reload_overrides", "helen_describe_dispatch", "helen_plan_call", "helen_has_persistent", "helen_has_w4",
+    "helen_get_kernel_stats", "helen_reload_overrides", "helen_describe_dispatch", "helen_plan_call", "helen_has_persistent",
 )
 RECURRENCE_KERNELS = ("gru_kernel", "gru_single8_kernel", "gru_half8_kernel", "gru_quarter4_kernel", "gru_pair_kernel")
 DECODER_PROJECTIONS = ("gemm_gi_kernel<16>", "gemm_dec_ws_kernel", "gemm_dec_wsp_kernel")
@@ -124,8 +124,6 @@ def load():
     lib.helen_plan_call.argtypes = [ci, ci, ctypes.POINTER(ci)]
     lib.helen_has_persistent.restype = ci
     lib.helen_has_persistent.argtypes = []
-    lib.helen_has_w4.restype = ci
-    lib.helen_has_w4.argtypes = []
     got = lib.helen_abi_version()
     if got != HELEN_ABI_VERSION:
         raise ImportError("libhelen_hip.so ABI %d != binding ABI %d; rebuild" % (got, HELEN_ABI_VERSION))

@@ -364,7 +364,7 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
         // gru_fused_bf16_pair_kernel runs them one after the other (all bit-identical).  Measured per launch of 8192
         // windows (profiles/r04_bf16_own.txt): encoder 0.322 against 0.319-0.335 ms, decoder 0.485 against 0.500 since
         // round 4's form of the kernel (a step's input part in its own region): both interleaved.  HELEN_BF16_IL = two digits, encoder
-        // then decoder: 0 = pair, 1 = interleaved, 2 = pair with waves 4-7 skewed by a phase, 3 = four waves (make W4=1)
+        // then decoder: 0 = pair, 1 = interleaved, 2 = pair with waves 4-7 skewed by a phase
         // (A/B probes).
         const char il_enc = m->overrides.bf16_il_enc ? m->overrides.bf16_il_enc : HELEN_BF16_ENC_DEFAULT;
         const char il_dec = m->overrides.bf16_il_dec ? m->overrides.bf16_il_dec : HELEN_BF16_DEC_DEFAULT;
@@ -374,17 +374,9 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
                        kY1bTileStride, (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride, tiles
 #define HELEN_DEC_ARGS m->y1p, kY1bTileStride, 0, T, m->w3i_dec, m->w3h_dec, m->bias_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, \
                        kY1bTileStride, m->whd, m->plogit, kPlTileStride, tiles
-#ifdef HELEN_WITH_W4
-            if (il_enc == '3') LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_w4_kernel<3, false>), grid, dim3(256), HELEN_ENC_ARGS);
-            else
-#endif
             if (il_enc == '1') LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_il_kernel<3, false>), grid, block, HELEN_ENC_ARGS);
             else if (il_enc == '2') LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_pair_kernel<3, false, true>), grid, block, HELEN_ENC_ARGS);
             else LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_pair_kernel<3, false>), grid, block, HELEN_ENC_ARGS);
-#ifdef HELEN_WITH_W4
-            if (il_dec == '3') LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_w4_kernel<8, true>), grid, dim3(256), HELEN_DEC_ARGS);
-            else
-#endif
             if (il_dec == '1') LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_il_kernel<8, true>), grid, block, HELEN_DEC_ARGS);
             else if (il_dec == '2') LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_pair_kernel<8, true, true>), grid, block, HELEN_DEC_ARGS);
             else LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_pair_kernel<8, true>), grid, block, HELEN_DEC_ARGS);
@@ -492,21 +484,6 @@ void free_model(HelenModel* m) {
     delete m;
 }
 
-// Environment overrides, minus the ones this build has no kernel for (said once on stderr instead of silently ignored).
-static Overrides checked_overrides() {
-    Overrides o = read_overrides();
-#ifndef HELEN_WITH_W4
-    if (o.bf16_il_enc == '3' || o.bf16_il_dec == '3') {
-        static bool said = false;
-        if (!said) fputs("helen: HELEN_BF16_IL=3 (four-wave bf16 kernels) needs a library built with `make W4=1`; using the defaults\n", stderr);
-        said = true;
-        if (o.bf16_il_enc == '3') o.bf16_il_enc = 0;
-        if (o.bf16_il_dec == '3') o.bf16_il_dec = 0;
-    }
-#endif
-    return o;
-}
-
 int create_impl(const HelenWeights* w, int device, int max_windows, int precision, HelenModel* m) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -523,7 +500,7 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
     {
         const char* hooks = getenv("HELEN_DEBUG_HOOKS");
         m->debug_hooks = hooks && hooks[0] == '1';
-        m->overrides = checked_overrides();
+        m->overrides = read_overrides();
         if (m->overrides.host_lock >= 0) m->host_lock = m->overrides.host_lock;
         if (m->overrides.verbose) fputs(describe_dispatch(m->cus, m->overrides).c_str(), stderr);
     }
@@ -659,7 +636,7 @@ int helen_reload_overrides(HelenModel* m) {
     if (!m) return fail(HELEN_EINVAL, "null argument");
     HELEN_ENTER(m);
     const int keep = m->overrides.persistent;      // (what was allocated at creation decides that one)
-    m->overrides = checked_overrides();
+    m->overrides = read_overrides();
     m->overrides.persistent = keep;
     m->host_lock = m->overrides.host_lock >= 0 ? m->overrides.host_lock : 0;
     return HELEN_OK;
@@ -691,14 +668,6 @@ int helen_plan_call(int cus, int tiles, int* out) {
 
 int helen_has_persistent(void) {
 #ifdef HELEN_WITH_PERSISTENT
-    return 1;
-#else
-    return 0;
-#endif
-}
-
-int helen_has_w4(void) {
-#ifdef HELEN_WITH_W4
     return 1;
 #else
     return 0;

@@ -16,9 +16,6 @@
 #include "kernels_fused_bf16.h"
 #include "kernels_fused_bf16_pair.h"
 #include "kernels_fused_bf16_il.h"
-#ifdef HELEN_WITH_W4        // make W4=1: the four-wave bf16 layer kernels (measured slower, see the header; quarantined)
-#include "kernels_fused_bf16_w4.h"
-#endif
 #include "kernels_heads.h"
 #ifdef HELEN_WITH_PERSISTENT      // the 19-chunk loop as one launch: quarantined (slower; see api.hip)
 #include "kernels_persistent.h"

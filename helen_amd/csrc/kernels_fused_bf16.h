@@ -7,6 +7,51 @@
 namespace helen {
 
 // ------------------------------------------------------------------------------------------------
+// The head slice of a wave (16 rows x its 16 hidden units -> 16 logits) on the bf16 pipe, from round 4 on.  Until then
+// it was four fp32 MFMAs (v_mfma_f32_16x16x4_f32) per wave and step: 32 cycles of matrix pipe each beside 16 for a bf16
+// MFMA of sixteen times the work, and measured 493 cycles a region for the two waves of a SIMD -- a fifth of the decoder
+// (profiles/r04_bf16_own.txt).  Now h and the head weights are split in two bf16 terms each (x = hi + lo, 16 significant
+// bits) and the three products that matter ride in TWO K32 MFMAs:
+//     A  = [ h_hi(4 units) | h_lo(4 units) ]  per lane (row l & 15, its unit quad 4q .. 4q+3), built in registers from the
+//          fp32 slice the wave reads anyway;
+//     B1 = [ W_hi | W_hi ],  B2 = [ W_lo | 0 ]   built once per kernel from the fp32 head fragment of the lane (class l & 15);
+//     pl = A . B1 + A . B2 = sum_k h_hi W_hi + h_lo W_hi + h_hi W_lo          (fp32 accumulate, products exact)
+// The term dropped is h_lo W_lo (2^-16 of a product); against the fp32 head a logit moves by <= 2e-4 at |logit| <= 12,
+// a hundredth of what bf16 gate operands already move it.  Every bf16 kernel uses these three functions: same bits.
+// ------------------------------------------------------------------------------------------------
+struct HeadW {
+    bf16x8 b1, b2;
+};
+__device__ __forceinline__ bf16x8 bf16x8_of(unsigned a, unsigned b, unsigned c, unsigned d) {
+    return __builtin_bit_cast(bf16x8, uint4{a, b, c, d});
+}
+__device__ __forceinline__ HeadW head_split_w(f32x4 w) {
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = bf16_bits(w[e]);
+        lo[e] = bf16_bits(w[e] - bf16_to_f32((unsigned short)hi[e]));
+    }
+    HeadW r;
+    r.b1 = bf16x8_of(hi[0] | hi[1] << 16, hi[2] | hi[3] << 16, hi[0] | hi[1] << 16, hi[2] | hi[3] << 16);
+    r.b2 = bf16x8_of(lo[0] | lo[1] << 16, lo[2] | lo[3] << 16, 0u, 0u);
+    return r;
+}
+__device__ __forceinline__ bf16x8 head_split_h(f32x4 h) {
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = bf16_bits(h[e]);
+        lo[e] = bf16_bits(h[e] - bf16_to_f32((unsigned short)hi[e]));
+    }
+    return bf16x8_of(hi[0] | hi[1] << 16, hi[2] | hi[3] << 16, lo[0] | lo[1] << 16, lo[2] | lo[3] << 16);
+}
+__device__ __forceinline__ f32x4 head_mfma(bf16x8 a, const HeadW& w) {
+    f32x4 pl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w.b1, splat4(0.f), 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w.b2, pl, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
 // One GRU layer direction, projection AND recurrence, for bf16 gate matmuls (fp32 accumulate, fp32
 // state, fp32 gates).  With bf16 operands a direction's W_ih and W_hh both fit the register file
 // (8 waves, wave v owns hidden units 16v..16v+15 = one 16-column tile per gate: W_hh 3 x 4 K32-groups
@@ -31,7 +76,7 @@ namespace helen {
 //   The decoder (DEC) writes no layer output at all: the heads are linear in [h_fwd | h_bwd], so each
 //   direction contributes its half of the 16 logits.  Wave v owns exactly the k-slice 16v..16v+15 of
 //   h (one fp32 MFMA A fragment in the LDS copy of h): at step s+1 it multiplies the slice of h(s) by its
-//   slice of the head weights (4 fp32 MFMAs, issued with the recurrent ones) and parks the 16x16 partial
+//   slice of the head weights (two bf16 MFMAs on two-term splits, see above; issued with the recurrent ones) and parks the 16x16 partial
 //   in LDS; after that step's barrier one wave (s mod 8) adds the eight partials in wave order and stores 1 KiB
 //   plogit[tile][slot = s][dir][64 lanes] (FRAG layout) instead of 8 KiB of y2.  The heads kernel then
 //   only adds two partial tiles and the bias.
@@ -71,8 +116,8 @@ __global__ __launch_bounds__(512) void gru_fused_bf16_kernel(
             for (int M = 0; M < MI; ++M) Wi[g][M] = wi[(M * 3) * 64];
         }
     }
-    f32x4 Bh = splat4(0.f);   // DEC: head weights for k = dir*128 + 16v + 4q + e, class j
-    if (DEC) Bh = Whd[(dir * 8 + v) * 64 + lane];
+    HeadW Bh = head_split_w(splat4(0.f));   // DEC: head weights for k = dir*128 + 16v + 4q + e, class j, as two bf16 terms
+    if (DEC) Bh = head_split_w(Whd[(dir * 8 + v) * 64 + lane]);
     float bi[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) bi[g] = bias[dir * kG + g * kH + u];
@@ -116,10 +161,7 @@ __global__ __launch_bounds__(512) void gru_fused_bf16_kernel(
 
     auto head_partial = [&](int hb, int pb) {   // h in hbuf[hb]: wave v's k-slice is one fp32 A fragment
         const f32x4 a = (hbuf + hb * 512)[v * 64 + lane];
-        f32x4 pl = splat4(0.f);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pl = mfma4(a[e], Bh[e], pl);
-        (part + (pb * 8 + v) * 64)[lane] = pl;
+        (part + (pb * 8 + v) * 64)[lane] = head_mfma(head_split_h(a), Bh);
     };
     auto head_store = [&](int slot) {           // one wave adds the eight slices in wave order
         if (v != (slot & 7)) return;

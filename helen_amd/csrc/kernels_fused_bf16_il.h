@@ -97,8 +97,8 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
             for (int M = MR; M < MI; ++M) wpark[((M - MR) * 3 + g) * 64] = wi[(M * 3) * 64];
         }
     }
-    f32x4 Bh = splat4(0.f);   // DEC: head weights for k = dir*128 + 16v + 4q + e, class j
-    if (DEC) Bh = Whd[(dir * 8 + v) * 64 + lane];
+    HeadW Bh = head_split_w(splat4(0.f));   // DEC: head weights for k = dir*128 + 16v + 4q + e, class j, as two bf16 terms
+    if (DEC) Bh = head_split_w(Whd[(dir * 8 + v) * 64 + lane]);
     float bi[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) bi[g] = bias[dir * kG + g * kH + u];
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
     long long tk[3] = {0, 0, 0};
     long long tlast = __builtin_readcyclecounter();
 #endif
-    constexpr int NIN = 3 * MI, NHEAD = DEC ? 4 : 0, NREC = 12;
+    constexpr int NIN = 3 * MI, NHEAD = DEC ? 2 : 0, NREC = 12;
     constexpr int NM = NIN + NHEAD + NREC;            // MFMAs of one M phase: the step's input part, head slice of h(s-1), recurrent part
     constexpr int NS = 44;                            // gate slots (the il kernel's program)
 
@@ -218,8 +218,15 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
                 aq[f % AD] = __builtin_bit_cast(bf16x8, t);
             }
         };
-        f32x4 hd = splat4(0.f);             // (before the fragments in the in-order LDS queue)
+        // (The head's fp32 slice of h_x(s-1) and the gate cells' previous h are ordinary loads.  As inline-asm loads in
+        // front of the fragments -- so that hipcc's waits for them cannot drain the prefetch ring -- they measured SLOWER:
+        // decoder 0.480 against 0.468 ms, encoder 0.345 against 0.335, profiles/r04_bf16_own.txt.)
+        f32x4 hd = splat4(0.f);
+#ifdef HELEN_BIL_HEADNOLOAD       // (timing probe: the head's MFMAs on a register constant)
+        hd = splat4(bn);
+#else
         if (DEC && has_prev) hd = hx[v * 64 + lane];
+#endif
         __builtin_amdgcn_sched_barrier(0);
         static_for<AD>([&](auto F) __attribute__((always_inline)) { fetch_a(F); });
         // fragment f has arrived when at most min(NF - 1 - f, AD - 1) younger fetches are outstanding
@@ -270,13 +277,22 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
                 hn[c + 1] = __builtin_fmaf(zg[c + 1], dd[c + 1], ng[c + 1]);
             }
         };
-        // The head slice: four fp32 MFMAs (v_mfma_f32_16x16x4_f32) between the input and the recurrent part.  They cost the
-        // two waves of a SIMD 493 cycles of a 2,530-cycle region (compiled out: MFMA stream 2,027 -> 1,534); spread over the
-        // input part or put first in the region they cost more (profiles/r04_bf16_own.txt).
+        // The head slice of h_x(s-1): two bf16 MFMAs on two-term splits (kernels_fused_bf16.h) between the input and the
+        // recurrent part; the split of h (twelve VALU instructions) rides in front of the first.  (As four fp32 MFMAs it cost
+        // the two waves of a SIMD 493 cycles of a 2,530-cycle region: profiles/r04_bf16_own.txt.)
+        bf16x8 ha;
         auto head_item = [&](auto E) __attribute__((always_inline)) {
             constexpr int e = decltype(E)::value;
 #ifndef HELEN_BIL_NOHEAD
-            if (has_prev) { pl = mfma4(hd[e], Bh[e], pl); HELEN_PIN(pl); }
+            if (has_prev) {
+                if constexpr (e == 0) {
+                    ha = head_split_h(hd);
+                    pl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha, Bh.b1, splat4(0.f), 0, 0, 0);
+                } else {
+                    pl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha, Bh.b2, pl, 0, 0, 0);
+                }
+                HELEN_PIN(pl);
+            }
 #endif
         };
         auto mfma_item = [&](auto I) __attribute__((always_inline)) {
@@ -434,10 +450,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
                 y_next[x] += 128 * 16;
             }
             const f32x4 a = (smem + x * kPerTile + hsel(last))[v * 64 + lane];
-            f32x4 pl = splat4(0.f);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pl = mfma4(a[e], Bh[e], pl);
-            (smem + x * kPerTile + kPart + (((T - 1) & 1) * 8 + v) * 64)[lane] = pl;
+            (smem + x * kPerTile + kPart + (((T - 1) & 1) * 8 + v) * 64)[lane] = head_mfma(head_split_h(a), Bh);
         }
         __syncthreads();
         if (v < 4) {

@@ -78,8 +78,8 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_pair_kernel(
             if (kParked) wpark[g * 64] = wi[(MR * 3) * 64];
         }
     }
-    f32x4 Bh = splat4(0.f);   // DEC: head weights for k = dir*128 + 16v + 4q + e, class j
-    if (DEC) Bh = Whd[(dir * 8 + v) * 64 + lane];
+    HeadW Bh = head_split_w(splat4(0.f));   // DEC: head weights for k = dir*128 + 16v + 4q + e, class j, as two bf16 terms
+    if (DEC) Bh = head_split_w(Whd[(dir * 8 + v) * 64 + lane]);
     float bi[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) bi[g] = bias[dir * kG + g * kH + u];
@@ -211,9 +211,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_pair_kernel(
             ahn = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Wh[2][M], ahn, 0, 0, 0);
         }
         if (DEC && has_prev) {                                   // this wave's k-slice of the head product of h_x(s-1)
-            const f32x4 a = hx[v * 64 + lane];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pl = mfma4(a[e], Bh[e], pl);
+            pl = head_mfma(head_split_h(hx[v * 64 + lane]), Bh);
         }
         // The input part of the OTHER tile's next step (independent of any h; gin[o] was consumed by that tile's
         // gates in the previous half-step): last in this phase, so that the gates of tile x behind the barrier find
@@ -314,10 +312,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_pair_kernel(
                 y_next[x] += 128 * 16;
             }
             const f32x4 a = (smem + x * kPerTile + last * 512)[v * 64 + lane];
-            f32x4 pl = splat4(0.f);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pl = mfma4(a[e], Bh[e], pl);
-            (smem + x * kPerTile + kPart + (((T - 1) & 1) * 8 + v) * 64)[lane] = pl;
+            (smem + x * kPerTile + kPart + (((T - 1) & 1) * 8 + v) * 64)[lane] = head_mfma(head_split_h(a), Bh);
         }
         __syncthreads();
         if (v < 4) {

@@ -130,13 +130,11 @@ int helen_model_device_bytes(const HelenModel* model, size_t* out_bytes);
  *                             position runs, encoder projection, its position runs, bf16 two-tile kernels?  (the enums of
  *                             dispatch.h) for a call of `tiles` tiles on `cus` CUs
  *   helen_has_persistent      1 if the library was built with the one-launch chunk loop (-DHELEN_WITH_PERSISTENT)
- *   helen_has_w4              1 if it was built with the four-wave bf16 layer kernels (-DHELEN_WITH_W4: HELEN_BF16_IL digit 3)
  */
 int helen_reload_overrides(HelenModel* model);
 int helen_describe_dispatch(int cus, char* out, size_t cap);
 int helen_plan_call(int cus, int tiles, int* out);
 int helen_has_persistent(void);
-int helen_has_w4(void);
 
 /*
  * The whole per-batch body of the reference loop (`models/predict_gpu.py:97-159`): uint8 -> f32,

@@ -135,29 +135,3 @@ def test_dispatch_table_dry_run(monkeypatch):
     src = open(os.path.join(ROOT, "helen_amd", "csrc", "api.hip")).read()
     assert src.count("getenv(") == 1 and "use_pair_recurrence" not in src and "use_split" not in src
 
-
-def test_asm_mfma_hazard_scanner():
-    """kernels_fused_bf16_w4.h issues its MFMAs as inline asm, behind which hipcc inserts no wait states; the build is only
-    safe if nothing the COMPILER placed reads an accumulator too soon.  scripts/dev/mfma_hazards.py is that check: here
-    its rules on hand-made streams, and -- in a build with `make W4=1` -- the shipped code object itself."""
-    import importlib.util
-    import os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("mfma_hazards", os.path.join(root, "scripts", "dev", "mfma_hazards.py"))
-    hz = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(hz)
-    mfma = "v_mfma_f32_16x16x32_bf16 v[10:13], v[20:23], a[0:3], v[10:13]"
-    other = "v_mfma_f32_16x16x32_bf16 v[14:17], v[20:23], a[4:7], v[14:17]"
-    assert hz.scan([mfma, "v_exp_f32_e32 v1, v2", "v_accvgpr_write_b32 a9, v11"])          # a spill two instructions later
-    assert hz.scan([mfma, "ds_write_b32 v40, v12"]) and hz.scan([mfma, "s_nop 7", "v_mov_b32_e32 v3, v10"])
-    assert not hz.scan([mfma, "s_nop 7", "s_nop 7", "s_nop 3", "v_mov_b32_e32 v3, v10"])   # 20 wait states
-    assert not hz.scan([mfma, other, other, "v_mov_b32_e32 v3, v10"])                      # two MFMAs of pipe time
-    assert not hz.scan([mfma, "v_mfma_f32_16x16x32_bf16 v[10:13], v[24:27], a[8:11], v[10:13]"])   # C of the next MFMA: interlocked
-    assert hz.scan([mfma, "v_mfma_f32_16x16x32_bf16 v[14:17], v[10:13], a[8:11], v[14:17]"])       # ... its A operand is not
-    assert not hz.scan([mfma, "v_exp_f32_e32 v1, v2", "v_mov_b32_e32 v10, v5"])            # a write is not a read
-    from helen_amd import _lib
-    if _lib.load().helen_has_w4():
-        kernels = {k: v for k, v in hz.kernels_of(_lib.LIB_PATH).items() if "w4_kernel" in k}
-        assert len(kernels) == 2
-        for name, lines in kernels.items():
-            assert sum(l.startswith("v_mfma_f32_16x16x32") for l in lines) > 200 and not hz.scan(lines), name
