@@ -213,6 +213,9 @@ std::vector<f32x4> pack_w_hh(const float* const w[2]) {
     return out;
 }
 
+// bf16 mode: the factor a gate row (r: 0..127, z: 128..255, n: 256..383) is multiplied by before it is rounded to bf16
+inline float gate_prescale(int row) { return row < 2 * kH ? -1.4426950408889634f : 2.8853900817779268f; }
+
 // fp32 -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does on the device side)
 short to_bf16(float f) {
     uint32_t u;
@@ -524,11 +527,31 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
         if ((rc = dev_alloc(m, &m->y1p, (size_t)m->max_tiles * kY1pTileStride))) return rc;
     }
     if (precision == HELEN_PRECISION_BF16) {
-        // the fused kernels read term 0 (= RNE(w)) of the three-term packings
-        if ((rc = upload(m, &m->w3h_enc, pack_w_hh_x3(w->enc_w_hh)))) return rc;
-        if ((rc = upload(m, &m->w3h_dec, pack_w_hh_x3(w->dec_w_hh)))) return rc;
-        if ((rc = upload(m, &m->w3i_dec, pack_w_ih_x3(w->dec_w_ih)))) return rc;
-        if ((rc = upload(m, &m->w3i_enc, pack_w_ih_x3(w->enc_w_ih, kF)))) return rc;
+        // The fused kernels read term 0 (= RNE(w)) of the three-term packings -- of PRESCALED weights: the rows of the r
+        // and z gates times -log2(e), those of the n gate times 2 log2(e) (in fp32, before the rounding to bf16), and the
+        // biases below likewise, so that a gate's accumulator is the argument of its exp2 (gru_cell2_pre, kernels_gru.h).
+        auto scaled = [&](const float* const src[2], int K) {
+            std::vector<float> out((size_t)2 * kG * K);
+            for (int d = 0; d < 2; ++d)
+                for (int r = 0; r < kG; ++r)
+                    for (int k = 0; k < K; ++k)
+                        out[((size_t)d * kG + r) * K + k] = src[d][(size_t)r * K + k] * gate_prescale(r);
+            return out;
+        };
+        auto packed_hh = [&](const float* const src[2]) {
+            const std::vector<float> v = scaled(src, kH);
+            const float* const two[2] = {v.data(), v.data() + (size_t)kG * kH};
+            return pack_w_hh_x3(two);
+        };
+        auto packed_ih = [&](const float* const src[2], int K) {
+            const std::vector<float> v = scaled(src, K);
+            const float* const two[2] = {v.data(), v.data() + (size_t)kG * K};
+            return pack_w_ih_x3(two, K);
+        };
+        if ((rc = upload(m, &m->w3h_enc, packed_hh(w->enc_w_hh)))) return rc;
+        if ((rc = upload(m, &m->w3h_dec, packed_hh(w->dec_w_hh)))) return rc;
+        if ((rc = upload(m, &m->w3i_dec, packed_ih(w->dec_w_ih, 2 * kH)))) return rc;
+        if ((rc = upload(m, &m->w3i_enc, packed_ih(w->enc_w_ih, kF)))) return rc;
         if ((rc = dev_alloc(m, &m->xb, (size_t)m->max_tiles * kSeq * 192))) return rc;
         if ((rc = dev_alloc(m, &m->y1p, (size_t)m->max_tiles * kY1bTileStride))) return rc;
     }
@@ -558,6 +581,10 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
             for (int c = 0; c < kG; ++c)
                 bias[dir * kG + c] = b_ih[dir][c] + (c < 2 * kH ? b_hh[dir][c] : 0.f);
             for (int u = 0; u < kH; ++u) bhn[dir * kH + u] = b_hh[dir][2 * kH + u];
+            if (precision == HELEN_PRECISION_BF16) {             // prescaled like the weights (above)
+                for (int c = 0; c < kG; ++c) bias[dir * kG + c] *= gate_prescale(c);
+                for (int u = 0; u < kH; ++u) bhn[dir * kH + u] *= gate_prescale(2 * kH + u);
+            }
         }
         if ((rc = upload(m, layer ? &m->bias_dec : &m->bias_enc, bias))) return rc;
         if ((rc = upload(m, layer ? &m->bhn_dec : &m->bhn_enc, bhn))) return rc;

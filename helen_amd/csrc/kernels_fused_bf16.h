@@ -206,7 +206,7 @@ __global__ __launch_bounds__(512) void gru_fused_bf16_kernel(
         }
         // B: gates
         {   // four cells as two packed pairs (gru_cell4): the gate math is what bounds this kernel
-            const f32x4 hn4 = gru_cell4(ar, az, ahn, gin[2], hprev);
+            const f32x4 hn4 = gru_cell4_pre(ar, az, ahn, gin[2], hprev);     // (weights and biases prescaled: kernels_gru.h)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 hprev[r] = hn4[r];

@@ -12,7 +12,7 @@
 #define HELEN_BF16_IL_ADEPTH(dec) ((dec) ? 5 : 7)
 #endif
 #ifndef HELEN_BF16_IL_LEAD         // gate slots ahead of the first MFMA of a region
-#define HELEN_BF16_IL_LEAD 6
+#define HELEN_BF16_IL_LEAD(dec) ((dec) ? 6 : 2)
 #endif
 
 #define HELEN_PIN(x) asm volatile("" : "+v"(x))
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
 #endif
     constexpr int NIN = 3 * MI, NHEAD = DEC ? 2 : 0, NREC = 12;
     constexpr int NM = NIN + NHEAD + NREC;            // MFMAs of one M phase: the step's input part, head slice of h(s-1), recurrent part
-    constexpr int NS = 44;                            // gate slots (the il kernel's program)
+    constexpr int NS = 40;                            // gate slots
 
     // One region between two barriers: the MFMA phase of tile X at step s, and -- if `gates` -- the gate math of tile
     // O = 1 - X at its newest step so (whose accumulators are in P*[O]), slot by slot behind the MFMAs.
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
         f32x4 ar = splat4(bi[0]), az = splat4(bi[1]), gnx = splat4(bi[2]), ahn = splat4(bn), pl = splat4(0.f);
         // gate state of tile o: four cells (rows 4q + c of unit u)
         const f32x4 gr = Pr[o], gz = Pz[o], gnn = Pn[o], ggn = Pg[o];
-        float t1[4], t2[4], e1[4], e2[4], rg[4], zg[4], t3[4], e3[4], u3[4], qq[4], ng[4], dd[4], hn[4], hp[4];
+        float e1[4], e2[4], rg[4], zg[4], t3[4], e3[4], u3[4], qq[4], ng[4], dd[4], hn[4], hp[4];
         const float* hpo = (const float*)(obase + hsel(ow ^ 1)) + hoff;   // h_o(so - 1): fp32 buffer so & 1
         // A fragments: the MI K32 groups of tile x's input row of step s, then the four of h_x(s-1).  AD in flight, fragment
         // f + AD fetched behind the last MFMA of group f.  Inline asm loads (an ordinary LDS load is free to sink below the
@@ -238,41 +238,38 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
             constexpr int k = decltype(K)::value;
             if constexpr (!gates || k >= NS) {
                 return;
-            } else if constexpr (k < 4) {                 // P1
-                t1[k] = gr[k] * -1.4426950408889634f;
-                t2[k] = gz[k] * -1.4426950408889634f;
-            } else if constexpr (k < 12) {                // T: e1, e2
-                constexpr int c = (k - 4) >> 1;
-                if constexpr (((k - 4) & 1) == 0) e1[c] = __builtin_amdgcn_exp2f(t1[c]);
-                else e2[c] = __builtin_amdgcn_exp2f(t2[c]);
-            } else if constexpr (k < 16) {                // P2
-                constexpr int c = k - 12;
+            } else if constexpr (k < 8) {                 // T: e1, e2 (the accumulators ARE the arguments of exp2: prescaled weights)
+                constexpr int c = k >> 1;
+                if constexpr ((k & 1) == 0) e1[c] = __builtin_amdgcn_exp2f(gr[c]);
+                else e2[c] = __builtin_amdgcn_exp2f(gz[c]);
+            } else if constexpr (k < 12) {                // P2
+                constexpr int c = k - 8;
                 e1[c] = 1.0f + e1[c];
                 e2[c] = 1.0f + e2[c];
-            } else if constexpr (k < 24) {                // T: r, z
-                constexpr int c = (k - 16) >> 1;
-                if constexpr (((k - 16) & 1) == 0) rg[c] = __builtin_amdgcn_rcpf(e1[c]);
+            } else if constexpr (k < 20) {                // T: r, z
+                constexpr int c = (k - 12) >> 1;
+                if constexpr (((k - 12) & 1) == 0) rg[c] = __builtin_amdgcn_rcpf(e1[c]);
                 else zg[c] = __builtin_amdgcn_rcpf(e2[c]);
-            } else if constexpr (k < 28) {                // P3 (and this cell's previous h on its way from LDS)
-                constexpr int c = k - 24;
-                t3[c] = __builtin_fmaf(rg[c], gnn[c], ggn[c]) * 2.8853900817779268f;
+            } else if constexpr (k < 24) {                // P3 (and this cell's previous h on its way from LDS)
+                constexpr int c = k - 20;
+                t3[c] = __builtin_fmaf(rg[c], gnn[c], ggn[c]);
                 hp[c] = hpo[4 * c];
-            } else if constexpr (k < 32) {                // T: e3
-                constexpr int c = k - 28;
+            } else if constexpr (k < 28) {                // T: e3
+                constexpr int c = k - 24;
                 e3[c] = __builtin_amdgcn_exp2f(t3[c]);
-            } else if constexpr (k < 34) {                // P4
-                constexpr int c = 2 * (k - 32);
+            } else if constexpr (k < 30) {                // P4
+                constexpr int c = 2 * (k - 28);
                 u3[c] = 1.0f + e3[c];
                 u3[c + 1] = 1.0f + e3[c + 1];
-            } else if constexpr (k < 38) {                // T: 1 / (1 + e3)
-                constexpr int c = k - 34;
+            } else if constexpr (k < 34) {                // T: 1 / (1 + e3)
+                constexpr int c = k - 30;
                 qq[c] = __builtin_amdgcn_rcpf(u3[c]);
-            } else if constexpr (k < 42) {                // P5
-                constexpr int c = k - 38;
+            } else if constexpr (k < 38) {                // P5
+                constexpr int c = k - 34;
                 ng[c] = __builtin_fmaf(-2.0f, qq[c], 1.0f);
                 dd[c] = hp[c] - ng[c];
             } else {                                      // P6
-                constexpr int c = 2 * (k - 42);
+                constexpr int c = 2 * (k - 38);
                 hn[c] = __builtin_fmaf(zg[c], dd[c], ng[c]);
                 hn[c + 1] = __builtin_fmaf(zg[c + 1], dd[c + 1], ng[c + 1]);
             }
@@ -333,7 +330,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
             }
         };
         // kLead gate slots go first: they cover the LDS latency of the first A fragment
-        constexpr int kLead = HELEN_BF16_IL_LEAD;
+        constexpr int kLead = HELEN_BF16_IL_LEAD(DEC);
         static_for<(NM + kLead > NS ? NM + kLead : NS)>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
             __builtin_amdgcn_sched_barrier(0);
@@ -432,7 +429,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
         float hp[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) hp[r] = ((const float*)(obase + hsel(last ^ 1)))[hoff + 4 * r];
-        const f32x4 hn4 = gru_cell4(Pr[1], Pz[1], Pn[1], Pg[1], hp);
+        const f32x4 hn4 = gru_cell4_pre(Pr[1], Pz[1], Pn[1], Pg[1], hp);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             ((float*)(obase + hsel(last)))[hoff + 4 * r] = hn4[r];

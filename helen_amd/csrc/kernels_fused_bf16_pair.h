@@ -248,10 +248,8 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_pair_kernel(
         if (!late) publish();
 #ifdef HELEN_BP_NOGATES   // timing probes: results are garbage
         const f32x4 hn4 = ar + az + ahn + gn;
-#elif defined(HELEN_BP_SCALAR_GATES)
-        const f32x4 hn4 = gru_cell4_scalar(ar, az, ahn, gn, hprev[x]);
 #else
-        const f32x4 hn4 = gru_cell4(ar, az, ahn, gn, hprev[x]);
+        const f32x4 hn4 = gru_cell4_pre(ar, az, ahn, gn, hprev[x]);       // (weights and biases prescaled: kernels_gru.h)
 #endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

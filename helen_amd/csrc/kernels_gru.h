@@ -64,6 +64,22 @@ __device__ __forceinline__ f32x2 gru_cell2(f32x2 sr, f32x2 sz, f32x2 an, f32x2 g
 __device__ __forceinline__ f32x2 gru_cell2(f32x2 ar, f32x2 az, f32x2 an, f32x2 gr, f32x2 gz, f32x2 gn, f32x2 hp) {
     return gru_cell2(ar + gr, az + gz, an, gn, hp);
 }
+// The same cell for PRESCALED pre-activations (bf16 mode, round 4): the rows of W_ih, W_hh and the biases of the r and z
+// gates are multiplied by -log2(e) and those of the n gate by 2 log2(e) before they are rounded to bf16 (api.hip), so the
+// accumulators arrive as the arguments of exp2 and three multiplications per cell disappear:
+//     r = rcp(1 + exp2(sr')), z = rcp(1 + exp2(sz')), n = fma(-2, rcp(1 + exp2(fma(r, an', gn'))), 1), h' = fma(z, h - n, n)
+__device__ __forceinline__ f32x2 gru_cell2_pre(f32x2 sr, f32x2 sz, f32x2 an, f32x2 gn, f32x2 hp) {
+    const f32x2 one = {1.0f, 1.0f}, m2 = {-2.0f, -2.0f};
+    const f32x2 rg = rcp_pair(one + exp2_pair(sr));
+    const f32x2 zg = rcp_pair(one + exp2_pair(sz));
+    const f32x2 ng = __builtin_elementwise_fma(m2, rcp_pair(one + exp2_pair(__builtin_elementwise_fma(rg, an, gn))), one);
+    return __builtin_elementwise_fma(zg, hp - ng, ng);
+}
+__device__ __forceinline__ f32x4 gru_cell4_pre(f32x4 sr, f32x4 sz, f32x4 an, f32x4 gn, const float (&hp)[4]) {
+    const f32x2 lo = gru_cell2_pre(sr.xy, sz.xy, an.xy, gn.xy, f32x2{hp[0], hp[1]});
+    const f32x2 hi = gru_cell2_pre(sr.zw, sz.zw, an.zw, gn.zw, f32x2{hp[2], hp[3]});
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
 __device__ __forceinline__ f32x4 gru_cell4(f32x4 sr, f32x4 sz, f32x4 an, f32x4 gn, const float (&hp)[4]) {
     const f32x2 lo = gru_cell2(sr.xy, sz.xy, an.xy, gn.xy, f32x2{hp[0], hp[1]});
     const f32x2 hi = gru_cell2(sr.zw, sz.zw, an.zw, gn.zw, f32x2{hp[2], hp[3]});

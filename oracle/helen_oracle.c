@@ -65,7 +65,13 @@ typedef struct {
     float* w_hh_t; /* [H, 3H] */
     const float* b_ih;
     const float* b_hh;
+    float* b_own;  /* bf16 emulation: the prescaled copies b_ih / b_hh point into */
 } Dir;
+
+/* bf16 emulation, as the HIP bf16 mode does it since round 4 (helen_amd/csrc/api.hip gate_prescale, kernels_gru.h
+ * gru_cell2_pre): the rows of the r and z gates are multiplied by -log2(e) and those of the n gate by 2 log2(e) in fp32
+ * BEFORE the rounding to bf16, the biases likewise, and the gates are evaluated on exp2 of the accumulators. */
+static inline float gate_prescale(int row, int H) { return row < 2 * H ? -1.4426950408889634f : 2.8853900817779268f; }
 
 static void dir_init(Dir* d, const float* w_ih, const float* w_hh, const float* b_ih,
                      const float* b_hh, int K, int H) {
@@ -73,16 +79,34 @@ static void dir_init(Dir* d, const float* w_ih, const float* w_hh, const float* 
     d->H = H;
     d->w_ih_t = transpose_(w_ih, 3 * H, K);
     d->w_hh_t = transpose_(w_hh, 3 * H, H);
-    if (g_precision) {
-        for (size_t i = 0; i < (size_t)3 * H * K; ++i) d->w_ih_t[i] = bf16r(d->w_ih_t[i]);
-        for (size_t i = 0; i < (size_t)3 * H * H; ++i) d->w_hh_t[i] = bf16r(d->w_hh_t[i]);
-    }
     d->b_ih = b_ih;
     d->b_hh = b_hh;
+    d->b_own = NULL;
+    if (g_precision) {
+        const int G = 3 * H;
+        for (int k = 0; k < K; ++k)
+            for (int j = 0; j < G; ++j) d->w_ih_t[(size_t)k * G + j] = bf16r(d->w_ih_t[(size_t)k * G + j] * gate_prescale(j, H));
+        for (int k = 0; k < H; ++k)
+            for (int j = 0; j < G; ++j) d->w_hh_t[(size_t)k * G + j] = bf16r(d->w_hh_t[(size_t)k * G + j] * gate_prescale(j, H));
+        /* the kernels add b_ih + b_hh of the r and z gates first, then scale the sum; the n gate's two biases separately */
+        d->b_own = (float*)malloc(sizeof(float) * 2 * (size_t)G);
+        for (int j = 0; j < G; ++j) {
+            if (j < 2 * H) {
+                d->b_own[j] = (b_ih[j] + b_hh[j]) * gate_prescale(j, H);
+                d->b_own[G + j] = 0.f;
+            } else {
+                d->b_own[j] = b_ih[j] * gate_prescale(j, H);
+                d->b_own[G + j] = b_hh[j] * gate_prescale(j, H);
+            }
+        }
+        d->b_ih = d->b_own;
+        d->b_hh = d->b_own + G;
+    }
 }
 static void dir_free(Dir* d) {
     free(d->w_ih_t);
     free(d->w_hh_t);
+    free(d->b_own);
 }
 
 /* One GRU direction over T steps for a block of nb <= OB windows (windows never interact; the
@@ -124,6 +148,13 @@ static void gru_dir(const Dir* d, const float* const* x, int xs, int T, int reve
             }
             float* hb = h[b];
             for (int j = 0; j < H; ++j) {
+                if (g_precision) { /* prescaled: the accumulators are the arguments of exp2 */
+                    const float r = 1.0f / (1.0f + exp2f(a[j] + c[j]));
+                    const float z = 1.0f / (1.0f + exp2f(a[H + j] + c[H + j]));
+                    const float n = 1.0f - 2.0f / (1.0f + exp2f(a[2 * H + j] + r * c[2 * H + j]));
+                    hb[j] = n + z * (hb[j] - n);
+                    continue;
+                }
                 const float r = sigmoidf_(a[j] + c[j]);
                 const float z = sigmoidf_(a[H + j] + c[H + j]);
                 const float n = tanhf(a[2 * H + j] + r * c[2 * H + j]);
