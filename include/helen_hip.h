@@ -78,7 +78,9 @@ typedef struct HelenModel HelenModel;
 enum {
     HELEN_PRECISION_FP32 = 0,  /* v_mfma_f32_16x16x4_f32, exact fp32 (BASELINE.json configs 1-3) */
     HELEN_PRECISION_BF16 = 1,  /* bf16 MFMA operands, fp32 accumulate/state (config 4); projections fused into
-                                  the recurrence, no gate pre-activations in memory */
+                                  the recurrence, no gate pre-activations in memory.  Gate weights and biases
+                                  are scaled by the gates' exp2 factors before they are rounded to bf16; the
+                                  heads take h and their weights as two bf16 terms each (16 significant bits) */
     HELEN_PRECISION_FP32X3 = 2 /* opt-in: gate matmuls as exact bf16 partial products (each fp32 operand =
                                   three bf16 terms, six leading products; pileup counts are one term),
                                   fp32 accumulate: fp32-class results on the bf16 matrix cores */
