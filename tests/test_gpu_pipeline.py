@@ -6,6 +6,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch
 
 from helen_amd import hdf5
 from helen_amd.weights import make_weights
@@ -103,6 +104,34 @@ def test_cli_polish_with_workers(workdir):
             store.write_prediction("chr20_synth", cs, cs + 1000, chunk, pos, eb, er)
     want = naive_stitch.stitch_directory(str(odir), threads=1)    # polish ran with -t 1 (helen.py default)
     assert list(want) == ["chr20_synth"] and want["chr20_synth"] == fasta[1]
+
+
+def test_cli_polish_in_bf16_mode(workdir):
+    """BASELINE.json configs[3] through the product's own command: `$HELEN_PRECISION=bf16 helen polish ...` writes the same
+    files with the same names and dtypes; its labels are the bf16 ENGINE's labels of the same windows (the command adds
+    nothing of its own) and all but a sliver of the fp32 oracle's."""
+    from helen_amd.engine import HelenEngine
+    from helen_amd.sequence_dataset import SequenceDataset
+    d, w, model, img_dir, expected = workdir
+    out = str(d / "out_cli_bf16")
+    env = dict(os.environ, HELEN_PRECISION="bf16")
+    r = subprocess.run([os.path.join(ROOT, "bin", "helen"), "polish", "-i", img_dir, "-m", model, "-b", "32", "-w", "2",
+                        "-o", out, "-p", "asm16", "-g", "-d_ids", "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    pdir = os.path.join(out, [x for x in os.listdir(out) if x.startswith("predictions_")][0])
+    files = [os.path.join(pdir, f) for f in sorted(os.listdir(pdir))]
+    assert [os.path.basename(f) for f in files] == ["asm16_0.hdf"]
+    ds = SequenceDataset(img_dir)
+    items = [ds[i] for i in range(len(ds))]
+    eng = HelenEngine(w, device=0, max_windows=128, precision="bf16")
+    b16, r16 = eng.polish(torch.from_numpy(np.stack([it[4] for it in items])).cuda())[:2]
+    b16, r16 = b16.cpu().numpy(), r16.cpu().numpy()
+    eng.close()
+    _check_prediction_files(files, {(it[1], it[3]): (b16[i], r16[i], it[5]) for i, it in enumerate(items)})
+    same = np.mean([np.mean(b16[i] == expected[(it[1], it[3])][0]) * 0.5 + np.mean(r16[i] == expected[(it[1], it[3])][1]) * 0.5
+                    for i, it in enumerate(items)])
+    assert same > 0.98, same          # random-init weights: thin margins (the trained-network bar is in test_gpu_parity.py)
+    assert os.path.getsize(os.path.join(out, "asm16.fa")) > 1000
 
 
 def test_drop_in_model_object(workdir):
