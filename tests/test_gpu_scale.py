@@ -427,6 +427,13 @@ def test_bf16_kernel_choice_gives_the_same_bits(scale_case, monkeypatch, two_til
     # a batch above the engine's capacity is sliced by the operator entry as polish() slices it
     for u, v_ in zip(small.chunk_forward(x[:2500], h[:2500]), big.chunk_forward(x[:2500], h[:2500])):
         assert torch.equal(u, v_)
+    # short and odd sequences through the two-tile kernels (prologue, steady loop and tail of the region schedule; the row
+    # ring's one-step lookahead at its ends): T = 1, 2, 3, 4, 5 and 37 against the one-tile-per-workgroup kernel
+    for T in (1, 2, 3, 4, 5, 37):
+        xs, hs = x[:, :T].contiguous(), h
+        parts = [small.chunk_forward(xs[i:i + 1024], hs[i:i + 1024]) for i in range(0, 4096, 1024)]
+        for name, u, v_ in zip(("base", "rle", "hidden"), big.chunk_forward(xs, hs), (torch.cat(t) for t in zip(*parts))):
+            assert torch.equal(u, v_), "T = %d: %s differs between the two-tile and the one-tile kernels" % (T, name)
     for e in (big, small, odd):
         e.close()
 
