@@ -367,8 +367,7 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
         // gru_fused_bf16_pair_kernel runs them one after the other (all bit-identical).  Measured per launch of 8192
         // windows (profiles/r04_bf16_own.txt): encoder 0.322 against 0.319-0.335 ms, decoder 0.485 against 0.500 since
         // round 4's form of the kernel (a step's input part in its own region): both interleaved.  HELEN_BF16_IL = two digits, encoder
-        // then decoder: 0 = pair, 1 = interleaved, 2 = pair with waves 4-7 skewed by a phase
-        // (A/B probes).
+        // then decoder: 0 = pair, 1 = interleaved (A/B probes).
         const char il_enc = m->overrides.bf16_il_enc ? m->overrides.bf16_il_enc : HELEN_BF16_ENC_DEFAULT;
         const char il_dec = m->overrides.bf16_il_dec ? m->overrides.bf16_il_dec : HELEN_BF16_DEC_DEFAULT;
         if (bf16_pair_pays(tiles, m->cus, m->overrides)) {
@@ -378,10 +377,8 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
 #define HELEN_DEC_ARGS m->y1p, kY1bTileStride, 0, T, m->w3i_dec, m->w3h_dec, m->bias_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, \
                        kY1bTileStride, m->whd, m->plogit, kPlTileStride, tiles
             if (il_enc == '1') LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_il_kernel<3, false>), grid, block, HELEN_ENC_ARGS);
-            else if (il_enc == '2') LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_pair_kernel<3, false, true>), grid, block, HELEN_ENC_ARGS);
             else LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_pair_kernel<3, false>), grid, block, HELEN_ENC_ARGS);
             if (il_dec == '1') LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_il_kernel<8, true>), grid, block, HELEN_DEC_ARGS);
-            else if (il_dec == '2') LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_pair_kernel<8, true, true>), grid, block, HELEN_DEC_ARGS);
             else LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_pair_kernel<8, true>), grid, block, HELEN_DEC_ARGS);
 #undef HELEN_ENC_ARGS
 #undef HELEN_DEC_ARGS

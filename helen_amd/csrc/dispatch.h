@@ -54,7 +54,7 @@ struct Overrides {
     int enc_ws8 = -1, enc_ws8p = -1, enc_ws8p_parts = 0;
     int split = -1, split_at = 0;
     int bf16_pair = -1;
-    char bf16_il_enc = 0, bf16_il_dec = 0;      // '0' pair, '1' interleaved, '2' skewed pair; 0 = the default
+    char bf16_il_enc = 0, bf16_il_dec = 0;      // '0' pair, '1' interleaved; 0 = the default
     int persistent = -1;                        // (only in builds with -DHELEN_WITH_PERSISTENT)
     int host_lock = -1;                         // helen_polish_host: 0 never page-lock caller memory, 1 ranges that own their pages, 2 all
     bool verbose = false;

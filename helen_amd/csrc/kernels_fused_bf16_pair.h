@@ -32,18 +32,10 @@ namespace helen {
 // row has a half-step plus an MFMA phase (~1.3 us) to arrive, and it is first read after that barrier.
 // grid (ceil(tiles / 2), 2 directions).  An odd tile count makes the last workgroup do its one tile twice.
 // ------------------------------------------------------------------------------------------------
-//
-// SKEW (round 3): waves 4-7 -- the second wave of every SIMD -- run the same half-steps with the barrier BEHIND the
-// gates instead of in front of them:
-//     waves 0-3:   ... | G(x,s)  M(o,s)  | G(o,s)  M(x,s+1) | ...
-//     waves 4-7:   ... | M(o,s)  G(o,s)  | M(x,s+1) G(x,s+1) | ...
-// so that in every interval between two barriers each SIMD has one wave in its gate math while the other is in its
-// MFMA phase (the bf16 MFMA and the VALU issue side by side from different waves, ub_bf16_overlap.txt case C
-// "offset") instead of both waves fighting first for the matrix pipe and then for the VALU.  Every M still reads only
-// what a barrier has published: M(o,s) of waves 4-7 needs G(o,s-1) of waves 0-3 (the interval before) and their own
-// (two before); M(o,s) of waves 0-3 needs G(o,s-1) of waves 4-7 (two before).  Same instructions per wave, same
-// results bit for bit.
-template <int MI, bool DEC, bool SKEW = false>
+// (Round 3 also measured this kernel with waves 4-7 skewed by a phase -- barrier behind the gates instead of in front --
+// so that each SIMD always had one wave in its gate math and one in its MFMAs: encoder 0.155 for 0.157 ms, decoder 0.249
+// for 0.241; the variant left the tree in round 4.)
+template <int MI, bool DEC>
 __global__ __launch_bounds__(512, 1) void gru_fused_bf16_pair_kernel(
     const f32x4* __restrict__ in, long in_tile_stride, int pos0, int T, const bf16x8* __restrict__ Wi3,
     const bf16x8* __restrict__ Wh3, const float* __restrict__ bias, const float* __restrict__ bhn,
@@ -183,10 +175,9 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_pair_kernel(
 #define HELEN_BP_TICK(i)
 #endif
     // One half-step of tile X at step s (CUR = s & 1).  STEADY: 2 <= s and s + 2 < T are compile-time facts.
-    auto half_step = [&](auto X, auto CUR, auto STEADY, auto LATE, int s) __attribute__((always_inline)) {
+    auto half_step = [&](auto X, auto CUR, auto STEADY, int s) __attribute__((always_inline)) {
         constexpr int x = decltype(X)::value, o = 1 - x, cur = decltype(CUR)::value;
         constexpr bool steady = decltype(STEADY)::value;
-        constexpr bool late = decltype(LATE)::value;             // waves 4-7 of the SKEW schedule: barrier behind the gates
         constexpr int ocur = x ? (cur ^ 1) : cur;                // buffer of h_o(so): (so + 1) & 1
         const bool has_prev = steady || s > 0;
         const bool has_prev2 = steady || s > 1;
@@ -245,7 +236,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_pair_kernel(
             a_pref = ((const bf16x8*)(smem + o * kPerTile + 1024 + ocur * 256))[lane];   // next phase starts on h_o
             __builtin_amdgcn_sched_barrier(0);
         };
-        if (!late) publish();
+        publish();
 #ifdef HELEN_BP_NOGATES   // timing probes: results are garbage
         const f32x4 hn4 = ar + az + ahn + gn;
 #else
@@ -262,38 +253,29 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_pair_kernel(
         if (DEC && has_prev) (base + kPart + (((s - 1) & 1) * 8 + v) * 64)[lane] = pl;
         __builtin_amdgcn_sched_barrier(0);
         HELEN_BP_TICK(3)
-        if (late) publish();
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using No = std::false_type;
     using Yes = std::true_type;
-    auto run = [&](auto LATE) __attribute__((always_inline)) {
-        auto step = [&](int s_) __attribute__((always_inline)) {
-            if (s_ & 1) {
-                half_step(I0{}, I1{}, No{}, LATE, s_);
-                half_step(I1{}, I1{}, No{}, LATE, s_);
-            } else {
-                half_step(I0{}, I0{}, No{}, LATE, s_);
-                half_step(I1{}, I0{}, No{}, LATE, s_);
-            }
-        };
-        int s = 0;
-        for (; s < T && s < 2; ++s) step(s);
-        for (; s + 3 < T; s += 2) {                           // steady state: s >= 2 and (s + 1) + 2 < T
-            half_step(I0{}, I0{}, Yes{}, LATE, s);
-            half_step(I1{}, I0{}, Yes{}, LATE, s);
-            half_step(I0{}, I1{}, Yes{}, LATE, s + 1);
-            half_step(I1{}, I1{}, Yes{}, LATE, s + 1);
+    auto step = [&](int s_) __attribute__((always_inline)) {
+        if (s_ & 1) {
+            half_step(I0{}, I1{}, No{}, s_);
+            half_step(I1{}, I1{}, No{}, s_);
+        } else {
+            half_step(I0{}, I0{}, No{}, s_);
+            half_step(I1{}, I0{}, No{}, s_);
         }
-        for (; s < T; ++s) step(s);
     };
-#ifdef HELEN_BF16_STATIC_PRIO   // probe: static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-    if (v >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
-    // (both schedules execute 2T barriers; s_barrier counts arrivals, whatever the program counter)
-    if (SKEW && v >= 4) run(Yes{});
-    else run(No{});
+    int s = 0;
+    for (; s < T && s < 2; ++s) step(s);
+    for (; s + 3 < T; s += 2) {                           // steady state: s >= 2 and (s + 1) + 2 < T
+        half_step(I0{}, I0{}, Yes{}, s);
+        half_step(I1{}, I0{}, Yes{}, s);
+        half_step(I0{}, I1{}, Yes{}, s + 1);
+        half_step(I1{}, I1{}, Yes{}, s + 1);
+    }
+    for (; s < T; ++s) step(s);
 #ifdef HELEN_BP_TIMING
     if (blockIdx.x == 0 && lane == 0)
         printf("bf16 pair %s dir %d wave %d: cycles per half-step  mfma phase %lld  vmcnt %lld  barrier %lld  gates %lld\n",

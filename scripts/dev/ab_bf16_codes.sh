@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer probe (run ON the GPU box): bf16 mode at batch 512 for a list of HELEN_BF16_IL codes (encoder digit, decoder
-# digit: 0 pair, 1 interleaved (the default for both), 2 skewed pair), optionally with another library:  LIB=name scripts/dev/ab_bf16_codes.sh 11 00 10
+# digit: 0 pair, 1 interleaved (the default for both)), optionally with another library:  LIB=name scripts/dev/ab_bf16_codes.sh 11 00 10
 mkdir -p gpurun_out/ab_il
 if [ -n "$LIB" ]; then export HELEN_HIP_LIB=$PWD/build/lib_$LIB.so; fi
 for il in "$@"; do
