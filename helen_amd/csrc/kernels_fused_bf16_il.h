@@ -36,8 +36,9 @@ namespace helen {
 //     wave: phases aligned 1588 cycles, offset 1466, one interleaved stream 1291).
 // So here the region between two barriers is ONE stream: MFMA i of M(x,s) followed by slot i of G(o,.) -- a slot is
 // one transcendental or two plain scalar instructions of the gate math of the other tile's newest step, four cells
-// per lane staggered so that no slot waits for the one before it.  The decoder's 40 MFMAs per region hide all 24
-// transcendentals and most of the plain work; the encoder's 21 hide half and the rest follows the last MFMA.
+// per lane staggered so that no slot waits for the one before it: 40 slots per region (24 transcendentals, 16 plain
+// pairs; the gates' exp2 factors are folded into the weights, kernels_gru.h gru_cell2_pre).  The decoder's 38 MFMAs per
+// region cover nearly all of them; the encoder's 21 cover half and the rest follows the last MFMA.
 // ------------------------------------------------------------------------------------------------
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -57,7 +58,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 // as every other bf16 kernel: bit-identical), the n gate's input part in its own chain.  Nothing is carried but the
 // finished accumulators awaiting their gate math, all 36 weight fragments of a decoder wave are resident, and the row a
 // region needs was DMA'd a whole step earlier (lookahead one step, ring of two).  Decoder launch of 8,192 windows:
-// 0.485 ms against the pair kernel's 0.500 (profiles/r04_bf16_own.txt); encoder as before.
+// 0.485 ms against the pair kernel's 0.500 when this form came in; with the bf16 head and the prescaled gates 0.447 against
+// 0.486 (profiles/r04_bf16_own.txt); encoder 0.317 against 0.321.
 // ------------------------------------------------------------------------------------------------
 template <int MI, bool DEC>
 __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
