@@ -98,6 +98,28 @@ def cpu_baseline(batch, seconds_target=12.0):
                       "8-window blocks, %d threads = usable CPUs under the cgroup quota), %.1f s" % (n, threads, dt)}
 
 
+def host_mode(seconds_target=8.0):
+    """The product's OWN path for runs without --gpu_mode (helen_amd/csrc/cpu_path.cpp through helen_amd/cpu_engine.py: not
+    the oracle), on a bounded sample with every usable thread: what `helen polish` without -g does per caller."""
+    from helen_amd.cpu_engine import CpuEngine
+    from helen_amd.weights import make_images, make_weights
+    threads = usable_cpus()
+    eng = CpuEngine(make_weights(input_scale=1.0 / 64.0), threads=threads)
+    probe = make_images(threads * 16, seed=3)          # one 16-window block per thread
+    t0 = time.time()
+    eng.polish_host(probe)
+    rate = probe.shape[0] / (time.time() - t0)
+    n = max(16, int(min(max(rate * seconds_target, probe.shape[0]), 8192)) // 16 * 16)
+    img = make_images(n, seed=4)
+    t0 = time.time()
+    eng.polish_host(img)
+    dt = time.time() - t0
+    eng.close()
+    return {"value": round(n / dt, 2), "unit": "windows/s", "threads": threads,
+            "what": "libhelen_cpu.so (the product's host path: fp32, OpenMP over 16-window blocks), %d uniform-random windows, "
+                    "%.1f s; labels pinned to the same goldens as the GPU path (tests/test_cpu_path.py)" % (n, dt)}
+
+
 def call_size_report(images, dev):
     """Throughput of ONE fp32 device call of fewer windows than the headline's 4096 (inputs resident in HBM; 1 warm-up call,
     then 6 timed ones): which kernels a call takes depends on how many tiles it has (quarter / half tiles on
@@ -747,6 +769,10 @@ def main():
                     out["modes"][prec] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B)
+            try:
+                out["host_mode"] = host_mode()
+            except Exception as e:          # noqa: BLE001 -- an extra leg must not take the headline down with it
+                out["host_mode"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
     eng.close()                # call_consensus builds its own engines (15.9 GB of scratch each)
     # (call_consensus is the fp32 product path: the opt-in arithmetic modes carry the leg only on request)
     e2e_windows = (E2E_DEFAULT_WINDOWS if args.precision == "fp32" else 0) if args.e2e is None else args.e2e
