@@ -167,6 +167,16 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
             ((unsigned short*)(smem + x * kPerTile + kPlane))[poff + 8 * r] =
                 bf16_bits(((const float*)(smem + x * kPerTile))[hoff + 4 * r]);
     __syncthreads();
+    // The encoder keeps the previous h of a lane's four cells in registers (it has them to spare) and writes the fp32
+    // state to LDS only once, at the end; the decoder's head reads that state every step, and its registers are full.
+    // (Encoder launch of 8,192 windows 0.315 -> 0.291 ms.  The decoder with registers for the gates and LDS for the head
+    // spills: 0.443 -> 0.465-0.501 ms, profiles/r04_bf16_own.txt.)
+    constexpr bool kRegH = !DEC;
+    float hprev[2][4];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hprev[x][r] = ((const float*)(smem + x * kPerTile))[hoff + 4 * r];
 
     // Pending gate math of each tile: the finished accumulators of its newest step.
     f32x4 Pr[2], Pz[2], Pn[2], Pg[2];
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
             } else if constexpr (k < 24) {                // P3 (and this cell's previous h on its way from LDS)
                 constexpr int c = k - 20;
                 t3[c] = __builtin_fmaf(rg[c], gnn[c], ggn[c]);
-                hp[c] = hpo[4 * c];
+                hp[c] = kRegH ? hprev[o][c] : hpo[4 * c];
             } else if constexpr (k < 28) {                // T: e3
                 constexpr int c = k - 24;
                 e3[c] = __builtin_amdgcn_exp2f(t3[c]);
@@ -355,7 +365,8 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
         if constexpr (gates) {     // new h of tile o -> LDS (fp32 state / layer output, bf16 plane)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                ((float*)(obase + hsel(ow)))[hoff + 4 * r] = hn[r];
+                if constexpr (kRegH) hprev[o][r] = hn[r];
+                else ((float*)(obase + hsel(ow)))[hoff + 4 * r] = hn[r];
                 ((unsigned short*)(obase + psel(ow)))[poff + 8 * r] = bf16_bits(hn[r]);
             }
         }
@@ -430,12 +441,16 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
         f32x4* const obase = smem + kPerTile;
         float hp[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hp[r] = ((const float*)(obase + hsel(last ^ 1)))[hoff + 4 * r];
+        for (int r = 0; r < 4; ++r) hp[r] = kRegH ? hprev[1][r] : ((const float*)(obase + hsel(last ^ 1)))[hoff + 4 * r];
         const f32x4 hn4 = gru_cell4_pre(Pr[1], Pz[1], Pn[1], Pg[1], hp);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             ((float*)(obase + hsel(last)))[hoff + 4 * r] = hn4[r];
             ((unsigned short*)(obase + psel(last)))[poff + 8 * r] = bf16_bits(hn4[r]);
+        }
+        if constexpr (kRegH) {      // tile 0's final state (its last gates ran in region (1, T-1), into buffer T & 1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ((float*)(smem + hsel(last)))[hoff + 4 * r] = hprev[0][r];
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
