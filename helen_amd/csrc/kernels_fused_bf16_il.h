@@ -12,7 +12,7 @@
 #define HELEN_BF16_IL_ADEPTH(dec) ((dec) ? 5 : 7)
 #endif
 #ifndef HELEN_BF16_IL_LEAD         // gate slots ahead of the first MFMA of a region
-#define HELEN_BF16_IL_LEAD(dec) ((dec) ? 6 : 2)
+#define HELEN_BF16_IL_LEAD(dec) ((dec) ? 6 : 1)
 #endif
 
 #define HELEN_PIN(x) asm volatile("" : "+v"(x))
