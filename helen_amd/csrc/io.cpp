@@ -973,6 +973,41 @@ int helen_io_emit_images(const char* path, int n, const char* contig, const int6
     return f.finish(root, bt, hp) ? 0 : fail("writing '%s' failed", path);
 }
 
+/* The general form of helen_io_emit_images: every window names its own contig, contig_end and position rows (the
+ * simulated assemblies of helen_amd.synthetic.write_assembly_dir: several contigs per file, insert and split rows).
+ *   contigs char [n, 256];  starts, ends, chunks int64 [n];  lengths int32 [n];  images uint8 [n, 1000, 90];
+ *   positions int64 [n, 1000, 3] (the first lengths[i] rows of each are stored) */
+int helen_io_emit_image_windows(const char* path, int n, const char* contigs, const int64_t* starts, const int64_t* ends,
+                                const int64_t* chunks, const int32_t* lengths, const uint8_t* images,
+                                const int64_t* positions) {
+    forget_path(path);
+    h5emit::File f;
+    if (!f.open(path)) return fail("cannot create '%s'", path);
+    std::vector<h5emit::Child> all;
+    char name[kName + 96];
+    for (int i = 0; i < n; ++i) {
+        const int L = lengths[i];
+        if (L < 0 || L > kSeq) return fail("bad length %d", L);
+        const char* contig = contigs + (size_t)i * kName;
+        if (strnlen(contig, kName) == (size_t)kName) return fail("contig name of window %d is not NUL-terminated", i);
+        const uint64_t one[1] = {1}, di[2] = {(uint64_t)L, (uint64_t)kFeat}, dp[2] = {(uint64_t)L, 3};
+        const int64_t cs = starts[i], ce = ends[i], ch = chunks[i];
+        std::vector<h5emit::Child> kids(6);
+        kids[0] = {"contig", f.string1(contig)};
+        kids[1] = {"contig_start", f.dataset(&cs, 8, 8, true, 1, one)};
+        kids[2] = {"contig_end", f.dataset(&ce, 8, 8, true, 1, one)};
+        kids[3] = {"feature_chunk_idx", f.dataset(&ch, 8, 8, true, 1, one)};
+        kids[4] = {"image", f.dataset(images + (size_t)i * kSeq * kFeat, (size_t)L * kFeat, 1, false, 2, di)};
+        kids[5] = {"position", f.dataset(positions + (size_t)i * kSeq * 3, (size_t)L * 24, 8, true, 2, dp)};
+        snprintf(name, sizeof(name), "%s-%lld-%lld-%lld", contig, (long long)cs, (long long)ce, (long long)ch);
+        all.push_back({name, f.group(kids)});
+    }
+    std::vector<h5emit::Child> top{{"images", f.group(all)}};
+    uint64_t bt = 0, hp = 0;
+    const uint64_t root = f.group(top, &bt, &hp);
+    return f.finish(root, bt, hp) ? 0 : fail("writing '%s' failed", path);
+}
+
 /* Images this process has read through the direct scanner (out[0]) and through libhdf5 (out[1]). */
 void helen_io_reader_counts(long long* out) {
     out[0] = g_fast_windows;

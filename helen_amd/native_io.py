@@ -40,6 +40,8 @@ def load():
     lib.helen_io_read_labeled.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, vp, vp, vp]
     lib.helen_io_emit_images.restype = ctypes.c_int
     lib.helen_io_emit_images.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, vp, vp, vp, vp]
+    lib.helen_io_emit_image_windows.restype = ctypes.c_int
+    lib.helen_io_emit_image_windows.argtypes = [ctypes.c_char_p, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp]
     lib.helen_io_reader_counts.restype = None
     lib.helen_io_reader_counts.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
     lib.helen_io_close_readers.restype = None
@@ -196,6 +198,22 @@ def emit_images(path, contig, starts, chunks, lengths, images):
     images = np.ascontiguousarray(images, np.uint8)
     rc = lib.helen_io_emit_images(os.fsencode(path), int(starts.shape[0]), contig.encode(), starts.ctypes.data,
                                   chunks.ctypes.data, lengths.ctypes.data, images.ctypes.data)
+    if rc != 0:
+        raise IOError(_err(lib))
+
+
+def emit_image_windows(path, contigs, starts, ends, chunks, lengths, images, positions):
+    """Image files of a simulated assembly through the direct emitter (helen_amd.synthetic.write_assembly_dir): per-window
+    contig names (list of str), contig_start / contig_end / feature_chunk_idx, stored rows, images and position rows."""
+    lib = load()
+    packed = pack_contigs(contigs)
+    starts, ends, chunks = (np.ascontiguousarray(a, np.int64) for a in (starts, ends, chunks))
+    lengths = np.ascontiguousarray(lengths, np.int32)
+    images = np.ascontiguousarray(images, np.uint8)
+    positions = np.ascontiguousarray(positions, np.int64)
+    rc = lib.helen_io_emit_image_windows(os.fsencode(path), int(starts.shape[0]), packed.ctypes.data, starts.ctypes.data,
+                                         ends.ctypes.data, chunks.ctypes.data, lengths.ctypes.data, images.ctypes.data,
+                                         positions.ctypes.data)
     if rc != 0:
         raise IOError(_err(lib))
 

@@ -103,20 +103,230 @@ def make_pileup_task(n_windows, seed=20260928, coverage=14, base_error=0.12, rl_
     base[rng.random((n_windows, L)) < 0.10] = 0
     rl = np.minimum(10, rng.geometric(0.55, size=(n_windows, L)))
     rl[base == 0] = 0
-    votes = np.zeros(n_windows * L * F, np.uint16)
-    cell = np.arange(n_windows * L, dtype=np.int64).reshape(n_windows, L) * F
+    img = _read_votes(base.ravel(), rl.ravel(), rng, coverage, base_error, rl_error).reshape(n_windows, L, F)
+    return img, base.astype(np.uint8), rl.astype(np.uint8)
+
+
+def _read_votes(base, rl, rng, coverage=14, base_error=0.12, rl_error=0.35):
+    """The noise process of make_pileup_task on flat arrays of true labels: -> uint8 [len(base), 90] feature rows."""
+    F = ImageSizeOptions.IMAGE_HEIGHT
+    n = base.shape[0]
+    votes = np.zeros(n * F, np.uint16)
+    cell = np.arange(n, dtype=np.int64) * F
     for _ in range(coverage):
-        strand = rng.integers(0, 2, size=(n_windows, L))
+        strand = rng.integers(0, 2, size=n)
         b = base.copy()
-        wrong = rng.random((n_windows, L)) < base_error
+        wrong = rng.random(n) < base_error
         b[wrong] = rng.integers(0, 5, size=int(wrong.sum()))
         r = rl.copy()
-        off = rng.random((n_windows, L)) < rl_error
+        off = rng.random(n) < rl_error
         step = np.where(rng.random(int(off.sum())) < np.where(rl[off] >= 5, 0.75, 0.5), -1, 1)
         r[off] = np.clip(r[off] + step, 1, 10)
         r[b == 0] = 0
         r[(b > 0) & (r == 0)] = 1
         feat = np.where(b == 0, strand * 45 + 44, strand * 45 + (b - 1) * 11 + r)
-        votes[(cell + feat).ravel()] += 8          # one vote per (window, position) and read: the indices are distinct
-    img = np.minimum(votes, 255).astype(np.uint8).reshape(n_windows, L, F)
-    return img, base.astype(np.uint8), rl.astype(np.uint8)
+        votes[cell + feat] += 8          # one vote per position and read: the indices are distinct
+    return np.minimum(votes, 255).astype(np.uint8).reshape(n, F)
+
+
+# ---- a simulated assembly: what `helen polish` is checked on end to end (SURVEY.md 8f, BASELINE.json configs[4] stand-in) ----
+_NOISE_VARIANTS = 64          # distinct noisy feature rows per true (base, run length) class
+
+
+class SimContig(object):
+    """One contig of a simulated draft assembly in MarginPolish's row space.  A ROW is a position key (pos, indx, split)
+    of dataloader_predict.py:69 / Stitch.py:221-231: (p, 0, 0) = draft position p, (p, 0, 1) = the continuation of a run
+    longer than 10, (p, 1, 0) = an insert column after p.  Every row has a true base label (0 = nothing there, 1..4 =
+    A, C, G, T) and a true run length; the polished truth is the rows decoded in key order, base x run length.
+
+    The contig is cut into REGIONS of `region_positions` draft positions, consecutive regions sharing `overlap` of them
+    (Options.py:17 SEQ_OVERLAP); a region's rows are cut into images of at most 1000 rows (`feature_chunk_idx` 0, 1, ...),
+    consecutive images sharing `chunk_overlap_rows` rows, the last one short.  `holes` = region indices left out (a
+    stretch no image covers: stitch fills it with N x 10, Stitch.py:176-187).
+
+    contig_start / contig_end of a region are offsets in the EXPANDED draft (run lengths spelled out), not row positions:
+    stitch takes `running_end - this_start` as the number of BASES two neighbours share (Stitch.py:141-147), so the
+    interval has to be in the sequence's own coordinates for the overlap alignment to see the shared stretch."""
+
+    def __init__(self, name, n_positions, seed, region_positions=2400, overlap=200, insert_rate=0.10,
+                 chunk_overlap_rows=16, holes=()):
+        rng = np.random.default_rng(seed)
+        n = int(n_positions)
+        L = ImageSizeOptions.SEQ_LENGTH
+        base0 = rng.integers(1, 5, size=n)
+        base0[rng.random(n) < 0.03] = 0                       # the draft has a base the truth has not
+        rl0 = np.minimum(10, rng.geometric(0.55, size=n))
+        rl0[base0 == 0] = 0
+        has_split = (rl0 == 10) & (rng.random(n) < 0.5)
+        has_insert = rng.random(n) < insert_rate
+        per = 1 + has_split.astype(np.int64) + has_insert.astype(np.int64)
+        first = np.concatenate([[0], np.cumsum(per)])         # row index of (p, 0, 0); first[n] = number of rows
+        rows = int(first[n])
+        pos = np.repeat(np.arange(n, dtype=np.int64), per)
+        indx = np.zeros(rows, np.int64)
+        split = np.zeros(rows, np.int64)
+        base = np.zeros(rows, np.int64)
+        rl = np.zeros(rows, np.int64)
+        base[first[:n]] = base0
+        rl[first[:n]] = rl0
+        at = first[:n][has_split] + 1
+        split[at] = 1
+        base[at] = base0[has_split]
+        rl[at] = np.minimum(10, rng.geometric(0.55, size=at.shape[0]))
+        at = (first[:n] + has_split)[has_insert] + 1
+        indx[at] = 1
+        ins_base = rng.integers(1, 5, size=at.shape[0])
+        ins_base[rng.random(at.shape[0]) < 0.7] = 0
+        base[at] = ins_base
+        ins_rl = np.minimum(10, rng.geometric(0.55, size=at.shape[0]))
+        ins_rl[ins_base == 0] = 0
+        rl[at] = ins_rl
+        self.name, self.n_positions = name, n
+        self.position = np.stack([pos, indx, split], axis=1)                       # int64 [rows, 3], in key order
+        self.label_base, self.label_rle = base.astype(np.uint8), rl.astype(np.uint8)
+        # which of the _NOISE_VARIANTS noisy renderings of its class a row shows
+        self.code = ((base * 11 + rl) * _NOISE_VARIANTS + rng.integers(0, _NOISE_VARIANTS, size=rows)).astype(np.int32)
+        step = region_positions - overlap
+        expanded = np.concatenate([[0], np.cumsum(np.where(base0 > 0, rl0, 1))])     # draft offset of position p
+        self.regions = []            # (contig_start, contig_end, first row, end row)
+        self.windows = []            # (region index, feature_chunk_idx, first row, end row)
+        k = 0
+        while True:
+            start = k * step
+            if k > 0 and start >= n - overlap:
+                break
+            end = min(start + region_positions, n)
+            if k not in holes:
+                lo, hi = int(first[start]), int(first[end])
+                self.regions.append((int(expanded[start]), int(expanded[end]), lo, hi))
+                c, at = 0, lo
+                while True:
+                    self.windows.append((len(self.regions) - 1, c, at, min(at + L, hi)))
+                    if at + L >= hi:
+                        break
+                    at += L - chunk_overlap_rows
+                    c += 1
+            k += 1
+
+    def truth(self):
+        """The polished sequence a perfect caller would produce for the whole contig."""
+        letters = np.frombuffer(b"NACGT", np.uint8)
+        return np.repeat(letters[self.label_base], self.label_rle).tobytes().decode()
+
+
+def _noise_bank(seed=77):
+    """uint8 [(5 * 11) * _NOISE_VARIANTS + 1, 90]: row (base * 11 + rl) * _NOISE_VARIANTS + v = the v-th noisy rendering of
+    a position whose truth is (base, rl), through the read-vote process of make_pileup_task; the last row is all zero
+    (what the reader pads short images with)."""
+    cls = np.arange(5 * 11)
+    base = np.repeat(cls // 11, _NOISE_VARIANTS)
+    rl = np.repeat(cls % 11, _NOISE_VARIANTS)
+    valid = ((base == 0) & (rl == 0)) | ((base > 0) & (rl > 0))
+    bank = np.zeros((base.shape[0] + 1, ImageSizeOptions.IMAGE_HEIGHT), np.uint8)
+    rng = np.random.default_rng(seed)
+    bank[:-1][valid] = _read_votes(base[valid], rl[valid], rng)
+    return bank
+
+
+def assembly_contigs(spec, seed=20260929):
+    """spec = [(name, n_positions, {SimContig keyword: value}), ...] -> [SimContig]; contig k is seeded seed + k."""
+    return [SimContig(name, n, seed + k, **kw) for k, (name, n, kw) in enumerate(spec)]
+
+
+def contig_windows(contig, bank, lo=0, hi=None):
+    """Images lo..hi of one SimContig as the arrays a file writer takes:
+    -> (starts, ends, chunk ids int64 [n], lengths int32 [n], images uint8 [n, 1000, 90], positions int64 [n, 1000, 3]);
+    rows past an image's length are zero / (-1, -1, -1), which no writer stores."""
+    L = ImageSizeOptions.SEQ_LENGTH
+    wins = contig.windows[lo:hi]
+    n = len(wins)
+    starts = np.array([contig.regions[w[0]][0] for w in wins], np.int64)
+    ends = np.array([contig.regions[w[0]][1] for w in wins], np.int64)
+    chunks = np.array([w[1] for w in wins], np.int64)
+    first = np.array([w[2] for w in wins], np.int64)
+    lengths = np.array([w[3] - w[2] for w in wins], np.int32)
+    row = first[:, None] + np.arange(L, dtype=np.int64)[None, :]
+    live = np.arange(L)[None, :] < lengths[:, None]
+    row = np.where(live, row, 0)
+    codes = np.where(live, contig.code[row], bank.shape[0] - 1)
+    images = bank[codes]
+    positions = np.where(live[:, :, None], contig.position[row], -1)
+    return starts, ends, chunks, lengths, images, positions
+
+
+def write_assembly_dir(directory, spec, n_files=1, seed=20260929, blocks=None, direct=False, only_files=None):
+    """A directory of MarginPolish-shaped image files for the simulated assembly `spec` (see assembly_contigs).  Each
+    contig's regions are cut into blocks[k] (default 1) runs of consecutive regions; the blocks, in contig order, go to
+    the files round-robin -- all images of a region share a file, a contig may span several.  Images are named
+    <contig>-<contig_start>-<contig_end>-<feature_chunk_idx>.  direct=True writes through the emitter of libhelen_io.so
+    (the benchmark's 300 k-window inputs in seconds) instead of libhdf5; only_files = the file indices this caller writes
+    (several ranks of a benchmark each write their share).
+    -> {"files": [paths], "windows": total images, "regions": total, "truth": {contig: sequence} (None when only_files is given),
+        "windows_per_file": [...]}"""
+    os.makedirs(directory, exist_ok=True)
+    bank = _noise_bank()
+    blocks = list(blocks) if blocks is not None else [1] * len(spec)
+    # which file a block goes to depends only on the blocks before it: block j -> file j % n_files
+    paths = [os.path.join(directory, "assembly_images_%04d.h5" % fi) for fi in range(n_files)]
+    mine = set(range(n_files)) if only_files is None else set(only_files)
+    per_file = [[] for _ in range(n_files)]     # (contig, first image, end image)
+    truth, j, windows, regions = {}, 0, 0, 0
+    for k, (name, n, kw) in enumerate(spec):
+        targets = [(j + b) % n_files for b in range(blocks[k])]
+        j += blocks[k]
+        if only_files is not None and not (set(targets) & mine):
+            continue
+        contig = SimContig(name, n, seed + k, **kw)
+        if only_files is None:
+            truth[name] = contig.truth()
+        windows += len(contig.windows)
+        regions += len(contig.regions)
+        # cut at region boundaries, about equal numbers of regions per block
+        region_of = np.array([w[0] for w in contig.windows])
+        for b in range(blocks[k]):
+            r_lo = len(contig.regions) * b // blocks[k]
+            r_hi = len(contig.regions) * (b + 1) // blocks[k]
+            lo, hi = int(np.searchsorted(region_of, r_lo)), int(np.searchsorted(region_of, r_hi))
+            if hi > lo and targets[b] in mine:
+                per_file[targets[b]].append((contig, lo, hi))
+    counts = []
+    for fi in range(n_files):
+        counts.append(sum(hi - lo for _, lo, hi in per_file[fi]))
+        if fi not in mine or not per_file[fi]:
+            continue
+        parts = [(c.name,) + contig_windows(c, bank, lo, hi) for c, lo, hi in per_file[fi]]
+        names = [p[0] for p in parts for _ in range(p[1].shape[0])]
+        cat = [np.concatenate([p[i] for p in parts]) for i in range(1, 7)]
+        if direct:
+            from . import native_io
+            native_io.emit_image_windows(paths[fi], names, *cat)
+        else:
+            _write_windows(paths[fi], names, *cat)
+    return {"files": [p for fi, p in enumerate(paths) if per_file[fi] and fi in mine], "windows": windows, "regions": regions,
+            "truth": truth if only_files is None else None, "windows_per_file": counts}
+
+
+def _write_windows(path, names, starts, ends, chunks, lengths, images, positions):
+    with hdf5.File(path, "w") as f:
+        for i, contig in enumerate(names):
+            L = int(lengths[i])
+            base = "images/%s-%d-%d-%d/" % (contig, starts[i], ends[i], chunks[i])
+            f.write(base + "contig", contig)
+            f.write(base + "contig_start", np.array([starts[i]], np.int64))
+            f.write(base + "contig_end", np.array([ends[i]], np.int64))
+            f.write(base + "feature_chunk_idx", np.array([chunks[i]], np.int64))
+            f.write(base + "image", images[i, :L], np.uint8)
+            f.write(base + "position", positions[i, :L], np.int64)
+
+
+# the simulated assembly of the chained `polish` parity fixture (tests/golden/make_golden_polish.py): three contigs in
+# three files -- 2400-position regions of three images with a hole; 1000-position regions of two; one region of thirteen
+# images (chunk ids 10..12 sort before 2 as strings, Stitch.py:211); a contig shorter than one image
+POLISH_CASE = [
+    ("ctgA", 30000, {"holes": (5,)}),
+    ("ctgB.long_region", 12000, {"region_positions": 11000}),
+    ("scaffold_3|tiny", 700, {}),
+    ("ctgC", 20000, {"region_positions": 1000, "chunk_overlap_rows": 0}),
+]
+POLISH_CASE_BLOCKS = [2, 1, 1, 2]
+POLISH_CASE_FILES = 3

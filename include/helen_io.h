@@ -91,6 +91,12 @@ void helen_io_close_readers(void);
 int helen_io_emit_images(const char* path, int n, const char* contig, const int64_t* starts, const int64_t* chunks,
                          const int32_t* lengths, const uint8_t* images);
 
+/* The same with per-window contig names (char [n, 256]), contig_end and position rows (int64 [n, 1000, 3], the first
+ * lengths[i] rows stored): the simulated assemblies of helen_amd.synthetic.write_assembly_dir. */
+int helen_io_emit_image_windows(const char* path, int n, const char* contigs, const int64_t* starts, const int64_t* ends,
+                                const int64_t* chunks, const int32_t* lengths, const uint8_t* images,
+                                const int64_t* positions);
+
 /* ---- writer: `DataStore.write_prediction` (`DataStore.py:83-133`) ---------------------------------------------- */
 
 /* DataStore(filename, 'w') (`predict_gpu.py:55`); NULL on error. */
