@@ -36,10 +36,6 @@ FLOP_PER_WINDOW = 1772441600.0        # 932,864 FLOP/step x 100 st
 # also carry the heads' product (8,192 FLOP per timestep).  Averaged over the encoder and
 # decoder launches, which the timing below also averages.
 GRU_FLOP_PER_WINDOW_LAUNCH = 100 * 2 * 2.0 * 384 * 128 + 100 * 8192 / 2.0
-# polish_persistent_kernel: the 19-chunk loop in one launch = per chunk both recurrences (h.W_hh^T), the decoder
-# projection (y1.W_ih^T, K = 256) and the heads' product -- everything of SURVEY.md 8d's 1.7724 GFLOP per window except
-# the encoder projection (which is its own launch, shared by overlapping chunks)
-CHUNKS_FLOP_PER_WINDOW_LAUNCH = 19 * (2 * 100 * 2 * 2.0 * 384 * 128 + 100 * 2 * 2.0 * 384 * 256 + 100 * 8192)
 FP32_MFMA_PEAK = 157.3e12             # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 BF16_MFMA_PEAK = 2.5e15               # MI355X_MICROARCH.md: bf16 MFMA, dense
 
@@ -628,7 +624,7 @@ def main():
 
     # HIP events around the dominant kernel only; the pairs are created during the warm-up (topped up to the
     # number of timed steps) and recycled afterwards: no event is created or destroyed inside the timed region
-    eng.set_profiling(["gru_enc", "gru_dec", "chunks"])
+    eng.set_profiling(["gru_enc", "gru_dec"])
     run(args.warmup)
     if args.warmup < args.steps:   # untimed: as many event pairs as the timed steps will need
         run(args.steps - args.warmup)
@@ -686,12 +682,11 @@ def main():
     if rank == 0:
         total_windows = world * args.steps * call_windows
         value = total_windows / elapsed
-        one_launch = stats["chunks"][1] > 0      # the chunk loop ran as polish_persistent_kernel
-        gru_ms = stats["chunks"][0] if one_launch else stats["gru_enc"][0] + stats["gru_dec"][0]
-        gru_n = stats["chunks"][1] if one_launch else stats["gru_enc"][1] + stats["gru_dec"][1]
+        gru_ms = stats["gru_enc"][0] + stats["gru_dec"][0]
+        gru_n = stats["gru_enc"][1] + stats["gru_dec"][1]
         avg_ms = gru_ms / max(gru_n, 1)
         win_per_launch = call_windows
-        achieved = (CHUNKS_FLOP_PER_WINDOW_LAUNCH if one_launch else GRU_FLOP_PER_WINDOW_LAUNCH) * win_per_launch / (avg_ms * 1e-3) / 1e12
+        achieved = GRU_FLOP_PER_WINDOW_LAUNCH * win_per_launch / (avg_ms * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(win_per_launch, args.precision)
         peak = BF16_MFMA_PEAK if args.precision == "bf16" else FP32_MFMA_PEAK
         bound, unit = "mfma", "TFLOP/s"
@@ -720,11 +715,9 @@ def main():
                        "batch": B, "batches_per_step": G, "windows_per_step": call_windows,
                        "positions": 1000, "features": 90, "windows_per_gpu": args.steps * call_windows,
                        "resident_windows_per_gpu": n_res, "sharding": "by rank, no collective"},
-            "roofline": {"bound": bound, "kernel": {"fp32": "polish_persistent_kernel (the 19-chunk loop of a call as one launch: per chunk both GRU recurrences, "
-                                            "the decoder projection and the heads, fp32 MFMA; 1.5098 GFLOP of the window's 1.7724)" if one_launch else
-                                            "gru_pair_kernel (GRU recurrence of two window tiles per 8-wave workgroup, fp32 MFMA; "
+            "roofline": {"bound": bound, "kernel": {"fp32": "gru_pair_kernel (GRU recurrence of two window tiles per 8-wave workgroup, fp32 MFMA; "
                                             "decoder launches include the heads' product)",
-                                    "bf16": "gru_fused_bf16_il_kernel (encoder) / gru_fused_bf16_pair_kernel (decoder): projection + recurrence per layer, "
+                                    "bf16": "gru_fused_bf16_il_kernel (encoder and decoder launches): projection + recurrence per layer, "
                                             "two window tiles per workgroup, bf16 MFMA; bound in practice by the fp32 gate math, not the matrix pipe",
                                     "fp32x3": "gru_x3_kernel (GRU recurrence, 6 bf16 MFMAs per fp32 product "
                                               "group; fraction is of the fp32 MFMA peak)"}[args.precision],
@@ -734,8 +727,8 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_measured_in_this_run": False if traffic is not None else None,
                          "avg_launch_ms": round(avg_ms, 4), "launches": gru_n,
-                         "avg_launch_ms_encoder": None if one_launch else round(stats["gru_enc"][0] / max(stats["gru_enc"][1], 1), 4),
-                         "avg_launch_ms_decoder": None if one_launch else round(stats["gru_dec"][0] / max(stats["gru_dec"][1], 1), 4),
+                         "avg_launch_ms_encoder": round(stats["gru_enc"][0] / max(stats["gru_enc"][1], 1), 4),
+                         "avg_launch_ms_decoder": round(stats["gru_dec"][0] / max(stats["gru_dec"][1], 1), 4),
                          "path_frac": round(value / world * FLOP_PER_WINDOW /
                                             (BF16_MFMA_PEAK if args.precision == "bf16" else FP32_MFMA_PEAK), 4)},
         }

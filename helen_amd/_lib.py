@@ -10,13 +10,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # HELEN_HIP_LIB: developer override to A/B-test kernel variants built side by side.
 LIB_PATH = os.environ.get("HELEN_HIP_LIB") or os.path.join(_HERE, "csrc", "libhelen_hip.so")
 
-HELEN_ABI_VERSION = 1
+HELEN_ABI_VERSION = 2
 HELEN_OK = 0
 HELEN_PRECISION_FP32 = 0
 HELEN_PRECISION_BF16 = 1
 HELEN_PRECISION_FP32X3 = 2
 
-KERNEL_CLASSES = ("pack", "gemm_enc", "gru_enc", "gemm_dec", "gru_dec", "heads", "chunks")
+KERNEL_CLASSES = ("pack", "gemm_enc", "gru_enc", "gemm_dec", "gru_dec", "heads")
 
 # every symbol include/helen_hip.h declares
 EXPORTS = (
@@ -24,7 +24,7 @@ EXPORTS = (
     "helen_model_device_bytes", "helen_polish_batch", "helen_polish_host", "helen_polish_submit", "helen_polish_flush",
     "helen_gru_chunk_forward", "helen_evaluate_batch", "helen_debug_inject_failure", "helen_set_profiling",
     "helen_reset_kernel_stats",
-    "helen_get_kernel_stats", "helen_reload_overrides", "helen_describe_dispatch", "helen_plan_call", "helen_has_persistent",
+    "helen_get_kernel_stats", "helen_reload_overrides", "helen_describe_dispatch", "helen_plan_call",
 )
 RECURRENCE_KERNELS = ("gru_kernel", "gru_single8_kernel", "gru_half8_kernel", "gru_quarter4_kernel", "gru_pair_kernel")
 DECODER_PROJECTIONS = ("gemm_gi_kernel<16>", "gemm_dec_ws_kernel", "gemm_dec_wsp_kernel")
@@ -122,8 +122,6 @@ def load():
     lib.helen_describe_dispatch.argtypes = [ci, ctypes.c_char_p, ctypes.c_size_t]
     lib.helen_plan_call.restype = ci
     lib.helen_plan_call.argtypes = [ci, ci, ctypes.POINTER(ci)]
-    lib.helen_has_persistent.restype = ci
-    lib.helen_has_persistent.argtypes = []
     got = lib.helen_abi_version()
     if got != HELEN_ABI_VERSION:
         raise ImportError("libhelen_hip.so ABI %d != binding ABI %d; rebuild" % (got, HELEN_ABI_VERSION))

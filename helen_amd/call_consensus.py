@@ -101,13 +101,19 @@ def call_consensus(image_dir, model_path, batch_size, num_workers, threads, outp
         else:
             # one rank runs in this process: the schema check of a few images per file runs BESIDE its start-up (the
             # reader raises the same IMAGE SIZE ERROR itself when it meets such an image; the check's findings are
-            # reported either way)
+            # reported either way).  The check enters libhdf5 from its own thread (helen_amd.hdf5, ctypes): it holds the
+            # lock libhelen_io.so serialises its own library calls with, so a libhdf5 that is not built thread-safe is
+            # never entered from two threads (a reader or writer that needs the library waits for the check to finish;
+            # the direct scanner and emitter never do).
             import threading
+
+            from . import native_io
             vet = {"error": None}
 
             def run_vet():
                 try:
-                    vet_image_directory(image_dir)
+                    with native_io.library_lock():
+                        vet_image_directory(image_dir)
                 except BaseException as e:          # noqa: BLE001 -- re-raised below
                     vet["error"] = e
             vet["thread"] = threading.Thread(target=run_vet, daemon=True)

@@ -23,15 +23,6 @@
 using namespace helen;
 
 static_assert(kDecStagePositions == HELEN_DWS_PB && kEncStagePositions == HELEN_EWS8_PB, "dispatch.h's stage sizes are the kernels'");
-// polish_persistent_kernel (the 19-chunk loop as ONE launch, kernels_persistent.h) is measured 0.6-0.8 % SLOWER than the
-// per-phase launches: it is compiled in only with -DHELEN_WITH_PERSISTENT (make PERSISTENT=1) and then
-// still opt-in per model ($HELEN_PERSISTENT=1 at helen_model_create).
-#ifndef HELEN_BF16_ENC_DEFAULT
-#define HELEN_BF16_ENC_DEFAULT '1'
-#endif
-#ifndef HELEN_BF16_DEC_DEFAULT
-#define HELEN_BF16_DEC_DEFAULT '1'
-#endif
 
 namespace {
 
@@ -98,11 +89,6 @@ struct HelenModel {
     f32x4* y1 = nullptr;
     f32x4* hid = nullptr;
     f32x4* pending = nullptr;
-    // the 19-chunk loop as one launch (polish_persistent_kernel): ticket + progress counters, a host-visible error word
-    unsigned* sync_area = nullptr;       // device: [0] = ticket, [64 ...] = progress[pairs][2]
-    unsigned* persistent_error = nullptr;   // hipHostMalloc'd, mapped
-    unsigned ticket_next = 0, epoch_next = 0;
-    bool persistent_off = false;         // set after a reported wait time-out: the per-phase launches take over
     // calls that do not fill the chip run as two independent tile groups on two internal streams (polish_batch_impl)
     hipStream_t sub_stream[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
@@ -363,23 +349,19 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
     if (m->precision == HELEN_PRECISION_BF16) {
         // projection fused into the recurrence: no gi at all; the encoder reads the packed pileup counts,
         // the decoder the encoder's bf16 output plane
-        // Two tiles per workgroup: gru_fused_bf16_il_kernel interleaves the gate math with the other tile's MFMAs,
-        // gru_fused_bf16_pair_kernel runs them one after the other (all bit-identical).  Measured per launch of 8192
-        // windows (profiles/r04_bf16_own.txt): encoder 0.322 against 0.319-0.335 ms, decoder 0.485 against 0.500 since
-        // round 4's form of the kernel (a step's input part in its own region): both interleaved.  HELEN_BF16_IL = two digits, encoder
-        // then decoder: 0 = pair, 1 = interleaved (A/B probes).
-        const char il_enc = m->overrides.bf16_il_enc ? m->overrides.bf16_il_enc : HELEN_BF16_ENC_DEFAULT;
-        const char il_dec = m->overrides.bf16_il_dec ? m->overrides.bf16_il_dec : HELEN_BF16_DEC_DEFAULT;
+        // Two tiles per workgroup from half the CUs in tiles on: gru_fused_bf16_il_kernel interleaves the gate math of one
+        // tile with the other tile's MFMAs (bit-identical to the one-tile kernel below).  Round 3's form, which ran the two
+        // phases one after the other (gru_fused_bf16_pair_kernel), lost to it at every size in round 4 (encoder 0.322
+        // against 0.319-0.335 ms, decoder 0.447 against 0.486 per launch of 8,192 windows, profiles/r04_bf16_own.txt) and
+        // left the tree in round 5.
         if (bf16_pair_pays(tiles, m->cus, m->overrides)) {
             const dim3 grid((tiles + 1) / 2, 2), block(512);
 #define HELEN_ENC_ARGS m->xb, (long)kSeq * 192, pos0, T, m->w3i_enc, m->w3h_enc, m->bias_enc, m->bhn_enc, m->hid, m->y1p, \
                        kY1bTileStride, (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride, tiles
 #define HELEN_DEC_ARGS m->y1p, kY1bTileStride, 0, T, m->w3i_dec, m->w3h_dec, m->bias_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, \
                        kY1bTileStride, m->whd, m->plogit, kPlTileStride, tiles
-            if (il_enc == '1') LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_il_kernel<3, false>), grid, block, HELEN_ENC_ARGS);
-            else LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_pair_kernel<3, false>), grid, block, HELEN_ENC_ARGS);
-            if (il_dec == '1') LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_il_kernel<8, true>), grid, block, HELEN_DEC_ARGS);
-            else LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_pair_kernel<8, true>), grid, block, HELEN_DEC_ARGS);
+            LAUNCH(HELEN_K_GRU_ENC, (gru_fused_bf16_il_kernel<3, false>), grid, block, HELEN_ENC_ARGS);
+            LAUNCH(HELEN_K_GRU_DEC, (gru_fused_bf16_il_kernel<8, true>), grid, block, HELEN_DEC_ARGS);
 #undef HELEN_ENC_ARGS
 #undef HELEN_DEC_ARGS
             return;
@@ -466,10 +448,9 @@ void free_model(HelenModel* m) {
     free_ring(m);
     void* ptrs[] = {m->plogit, m->w3i_enc, m->xb, m->w3i_dec, m->y1p, m->w3h_enc, m->w3h_dec, m->wp_enc, m->wp_dec, m->whp_enc, m->whp_dec, m->whd, m->bias_enc, m->bias_dec,
                     m->bhn_enc, m->bhn_dec, m->bhd, m->xa, m->gi_enc, m->gi_dec, m->y1,
-                    m->hid, m->pending, m->sync_area};
+                    m->hid, m->pending};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    if (m->persistent_error) (void)hipHostFree(m->persistent_error);
     for (int k = 0; k < 2; ++k) {
         if (m->sub_stream[k]) (void)hipStreamDestroy(m->sub_stream[k]);
         if (m->ev_join[k]) (void)hipEventDestroy(m->ev_join[k]);
@@ -597,15 +578,6 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
     if ((rc = dev_alloc(m, &m->plogit, nt * kPlTileStride))) return rc;   // the decoder emits partial logits, no y2
     if ((rc = dev_alloc(m, &m->hid, nt * (kHidStride / 4)))) return rc;
     if ((rc = dev_alloc(m, &m->pending, nt * 2 * kJump * 64))) return rc;
-#ifdef HELEN_WITH_PERSISTENT
-    if (precision == HELEN_PRECISION_FP32 && m->overrides.persistent == 1) {
-        const size_t words = 64 + (nt + 1) / 2 * 2;
-        if ((rc = dev_alloc(m, &m->sync_area, words))) return rc;
-        HIP_TRY(hipMemset(m->sync_area, 0, words * sizeof(unsigned)));
-        HIP_TRY(hipHostMalloc((void**)&m->persistent_error, sizeof(unsigned), hipHostMallocMapped));
-        *m->persistent_error = 0;
-    }
-#endif
     return HELEN_OK;
 }
 
@@ -659,9 +631,7 @@ int helen_model_device_bytes(const HelenModel* m, size_t* out_bytes) {
 int helen_reload_overrides(HelenModel* m) {
     if (!m) return fail(HELEN_EINVAL, "null argument");
     HELEN_ENTER(m);
-    const int keep = m->overrides.persistent;      // (what was allocated at creation decides that one)
     m->overrides = read_overrides();
-    m->overrides.persistent = keep;
     m->host_lock = m->overrides.host_lock >= 0 ? m->overrides.host_lock : 0;
     return HELEN_OK;
 }
@@ -690,31 +660,10 @@ int helen_plan_call(int cus, int tiles, int* out) {
     return HELEN_OK;
 }
 
-int helen_has_persistent(void) {
-#ifdef HELEN_WITH_PERSISTENT
-    return 1;
-#else
-    return 0;
-#endif
-}
-
-// The chunk loop as ONE launch (polish_persistent_kernel): only in builds with -DHELEN_WITH_PERSISTENT, and then only for
-// a model created under $HELEN_PERSISTENT=1 (same device bodies, same bits; 0.6-0.8 % slower).
-static bool use_persistent(const HelenModel* m, int tiles) {
-#ifdef HELEN_WITH_PERSISTENT
-    (void)tiles;
-    return m->precision == HELEN_PRECISION_FP32 && !m->persistent_off && m->sync_area && m->overrides.persistent == 1;
-#else
-    (void)m;
-    (void)tiles;
-    return false;
-#endif
-}
 
 // uint8 windows -> operand tiles -> encoder input projection for all 1000 positions (overlapping chunks
 // share it) -> zero initial hidden (predict_gpu.py:97-99): everything before the chunk loop.
-static int launch_front(HelenModel* m, hipStream_t s, const uint8_t* images, int n_windows, int tiles,
-                        bool zero_hidden = true) {
+static int launch_front(HelenModel* m, hipStream_t s, const uint8_t* images, int n_windows, int tiles) {
     if (m->precision == HELEN_PRECISION_FP32X3 || m->precision == HELEN_PRECISION_BF16) {
         // pileup counts are exact in bf16: pack them straight into A fragments; three exact products per w
         // (fp32x3) or the one product with w rounded to bf16 (bf16)
@@ -731,77 +680,17 @@ static int launch_front(HelenModel* m, hipStream_t s, const uint8_t* images, int
                dim3(256), images, n_windows, kSeq, m->xa);
         launch_enc_gemm(m, s, tiles, kSeq);
     }
-    // zero initial hidden per batch (predict_gpu.py:99; polish_persistent_kernel does it itself)
-    if (zero_hidden) HIP_TRY(hipMemsetAsync(m->hid, 0, (size_t)tiles * kHidStride * sizeof(float), s));
+    // zero initial hidden per batch (predict_gpu.py:99)
+    HIP_TRY(hipMemsetAsync(m->hid, 0, (size_t)tiles * kHidStride * sizeof(float), s));
     return HELEN_OK;
 }
-
-#ifdef HELEN_WITH_PERSISTENT
-static int launch_persistent(HelenModel* m, hipStream_t s, int tiles, int n_windows, uint8_t* bases, uint8_t* rles,
-                             float* acc_base_opt, float* acc_rle_opt) {
-    if (*(volatile unsigned*)m->persistent_error) {
-        // a hand-off of an EARLIER call gave up waiting (its labels are not to be trusted): say so, reset, and leave
-        // this handle on the per-phase launches
-        *m->persistent_error = 0;
-        m->persistent_off = true;
-        (void)hipStreamSynchronize(s);
-        (void)hipMemset(m->sync_area, 0, (64 + (size_t)(m->max_tiles + 1) / 2 * 2) * sizeof(unsigned));
-        m->ticket_next = m->epoch_next = 0;
-        return fail(HELEN_EHIP, "polish_persistent_kernel: a workgroup hand-off of an earlier call timed out (device shared or "
-                                "wedged?); its results are invalid.  This handle now uses the per-phase launches");
-    }
-    const int npairs = (tiles + 1) / 2;
-    PolishPersistentArgs a;
-    a.gi_enc = m->gi_enc;
-    a.gi_enc_tile_stride = kGiEncTileStride;
-    a.whp_enc = m->whp_enc;
-    a.bhn_enc = m->bhn_enc;
-    a.hid = m->hid;
-    a.y1 = m->y1;
-    a.y_tile_stride = kYTileStride;
-    a.wp_dec = m->wp_dec;
-    a.bias_dec = m->bias_dec;
-    a.gi_dec = m->gi_dec;
-    a.gi_dec_tile_stride = kGiDecTileStride;
-    a.whp_dec = m->whp_dec;
-    a.bhn_dec = m->bhn_dec;
-    a.whd = m->whd;
-    a.plogit = m->plogit;
-    a.pl_tile_stride = kPlTileStride;
-    a.bhd = m->bhd;
-    a.pending = m->pending;
-    a.bases = bases;
-    a.rles = rles;
-    a.acc_base = acc_base_opt;
-    a.acc_rle = acc_rle_opt;
-    a.n_windows = n_windows;
-    a.ntiles = tiles;
-    a.ticket = m->sync_area;
-    a.ticket_base = m->ticket_next;
-    a.progress = m->sync_area + 64;
-    a.epoch_base = m->epoch_next;
-    void* dev_err = nullptr;
-    HIP_TRY(hipHostGetDevicePointer(&dev_err, m->persistent_error, 0));
-    a.error = (unsigned*)dev_err;
-    m->ticket_next += 2u * (unsigned)npairs;
-    m->epoch_next += 2u * (unsigned)kChunks;
-    LAUNCH(HELEN_K_CHUNKS, polish_persistent_kernel, dim3(2 * npairs), dim3(512), a);
-    return HELEN_OK;
-}
-
-#endif
 
 // The launch sequence of one call over `tiles` tiles whose scratch starts at the model's (possibly shifted) pointers.
 static int polish_range(HelenModel* m, hipStream_t s, const uint8_t* images, int n_windows, uint8_t* bases,
-                        uint8_t* rles, float* acc_base_opt, float* acc_rle_opt, bool allow_persistent) {
+                        uint8_t* rles, float* acc_base_opt, float* acc_rle_opt) {
     const int tiles = (n_windows + kTile - 1) / kTile;
-    const bool persistent = allow_persistent && use_persistent(m, tiles);
-    int rc = launch_front(m, s, images, n_windows, tiles, !persistent);
+    int rc = launch_front(m, s, images, n_windows, tiles);
     if (rc) return rc;
-#ifdef HELEN_WITH_PERSISTENT
-    if (persistent)                      // pack, encoder projection, the chunk loop: three launches
-        return launch_persistent(m, s, tiles, n_windows, bases, rles, acc_base_opt, acc_rle_opt);
-#endif
     for (int c = 0; c < kChunks; ++c) {  // predict_gpu.py:114-149
         launch_chunk(m, s, tiles, c * kJump, kWin, kSeq);
         LAUNCH(HELEN_K_HEADS, heads_kernel, dim3(tiles, kWin / kHeadsSpan), dim3(256), m->plogit, kPlTileStride,
@@ -864,8 +753,8 @@ static int polish_batch_impl(HelenModel* m, const uint8_t* images, int n_windows
     const int tiles = (n_windows + kTile - 1) / kTile;
     // (TileWindow shifts the fp32 scratch only)
     const CallPlan call = plan_call(tiles, m->cus, m->precision == HELEN_PRECISION_FP32, m->overrides);
-    if (!call.split || use_persistent(m, tiles)) {
-        const int rc = polish_range(m, s, images, n_windows, bases, rles, acc_base_opt, acc_rle_opt, true);
+    if (!call.split) {
+        const int rc = polish_range(m, s, images, n_windows, bases, rles, acc_base_opt, acc_rle_opt);
         return rc ? rc : check_launch("helen_polish_batch");
     }
     if (!m->ev_fork) {
@@ -887,7 +776,7 @@ static int polish_batch_impl(HelenModel* m, const uint8_t* images, int n_windows
             rc = polish_range(m, m->sub_stream[k], images + (size_t)first * kSeq * kF, count,
                               bases + (size_t)first * kSeq, rles + (size_t)first * kSeq,
                               acc_base_opt ? acc_base_opt + (size_t)first * kSeq * kNB : nullptr,
-                              acc_rle_opt ? acc_rle_opt + (size_t)first * kSeq * kNR : nullptr, false);
+                              acc_rle_opt ? acc_rle_opt + (size_t)first * kSeq * kNR : nullptr);
         }
         // (whatever happened, the caller's stream waits for what was enqueued)
         HIP_TRY(hipEventRecord(m->ev_join[k], m->sub_stream[k]));
@@ -1303,14 +1192,6 @@ int helen_debug_inject_failure(HelenModel* m, int sub_batch) {
     if (!m->debug_hooks)
         return fail(HELEN_EINVAL, "debug hooks are off: the model was not created under HELEN_DEBUG_HOOKS=1");
     HELEN_ENTER(m);      // never while another thread is inside a call on this handle
-    if (sub_batch == HELEN_DEBUG_PERSISTENT_TIMEOUT) {
-        // pretend a workgroup hand-off of polish_persistent_kernel gave up: the word the device would have set
-        if (!m->persistent_error)
-            return fail(HELEN_EINVAL, "this model has no one-launch chunk loop (fp32, a build with -DHELEN_WITH_PERSISTENT, "
-                                      "created under HELEN_PERSISTENT=1)");
-        *m->persistent_error = 1;
-        return HELEN_OK;
-    }
     m->fail_at_sub = sub_batch;
     return HELEN_OK;
 }

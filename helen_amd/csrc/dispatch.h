@@ -54,8 +54,6 @@ struct Overrides {
     int enc_ws8 = -1, enc_ws8p = -1, enc_ws8p_parts = 0;
     int split = -1, split_at = 0;
     int bf16_pair = -1;
-    char bf16_il_enc = 0, bf16_il_dec = 0;      // '0' pair, '1' interleaved; 0 = the default
-    int persistent = -1;                        // (only in builds with -DHELEN_WITH_PERSISTENT)
     int host_lock = -1;                         // helen_polish_host: 0 never page-lock caller memory, 1 ranges that own their pages, 2 all
     bool verbose = false;
 };
@@ -78,12 +76,13 @@ inline Overrides read_overrides() {
     o.split = flag_of("HELEN_SPLIT");
     if (const char* n = getenv("HELEN_SPLIT_AT")) o.split_at = atoi(n);
     o.bf16_pair = flag_of("HELEN_BF16_PAIR");
-    if (const char* il = getenv("HELEN_BF16_IL")) {
-        if (il[0]) o.bf16_il_enc = il[0];
-        if (il[0] && il[1]) o.bf16_il_dec = il[1];
+    // exactly none | own | all ("0" = none); anything else is ignored: a typo must not re-open the in-place page-locking
+    if (const char* hl = getenv("HELEN_HOST_LOCK")) {
+        if (!strcmp(hl, "none") || !strcmp(hl, "0")) o.host_lock = 0;
+        else if (!strcmp(hl, "own")) o.host_lock = 1;
+        else if (!strcmp(hl, "all")) o.host_lock = 2;
+        else fprintf(stderr, "helen: HELEN_HOST_LOCK=%s ignored (none | own | all)\n", hl);
     }
-    o.persistent = flag_of("HELEN_PERSISTENT");
-    if (const char* hl = getenv("HELEN_HOST_LOCK")) o.host_lock = !strcmp(hl, "none") ? 0 : !strcmp(hl, "all") ? 2 : 1;
     o.verbose = flag_of("HELEN_VERBOSE") == 1;
     return o;
 }

@@ -524,7 +524,8 @@ class File {
         h->cur_rows = u16(o + 30);
         if (h->width == 0 || h->start_block == 0 || (h->start_block & (h->start_block - 1)) ||
             (h->max_direct & (h->max_direct - 1)) || h->max_direct < h->start_block || h->max_heap_bits > 64 ||
-            h->max_heap_bits < 8)
+            h->max_heap_bits < 8 || h->cur_rows > h->max_heap_bits ||
+            log2_floor(h->start_block) + (int)h->cur_rows > 62 || h->width > (1u << 20))
             return false;
         h->off_bytes = (int)(h->max_heap_bits + 7) / 8;
         // H5HFhdr.c: min(bytes of an offset inside the largest direct block, bytes that hold the largest managed object size)
@@ -545,7 +546,9 @@ class File {
             uint64_t row_base = base;
             bool found = false;
             for (unsigned r = 0; r < rows; ++r) {
+                if (r >= 2 && (unsigned)log2_floor(h.start_block) + (r - 1) > 62) return false;       // the shift below
                 const uint64_t bs = row_block_size(h, r);
+                if (bs > (~0ull >> 1) / h.width) return false;                                          // bs * width would wrap
                 const uint64_t span = bs * h.width;
                 if (off < row_base + span) {
                     const uint64_t col = (off - row_base) / bs;
@@ -610,9 +613,12 @@ class File {
             const std::vector<int>* cum_size;
             std::vector<const uint8_t*>* recs;
             uint64_t* budget;
+            uint64_t total;
             bool node(uint64_t at, uint64_t nrec, unsigned depth) {
                 if (*budget == 0) return false;
                 --*budget;
+                // (child pointers that alias one node must not grow the list past what the header promises)
+                if (nrec > total || recs->size() + nrec > total) return false;
                 const uint64_t body = 6 + nrec * rsize;
                 if (!f->ok(at, body)) return false;
                 if (depth == 0) {
@@ -630,7 +636,7 @@ class File {
                 }
                 return true;
             }
-        } w{this, rsize, nrec_size, &cum_size, recs, &budget};
+        } w{this, rsize, nrec_size, &cum_size, recs, &budget, total};
         if (!w.node(root, root_n, depth)) return false;
         return recs->size() == total;
     }

@@ -1014,6 +1014,11 @@ void helen_io_reader_counts(long long* out) {
     out[1] = g_library_windows;
 }
 
+/* The lock around every libhdf5 call of this library, for a thread of the same process that enters libhdf5 through
+ * another binding: lock, use the library, unlock -- on one thread (the mutex is recursive). */
+void helen_io_library_lock(void) { g_library_mutex.lock(); }
+void helen_io_library_unlock(void) { g_library_mutex.unlock(); }
+
 /* Drop every cached read handle of this process. */
 void helen_io_close_readers(void) {
     forget_index(nullptr);
@@ -1381,6 +1386,129 @@ static long long decode_records(std::vector<Rec>& recs, char* out, long long cap
     }
     out[len] = 0;
     return len;
+}
+
+/* helen_io_region_sequence for regions whose images are still in memory (the labels a device call has just delivered:
+ * helen_amd.stitch_stream decodes a region as soon as its last image has been written, beside the device stage).
+ * Region r is made of the windows rows[first[r] .. first[r + 1]) of the arrays -- the caller lists them in the STRING
+ * order of their chunk ids, each chunk id once (what the prediction file holds, Stitch.py:211 and DataStore.py:123).  The
+ * position values are taken as the prediction file stores them: uint32 (a -1 padding row wraps to 4294967295 and
+ * is a key like any other, Stitch.py:226 never skips it).  Sequences go to `out` back to back, offsets[r] .. offsets[r + 1];
+ * `threads` threads of this call share the regions.  Returns the total length, -2 if `cap` is too small. */
+long long helen_io_decode_regions(int n_regions, const int32_t* first, const int32_t* rows, const int64_t* positions,
+                                  const uint8_t* bases, const uint8_t* rles, int threads, char* out, long long cap,
+                                  int64_t* offsets) {
+    if (n_regions <= 0) {
+        if (offsets) offsets[0] = 0;
+        return 0;
+    }
+    std::vector<std::string> seqs((size_t)n_regions);
+    std::atomic<int> next{0};
+    std::atomic<bool> bad{false};
+    auto work = [&]() {
+        std::vector<Rec> recs;
+        std::vector<char> buf;
+        for (;;) {
+            const int r = next.fetch_add(1);
+            if (r >= n_regions) return;
+            recs.clear();
+            uint32_t order = 0;
+            for (int k = first[r]; k < first[r + 1]; ++k) {
+                const size_t w = (size_t)rows[k];
+                const int64_t* p = positions + w * kSeq * 3;
+                const uint8_t* b = bases + w * kSeq;
+                const uint8_t* l = rles + w * kSeq;
+                for (int i = 0; i < kSeq; ++i)
+                    recs.push_back({(int64_t)(uint32_t)p[3 * i], (int64_t)(uint32_t)p[3 * i + 1], (int64_t)(uint32_t)p[3 * i + 2],
+                                    b[i], l[i], order++});
+            }
+            size_t need = 1;
+            for (const Rec& x : recs) need += x.rle;
+            buf.resize(need);
+            const long long len = decode_records(recs, buf.data(), (long long)buf.size());
+            if (len < 0) {
+                bad = true;
+                return;
+            }
+            seqs[(size_t)r].assign(buf.data(), (size_t)len);
+        }
+    };
+    const int T = std::max(1, std::min(threads, n_regions));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    if (bad) return fail("region decode failed");
+    long long total = 0;
+    for (auto& s : seqs) total += (long long)s.size();
+    if (total > cap) {
+        fail("buffer too small: need %lld", total);
+        return -2;
+    }
+    long long at = 0;
+    for (int r = 0; r < n_regions; ++r) {
+        offsets[r] = at;
+        memcpy(out + at, seqs[(size_t)r].data(), seqs[(size_t)r].size());
+        at += (long long)seqs[(size_t)r].size();
+    }
+    offsets[n_regions] = at;
+    return total;
+}
+
+/* The overlap alignments of `n` joins in one call (Stitch.py:104-134 per join): join k aligns query
+ * blob[r_off[k] .. + r_len[k]) against reference blob[l_off[k] .. + l_len[k]) as helen_ssw_align does and reduces the
+ * result to what alignment_stitch uses: out[3 k] = best score, out[3 k + 1], out[3 k + 2] = (reference index, query
+ * index) of the first M run (= and X merged) of at least `min_run`, or (-1, -1) (`get_confident_positions`,
+ * Stitch.py:34-94).  An empty side gives score 0.  Single-threaded and re-entrant: callers run several at once. */
+int helen_ssw_join_batch(int n, const char* blob, const int64_t* l_off, const int32_t* l_len, const int64_t* r_off,
+                         const int32_t* r_len, int match, int mismatch, int gap_open, int gap_extend, int min_run,
+                         int32_t* out) {
+    std::vector<char> cigar;
+    for (int k = 0; k < n; ++k) {
+        int32_t* o = out + 3 * (size_t)k;
+        o[0] = 0;
+        o[1] = o[2] = -1;
+        if (l_len[k] <= 0 || r_len[k] <= 0) continue;
+        cigar.resize((size_t)16 * ((size_t)l_len[k] + (size_t)r_len[k]) + 64);
+        int res[6];
+        const int rc = helen_ssw_align(blob + l_off[k], l_len[k], blob + r_off[k], r_len[k], match, mismatch, gap_open,
+                                       gap_extend, res, cigar.data(), (int)cigar.size());
+        if (rc < 0) return fail("join %d: the aligner failed", k);
+        o[0] = res[0];
+        if (rc != 0 || res[0] == 0) continue;
+        // runs of the extended CIGAR with = and X merged into M
+        long long ref_index = res[1], read_index = 0, run = 0;
+        char run_op = 0;
+        bool found = false;
+        auto close_run = [&]() {          // the run that just ended (or the last one)
+            if (!run_op || found) return;
+            if (run_op == 'M' && run >= min_run) {
+                o[1] = (int32_t)ref_index;
+                o[2] = (int32_t)read_index;
+                found = true;
+                return;
+            }
+            if (run_op == 'S' || run_op == 'I') read_index += run;
+            else if (run_op == 'D') ref_index += run;
+            else if (run_op == 'M') { ref_index += run; read_index += run; }
+        };
+        const char* c = cigar.data();
+        while (*c && !found) {
+            long long len = 0;
+            while (*c >= '0' && *c <= '9') len = len * 10 + (*c++ - '0');
+            char op = *c ? *c++ : 0;
+            if (op == '=' || op == 'X') op = 'M';
+            if (op == run_op) {
+                run += len;
+            } else {
+                close_run();
+                run_op = op;
+                run = len;
+            }
+        }
+        close_run();
+    }
+    return 0;
 }
 
 int helen_io_writer_close(void* handle) {

@@ -14,9 +14,5 @@
 #include "kernels_gru_half8.h"
 #include "kernels_x3.h"
 #include "kernels_fused_bf16.h"
-#include "kernels_fused_bf16_pair.h"
 #include "kernels_fused_bf16_il.h"
 #include "kernels_heads.h"
-#ifdef HELEN_WITH_PERSISTENT      // the 19-chunk loop as one launch: quarantined (slower; see api.hip)
-#include "kernels_persistent.h"
-#endif

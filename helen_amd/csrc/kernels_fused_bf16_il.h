@@ -3,7 +3,7 @@
 #pragma once
 #include <type_traits>
 
-#include "kernels_fused_bf16_pair.h"
+#include "kernels_fused_bf16.h"
 
 #ifndef HELEN_BF16_IL_PARKED       // K32 groups of the decoder's W_ih kept in LDS instead of registers (24 KiB each): none needed
 #define HELEN_BF16_IL_PARKED 0
@@ -20,12 +20,23 @@
 namespace helen {
 
 // ------------------------------------------------------------------------------------------------
-// Same arithmetic as gru_fused_bf16_kernel / gru_fused_bf16_pair_kernel (same MFMA order per accumulator, the same
-// IEEE operations per gate component, same order of the head partial sums: results are bit-identical) and the
-// same two-tile structure as gru_fused_bf16_pair_kernel:
+// Same arithmetic as gru_fused_bf16_kernel (same MFMA order per accumulator, the same IEEE operations per gate
+// component, same order of the head partial sums: results are bit-identical).  With bf16 operands a tile-step is only
+// 21 (encoder) / 36 (decoder) bf16 MFMAs per wave -- 700 / 1200 cycles of a SIMD's matrix pipe -- plus the same ~620
+// cycles of gate math as in fp32, so what one tile per workgroup leaves exposed per step (a barrier, an LDS round trip
+// for the new h, the tail of the MFMA pipe before the gates) costs as much as the work itself: gru_fused_bf16_kernel
+// measures 2070 / 3140 cycles per tile-step.  Here ONE workgroup of 8 waves walks TWO tiles of 16 windows:
 //     M(0,s) | G(0,s) M(1,s) | G(1,s) M(0,s+1) | ...        M = MFMA phase, G = gate math, | = the barrier
-// What changes is the order of instructions BETWEEN two barriers.  The pair kernel runs G(x,s) and then M(o,.) --
-// and measured (scripts/ubench/bf16_mfma_valu_overlap.hip, profiles/ub_bf16_overlap.txt) a SIMD then pays the MFMAs
+//   M(x,s): tile x's whole step s -- bias, input part x . W_ih^T from the LDS ring, recurrent part on the bf16 plane of
+//           h_x(s-1) -- and this wave's k-slice of the head product of h_x(s-1) (decoder);
+//   the barrier publishes the OTHER tile's h (written in the previous half-step's G) and the input rows an earlier
+//           half-step's LDS-DMA brought in (the issuing wave waits for them with a COUNTED vmcnt at the barrier);
+//   G(x,s): gates, new h -> LDS (fp32 + bf16 plane), head partials -> LDS.
+// The weights (W_hh 48 + W_ih 36 / 96 registers) are shared by both tiles; each tile has its own h buffers, input ring
+// and partial-logit slots.  grid (ceil(tiles / 2), 2 directions); an odd tile count makes the last workgroup do its one
+// tile twice.
+// What matters is the order of instructions BETWEEN two barriers.  Round 3's form of this kernel
+// (gru_fused_bf16_pair_kernel, removed in round 5) ran G(x,s) and then M(o,.) -- and measured (scripts/ubench/bf16_mfma_valu_overlap.hip, profiles/ub_bf16_overlap.txt) a SIMD then pays the MFMAs
 // plus the gate math in full: v_mfma_f32_16x16x32_bf16 issues every 17 cycles, but
 //   - in the SAME wave's stream one transcendental (v_exp_f32 / v_rcp_f32) or two plain fp32 VALU instructions
 //     behind each MFMA are free (17.0 -> 17.7 / 17.2 cycles per MFMA; a second transcendental costs 8.2, a third

@@ -42,6 +42,10 @@ def load():
     lib.helen_io_emit_images.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, vp, vp, vp, vp]
     lib.helen_io_emit_image_windows.restype = ctypes.c_int
     lib.helen_io_emit_image_windows.argtypes = [ctypes.c_char_p, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp]
+    lib.helen_io_library_lock.restype = None
+    lib.helen_io_library_lock.argtypes = []
+    lib.helen_io_library_unlock.restype = None
+    lib.helen_io_library_unlock.argtypes = []
     lib.helen_io_reader_counts.restype = None
     lib.helen_io_reader_counts.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
     lib.helen_io_close_readers.restype = None
@@ -216,6 +220,22 @@ def emit_image_windows(path, contigs, starts, ends, chunks, lengths, images, pos
                                          positions.ctypes.data)
     if rc != 0:
         raise IOError(_err(lib))
+
+
+class library_lock(object):
+    """Context manager: the lock libhelen_io.so takes around every call it makes into libhdf5 (io.cpp g_library_mutex).
+    A thread that uses libhdf5 through another binding (helen_amd.hdf5) beside the native reader / writer holds it for
+    the duration; without libhelen_io.so nothing native uses the library and the lock is a no-op."""
+
+    def __enter__(self):
+        self._lib = load()
+        if self._lib is not None:
+            self._lib.helen_io_library_lock()
+        return self
+
+    def __exit__(self, *exc):
+        if self._lib is not None:
+            self._lib.helen_io_library_unlock()
 
 
 def close_readers():

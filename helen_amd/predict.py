@@ -196,14 +196,14 @@ class _WriterPool(object):
             self.t_busy = None
 
 
-def _feeder_loop(calls, free_slots, ready_q, pool, cap, err, num_workers=0):
+def _feeder_loop(calls, free_slots, ready_q, pool, cap, err, num_workers=0, stop=None):
     """Feeder thread: for each device call take a free slot and get its windows read into it -- by
     the worker pool, in about two contiguous tasks per worker so that every worker has something
     to do whatever the loader batch size is, or inline when num_workers == 0."""
     try:
         for batches in calls:
             slot = free_slots.get()
-            if slot is None:        # a writer failed: the main loop must not wait for more slots
+            if slot is None or (stop is not None and stop.is_set()):   # a writer failed / the run is being torn down
                 return
             pairs = [p for b in batches for p in b]
             futures = []
@@ -228,17 +228,21 @@ def reader_mode(runs, num_workers, writers):
     serialised inside a process), when a writer pool needs slots other processes can attach, or on request
     ($HELEN_READERS=processes)."""
     from . import native_io
+    if not native_io.available() or writers > 1:      # (a writer pool attaches the slots by path: no override changes that)
+        return "processes"
     want = os.environ.get("HELEN_READERS", "")
     if want in ("threads", "processes"):
-        return want if native_io.available() else "processes"
-    if not native_io.available() or writers > 1:
-        return "processes"
+        return want
     if num_workers > 1 and any(lib for _, _, lib in runs):
         return "processes"
     return "threads"
 
 
-def _thread_feeder_loop(calls, free_slots, ready_q, make_slot, n_slots, threads, batch_size, err, device_id, reap_q):
+_NO_SLOT = object()
+
+
+def _thread_feeder_loop(calls, free_slots, ready_q, make_slot, n_slots, threads, batch_size, err, device_id, reap_q,
+                        stop=None):
     """Feeder of the "threads" mode: per device call a free slot (the first `n_slots` are made here, one at a time, as
     the pipeline asks for them: page-locked allocations cost ~0.1 s each and only the first one is waited for), the
     call's (file, first, count) runs read by `threads` native threads, files the reader has left handed to the reaper."""
@@ -250,16 +254,18 @@ def _thread_feeder_loop(calls, free_slots, ready_q, make_slot, n_slots, threads,
         made = 0
         last_path = None
         for runs in calls:
-            slot = None
+            if stop is not None and stop.is_set():
+                return
+            slot = _NO_SLOT
             if made < n_slots:
                 try:
                     slot = free_slots.get_nowait()
                 except queue.Empty:
                     slot = make_slot()
                     made += 1
-            if slot is None:
+            if slot is _NO_SLOT:
                 slot = free_slots.get()
-            if slot is None:        # a writer failed: the main loop must not wait for more slots
+            if slot is None or (stop is not None and stop.is_set()):   # a writer failed / the run is being torn down
                 return
             n = sum(c for _, _, c in runs)
             lib = native_io.read_image_runs(runs, threads, slot.images[:n], slot.positions[:n], slot.meta[:n],
@@ -377,16 +383,17 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
             pool = cf.ProcessPoolExecutor(num_workers, mp_context=mp.get_context("spawn"))
     ferr, werr = [], []
     reaper = None
+    stop_feeding = threading.Event()
     if mode == "threads":
         reap_q = queue.Queue()
         reaper = threading.Thread(target=_reaper_loop, args=(reap_q,), daemon=True)
         reaper.start()
         feeder = threading.Thread(target=_thread_feeder_loop, daemon=True,
                                   args=(calls, free_slots, ready_q, make_slot, n_slots, max(1, num_workers), batch_size,
-                                        ferr, None if on_host else device_id, reap_q))
+                                        ferr, None if on_host else device_id, reap_q, stop_feeding))
     else:
-        feeder = threading.Thread(target=_feeder_loop, args=(calls, free_slots, ready_q, pool, cap, ferr, num_workers),
-                                  daemon=True)
+        feeder = threading.Thread(target=_feeder_loop, daemon=True,
+                                  args=(calls, free_slots, ready_q, pool, cap, ferr, num_workers, stop_feeding))
     for k in STAGE_SECONDS:
         STAGE_SECONDS[k] = 0.0
     if writers == 1:
@@ -483,6 +490,20 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         # shared-memory slots each take 0.1-0.3 s to let go of.
         took = {}
         writer_done = threading.Event()
+        if werr or ferr or sys.exc_info()[0] is not None:
+            # the loop ended early: a feeder blocked on the bounded ready queue or waiting for a slot would never see
+            # its end -- take what it has queued, hand it the give-up sentinel, and let it (and the reaper it feeds) finish
+            stop_feeding.set()
+            free_slots.put(None)
+            deadline = time.time() + 30.0
+            while feeder.is_alive() and time.time() < deadline:
+                try:
+                    ready_q.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            feeder.join(timeout=1.0)
+            if reaper is not None:
+                reaper.join(timeout=10.0)
 
         def release_device():
             t = time.time()

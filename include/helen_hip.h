@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HELEN_ABI_VERSION 1
+#define HELEN_ABI_VERSION 2
 
 enum {
     HELEN_OK = 0,
@@ -94,8 +94,7 @@ enum {
     HELEN_K_GEMM_DEC = 3,    /* decoder input projection  Y1.W_ih^T + b */
     HELEN_K_GRU_DEC = 4,     /* decoder recurrence */
     HELEN_K_HEADS = 5,       /* heads + softmax + accumulate + argmax (or + cross-entropy terms) */
-    HELEN_K_CHUNKS = 6,      /* the whole 19-chunk loop as one launch: classes 2-5 of every chunk (fp32, large calls) */
-    HELEN_K_COUNT = 7
+    HELEN_K_COUNT = 6
 };
 
 /* ABI version of the loaded library (== HELEN_ABI_VERSION of the header it was built from). */
@@ -125,18 +124,16 @@ int helen_model_device_bytes(const HelenModel* model, size_t* out_bytes);
  * Which kernels a call takes is one table derived from the device's CU count (helen_amd/csrc/dispatch.h); every
  * choice gives the same bits.  The environment's A/B switches (HELEN_GRU_PAIR, HELEN_GRU_SINGLE8, HELEN_GRU_HALF8,
  * HELEN_GRU_QUARTER4, HELEN_DEC_WS, HELEN_DEC_WSP[_PARTS], HELEN_ENC_WS8, HELEN_ENC_WS8P[_PARTS], HELEN_SPLIT[_AT],
- * HELEN_BF16_PAIR, HELEN_BF16_IL, HELEN_HOST_LOCK, HELEN_VERBOSE = print the table) are read ONCE, when the model is
+ * HELEN_BF16_PAIR, HELEN_HOST_LOCK, HELEN_VERBOSE = print the table) are read ONCE, when the model is
  * created; helen_reload_overrides reads them again for this model (tests and probes that flip one between calls).
  *   helen_describe_dispatch   the table for a device of `cus` compute units, as text (a dry run: no device needed)
  *   helen_plan_call           out[8] = split?, tiles of the first group, recurrence kernel, decoder projection, its
  *                             position runs, encoder projection, its position runs, bf16 two-tile kernels?  (the enums of
  *                             dispatch.h) for a call of `tiles` tiles on `cus` CUs
- *   helen_has_persistent      1 if the library was built with the one-launch chunk loop (-DHELEN_WITH_PERSISTENT)
  */
 int helen_reload_overrides(HelenModel* model);
 int helen_describe_dispatch(int cus, char* out, size_t cap);
 int helen_plan_call(int cus, int tiles, int* out);
-int helen_has_persistent(void);
 
 /*
  * The whole per-batch body of the reference loop (`models/predict_gpu.py:97-159`): uint8 -> f32,
@@ -163,7 +160,9 @@ int helen_polish_batch(HelenModel* model, const uint8_t* images, int n_windows, 
  * mirrors the library owns (78.9 k) -- it is NOT page-locked in place by default: on this ROCm a registration maps the
  * caller's pages in place without a reference count, so unregistering a range takes GPU access away from every page
  * it shares with any other registration of the process (api.hip: helen_polish_host has the whole story;
- * $HELEN_HOST_LOCK=own | all at model creation restores the in-place rules of rounds 2-3).
+ * $HELEN_HOST_LOCK=own | all at model creation restores the in-place rules of rounds 2-3.  Those two settings are
+ * UNSUPPORTED, at your own risk: they re-open the exposure to the GPU memory-access fault described there, which was
+ * never reproduced in isolation; accepted values are exactly none | own | all, anything else is ignored).
  * Synchronous: returns when the labels are in host memory; on an error nothing is left in flight.
  * Hand it MANY sub-batches per call: the first upload and the last download are the only exposed
  * copies.  Replaces the DataLoader -> `.to(device_id)` -> `.cpu()` hand-offs of
@@ -197,9 +196,6 @@ int helen_polish_flush(HelenModel* model);
  * created (the test suite sets it for the one test that needs it); refused while another thread is in a call.
  */
 int helen_debug_inject_failure(HelenModel* model, int sub_batch);
-/* sub_batch value that instead marks a hand-off time-out of the one-launch chunk loop (HELEN_PERSISTENT=1), as the
- * device would: the next helen_polish_batch on that path must report it and fall back to the per-phase launches. */
-#define HELEN_DEBUG_PERSISTENT_TIMEOUT (-2)
 
 /*
  * One TransducerGRU.forward call (`models/TransducerModel.py:60-79`), the operator-level

@@ -80,6 +80,12 @@ int helen_io_image_storage(const char* path, int* out);
 int helen_io_read_labeled(const char* path, const char* names, int n, uint8_t* images, uint8_t* label_base,
                           uint8_t* label_rle);
 
+/* libhdf5 is not assumed thread-safe: every call this library makes into it is under one process-wide recursive lock.
+ * A thread that uses libhdf5 through another binding beside this library takes the same lock for the duration
+ * (lock and unlock on the same thread). */
+void helen_io_library_lock(void);
+void helen_io_library_unlock(void);
+
 /* out[0] / out[1] = images this process has read through the direct scanner / through libhdf5. */
 void helen_io_reader_counts(long long* out);
 /* Drop every cached file handle and mapping of this process. */
@@ -129,6 +135,23 @@ int helen_io_list_regions(const char* path, const char* contig, long long* sizes
  * Returns the length (NUL-terminated in `out`), -2 if `cap` is too small. */
 long long helen_io_region_sequence(const char* path, const char* contig, const char* region, char* out,
                                    long long cap);
+
+/* helen_io_region_sequence for regions whose images are still in memory (labels a device call has just delivered): region
+ * r = the windows rows[first[r] .. first[r + 1]) of positions int64 [*, 1000, 3] / bases, rles uint8 [*, 1000], listed
+ * by the caller in the STRING order of their chunk ids, each id once.  Position values are taken as the prediction
+ * file stores them (uint32: a -1 padding row is the key 4294967295).  Sequences go to `out` back to back with
+ * offsets[n_regions + 1]; `threads` threads of this call share the work.  Returns the total length, -2 if cap is short. */
+long long helen_io_decode_regions(int n_regions, const int32_t* first, const int32_t* rows, const int64_t* positions,
+                                  const uint8_t* bases, const uint8_t* rles, int threads, char* out, long long cap,
+                                  int64_t* offsets);
+
+/* `n` overlap alignments in one call (`Stitch.py:104-134` per join), reduced to what `alignment_stitch` uses: join k
+ * aligns query blob[r_off[k], +r_len[k]) against reference blob[l_off[k], +l_len[k]) as helen_ssw_align does;
+ * out[3k] = best score, out[3k+1], out[3k+2] = (reference index, query index) of the first M run (= and X merged)
+ * of at least `min_run`, or (-1, -1) (`get_confident_positions`, `Stitch.py:34-94`).  Single-threaded, re-entrant. */
+int helen_ssw_join_batch(int n, const char* blob, const int64_t* l_off, const int32_t* l_len, const int64_t* r_off,
+                         const int32_t* r_len, int match, int mismatch, int gap_open, int gap_extend, int min_run,
+                         int32_t* out);
 
 /* HELEN.Aligner(match, mismatch, gap_open, gap_extend) + SetReferenceSequence(ref) + Align_cpp(query, Filter(), &al, 0)
  * (`Stitch.py:110-134`; native `ssw.c` / `ssw_cpp.cpp`): the same score, begin / end cells, extended CIGAR and
