@@ -357,32 +357,46 @@ def gather_strings(dist, world, text):
     return [bytes(e[:int(k.item())].tolist()).decode(errors="replace") for e, k in zip(every, sizes)]
 
 
+def trained_weights():
+    """The weights of tests/golden/trained_synth.npz: the reference's TransducerGRU trained (build container,
+    tests/golden/make_trained_synth.py) on the read-vote noise model the simulated assembly is rendered with."""
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", "trained_synth.npz"))
+    return {k: np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files if not k.startswith("_")}
+
+
 def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_device, dist, may_shrink=False):
-    """The whole `call_consensus` of the product over `world` ranks -- synthetic MarginPolish image directory (HDF5,
-    16 files per rank, sharded round-robin by file as CallConsensusInterface.py:138-145) -> per rank: reader threads
-    (page-locked slots) -> device -> ONE prediction HDF5 -- wall-clocked from the call to its return: host budgeting, process start-up,
-    model load and the final close included (SURVEY.md 8d "end-to-end").  Every bench rank writes its share of the
-    inputs (direct emitter of libhelen_io.so, RAM-backed directory); rank 0 then runs call_consensus, which starts
-    its OWN process per device exactly as the CLI does, while the other bench ranks sleep on a file (not in a
-    collective: their GPUs must be idle).  Returns the `end_to_end` object on rank 0, None elsewhere."""
+    """The product's commands over `world` ranks on a SIMULATED ASSEMBLY (helen_amd.synthetic.write_assembly_dir: contigs cut
+    into 2400-position regions of three images, insert rows, short last images; pileups from the read-vote noise model;
+    the TRAINED network of tests/golden/trained_synth.npz, so the called sequence is ~1 kb per image and neighbouring
+    regions agree where they overlap), 16 image files per rank sharded round-robin (CallConsensusInterface.py:138-145):
+      1. `call_consensus` -- image directory -> one prediction HDF5 per rank -- wall-clocked from the call to its return:
+         host budgeting, process start-up, model load and the final close included (SURVEY.md 8d "end-to-end") = `value`;
+      2. `polish` -- the same plus stitch -> FASTA (PolishInterface.py:49-105), stitch pipelined behind the inference
+         (helen_amd/stitch_stream.py) = `polish_seconds`, and the FASTA compared with the two-phase stitch of the same
+         prediction files.
+    Every bench rank writes its share of the inputs (direct emitter of libhelen_io.so, RAM-backed directory); rank 0 then
+    runs the commands, which start their OWN process per device exactly as the CLI does, while the other bench ranks
+    sleep on a file (not in a collective: their GPUs must be idle).  Returns the `end_to_end` object on rank 0."""
     import shutil
     import tempfile
 
     from helen_amd import hdf5
     from helen_amd import predict as P
-    from helen_amd.call_consensus import call_consensus
+    from helen_amd.call_consensus import call_consensus, polish_genome
     from helen_amd.host_plan import SLOT_BYTES_PER_WINDOW, shm_free_bytes
     from helen_amd.model_handler import ModelHandler
-    from helen_amd.synthetic import write_image_file_direct
-    from helen_amd.weights import make_images
-    def need_bytes(per_rank):     # inputs + slots + outputs, all ranks, all RAM-backed
-        return per_rank * world * (116000 + 16000) + world * 5 * 4096 * SLOT_BYTES_PER_WINDOW
+    from helen_amd.synthetic import assembly_spec, write_assembly_dir
+    def need_bytes(per_rank):     # inputs + slots + outputs (two runs) + FASTA, all ranks, all RAM-backed
+        return per_rank * world * (116000 + 2 * 16000 + 2 * 1500) + world * 5 * 4096 * SLOT_BYTES_PER_WINDOW
     box = [None, windows_per_rank]
     if rank == 0:
         free = shm_free_bytes()
         # the default leg (no --e2e given) shrinks to what /dev/shm holds for all ranks, down to two device calls per rank
         while may_shrink and box[1] > 8192 and free <= need_bytes(box[1]) * 1.1:
             box[1] -= 4096
+        if box[1] != windows_per_rank:
+            sys.stderr.write("INFO: /dev/shm HAS %.1f GB FREE: THE END-TO-END LEG SHRINKS TO %d WINDOWS PER RANK.\n" % (free / 1e9, box[1]))
         if free > need_bytes(box[1]) * 1.1:
             box[0] = tempfile.mkdtemp(prefix="helen_e2e_", dir="/dev/shm")
         elif world == 1:
@@ -390,7 +404,6 @@ def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_de
     if dist is not None:
         dist.broadcast_object_list(box, src=0)
     d, windows_per_rank = box
-    total = windows_per_rank * world
     if d is None:
         return {"value": None, "skipped": "/dev/shm has %.1f GB free, the %d-rank leg needs %.1f GB"
                                           % (shm_free_bytes() / 1e9, world, need_bytes(windows_per_rank) / 1e9)} if rank == 0 else None
@@ -398,17 +411,14 @@ def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_de
     try:
         img_dir = os.path.join(d, "img")
         os.makedirs(img_dir, exist_ok=True)
-        per_file = -(-windows_per_rank // E2E_FILES_PER_RANK)
+        n_files = E2E_FILES_PER_RANK * world
+        spec = assembly_spec(windows_per_rank * world, n_files)
         t0 = time.time()
         write_error = None
         try:
-            for k in range(E2E_FILES_PER_RANK):            # file index fi = k * world + rank: round-robin gives them back
-                fi = k * world + rank
-                n = min(per_file, windows_per_rank - k * per_file)
-                if n <= 0:
-                    break
-                write_image_file_direct(os.path.join(img_dir, "synthetic_images_%04d.h5" % fi),
-                                        make_images(n, seed=20260928 + fi), first_window=fi * per_file)
+            # file fi goes to caller fi % world (round-robin over the sorted list): this rank writes its own
+            write_assembly_dir(img_dir, spec, n_files, direct=True, only_files=[fi for fi in range(n_files) if fi % world == rank],
+                               processes=max(1, min(8, usable_cpus() // world)))
         except Exception as e:          # noqa: BLE001 -- agreed on by all ranks below
             write_error = "%s: %s" % (type(e).__name__, e)
         t_write = time.time() - t0
@@ -425,24 +435,39 @@ def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_de
         out = os.path.join(d, "out")
         import contextlib
         device_ids = ",".join("0" if single_device else str(r) for r in range(world))
+        threads = max(1, min(16, usable_cpus()))
         t0 = time.time()
         with contextlib.redirect_stdout(sys.stderr):     # the CLI prints the output file name: keep stdout to the JSON line
-            call_consensus(img_dir, model, batch, workers, 1, out, "p", True, device_ids, world)
+            call_consensus(img_dir, model, batch, workers, threads, out, "p", True, device_ids, world)
         dt = time.time() - t0
         run = dict(P.LAST_RUN)
+        total = sum(r.get("windows", 0) for r in run.get("ranks", []))
         files = sorted(os.listdir(out))
         stored = 0
         for name in files:
             with hdf5.File(os.path.join(out, name)) as f:
                 stored += sum(len(f.keys("predictions/" + c)) for c in f.keys("predictions"))
-        # the second half of `helen polish`: prediction HDF5 -> FASTA (random weights call random labels, so the
-        # regions' overlaps do not agree: a scale check of stitch; scripts/stitch_bench.py measures it on consistent ones)
+        # the two-phase stitch of those files (what `helen stitch` does, and what `polish` did until round 4) ...
         from helen_amd.stitch import perform_stitch
-        threads = max(1, min(16, usable_cpus()))
         t0 = time.time()
         with contextlib.redirect_stdout(sys.stderr):
             fasta = perform_stitch(out, os.path.join(d, "fa"), "asm", threads)
         dt_stitch = time.time() - t0
+        # ... and the whole `polish` command's work in one go, stitch pipelined behind the inference
+        t0 = time.time()
+        with contextlib.redirect_stdout(sys.stderr):
+            polish_genome(img_dir, model, batch, workers, threads, os.path.join(d, "polish"), "asm", True, device_ids, world)
+        dt_polish = time.time() - t0
+        polish_run = dict(P.LAST_RUN)
+        fasta2 = os.path.join(d, "polish", "asm.fa")
+        same = os.path.getsize(fasta) == os.path.getsize(fasta2)
+        if same:
+            with open(fasta, "rb") as a, open(fasta2, "rb") as b:
+                while same:
+                    x, y = a.read(1 << 24), b.read(1 << 24)
+                    same = x == y
+                    if not x:
+                        break
         plan = run.get("host_plan", {})
         # the same run without its fixed costs: every rank's windows over the slowest rank's loop time (first slot
         # submitted .. last labels back; process start-up, model load, page-locking, file close and tear-down excluded)
@@ -451,6 +476,8 @@ def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_de
         steady = round(total / max(loops), 1) if loops and max(loops) > 0 else None
         return {"value": round(total / dt, 1), "unit": "windows/s", "n_ranks": world, "windows": total,
                 "seconds": round(dt, 3), "value_without_setup_and_close": steady,
+                "weights": "trained_synth", "workload": "simulated assembly: %d contigs, %d regions of 2400 positions (three images "
+                                                        "each, the last short), insert rows, %d image files" % (len(spec), stored, n_files),
                 "usable_cpus": plan.get("usable_cpus"),
                 "reader_workers_requested": workers,
                 "reader_workers_per_rank": plan.get("reader_workers_per_rank"),
@@ -460,10 +487,19 @@ def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_de
                 "per_rank": [{k: r.get(k) for k in ("rank", "device", "windows", "seconds", "stage_seconds",
                                                     "setup_seconds", "close_seconds", "reader_workers", "slots",
                                                     "cpus_pinned", "numa_node")} for r in run.get("ranks", [])],
-                "host_plan_notes": plan.get("notes"),
+                "host_plan_notes": plan.get("host_plan_notes") if "host_plan_notes" in plan else plan.get("notes"),
                 "output_files": files, "regions_stored": stored,
-                "stitch": {"seconds": round(dt_stitch, 3), "threads": threads, "fasta_bytes": os.path.getsize(fasta)},
-                "polish_seconds": round(dt + dt_stitch, 3),
+                "stitch": {"seconds": round(dt_stitch, 3), "threads": threads, "fasta_bytes": os.path.getsize(fasta),
+                           "what": "two-phase: perform_stitch on the finished prediction files"},
+                "two_phase_polish_seconds": round(dt + dt_stitch, 3),
+                "polish_seconds": round(dt_polish, 3),
+                "polish_windows_per_s": round(total / dt_polish, 1),
+                "polish": {"what": "polish_genome: call_consensus + stitch pipelined behind the inference (helen_amd/stitch_stream.py), "
+                                   "image directory -> prediction HDF5 + FASTA",
+                           "seconds": round(dt_polish, 3), "predict_seconds": polish_run.get("seconds"),
+                           "fasta_equals_two_phase": bool(same),
+                           "per_rank": [{k: r.get(k) for k in ("rank", "windows", "seconds", "stage_seconds", "stitch_stream")}
+                                        for r in polish_run.get("ranks", [])]},
                 "what": "call_consensus(image_dir -> one prediction HDF5 per rank) over %d rank(s) incl. host "
                         "budgeting, process start-up, model load and close; %d synthetic windows per rank written in "
                         "%.1f s to %s" % (world, windows_per_rank, t_write, os.path.dirname(d))}
@@ -772,7 +808,7 @@ def main():
     e2e = None
     if e2e_windows > 0:
         try:
-            e2e = end_to_end(e2e_windows, args.e2e_workers, B, make_weights(input_scale=1.0 / 64.0), rank, world,
+            e2e = end_to_end(e2e_windows, args.e2e_workers, B, trained_weights(), rank, world,
                              args.single_device, dist, may_shrink=args.e2e is None)
         except (Exception, SystemExit) as e:    # noqa: BLE001 -- this leg must not take the headline down with it (call_consensus exits on bad input)
             e2e = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}

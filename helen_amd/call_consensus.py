@@ -47,7 +47,9 @@ def vet_image_directory(image_dir, images_per_file=4):
 
 
 def call_consensus(image_dir, model_path, batch_size, num_workers, threads, output_dir,
-                   output_prefix, gpu_mode, device_ids, callers):
+                   output_prefix, gpu_mode, device_ids, callers, stitch_threads=None):
+    """(CallConsensusInterface.py:47-156.)  `stitch_threads` is polish_genome's: the regions are decoded and their overlaps
+    aligned behind the inference (helen_amd.stitch_stream) and come back as the return value (None otherwise)."""
     if not os.path.isfile(model_path):
         _err("CAN NOT LOCATE MODEL FILE.")
         sys.exit(1)
@@ -118,25 +120,29 @@ def call_consensus(image_dir, model_path, batch_size, num_workers, threads, outp
                     vet["error"] = e
             vet["thread"] = threading.Thread(target=run_vet, daemon=True)
             vet["thread"].start()
+    streams = None
     try:
         if gpu_mode:
-            predict_gpu(file_chunks, output_filename, model_path, batch_size, callers, device_ids,
-                        num_workers)
+            streams = predict_gpu(file_chunks, output_filename, model_path, batch_size, callers, device_ids,
+                                  num_workers, stitch_threads=stitch_threads)
         else:
             from .predict import predict_cpu
-            predict_cpu(file_chunks, output_filename, model_path, batch_size, callers, threads_per_caller, num_workers)
+            streams = predict_cpu(file_chunks, output_filename, model_path, batch_size, callers, threads_per_caller,
+                                  num_workers, stitch_threads=stitch_threads)
     finally:
         if vet is not None:
             vet["thread"].join()
     if vet is not None and vet["error"] is not None:
         raise vet["error"]
     sys.stderr.write("INFO: PREDICTION GENERATED SUCCESSFULLY.\n")
+    return streams
 
 
 def polish_genome(image_dir, model_path, batch_size, num_workers, threads, output_dir,
                   output_prefix, gpu_mode, device_ids, callers):
     """call_consensus into `<output_dir>/predictions_<timestamp>/`, then stitch the predictions into
     `<output_dir>/<output_prefix>.fa` (PolishInterface.py:49-105)."""
+    from . import stitch_stream
     from .stitch import perform_stitch
     output_dir = file_manager.handle_output_directory(output_dir)
     timestr = datetime.now().strftime("%m%d%Y_%H%M%S")
@@ -146,12 +152,18 @@ def polish_genome(image_dir, model_path, batch_size, num_workers, threads, outpu
     sys.stderr.write("INFO: RUN-ID: " + timestr + "\n")
     sys.stderr.write("INFO: PREDICTION OUTPUT DIRECTORY: " + prediction_dir + "\n")
     sys.stderr.write("INFO: CALL CONSENSUS STARTING\n")
-    call_consensus(image_dir, model_path, batch_size, num_workers, threads, prediction_dir,
-                   output_prefix, gpu_mode, device_ids, callers)
+    # stitch runs BEHIND the inference: regions are decoded and neighbours aligned while the device stage works
+    # (helen_amd.stitch_stream); what follows the last window is the joins in the reference's order
+    streams = call_consensus(image_dir, model_path, batch_size, num_workers, threads, prediction_dir,
+                             output_prefix, gpu_mode, device_ids, callers,
+                             stitch_threads=threads if stitch_stream.enabled() else None)
     t1 = time.time()
     sys.stderr.write("INFO: STITCH STARTING\n")
     print(prediction_dir)
-    perform_stitch(prediction_dir, output_dir, output_prefix, threads)
+    if streams is not None:
+        stitch_stream.finish_stitch(streams, prediction_dir, output_dir, output_prefix, threads)
+    else:
+        perform_stitch(prediction_dir, output_dir, output_prefix, threads)
     t2 = time.time()
 
     def fmt(a, b):

@@ -1402,35 +1402,58 @@ long long helen_io_decode_regions(int n_regions, const int32_t* first, const int
         if (offsets) offsets[0] = 0;
         return 0;
     }
+    // An image's rows come in key order and a region's images follow each other on the contig, so a region is built by
+    // APPENDING image after image; only where two images share rows (or a writer interleaved them) is there a merge,
+    // and only an image that is not in key order itself is sorted.  Keys as the file stores them: three uint32.
+    struct Item {
+        uint32_t pos, indx, split;
+        uint8_t base, rle;
+    };
+    auto less = [](const Item& a, const Item& b) {
+        if (a.pos != b.pos) return a.pos < b.pos;
+        if (a.indx != b.indx) return a.indx < b.indx;
+        return a.split < b.split;
+    };
+    auto same = [](const Item& a, const Item& b) { return a.pos == b.pos && a.indx == b.indx && a.split == b.split; };
     std::vector<std::string> seqs((size_t)n_regions);
     std::atomic<int> next{0};
     std::atomic<bool> bad{false};
     auto work = [&]() {
-        std::vector<Rec> recs;
-        std::vector<char> buf;
+        std::vector<Item> acc, img, merged;
+        static const char kDecode[5] = {0, 'A', 'C', 'G', 'T'};
         for (;;) {
             const int r = next.fetch_add(1);
             if (r >= n_regions) return;
-            recs.clear();
-            uint32_t order = 0;
+            acc.clear();
             for (int k = first[r]; k < first[r + 1]; ++k) {
                 const size_t w = (size_t)rows[k];
                 const int64_t* p = positions + w * kSeq * 3;
                 const uint8_t* b = bases + w * kSeq;
                 const uint8_t* l = rles + w * kSeq;
-                for (int i = 0; i < kSeq; ++i)
-                    recs.push_back({(int64_t)(uint32_t)p[3 * i], (int64_t)(uint32_t)p[3 * i + 1], (int64_t)(uint32_t)p[3 * i + 2],
-                                    b[i], l[i], order++});
+                img.resize(kSeq);
+                bool ordered = true;
+                for (int i = 0; i < kSeq; ++i) {
+                    img[i] = {(uint32_t)p[3 * i], (uint32_t)p[3 * i + 1], (uint32_t)p[3 * i + 2], b[i], l[i]};
+                    if (i > 0 && less(img[i], img[i - 1])) ordered = false;
+                }
+                if (!ordered) std::stable_sort(img.begin(), img.end(), less);     // (equal keys keep their row order)
+                if (acc.empty() || less(acc.back(), img.front())) {
+                    acc.insert(acc.end(), img.begin(), img.end());
+                } else {                                                           // ties: the earlier image first
+                    merged.resize(acc.size() + img.size());
+                    std::merge(acc.begin(), acc.end(), img.begin(), img.end(), merged.begin(), less);
+                    acc.swap(merged);
+                }
             }
-            size_t need = 1;
-            for (const Rec& x : recs) need += x.rle;
-            buf.resize(need);
-            const long long len = decode_records(recs, buf.data(), (long long)buf.size());
-            if (len < 0) {
-                bad = true;
-                return;
+            std::string& seq = seqs[(size_t)r];
+            size_t need = 0;
+            for (const Item& x : acc) need += x.rle;
+            seq.reserve(need);
+            for (size_t k = 0; k < acc.size(); ++k) {
+                if (k > 0 && same(acc[k], acc[k - 1])) continue;                    // first writer wins
+                const char ch = acc[k].base < 5 ? kDecode[acc[k].base] : 0;
+                if (ch) seq.append((size_t)acc[k].rle, ch);
             }
-            seqs[(size_t)r].assign(buf.data(), (size_t)len);
         }
     };
     const int T = std::max(1, std::min(threads, n_regions));

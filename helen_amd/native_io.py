@@ -82,6 +82,11 @@ def load():
     lib.helen_io_region_sequence.restype = ctypes.c_longlong
     lib.helen_io_region_sequence.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
                                              ctypes.c_char_p, ctypes.c_longlong]
+    lib.helen_io_decode_regions.restype = ctypes.c_longlong
+    lib.helen_io_decode_regions.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, vp, ctypes.c_longlong, vp]
+    lib.helen_ssw_join_batch.restype = ctypes.c_int
+    lib.helen_ssw_join_batch.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, vp]
     lib.helen_ssw_align.restype = ctypes.c_int
     lib.helen_ssw_align.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -372,6 +377,50 @@ def region_sequence(path, contig, region, as_bytes=False):
         if n < 0:
             raise IOError(_err(lib))
         return buf.raw[:n] if as_bytes else buf.raw[:n].decode()
+
+
+def decode_regions(first, rows, positions, bases, rles, threads=1):
+    """Sequences of regions whose images are in memory (helen_io_decode_regions): region r = windows
+    rows[first[r]:first[r + 1]] of positions int64 [*, 1000, 3] / bases, rles uint8 [*, 1000], listed in the string order
+    of their chunk ids.  -> (blob bytes-like uint8 array, offsets int64 [n_regions + 1])"""
+    lib = load()
+    first = np.ascontiguousarray(first, np.int32)
+    rows = np.ascontiguousarray(rows, np.int32)
+    n = int(first.shape[0]) - 1
+    for a, dt in ((positions, np.int64), (bases, np.uint8), (rles, np.uint8)):
+        if a.dtype != dt or not a.flags.c_contiguous:
+            raise ValueError("decode_regions wants C-contiguous int64 positions and uint8 labels")
+    offsets = np.zeros(n + 1, np.int64)
+    cap = int(rows.shape[0]) * 1000 * 10 + 16          # a row decodes to at most ten bases (run-length labels 0..10)
+    # (a label above 10 cannot come out of the 11-class head; a foreign array that holds one gets the exact retry below)
+    out = np.empty(min(cap, max(1 << 16, int(rows.shape[0]) * 1000 * 3)), np.uint8)
+    while True:
+        got = lib.helen_io_decode_regions(n, first.ctypes.data, rows.ctypes.data, positions.ctypes.data, bases.ctypes.data,
+                                          rles.ctypes.data, int(threads), out.ctypes.data, int(out.shape[0]), offsets.ctypes.data)
+        if got == -2:
+            need = int(_err(lib).rsplit(" ", 1)[-1])
+            out = np.empty(need + 16, np.uint8)
+            continue
+        if got < 0:
+            raise IOError(_err(lib))
+        return out[:got], offsets
+
+
+def ssw_join_batch(blob, l_off, l_len, r_off, r_len, match, mismatch, gap_open, gap_extend, min_run):
+    """`n` overlap alignments reduced to (score, pos_a, pos_b) each (helen_ssw_join_batch) -> int32 [n, 3]."""
+    lib = load()
+    n = int(len(l_off))
+    out = np.zeros((n, 3), np.int32)
+    if n == 0:
+        return out
+    l_off, r_off = np.ascontiguousarray(l_off, np.int64), np.ascontiguousarray(r_off, np.int64)
+    l_len, r_len = np.ascontiguousarray(l_len, np.int32), np.ascontiguousarray(r_len, np.int32)
+    buf = np.frombuffer(blob, np.uint8) if not isinstance(blob, np.ndarray) else blob
+    rc = lib.helen_ssw_join_batch(n, buf.ctypes.data, l_off.ctypes.data, l_len.ctypes.data, r_off.ctypes.data,
+                                  r_len.ctypes.data, match, mismatch, gap_open, gap_extend, min_run, out.ctypes.data)
+    if rc != 0:
+        raise IOError(_err(lib))
+    return out
 
 
 class Alignment(object):

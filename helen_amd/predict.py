@@ -43,8 +43,9 @@ LAST_PREDICT = {}
 LAST_RUN = {}
 
 
-def _writer_loop(wq, store, free_slots, err):
-    """Writer thread: labels of one device call -> prediction HDF5, then recycle the slot."""
+def _writer_loop(wq, store, free_slots, err, sq=None):
+    """Writer thread: labels of one device call -> prediction HDF5, then recycle the slot -- or, when `polish` stitches
+    behind the inference (`sq`), pass it on to the stitch stage, which recycles it."""
     try:
         while True:
             item = wq.get()
@@ -54,10 +55,37 @@ def _writer_loop(wq, store, free_slots, err):
             t0 = time.time()
             store.write_batch(slot.contigs[:n], slot.meta[:n], slot.positions[:n], bases, rles)
             STAGE_SECONDS["write"] += time.time() - t0
-            free_slots.put(slot)
+            if sq is not None:
+                sq.put(item)
+            else:
+                free_slots.put(slot)
     except Exception as e:  # surfaced by the caller
         err.append(e)
         free_slots.put(None)
+    finally:
+        if sq is not None:
+            sq.put(None)
+
+
+def _stitch_loop(sq, stream, free_slots, err):
+    """Stitch stage of `polish` (helen_amd.stitch_stream): the regions whose images the writer has just stored are decoded
+    from the slot's label buffers and their overlap alignments handed to worker threads; then the slot is recycled."""
+    failed = False
+    while True:
+        item = sq.get()
+        if item is None:
+            return
+        slot, n, bases, rles = item
+        if not failed:
+            try:
+                t0 = time.time()
+                stream.feed(slot.contigs[:n], slot.meta[:n], slot.positions[:n], bases, rles)
+                STAGE_SECONDS["stitch"] = STAGE_SECONDS.get("stitch", 0.0) + time.time() - t0
+            except Exception as e:  # surfaced by the caller; the slots keep circulating so that nothing hangs
+                failed = True
+                err.append(e)
+                free_slots.put(None)
+        free_slots.put(slot)
 
 
 class _DeviceStage(object):
@@ -327,7 +355,12 @@ def _remove_stale_outputs(output_filename, rank):
             os.unlink(path)
 
 
-def predict(test_file, output_filename, model_path, batch_size, num_workers, rank, device_id, plan=None, cpu_threads=None):
+# what the stitch stage of the last predict() of this process collected (helen_amd.stitch_stream.StreamResult), or None
+LAST_STREAM = [None]
+
+
+def predict(test_file, output_filename, model_path, batch_size, num_workers, rank, device_id, plan=None, cpu_threads=None,
+            stitch_threads=None):
     """Run inference over the image files `test_file` (a list) on device `device_id` and write
     `<output_filename>_<rank>.hdf` (predict_gpu.py:38-179).  `plan` (helen_amd.host_plan.RankPlan, from
     predict_gpu) caps the reader processes at what the host grants this rank and names its slots.
@@ -384,6 +417,14 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     ferr, werr = [], []
     reaper = None
     stop_feeding = threading.Event()
+    # `polish`: stitch runs behind the inference (stitch_threads = its -t); only with the one-file writer of this process
+    stream = sq = stitcher = None
+    LAST_STREAM[0] = None
+    if stitch_threads is not None and writers == 1:
+        from . import stitch_stream
+        if stitch_stream.enabled():
+            stream = stitch_stream.RegionStream(prediction_file_name(output_filename, rank), stitch_threads)
+            sq = queue.Queue()
     if mode == "threads":
         reap_q = queue.Queue()
         reaper = threading.Thread(target=_reaper_loop, args=(reap_q,), daemon=True)
@@ -397,10 +438,13 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     for k in STAGE_SECONDS:
         STAGE_SECONDS[k] = 0.0
     if writers == 1:
-        writer = threading.Thread(target=_writer_loop, args=(wq, prediction_data_file, free_slots, werr),
+        writer = threading.Thread(target=_writer_loop, args=(wq, prediction_data_file, free_slots, werr, sq),
                                   daemon=True)
         writer.start()
         writer_pool = None
+        if stream is not None:
+            stitcher = threading.Thread(target=_stitch_loop, args=(sq, stream, free_slots, werr), daemon=True)
+            stitcher.start()
     else:
         writer_pool = _WriterPool(output_filename, rank, writers, free_slots, werr)
     feeder.start()
@@ -534,6 +578,8 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         t_side = time.time()
         if writer_pool is None:
             writer.join()
+            if stitcher is not None:
+                stitcher.join()
         else:
             writer_pool.close()
         t_drained = time.time()
@@ -547,18 +593,26 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         t_closed = time.time()
         for t in side:
             t.join()
+        if stream is not None and (ferr or werr or close_error is not None or sys.exc_info()[0] is not None):
+            stream.abort()
     if ferr:
         raise ferr[0]
     if werr:
         raise werr[0]
     if close_error is not None:
         raise close_error
+    stitch_wait = 0.0
+    if stream is not None:
+        t_s = time.time()
+        LAST_STREAM[0] = stream.finish()        # the overlap alignments still queued with the worker threads
+        stitch_wait = time.time() - t_s
     LAST_PREDICT.clear()
     LAST_PREDICT.update({
         "rank": rank, "device": device_id, "windows": total_windows, "seconds": round(time.time() - start_time, 3),
         "stage_seconds": {k: round(v, 3) for k, v in STAGE_SECONDS.items()},
         "setup_seconds": round(t_setup - start_time, 3), "close_seconds": round(time.time() - t_loop_end, 3),
         "reader_workers": num_workers, "reader_mode": mode, "slots": n_slots, "device_calls": len(calls),
+        "stitch_stream": None if stream is None else dict(LAST_STREAM[0].stats, wait_seconds=round(stitch_wait, 3)),
         "cpus_pinned": None if plan is None or not plan.cpus else len(plan.cpus),
         "numa_node": None if plan is None else plan.numa_node})
     if rank == 0:
@@ -579,7 +633,7 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
 
 def _setup_cpu(rank, total_callers, args, all_input_files, result_q=None):
     """One caller of a run without --gpu_mode (predict_cpu.py:177-195; no process group is created: it was never used)."""
-    output_filepath, model_path, batch_size, num_workers, threads = args
+    output_filepath, model_path, batch_size, num_workers, threads, stitch_threads = args
     if result_q is not None:
         import signal
 
@@ -590,16 +644,45 @@ def _setup_cpu(rank, total_callers, args, all_input_files, result_q=None):
             os.setpgid(0, 0)
         except OSError:
             pass
-    predict(all_input_files[rank], output_filepath, model_path, batch_size, num_workers, rank, None, cpu_threads=threads)
+    predict(all_input_files[rank], output_filepath, model_path, batch_size, num_workers, rank, None, cpu_threads=threads,
+            stitch_threads=stitch_threads)
     if result_q is not None:
-        result_q.put((rank, dict(LAST_PREDICT)))
+        result_q.put((rank, _rank_report()))
 
 
-def predict_cpu(file_chunks, output_filepath, model_path, batch_size, total_callers, threads, num_workers):
+def _rank_report():
+    """What a spawned rank sends its parent: LAST_PREDICT, with the stitch stage's regions parked in a file."""
+    info = dict(LAST_PREDICT)
+    if LAST_STREAM[0] is not None:
+        from .stitch_stream import spill_directory
+        info["stream_file"] = LAST_STREAM[0].save(spill_directory())
+        LAST_STREAM[0] = None
+    return info
+
+
+def _collect_streams(in_process, rank_infos):
+    """The StreamResults of a run (helen_amd.stitch_stream): this process's own, or the files its ranks left."""
+    from .stitch_stream import StreamResult
+    if in_process:
+        return [LAST_STREAM[0]] if LAST_STREAM[0] is not None else None
+    paths = [r.pop("stream_file", None) for r in rank_infos]
+    if not paths or any(p is None for p in paths):
+        for p in paths:
+            if p is not None:
+                try:
+                    os.unlink(p)
+                except OSError:
+                    pass
+        return None
+    return [StreamResult.load(p) for p in paths]
+
+
+def predict_cpu(file_chunks, output_filepath, model_path, batch_size, total_callers, threads, num_workers,
+                stitch_threads=None):
     """`callers` processes, each over its own file list with `threads` threads, each writing `<output>_<rank>.hdf`
     (models/predict_cpu.py:198-248).  The engine is libhelen_cpu.so (no ONNX export: the .pkl is all it needs); a failing
     caller takes the others down, as mp.spawn(join=True) does (:245-248)."""
-    args = (output_filepath, model_path, batch_size, num_workers, max(1, int(threads)))
+    args = (output_filepath, model_path, batch_size, num_workers, max(1, int(threads)), stitch_threads)
     LAST_RUN.clear()
     LAST_RUN.update({"host_plan": None, "ranks": []})
     t0 = time.time()
@@ -607,17 +690,19 @@ def predict_cpu(file_chunks, output_filepath, model_path, batch_size, total_call
         _setup_cpu(0, 1, args, file_chunks)
         LAST_RUN["ranks"] = [dict(LAST_PREDICT)]
         LAST_RUN["seconds"] = round(time.time() - t0, 3)
-        return
+        return _collect_streams(True, None)
     results, failed = run_ranks(_setup_cpu, [(r, total_callers, args, file_chunks) for r in range(total_callers)])
     LAST_RUN["ranks"] = [results[r] for r in sorted(results)]
     LAST_RUN["seconds"] = round(time.time() - t0, 3)
+    streams = _collect_streams(False, LAST_RUN["ranks"]) if len(results) == total_callers else None
     if failed:
         raise RuntimeError("prediction process(es) failed: " + ", ".join(
             "rank %d exit %s" % f for f in failed) + "; the other callers were terminated")
+    return streams
 
 
 def _setup(rank, total_callers, args, all_input_files, all_devices, plans=None, result_q=None):
-    output_filepath, model_path, batch_size, num_workers = args
+    output_filepath, model_path, batch_size, num_workers, stitch_threads = args
     plan = plans[rank] if plans is not None else None
     if result_q is not None:
         # a spawned rank: SIGTERM from the parent (a sibling failed) must unwind through predict()'s tear-down --
@@ -634,9 +719,9 @@ def _setup(rank, total_callers, args, all_input_files, all_devices, plans=None, 
     from .host_plan import apply_rank_plan
     apply_rank_plan(plan)
     predict(all_input_files[rank], output_filepath, model_path, batch_size, num_workers, rank,
-            all_devices[rank], plan=plan)
+            all_devices[rank], plan=plan, stitch_threads=stitch_threads)
     if result_q is not None:
-        result_q.put((rank, dict(LAST_PREDICT)))
+        result_q.put((rank, _rank_report()))
 
 
 def run_ranks(target, argsets, slot_prefixes=(), grace_seconds=10.0):
@@ -715,7 +800,7 @@ def run_ranks(target, argsets, slot_prefixes=(), grace_seconds=10.0):
 
 
 def predict_gpu(file_chunks, output_filepath, model_path, batch_size, total_callers, devices,
-                num_workers):
+                num_workers, stitch_threads=None):
     """One process per device, each over its own file list (predict_gpu.py:207-226).  A failing child raises
     here AND takes its siblings down, as mp.spawn(join=True) does (predict_gpu.py:223): the parent waits on all
     ranks at once, and the first non-zero exit terminates the others (SIGTERM, which a rank turns into its normal
@@ -724,7 +809,9 @@ def predict_gpu(file_chunks, output_filepath, model_path, batch_size, total_call
     Before anything starts the host is budgeted over all ranks (helen_amd.host_plan): reader processes per rank
     from the usable CPUs, NUMA pinning of each rank to its GPU's node, one RAM-backed slot budget."""
     from .host_plan import plan_host, storage_of_files
-    args = (output_filepath, model_path, batch_size, num_workers)
+    if stitch_threads is not None:          # `polish`: each rank gets its share of the stitch threads
+        stitch_threads = max(1, int(stitch_threads) // max(1, total_callers))
+    args = (output_filepath, model_path, batch_size, num_workers, stitch_threads)
     group = max(1, DEVICE_CALL_WINDOWS // batch_size)
     host = plan_host(list(devices[:total_callers]), num_workers, group * batch_size,
                      storage=[storage_of_files(file_chunks[r]) for r in range(total_callers)])
@@ -736,12 +823,14 @@ def predict_gpu(file_chunks, output_filepath, model_path, batch_size, total_call
         _setup(0, 1, args, file_chunks, devices, plans=host.ranks)
         LAST_RUN["ranks"] = [dict(LAST_PREDICT)]
         LAST_RUN["seconds"] = round(time.time() - t0, 3)
-        return
+        return _collect_streams(True, None)
     results, failed = run_ranks(_setup, [(r, total_callers, args, file_chunks, devices, host.ranks)
                                          for r in range(total_callers)],
                                 [rp.slot_prefix for rp in host.ranks])
     LAST_RUN["ranks"] = [results[r] for r in sorted(results)]
     LAST_RUN["seconds"] = round(time.time() - t0, 3)
+    streams = _collect_streams(False, LAST_RUN["ranks"]) if len(results) == total_callers else None
     if failed:
         raise RuntimeError("prediction process(es) failed: " + ", ".join(
             "rank %d exit %s" % f for f in failed) + "; the other ranks were terminated")
+    return streams

@@ -73,10 +73,16 @@ def _as_bytes(sequence):
     return sequence.encode() if isinstance(sequence, str) else sequence
 
 
-def _alignment_stitch(sequence_chunks):
+def _ssw(left_chunk, right_chunk):
+    return native_io.ssw_align(left_chunk, right_chunk, StitchOptions.MATCH_PENALTY, StitchOptions.MISMATCH_PENALTY,
+                               StitchOptions.GAP_PENALTY, StitchOptions.GAP_EXTEND_PENALTY)
+
+
+def _alignment_stitch(sequence_chunks, aligner=None):
     """alignment_stitch on bytes: the sequences of a contig are hundreds of megabytes, and every str <-> bytes
     conversion of the running sequence is a copy of all of it.  Chunk sequences may be str or bytes; the running
-    sequence comes back as a bytearray."""
+    sequence comes back as a bytearray.  `aligner(left, right)` may answer a join from a table of alignments made
+    earlier -- (best score, pos_a, pos_b) for exactly these two strings, or None (helen_amd.stitch_stream)."""
     sequence_chunks = sorted(sequence_chunks, key=lambda e: (e[1], e[2]))
     contig, running_start, running_end, first = sequence_chunks[0]
     running = bytearray(_as_bytes(first))
@@ -90,11 +96,14 @@ def _alignment_stitch(sequence_chunks):
             # python slicing semantics of the reference: s[-n:] is all of s when n >= len(s)
             left_chunk = bytes(running[-overlap_bases:])
             right_chunk = bytes(this_sequence[:overlap_bases])
+            alignment = known = None
             if len(left_chunk) > 0 and len(right_chunk) > 0:
-                alignment = native_io.ssw_align(left_chunk, right_chunk, StitchOptions.MATCH_PENALTY,
-                                                StitchOptions.MISMATCH_PENALTY, StitchOptions.GAP_PENALTY,
-                                                StitchOptions.GAP_EXTEND_PENALTY)
-                best_score, pos = alignment.best_score, None
+                known = aligner(left_chunk, right_chunk) if aligner is not None else None
+                if known is not None:
+                    best_score = known[0]
+                else:
+                    alignment = _ssw(left_chunk, right_chunk)
+                    best_score = alignment.best_score
             else:
                 best_score = 0      # Align_cpp returns false on an empty sequence: score stays 0
             if best_score == 0:
@@ -104,8 +113,10 @@ def _alignment_stitch(sequence_chunks):
                     running += right_chunk
                     running_end = this_end
             else:
-                pos_a, pos_b = get_confident_positions(alignment)
+                pos_a, pos_b = known[1:] if known is not None else get_confident_positions(alignment)
                 if pos_a == -1 or pos_b == -1:
+                    if alignment is None:
+                        alignment = _ssw(left_chunk, right_chunk)      # (for the CIGAR text of the warning)
                     sys.stderr.write("WARNING: NO OVERLAPS IN ALIGNMENT : \n")
                     sys.stderr.write("LEFT : " + left_chunk.decode() + "\n")
                     sys.stderr.write("RIGHT: " + right_chunk.decode() + "\n")

@@ -1,0 +1,348 @@
+"""Stitch pipelined behind inference: `helen polish` decodes regions and aligns neighbours WHILE the device stage runs.
+
+The reference's `polish` is two phases -- call_consensus writes the prediction files, then perform_stitch reads them back
+(PolishInterface.py:75-105) -- and with the inference on an MI355X the second phase is as long as the first.  Nothing in
+stitch needs the whole prediction file before it starts:
+  * a region's sequence (`small_chunk_stitch`'s position dictionaries, Stitch.py:204-247) depends on that region's own
+    images only: RegionStream decodes it from the label buffers right after the writer stage has stored them (the
+    prediction file is still written, byte for byte the same: stitch reads the buffers, not the file);
+  * the overlap alignment of two neighbouring regions (Stitch.py:104-134) is a pure function of the two strings it is
+    given: the tail of the running sequence and the head of the next region.  In every ordinary join the running tail IS
+    the previous region's tail, so the alignment is computed speculatively by worker threads as soon as both regions are
+    decoded, and kept in a table keyed by the two strings.
+What is left for after the last window is `finish_stitch`: the reference's own join order -- regions sorted by
+(start, end), runs of max(2, regions // threads + 1) regions stitched left to right, the runs stitched to each other
+(Stitch.py:257-301) -- executed once, single-threaded, taking each alignment from the table when the strings it is
+about to align are the speculated ones and from the aligner otherwise.  The FASTA is therefore the one perform_stitch
+writes from the files (tests/test_stitch_stream.py compares the two on adversarial inputs), whatever was speculated.
+
+A region whose images do not arrive back to back (possible only in a hand-made image file: MarginPolish writes a
+region's images consecutively) is decoded from the finished prediction file instead, like perform_stitch does.
+"""
+import bisect
+import concurrent.futures
+import os
+import pickle
+import sys
+import tempfile
+
+import numpy as np
+
+from . import file_manager, native_io
+from .stitch import StitchOptions, _alignment_stitch, get_file_paths_from_directory
+
+# images of one region a stream holds back at most (a region of more images is finished from the file)
+_CARRY_LIMIT = 4096
+
+
+def enabled():
+    """Pipelining is the default of `polish`; $HELEN_STITCH_PIPELINE=0 runs the two phases one after the other."""
+    return os.environ.get("HELEN_STITCH_PIPELINE", "1") != "0" and native_io.available()
+
+
+class RegionStream(object):
+    """The regions of ONE prediction file (one rank), decoded as the writer stage delivers their images.
+
+    feed() is called from one thread, in the order the images are written; finish() after the last one.  `threads`
+    worker threads run the speculative overlap alignments (native, the interpreter lock released)."""
+
+    def __init__(self, prediction_file, threads=1, decode_threads=None):
+        self.file = os.path.abspath(prediction_file)
+        self.threads = max(1, int(threads))
+        self.decode_threads = max(1, min(4, self.threads)) if decode_threads is None else decode_threads
+        self.regions = {}          # (contig, start, end) -> sequence bytes, or None = take it from the file
+        self.written = {}          # (contig, start, end) -> set of chunk ids the writer has stored for it
+        self.carry = None          # the newest region, still growing: [key, [(chunk id, positions, bases, rles), ...]]
+        self.placed = {}           # contig -> (start, end) of its decoded regions, sorted
+        self.joins = {}            # (left bytes, right bytes) -> (score, pos_a, pos_b)
+        self.pool = concurrent.futures.ThreadPoolExecutor(self.threads) if native_io.available() else None
+        self.pending = []
+        self.seconds = {"decode": 0.0, "joins_submitted": 0, "regions": 0, "from_file": 0}
+
+    # ---- feeding ----
+    def feed(self, contigs, meta, positions, bases, rles):
+        """`n` images in writing order: contigs uint8 [n, 256], meta int64 [n, 3] = contig_start, contig_end, chunk id,
+        positions int64 [n, 1000, 3], bases / rles uint8 [n, 1000] -- the arrays DataStore.write_batch has just stored.
+        Nothing of them is referenced after the call returns."""
+        import time
+        t0 = time.time()
+        n = int(meta.shape[0])
+        if n == 0:
+            return
+        contigs = np.asarray(contigs)
+        # (a name ends at its first NUL; what follows in the slot's row may be left over from a longer name)
+        contigs = contigs * (np.cumsum(contigs == 0, axis=1, dtype=np.int32) == 0)
+        # runs of consecutive images of one region
+        change = np.ones(n, bool)
+        if n > 1:
+            change[1:] = (meta[1:, 0] != meta[:-1, 0]) | (meta[1:, 1] != meta[:-1, 1]) | \
+                np.any(contigs[1:] != contigs[:-1], axis=1)
+        seg_first = np.flatnonzero(change)
+        seg_end = np.append(seg_first[1:], n)
+        keys = []
+        for a in seg_first.tolist():
+            keys.append((bytes(contigs[a]).split(b"\0", 1)[0].decode(), int(meta[a, 0]), int(meta[a, 1])))
+        # a region that shows up in two separate runs of this call (its images are not back to back): from the file
+        count = {}
+        for k in keys:
+            count[k] = count.get(k, 0) + 1
+        for k, c in count.items():
+            if c > 1 and self.regions.get(k, b"") is not None:
+                self._from_file(k)
+        first_seg = 0
+        if self.carry is not None:
+            if keys[0] == self.carry[0]:
+                self._extend_carry(meta, positions, bases, rles, int(seg_first[0]), int(seg_end[0]))
+                first_seg = 1
+                if len(keys) > 1:
+                    self._close_carry()
+            else:
+                self._close_carry()
+        if first_seg < len(keys):
+            # the last run may continue in the next call: it becomes the carry; the others are complete
+            last = len(keys) - 1
+            self._decode_segments(keys[first_seg:last], seg_first[first_seg:last], seg_end[first_seg:last],
+                                  meta, positions, bases, rles)
+            self.carry = [keys[last], []]
+            self._extend_carry(meta, positions, bases, rles, int(seg_first[last]), int(seg_end[last]))
+        self.seconds["decode"] += time.time() - t0
+
+    def _extend_carry(self, meta, positions, bases, rles, lo, hi):
+        held = self.carry[1]
+        if held is None:
+            return
+        if len(held) + hi - lo > _CARRY_LIMIT:
+            self.carry[1] = None                      # too large to hold: from the file
+            return
+        for i in range(lo, hi):
+            held.append((int(meta[i, 2]), positions[i].copy(), bases[i].copy(), rles[i].copy()))
+
+    def _close_carry(self):
+        key, held = self.carry
+        self.carry = None
+        if held is None or key in self.regions:       # held back too much, or the region was seen before: from the file
+            if self.regions.get(key, b"") is not None:
+                self._from_file(key)
+            return
+        ids = [h[0] for h in held]
+        order = _string_order_once(ids, self.written.setdefault(key, set()))
+        pos = np.ascontiguousarray(np.stack([held[i][1] for i in order]))
+        b = np.ascontiguousarray(np.stack([held[i][2] for i in order]))
+        r = np.ascontiguousarray(np.stack([held[i][3] for i in order]))
+        blob, off = native_io.decode_regions(np.array([0, len(order)], np.int32), np.arange(len(order), dtype=np.int32),
+                                             pos, b, r, 1)
+        self._accept([key], blob, off)
+
+    def _from_file(self, key):
+        self.regions[key] = None
+        self.seconds["from_file"] += 1
+
+    def _decode_segments(self, keys, seg_first, seg_end, meta, positions, bases, rles):
+        if not keys:
+            return
+        firsts, rows, good = [0], [], []
+        ids = meta[:, 2]
+        for key, a, e in zip(keys, seg_first.tolist(), seg_end.tolist()):
+            if key in self.regions:                  # images of a region that was closed earlier: not back to back
+                if self.regions[key] is not None:
+                    self._from_file(key)
+                continue
+            seen = self.written.setdefault(key, set())
+            seg_ids = ids[a:e].tolist()
+            if not seen and all(0 <= x < 10 for x in seg_ids) and all(x < y for x, y in zip(seg_ids, seg_ids[1:])):
+                order = range(e - a)                 # single digits in increasing order: string order as they stand
+                seen.update(seg_ids)
+            else:
+                order = _string_order_once(seg_ids, seen)
+            rows.extend(a + i for i in order)
+            firsts.append(len(rows))
+            good.append(key)
+        if not good:
+            return
+        blob, off = native_io.decode_regions(np.array(firsts, np.int32), np.array(rows, np.int32), positions, bases, rles,
+                                             self.decode_threads)
+        self._accept(good, blob, off)
+
+    def _accept(self, keys, blob, off):
+        """Sequences of freshly decoded regions (in stream order): keep them, and hand the joins between stream
+        neighbours that stitch will most likely make to the alignment workers."""
+        blob = blob.tobytes()
+        off = off.tolist()
+        seqs = [blob[off[k]:off[k + 1]] for k in range(len(keys))]
+        jobs = []            # (left string, right string)
+
+        def join(a, b):
+            # stitch joins the regions of a contig in (start, end) order; what it aligns is the last / first
+            # `end(a) - start(b)` bases of the two (Stitch.py:141-147)
+            if b[0] < a[1]:
+                ov = a[1] - b[0]
+                ov += int(ov * StitchOptions.BASE_ERROR_RATE)
+                sa, sb = self.regions.get((contig,) + a), self.regions.get((contig,) + b)
+                if sa and sb:
+                    jobs.append((sa[-ov:], sb[:ov]))
+
+        for key, seq in zip(keys, seqs):
+            self.regions[key] = seq
+            contig, span = key[0], key[1:]
+            placed = self.placed.setdefault(contig, [])
+            # the region's neighbours by POSITION among the regions decoded so far (images come in name order, which is
+            # position order only between starts of the same number of digits)
+            i = len(placed) if not placed or placed[-1] < span else bisect.bisect_left(placed, span)
+            placed.insert(i, span)
+            if i > 0:
+                join(placed[i - 1], span)
+            if i + 1 < len(placed):
+                join(span, placed[i + 1])
+        self.seconds["regions"] += len(keys)
+        if jobs and self.pool is not None:
+            self.seconds["joins_submitted"] += len(jobs)
+            per = max(8, -(-len(jobs) // self.threads))
+            for lo in range(0, len(jobs), per):
+                self.pending.append(self.pool.submit(_align_jobs, jobs[lo:lo + per]))
+
+    # ---- the end of the stream ----
+    def abort(self):
+        """The run failed: drop what is queued, let the workers go."""
+        if self.pool is not None:
+            self.pool.shutdown(wait=False, cancel_futures=True)
+            self.pool = None
+        self.pending = []
+
+    def finish(self):
+        """-> StreamResult: every region of this file with its sequence (None = read it from the file) and the table of
+        speculated joins.  Waits for the alignment workers."""
+        if self.carry is not None:
+            self._close_carry()
+        for fut in self.pending:
+            for left, right, res in fut.result():
+                self.joins[(left, right)] = res
+        self.pending = []
+        if self.pool is not None:
+            self.pool.shutdown()
+            self.pool = None
+        return StreamResult(self.file, self.regions, self.joins, dict(self.seconds))
+
+
+def _string_order_once(ids, seen):
+    """Indices of `ids` in the STRING order of the chunk ids (sorted(set of str), Stitch.py:208-211), each id once -- the
+    first image of an id is the one the writer stored (DataStore.py:123), also across calls (`seen`)."""
+    first = {}
+    for i, x in enumerate(ids):
+        if x not in seen and x not in first:
+            first[x] = i
+    seen.update(first)
+    return [first[x] for x in sorted(first, key=str)]
+
+
+def _align_jobs(jobs):
+    """[(left, right)] -> [(left, right, (score, pos_a, pos_b))] through helen_ssw_join_batch (one native call)."""
+    blob = b"".join(x for pair in jobs for x in pair)
+    l_off, l_len, r_off, r_len = [], [], [], []
+    at = 0
+    for left, right in jobs:
+        l_off.append(at)
+        l_len.append(len(left))
+        at += len(left)
+        r_off.append(at)
+        r_len.append(len(right))
+        at += len(right)
+    out = native_io.ssw_join_batch(blob, l_off, l_len, r_off, r_len, StitchOptions.MATCH_PENALTY,
+                                   StitchOptions.MISMATCH_PENALTY, StitchOptions.GAP_PENALTY,
+                                   StitchOptions.GAP_EXTEND_PENALTY, StitchOptions.OVERLAP_THRESHOLD).tolist()
+    return [(left, right, tuple(res)) for (left, right), res in zip(jobs, out)]
+
+
+class StreamResult(object):
+    """What one rank's RegionStream hands the final pass; travels between processes as a file (save / load)."""
+
+    def __init__(self, file, regions, joins, stats):
+        self.file, self.regions, self.joins, self.stats = file, regions, joins, stats
+
+    def save(self, directory=None):
+        fd, path = tempfile.mkstemp(prefix="helen_stream_%d_" % os.getpid(), suffix=".pkl", dir=directory)
+        with os.fdopen(fd, "wb") as f:
+            pickle.dump((self.file, self.regions, self.joins, self.stats), f, protocol=pickle.HIGHEST_PROTOCOL)
+        return path
+
+    @staticmethod
+    def load(path, remove=True):
+        try:
+            with open(path, "rb") as f:
+                out = StreamResult(*pickle.load(f))
+        finally:
+            if remove:
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
+        return out
+
+
+def spill_directory():
+    for d in ("/dev/shm",):
+        if os.path.isdir(d) and os.access(d, os.W_OK):
+            return d
+    return None
+
+
+def finish_stitch(results, input_directory, output_path, output_prefix, threads):
+    """perform_stitch (StitchInterface.py:40-106) from the streams of the run that has just written `input_directory`:
+    the same contig order, region order, runs and joins -- and the same FASTA -- with the regions' sequences and most of
+    the overlap alignments already there.  `results` = one StreamResult per prediction file of the directory."""
+    by_file = {os.path.abspath(r.file): r for r in results}
+    files = get_file_paths_from_directory(input_directory)
+    missing = [f for f in files if os.path.abspath(f) not in by_file]
+    if missing or len(files) != len(by_file):
+        raise RuntimeError("the prediction directory and the streamed regions do not match (%s): run `helen stitch` on %s"
+                           % (missing[:2], input_directory))
+    joins = {}
+    for r in results:
+        joins.update(r.joins)
+    # regions per contig: files in the directory's listing order, a file's regions in NAME order (StitchInterface.py:84-95)
+    per_contig = {}
+    for path in files:
+        r = by_file[os.path.abspath(path)]
+        named = {}
+        for (contig, start, end), seq in r.regions.items():
+            named.setdefault(contig, []).append(("%s-%d-%d" % (contig, start, end), start, end, seq))
+        for contig, rows in named.items():
+            rows.sort(key=lambda e: e[0])
+            per_contig.setdefault(contig, []).extend((path,) + row for row in rows)
+    output_dir = file_manager.handle_output_directory(output_path)
+    output_filename = os.path.join(output_dir, output_prefix + '.fa')
+    sys.stderr.write("INFO: OUTPUT FILE: " + output_filename + "\n")
+    contigs = sorted(per_contig)
+    hits = [0, 0]
+
+    def aligner(left, right):
+        got = joins.get((left, right))
+        hits[0 if got is not None else 1] += 1
+        return got
+
+    with open(output_filename, 'wb') as fasta:
+        for i, contig in enumerate(contigs):
+            prefix = "{:04d}/{:04d}:".format(i, len(contigs))
+            sys.stderr.write("INFO: " + prefix + " PROCESSING CONTIG: " + contig + "\n")
+            key_list = sorted(per_contig[contig], key=lambda e: (e[2], e[3]))
+            n = max(StitchOptions.MIN_SEQUENCE_REQUIRED_FOR_MULTITHREADING, int(len(key_list) / threads) + 1)
+            partial = []
+            for lo in range(0, len(key_list), n):                       # FileManager.chunks
+                chunk = []
+                for path, name, start, end, seq in key_list[lo:lo + n]:
+                    if seq is None:
+                        seq = native_io.region_sequence(path, contig, name, as_bytes=True)
+                    chunk.append((contig, start, end, seq))
+                chunk.sort(key=lambda e: (e[1], e[2]))
+                c, s, e, running = _alignment_stitch(chunk, aligner)
+                partial.append((c, s, e, bytes(running)))
+            partial.sort(key=lambda e: (e[1], e[2]))
+            sequence = _alignment_stitch(partial, aligner)[3] if partial else b""
+            sys.stderr.write("INFO: " + prefix + " FINISHED PROCESSING " + contig
+                             + ", POLISHED SEQUENCE LENGTH: " + str(len(sequence)) + ".\n")
+            if len(sequence) > 0:
+                fasta.write(b'>' + contig.encode() + b"\n")
+                fasta.write(sequence)
+                fasta.write(b"\n")
+    sys.stderr.write("INFO: STITCH PIPELINED BEHIND INFERENCE: %d JOINS FROM THE TABLE, %d ALIGNED NOW, %d REGION(S) READ BACK "
+                     "FROM THE FILES.\n" % (hits[0], hits[1], sum(r.stats.get("from_file", 0) for r in results)))
+    return output_filename

@@ -254,18 +254,44 @@ def contig_windows(contig, bank, lo=0, hi=None):
     return starts, ends, chunks, lengths, images, positions
 
 
-def write_assembly_dir(directory, spec, n_files=1, seed=20260929, blocks=None, direct=False, only_files=None):
+def _write_assembly_files(args):
+    directory, spec, n_files, seed, blocks, direct, only = args
+    made = write_assembly_dir(directory, spec, n_files, seed, blocks, direct, only_files=only)
+    return made["files"], made["windows"], made["regions"], made["windows_per_file"]
+
+
+def assembly_spec(windows, n_files, contigs_per_file=2, region_positions=2400, overlap=200, name="chr%02d_sim"):
+    """A simulated assembly of about `windows` images for a benchmark: n_files * contigs_per_file contigs of equal length,
+    contig k in file k % n_files (three images per 2400-position region, the last one short)."""
+    n_contigs = n_files * contigs_per_file
+    regions = max(1, windows // (3 * n_contigs))
+    positions = regions * (region_positions - overlap) + overlap
+    return [(name % k, positions, {"region_positions": region_positions, "overlap": overlap}) for k in range(n_contigs)]
+
+
+def write_assembly_dir(directory, spec, n_files=1, seed=20260929, blocks=None, direct=False, only_files=None, processes=0):
     """A directory of MarginPolish-shaped image files for the simulated assembly `spec` (see assembly_contigs).  Each
     contig's regions are cut into blocks[k] (default 1) runs of consecutive regions; the blocks, in contig order, go to
     the files round-robin -- all images of a region share a file, a contig may span several.  Images are named
     <contig>-<contig_start>-<contig_end>-<feature_chunk_idx>.  direct=True writes through the emitter of libhelen_io.so
     (the benchmark's 300 k-window inputs in seconds) instead of libhdf5; only_files = the file indices this caller writes
-    (several ranks of a benchmark each write their share).
+    (several ranks of a benchmark each write their share); processes = N > 1 writes the files in N worker processes.
     -> {"files": [paths], "windows": total images, "regions": total, "truth": {contig: sequence} (None when only_files is given),
         "windows_per_file": [...]}"""
     os.makedirs(directory, exist_ok=True)
-    bank = _noise_bank()
     blocks = list(blocks) if blocks is not None else [1] * len(spec)
+    if processes and processes > 1:
+        import concurrent.futures
+        import multiprocessing as mp
+        todo = sorted(range(n_files) if only_files is None else only_files)
+        with concurrent.futures.ProcessPoolExecutor(min(processes, len(todo)), mp_context=mp.get_context("spawn")) as ex:
+            parts = list(ex.map(_write_assembly_files, [(directory, spec, n_files, seed, blocks, direct, [fi]) for fi in todo]))
+        counts = [0] * n_files
+        for fi, p in zip(todo, parts):
+            counts[fi] = p[3][fi]
+        return {"files": [f for p in parts for f in p[0]], "windows": sum(p[1] for p in parts),
+                "regions": sum(p[2] for p in parts), "truth": None, "windows_per_file": counts}
+    bank = _noise_bank()
     # which file a block goes to depends only on the blocks before it: block j -> file j % n_files
     paths = [os.path.join(directory, "assembly_images_%04d.h5" % fi) for fi in range(n_files)]
     mine = set(range(n_files)) if only_files is None else set(only_files)
