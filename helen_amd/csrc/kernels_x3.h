@@ -34,6 +34,26 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short b) {
     return __builtin_bit_cast(float, (unsigned)b << 16);
 }
 
+// Round 5, two changes (each behind a build switch for the A/B record, profiles/r05_fp32x3_levers.txt):
+//   HELEN_X3_HEAD_BF16      the decoder's head slice on the bf16 pipe: the three planes of h(s-1) a wave has in registers for
+//                           the recurrence are the A operand, the head weights of its K32 group are split in three bf16
+//                           terms once per kernel, and the six leading products are shared by the two waves of a group
+//                           (three bf16 MFMAs per wave and step instead of four v_mfma_f32_16x16x4_f32, which hold the
+//                           SIMD's VALU for 32 cycles each) -- the same fp32-class product as the recurrence's own;
+//   HELEN_X3_PACKED_PLANES  the new h goes into the bf16 planes as 32-bit words: two lanes that own neighbouring hidden
+//                           units exchange half of their rows (one DPP swap per plane) and each stores two rows of the
+//                           PAIR instead of four 2-byte values -- half the LDS stores and none of the 2-byte stores'
+//                           bank conflicts (15.6 M conflict cycles per launch, profiles/r04_fp32x3_pmc_summary.json).
+#ifndef HELEN_X3_HEAD_BF16
+#define HELEN_X3_HEAD_BF16 1
+#endif
+#ifndef HELEN_X3_PACKED_PLANES
+#define HELEN_X3_PACKED_PLANES 1
+#endif
+__device__ __forceinline__ unsigned bf16_pair_bits(float lo, float hi) {      // v_cvt_pk_bf16_f32: lo in bits 0-15
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){lo, hi}, bf16x2_t));
+}
+
 __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ gi, long gi_tile_stride,
                                                      int slot0_fwd, int slot0_bwd, int T,
                                                      const bf16x8* __restrict__ W3,
@@ -81,8 +101,34 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
                 for (int t = 0; t < 3; ++t) W[g][M][t] = wp[((g * 4 + M) * 3 + t) * 64];
     }
     const float bn = bhn[dir * kH + u];
+#if HELEN_X3_HEAD_BF16
+    // decoder: the head weights of K32 group Mv = v & 3 as a B operand in three bf16 terms: k = dir*128 + 32 Mv + 8q + e,
+    // class j.  Waves v and v + 4 share the group: v < 4 takes the three small products, v >= 4 the three large ones.
+    const int Mv = v & 3;
+    bf16x8 Bh3[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) Bh3[t] = __builtin_bit_cast(bf16x8, uint4{0u, 0u, 0u, 0u});
+    if (dec) {
+        const f32x4* ws = Whd + (size_t)(dir * 8 + 2 * Mv + (q >> 1)) * 64 + (2 * (q & 1)) * 16 + j;
+        const f32x4 w0 = ws[0], w1 = ws[16];
+        unsigned short tb[3][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = e < 4 ? w0[e & 3] : w1[e & 3];
+            tb[0][e] = bf16_bits(x);
+            const float r1 = x - bf16_to_f32(tb[0][e]);
+            tb[1][e] = bf16_bits(r1);
+            tb[2][e] = bf16_bits(r1 - bf16_to_f32(tb[1][e]));
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            Bh3[t] = __builtin_bit_cast(bf16x8, uint4{tb[t][0] | (unsigned)tb[t][1] << 16, tb[t][2] | (unsigned)tb[t][3] << 16,
+                                                       tb[t][4] | (unsigned)tb[t][5] << 16, tb[t][6] | (unsigned)tb[t][7] << 16});
+    }
+#else
     f32x4 Bh = splat4(0.f);   // decoder: head weights for k = dir*128 + 16v + 4q + e, class j
     if (dec) Bh = Whd[(dir * 8 + v) * 64 + lane];
+#endif
 
     const f32x4* gi_p = gi + (size_t)tile * gi_tile_stride + (size_t)dir * (kNTile * 64) + v * 64 + lane;
     constexpr long kPosStride = 2 * kNTile * 64;
@@ -97,6 +143,34 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
     // this lane's 4 values: rows 4q + r of unit u.  fp32 h: float index ((u>>2)*16 + 4q + r)*4 + (u&3);
     // planes: bf16 index ((u>>3)*16 + 4q + r)*8 + (u&7) inside a 256-unit plane
     const int hoff = ((u >> 2) * kTile + 4 * q) * 4 + (u & 3);
+#if HELEN_X3_PACKED_PLANES
+    // two lanes own neighbouring hidden units (u even, u + 1): the even one stores rows 4q, 4q+1 of the pair, the odd one rows
+    // 4q+2, 4q+3, as 32-bit words (unit u in the low half).  Word offset of the first of the two rows inside a plane:
+    const int odd = j & 1;
+    const int pwoff = ((((u & ~1) >> 3) * kTile + 4 * q + 2 * odd) * 8 + ((u & ~1) & 7)) >> 1;
+    auto store_h4 = [&](int buf, const f32x4 h) {
+        float* hb = (float*)(hbuf + buf * 512);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hb[hoff + 4 * r] = h[r];
+        unsigned* pw = (unsigned*)(planes + buf * 768);
+        float x0 = h[0], x1 = h[1], x2 = h[2], x3 = h[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const unsigned p01 = bf16_pair_bits(x0, x1), p23 = bf16_pair_bits(x2, x3);
+            if (t < 2) {                                                   // what the next term has to carry
+                x0 -= __builtin_bit_cast(float, p01 << 16);
+                x1 -= __builtin_bit_cast(float, p01 & 0xffff0000u);
+                x2 -= __builtin_bit_cast(float, p23 << 16);
+                x3 -= __builtin_bit_cast(float, p23 & 0xffff0000u);
+            }
+            const unsigned send = odd ? p01 : p23;
+            const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+            const unsigned xw = odd ? recv : p01, yw = odd ? p23 : recv;   // unit u even, unit u + 1
+            pw[t * 1024 + pwoff] = __builtin_amdgcn_perm(yw, xw, 0x05040100u);        // first row: the two low halves
+            pw[t * 1024 + pwoff + 4] = __builtin_amdgcn_perm(yw, xw, 0x07060302u);    // second row: the two high halves
+        }
+    };
+#else
     const int poff = ((u >> 3) * kTile + 4 * q) * 8 + (u & 7);
     auto store_h = [&](int buf, int r, float h) {
         ((float*)(hbuf + buf * 512))[hoff + 4 * r] = h;
@@ -110,6 +184,27 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
         pl[1 * 2048 + poff + 8 * r] = t2;
         pl[2 * 2048 + poff + 8 * r] = t3;
     };
+    auto store_h4 = [&](int buf, const f32x4 h) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) store_h(buf, r, h[r]);
+    };
+#endif
+#if HELEN_X3_HEAD_BF16
+    // three of the six leading products of h . W_head^T over this wave's K32 group, from the planes `at` of h
+    auto head_partial = [&](const bf16x8 (&at)[3], int pb) {
+        f32x4 pl = splat4(0.f);
+        if (v < 4) {             // smallest first: h1 w3, h3 w1, h2 w2
+            pl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[0], Bh3[2], pl, 0, 0, 0);
+            pl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[2], Bh3[0], pl, 0, 0, 0);
+            pl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[1], Bh3[1], pl, 0, 0, 0);
+        } else {                 // h1 w2, h2 w1, h1 w1
+            pl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[0], Bh3[1], pl, 0, 0, 0);
+            pl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[1], Bh3[0], pl, 0, 0, 0);
+            pl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[0], Bh3[0], pl, 0, 0, 0);
+        }
+        (part + (pb * 8 + v) * 64)[lane] = pl;
+    };
+#else
     auto head_partial = [&](int hb, int pb) {   // h in hbuf[hb]: wave v's k-slice is one fp32 A fragment
         const f32x4 a = (hbuf + hb * 512)[v * 64 + lane];
         f32x4 pl = splat4(0.f);
@@ -117,6 +212,7 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
         for (int e = 0; e < 4; ++e) pl = mfma4(a[e], Bh[e], pl);
         (part + (pb * 8 + v) * 64)[lane] = pl;
     };
+#endif
     auto head_store = [&](int slot) {           // one wave adds the eight slices in wave order
         if (v != (slot & 7)) return;
         const f32x4* pp = part + (slot & 1) * 8 * 64 + lane;
@@ -134,8 +230,7 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
     float hprev[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) hprev[r] = ((const float*)hbuf)[hoff + 4 * r];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) store_h(0, r, hprev[r]);     // planes of h0 (fp32 copy rewritten in place)
+    store_h4(0, f32x4{hprev[0], hprev[1], hprev[2], hprev[3]});     // planes of h0 (fp32 copy rewritten in place)
     __syncthreads();
 #ifdef HELEN_GRU_TIMING
     long long tk[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -148,11 +243,16 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
         acc[0] = splat4(0.f);
         acc[1] = splat4(0.f);
         acc[2] = splat4(bn);
+#if !HELEN_X3_HEAD_BF16
         if (dec && s > 0) head_partial(cur, (s - 1) & 1);    // h(s-1) sits in hbuf[cur] since the last barrier
+#endif
 #pragma unroll
         for (int M = 0; M < 4; ++M) {
             const bf16x8 a1 = pa[0 * 256 + M * 64], a2 = pa[1 * 256 + M * 64], a3 = pa[2 * 256 + M * 64];
             const bf16x8 at[3] = {a1, a2, a3};
+#if HELEN_X3_HEAD_BF16
+            if (dec && s > 0 && M == Mv) head_partial(at, (s - 1) & 1);   // the planes of h(s-1) are this step's A operand
+#endif
             constexpr int TA[6] = {0, 2, 1, 0, 1, 0};   // six leading products, smallest first;
             constexpr int TB[6] = {2, 0, 1, 1, 0, 0};   // product index outermost: 3 accumulators rotate
 #pragma unroll
@@ -185,10 +285,8 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
             const f32x4 hn4 = gru_cell4(acc[0], acc[1], acc[2], G[0], G[1], G[2], hprev);
 #endif
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                hprev[r] = hn4[r];
-                store_h(cur ^ 1, r, hn4[r]);
-            }
+            for (int r = 0; r < 4; ++r) hprev[r] = hn4[r];
+            store_h4(cur ^ 1, hn4);
         }
         HELEN_TICK(3)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -211,7 +309,13 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
                dir, v, tk[0] / T, tk[1] / T, tk[2] / T, tk[3] / T, tk[4] / T, tk[5] / T);
 #endif
     if (dec) {   // the last step's logits
+#if HELEN_X3_HEAD_BF16
+        const bf16x8* pl = (const bf16x8*)(planes + (T & 1) * 768) + lane + Mv * 64;
+        const bf16x8 at[3] = {pl[0], pl[256], pl[512]};
+        head_partial(at, (T - 1) & 1);
+#else
         head_partial(T & 1, (T - 1) & 1);
+#endif
         __syncthreads();
         head_store(T - 1);
     }

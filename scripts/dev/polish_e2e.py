@@ -1,7 +1,7 @@
-"""Developer probe (GPU box): `python -m helen_amd polish` on a synthetic chr20-sized directory, wall-clocked as a user
-would see it (process start, imports, call_consensus, stitch).  Random weights give random labels, so the overlaps of
-neighbouring regions do not agree and stitch mostly inserts fillers: a plumbing / scale check, not a stitch benchmark
-(scripts/stitch_bench.py is that)."""
+"""Developer probe (GPU box): `bin/helen polish -g` on a simulated assembly of ~N images (helen_amd.synthetic, the trained
+network of tests/golden/trained_synth.npz), wall-clocked as a user sees it: process start, imports, device context,
+call_consensus, stitch (pipelined behind the inference; HELEN_STITCH_PIPELINE=0 for the two phases of round 4).
+    python scripts/dev/polish_e2e.py [N=300000] [threads=16] [repeats=2]"""
 import os
 import shutil
 import subprocess
@@ -9,31 +9,47 @@ import sys
 import tempfile
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from helen_amd.model_handler import ModelHandler  # noqa: E402
-from helen_amd.synthetic import write_image_dir  # noqa: E402
-from helen_amd.weights import make_weights  # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 300000
-threads = sys.argv[2] if len(sys.argv) > 2 else "16"
-d = tempfile.mkdtemp(prefix="helen_polish_", dir="/dev/shm")
-try:
-    model = os.path.join(d, "model.pkl")
-    ModelHandler.save_model(make_weights(seed=20260928, head_scale=8.0, input_scale=1 / 64.0), None, 128, 1, 0, model)
-    t0 = time.time()
-    write_image_dir(os.path.join(d, "img"), n, n_files=16, direct=True)
-    print("inputs written in %.1f s" % (time.time() - t0), flush=True)
-    t0 = time.time()
-    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([os.path.join(root, "bin", "helen"), "polish", "-i", os.path.join(d, "img"), "-m", model, "-b", "256",
-                        "-w", "8", "-t", threads, "-o", os.path.join(d, "out"), "-p", "asm", "-g"], cwd=root,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    dt = time.time() - t0
-    info = [l for l in r.stderr.splitlines() if l.startswith("INFO") and ("WINDOWS IN" in l or "POLISHED" in l or "STITCH" in l)]
-    print("rc", r.returncode, "polish wall %.2f s = %.0f windows/s" % (dt, n / dt))
-    print("\n".join(info[-4:]))
-    print("stderr lines:", len(r.stderr.splitlines()), " outputs:", sorted(os.listdir(os.path.join(d, "out"))))
-    if r.returncode != 0:
-        print(r.stderr[-3000:])
-finally:
-    shutil.rmtree(d, ignore_errors=True)
+from helen_amd.model_handler import ModelHandler  # noqa: E402
+from helen_amd.synthetic import assembly_spec, write_assembly_dir  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300000
+    threads = sys.argv[2] if len(sys.argv) > 2 else "16"
+    repeats = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    d = tempfile.mkdtemp(prefix="helen_polish_", dir="/dev/shm")
+    try:
+        model = os.path.join(d, "model.pkl")
+        z = np.load(os.path.join(ROOT, "tests", "golden", "trained_synth.npz"))
+        ModelHandler.save_model({k: z[k] for k in z.files if not k.startswith("_")}, None, 128, 1, 0, model)
+        t0 = time.time()
+        made = write_assembly_dir(os.path.join(d, "img"), assembly_spec(n, 16), 16, direct=True, processes=8)
+        n = made["windows"]
+        print("inputs (%d images, %d regions) written in %.1f s" % (n, made["regions"], time.time() - t0), flush=True)
+        for mode in ["1"] * repeats + ["0"]:
+            out = os.path.join(d, "out" + mode)
+            shutil.rmtree(out, ignore_errors=True)
+            t0 = time.time()
+            r = subprocess.run([os.path.join(ROOT, "bin", "helen"), "polish", "-i", os.path.join(d, "img"), "-m", model, "-b", "256",
+                                "-w", "8", "-t", threads, "-o", out, "-p", "asm", "-g"], cwd=ROOT,
+                               env=dict(os.environ, HELEN_STITCH_PIPELINE=mode), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               text=True)
+            dt = time.time() - t0
+            info = [ln for ln in r.stderr.splitlines() if ln.startswith("INFO") and ("WINDOWS IN" in ln or "PIPELINED" in ln or "TIME" in ln)]
+            print("HELEN_STITCH_PIPELINE=%s rc %d: polish wall %.2f s = %.0f windows/s (FASTA %d bytes)"
+                  % (mode, r.returncode, dt, n / dt, os.path.getsize(os.path.join(out, "asm.fa")) if r.returncode == 0 else -1))
+            print("\n".join("    " + ln for ln in info[-6:]))
+            if r.returncode != 0:
+                print(r.stderr[-3000:])
+        a, b = (open(os.path.join(d, "out" + m, "asm.fa"), "rb").read() for m in "10")
+        print("pipelined FASTA == two-phase FASTA:", a == b)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -368,8 +368,13 @@ def test_bench_two_ranks_end_to_end_line():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     e = line["end_to_end"]
-    assert line["n_gpus"] == 2 and e["n_ranks"] == 2 and e["windows"] == 16384 and e["regions_stored"] == 16384, e
+    # (the leg's input is a simulated assembly of three-image regions: about the windows asked for, in whole regions)
+    assert line["n_gpus"] == 2 and e["n_ranks"] == 2 and 0.97 * 16384 <= e["windows"] <= 16384, e
+    assert e["regions_stored"] * 3 == e["windows"] and e["weights"] == "trained_synth"
     assert e["output_files"] == ["p_0.hdf", "p_1.hdf"] and len(e["per_rank"]) == 2
+    # the whole `polish` of the same directory, stitch pipelined behind the inference: the FASTA of the two-phase stitch
+    assert e["polish"]["fasta_equals_two_phase"] is True and e["polish_seconds"] > 0
+    assert all(r_["stitch_stream"]["regions"] * 3 == r_["windows"] for r_ in e["polish"]["per_rank"]), e["polish"]
     assert e["value"] > 0 and e["usable_cpus"] >= 1 and e["predicted_host_ceiling"] > 0
     assert line["barrier"] == "gloo all-reduce" and line["rccl"].startswith("not used"), line["rccl"]
     print(json.dumps(e))
@@ -387,9 +392,10 @@ def test_bench_eight_ranks_end_to_end_line():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     e = line["end_to_end"]
     assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and len(line["per_rank_windows_per_s"]) == 8
-    assert e["n_ranks"] == 8 and e["windows"] == 8 * 8192 and e["regions_stored"] == 8 * 8192, e
+    assert e["n_ranks"] == 8 and 0.97 * 8 * 8192 <= e["windows"] <= 8 * 8192 and e["regions_stored"] * 3 == e["windows"], e
     assert e["output_files"] == ["p_%d.hdf" % k for k in range(8)] and len(e["per_rank"]) == 8
-    assert all(r_["windows"] == 8192 and r_["reader_workers"] >= 1 for r_ in e["per_rank"])
+    assert all(r_["windows"] * 8 == e["windows"] and r_["reader_workers"] >= 1 for r_ in e["per_rank"])
+    assert e["polish"]["fasta_equals_two_phase"] is True
     assert sum(e["reader_workers_per_rank"]) + 2 * 8 <= max(e["usable_cpus"], 3 * 8)       # the host budget holds
     assert e["predicted_bound"] in ("device", "host readers")
     print(json.dumps({k: e[k] for k in ("value", "usable_cpus", "reader_workers_per_rank", "predicted_bound")}))
