@@ -365,6 +365,47 @@ def trained_weights():
     return {k: np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files if not k.startswith("_")}
 
 
+def e2e_size(windows_per_rank, world, may_shrink, free=None):
+    """What the end-to-end leg will run with: (windows per rank, bytes of RAM-backed space it needs, where it goes).
+    The default leg (no --e2e given) shrinks to what /dev/shm holds for ALL ranks, down to two device calls per rank;
+    with one rank it may go to the temp directory instead; otherwise it is skipped."""
+    from helen_amd.host_plan import SLOT_BYTES_PER_WINDOW, shm_free_bytes
+
+    def need_bytes(per_rank):     # inputs + slots + outputs (two runs) + FASTA, all ranks, all RAM-backed
+        return per_rank * world * (116000 + 2 * 16000 + 2 * 1500) + world * 5 * 4096 * SLOT_BYTES_PER_WINDOW
+    free = shm_free_bytes() if free is None else free
+    n = windows_per_rank
+    while may_shrink and n > 8192 and free <= need_bytes(n) * 1.1:
+        n = max(8192, n - 4096)
+    where = "/dev/shm" if free > need_bytes(n) * 1.1 else ("tmp" if world == 1 else None)
+    return n, need_bytes(n), where, free
+
+
+def plan_only(args, rank, world):
+    """`--plan-only`: what this invocation WOULD do, decided without touching a device -- the legs, the call size, the
+    end-to-end leg's size after the /dev/shm check, the files and worker processes of its input generation, and the host
+    plan of its `world` ranks.  (A dry run of the driver's command shapes on a machine without the GPUs.)"""
+    from helen_amd.host_plan import plan_host
+    from helen_amd.synthetic import assembly_spec
+    e2e_windows = (E2E_DEFAULT_WINDOWS if args.precision == "fp32" else 0) if args.e2e is None else args.e2e
+    out = {"plan_only": True, "n_gpus": world, "rank": rank, "steps": args.steps, "warmup": args.warmup,
+           "windows_per_step": args.batch * args.coalesce, "precision": args.precision,
+           "legs": {"cpu_baseline": not args.no_cpu_baseline and world == 1, "host_path": not args.no_host_path,
+                    "modes": not args.no_modes and args.precision == "fp32", "margins": not args.no_margins,
+                    "end_to_end": e2e_windows > 0},
+           "devices": "cuda:0 for every rank (--single-device)" if args.single_device else "cuda:LOCAL_RANK"}
+    if e2e_windows > 0:
+        n, need, where, free = e2e_size(e2e_windows, world, args.e2e is None)
+        n_files = E2E_FILES_PER_RANK * world
+        spec = assembly_spec(n * world, n_files)
+        host = plan_host(list(range(world)), args.e2e_workers, 4096)
+        out["end_to_end"] = {"windows_per_rank_asked": e2e_windows, "windows_per_rank": n, "shrunk": n != e2e_windows,
+                             "ram_bytes_needed": need, "shm_free_bytes": free, "directory": where, "image_files": n_files,
+                             "contigs": len(spec), "generation_processes_per_rank": max(1, min(8, usable_cpus() // world)),
+                             "stitch_threads": max(1, min(16, usable_cpus())), "host_plan": host.as_dict()}
+    return out
+
+
 def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_device, dist, may_shrink=False):
     """The product's commands over `world` ranks on a SIMULATED ASSEMBLY (helen_amd.synthetic.write_assembly_dir: contigs cut
     into 2400-position regions of three images, insert rows, short last images; pileups from the read-vote noise model;
@@ -384,29 +425,22 @@ def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_de
     from helen_amd import hdf5
     from helen_amd import predict as P
     from helen_amd.call_consensus import call_consensus, polish_genome
-    from helen_amd.host_plan import SLOT_BYTES_PER_WINDOW, shm_free_bytes
+    from helen_amd.host_plan import shm_free_bytes
     from helen_amd.model_handler import ModelHandler
     from helen_amd.synthetic import assembly_spec, write_assembly_dir
-    def need_bytes(per_rank):     # inputs + slots + outputs (two runs) + FASTA, all ranks, all RAM-backed
-        return per_rank * world * (116000 + 2 * 16000 + 2 * 1500) + world * 5 * 4096 * SLOT_BYTES_PER_WINDOW
-    box = [None, windows_per_rank]
+    box = [None, windows_per_rank, 0]
     if rank == 0:
-        free = shm_free_bytes()
-        # the default leg (no --e2e given) shrinks to what /dev/shm holds for all ranks, down to two device calls per rank
-        while may_shrink and box[1] > 8192 and free <= need_bytes(box[1]) * 1.1:
-            box[1] -= 4096
+        box[1], box[2], where, free = e2e_size(windows_per_rank, world, may_shrink)
         if box[1] != windows_per_rank:
             sys.stderr.write("INFO: /dev/shm HAS %.1f GB FREE: THE END-TO-END LEG SHRINKS TO %d WINDOWS PER RANK.\n" % (free / 1e9, box[1]))
-        if free > need_bytes(box[1]) * 1.1:
-            box[0] = tempfile.mkdtemp(prefix="helen_e2e_", dir="/dev/shm")
-        elif world == 1:
-            box[0] = tempfile.mkdtemp(prefix="helen_e2e_")
+        if where is not None:
+            box[0] = tempfile.mkdtemp(prefix="helen_e2e_", dir="/dev/shm" if where == "/dev/shm" else None)
     if dist is not None:
         dist.broadcast_object_list(box, src=0)
-    d, windows_per_rank = box
+    d, windows_per_rank, need = box
     if d is None:
         return {"value": None, "skipped": "/dev/shm has %.1f GB free, the %d-rank leg needs %.1f GB"
-                                          % (shm_free_bytes() / 1e9, world, need_bytes(windows_per_rank) / 1e9)} if rank == 0 else None
+                                          % (shm_free_bytes() / 1e9, world, need / 1e9)} if rank == 0 else None
     done = os.path.join(d, "done")
     try:
         img_dir = os.path.join(d, "img")
@@ -536,7 +570,22 @@ def main():
                     help="process-group backend for the barrier / max-time reduce (nccl = RCCL)")
     ap.add_argument("--single-device", action="store_true",
                     help="testing aid: every rank uses cuda:0 (exercise the N>1 code path on one GPU)")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="print what this invocation would do (legs, sizes, host plan of the N ranks) as one JSON line and "
+                         "exit, without touching a device: a dry run of the launcher's command shapes")
     args = ap.parse_args()
+
+    if args.plan_only:
+        # under a launcher (WORLD_SIZE set) every rank reaches this point; rank 0 answers.  Started plainly with
+        # --gpus N it answers for the N ranks it would become.
+        world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+        if world != args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d\n" % (args.gpus, world))
+            sys.exit(2)
+        rank = int(os.environ.get("RANK", "0"))
+        if rank == 0:
+            print(json.dumps(plan_only(args, rank, world)))
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started plainly with --gpus N: become N ranks, one per GPU (predict_gpu.py:207-226 spawns one process

@@ -34,11 +34,17 @@
 
 static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-/* Arithmetic of the gate matmuls: 0 = fp32 (the reference), 1 = operands rounded to bf16 (RNE),
- * fp32 accumulate/state -- the emulation the bf16 HIP variant (BASELINE.json configs[3]) is
- * checked against.  Heads, gates and softmax stay fp32 in both. */
+/* Arithmetic of the gate matmuls: 0 = fp32 (the reference); 1, 2 = operands rounded to bf16 (RNE), fp32
+ * accumulate/state -- what the bf16 HIP variant (BASELINE.json configs[3]) is checked against.  Heads, gates and
+ * softmax stay fp32 in all of them.
+ *   2 = the TEXTBOOK form, written without looking at the kernels: W_ih, W_hh, x and h rounded to bf16 as they
+ *       stand, fp32 accumulate, fp32 biases, sigmoid / tanh as in the reference.  This is the SPECIFICATION of
+ *       "bf16 gate GEMMs" (DESIGN.md 5).
+ *   1 = the same with the kernels' own operand preparation (weights and biases prescaled by -log2 e / 2 log2 e
+ *       BEFORE the rounding, gates on exp2): a tight implementation check -- it follows the kernel, so agreeing
+ *       with it says the kernel does what it means to, not that what it means to do is right.  That is mode 2's job. */
 static int g_precision = 0;
-void oracle_set_precision(int p) { g_precision = p ? 1 : 0; }
+void oracle_set_precision(int p) { g_precision = (p == 1 || p == 2) ? p : 0; }
 int oracle_get_precision(void) { return g_precision; }
 
 static inline float bf16r(float f) {
@@ -82,7 +88,12 @@ static void dir_init(Dir* d, const float* w_ih, const float* w_hh, const float* 
     d->b_ih = b_ih;
     d->b_hh = b_hh;
     d->b_own = NULL;
-    if (g_precision) {
+    if (g_precision == 2) { /* textbook: the operands as they stand, rounded */
+        const int G = 3 * H;
+        for (size_t i = 0; i < (size_t)K * G; ++i) d->w_ih_t[i] = bf16r(d->w_ih_t[i]);
+        for (size_t i = 0; i < (size_t)H * G; ++i) d->w_hh_t[i] = bf16r(d->w_hh_t[i]);
+    }
+    if (g_precision == 1) {
         const int G = 3 * H;
         for (int k = 0; k < K; ++k)
             for (int j = 0; j < G; ++j) d->w_ih_t[(size_t)k * G + j] = bf16r(d->w_ih_t[(size_t)k * G + j] * gate_prescale(j, H));
@@ -148,7 +159,7 @@ static void gru_dir(const Dir* d, const float* const* x, int xs, int T, int reve
             }
             float* hb = h[b];
             for (int j = 0; j < H; ++j) {
-                if (g_precision) { /* prescaled: the accumulators are the arguments of exp2 */
+                if (g_precision == 1) { /* prescaled: the accumulators are the arguments of exp2 */
                     const float r = 1.0f / (1.0f + exp2f(a[j] + c[j]));
                     const float z = 1.0f / (1.0f + exp2f(a[H + j] + c[H + j]));
                     const float n = 1.0f - 2.0f / (1.0f + exp2f(a[2 * H + j] + r * c[2 * H + j]));

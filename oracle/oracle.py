@@ -115,7 +115,7 @@ def set_threads(n):
 def set_precision(name):
     """'fp32' (the reference arithmetic) or 'bf16' (gate-matmul operands rounded to bf16, fp32
     accumulate/state): the emulation the bf16 HIP variant is checked against."""
-    _load().oracle_set_precision({"fp32": 0, "bf16": 1}[name])
+    _load().oracle_set_precision({"fp32": 0, "bf16": 1, "bf16_textbook": 2}[name])
 
 
 def gru_chunk_forward(weights, x, h_in):

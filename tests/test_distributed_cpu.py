@@ -69,3 +69,34 @@ def test_bench_refuses_more_ranks_than_gpus():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 2 and "WORLD_SIZE is 4" in out.stderr
+
+
+def test_bench_plans_eight_ranks_without_a_device():
+    """The driver's 8-GPU command shape on a machine without the GPUs: `bench.py --gpus 8 --steps 20 --warmup 5` under a
+    launcher's environment (WORLD_SIZE=8), dry (`--plan-only`): the arguments parse, every default leg is planned, the
+    end-to-end leg is sized against /dev/shm for ALL eight ranks (and says when it shrinks), the host plan covers eight
+    ranks within the usable CPUs -- and no device is touched (there is none here).  Ranks other than 0 print nothing."""
+    import json
+    env = dict(os.environ, WORLD_SIZE="8", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--plan-only"]
+    out = subprocess.run(base, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    plan = json.loads(out.stdout.strip().splitlines()[-1])
+    assert plan["plan_only"] and plan["n_gpus"] == 8 and plan["windows_per_step"] == 4096
+    assert plan["legs"] == {"cpu_baseline": False, "host_path": True, "modes": True, "margins": True, "end_to_end": True}
+    e = plan["end_to_end"]
+    assert e["image_files"] == 128 and e["contigs"] == 256 and 8192 <= e["windows_per_rank"] <= 300000
+    assert e["shrunk"] == (e["windows_per_rank"] != 300000)
+    assert e["directory"] in ("/dev/shm", None) and (e["directory"] is None or e["ram_bytes_needed"] * 1.1 < e["shm_free_bytes"])
+    hp = e["host_plan"]
+    assert hp["n_ranks"] == 8 and len(hp["ranks"]) == 8 and all(r["reader_workers"] >= 1 for r in hp["ranks"])
+    assert sum(hp["reader_workers_per_rank"]) + 2 * 8 <= max(hp["usable_cpus"], 3 * 8)
+    # another rank of the same launch says nothing; a WORLD_SIZE that contradicts --gpus is refused
+    quiet = subprocess.run(base, capture_output=True, text=True, timeout=300, env=dict(env, RANK="5", LOCAL_RANK="5"))
+    assert quiet.returncode == 0 and quiet.stdout.strip() == ""
+    wrong = subprocess.run(base, capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="4"))
+    assert wrong.returncode == 2 and "WORLD_SIZE is 4" in wrong.stderr
+    # started plainly, it answers for the ranks it would become
+    plain = subprocess.run(base, capture_output=True, text=True, timeout=300,
+                           env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert plain.returncode == 0 and json.loads(plain.stdout.strip().splitlines()[-1])["n_gpus"] == 8

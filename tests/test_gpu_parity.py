@@ -212,14 +212,24 @@ def test_bf16_variant_against_emulation_and_fp32(case):
         base, rle, hidden = eng.chunk_forward(xf[:, i:i + 100].contiguous(), hidden)
         if c in (0, 9, 18):
             logits[c] = (base.cpu().numpy(), rle.cpu().numpy())
-    oracle.set_precision("bf16")
-    try:
-        emu = oracle.polish_batch(w, img, traces=True)
-    finally:
-        oracle.set_precision("fp32")
+    # two emulations: "bf16_textbook" is the SPECIFICATION (operands rounded as they stand, written without looking at the
+    # kernels); "bf16" prepares the operands the way the kernels do (prescaled before rounding) and is the tight check
+    emus = {}
+    for mode in ("bf16", "bf16_textbook"):
+        oracle.set_precision(mode)
+        try:
+            emus[mode] = oracle.polish_batch(w, img, traces=True)
+        finally:
+            oracle.set_precision("fp32")
+    emu, spec = emus["bf16"], emus["bf16_textbook"]
     for k, c in enumerate((0, 9, 18)):
         np.testing.assert_allclose(logits[c][0], emu["logit_base"][c], atol=BF16_LOGIT_ATOL_VS_EMULATION, rtol=0)
         np.testing.assert_allclose(logits[c][1], emu["logit_rle"][c], atol=BF16_LOGIT_ATOL_VS_EMULATION, rtol=0)
+        # against the textbook emulation: two different roundings of the same fp32 weights -- the distance is that of
+        # either from the fp32 logits
+        sb = np.abs(logits[c][0] - spec["logit_base"][c]).max()
+        sr = np.abs(logits[c][1] - spec["logit_rle"][c]).max()
+        assert sb < BF16_LOGIT_ATOL_VS_FP32 and sr < BF16_LOGIT_ATOL_VS_FP32, (sb, sr)
         # against the reference's fp32 logits
         eb = np.abs(logits[c][0] - g["logit_base"][k]).max()
         er = np.abs(logits[c][1] - g["logit_rle"][k]).max()
@@ -227,9 +237,12 @@ def test_bf16_variant_against_emulation_and_fp32(case):
     b, r = bases.cpu().numpy(), rles.cpu().numpy()
     mis_emu = ((b != emu["bases"]).mean() + (r != emu["rles"]).mean()) / 2
     mis_ref = ((b != g["bases"]).mean() + (r != g["rles"]).mean()) / 2
-    print("bf16 %s: label mismatch vs bf16 emulation %.4f%%, vs fp32 reference %.4f%%"
-          % (case, 100 * mis_emu, 100 * mis_ref))
-    assert mis_emu < BF16_LABEL_MISMATCH_MAX and mis_ref < BF16_LABEL_MISMATCH_MAX
+    mis_spec = ((b != spec["bases"]).mean() + (r != spec["rles"]).mean()) / 2
+    spec_ref = ((spec["bases"] != g["bases"]).mean() + (spec["rles"] != g["rles"]).mean()) / 2
+    print("bf16 %s: label mismatch vs the kernel-shaped emulation %.4f%%, vs the textbook emulation %.4f%%, vs the fp32 "
+          "reference %.4f%% (textbook emulation vs fp32 reference: %.4f%%); max |logit - textbook| base %.3g rle %.3g"
+          % (case, 100 * mis_emu, 100 * mis_spec, 100 * mis_ref, 100 * spec_ref, sb, sr))
+    assert mis_emu < BF16_LABEL_MISMATCH_MAX and mis_ref < BF16_LABEL_MISMATCH_MAX and mis_spec < BF16_LABEL_MISMATCH_MAX
     eng.close()
 
 
