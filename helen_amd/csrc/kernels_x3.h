@@ -34,25 +34,17 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short b) {
     return __builtin_bit_cast(float, (unsigned)b << 16);
 }
 
-// Round 5, two changes (each behind a build switch for the A/B record, profiles/r05_fp32x3_levers.txt):
-//   HELEN_X3_HEAD_BF16      the decoder's head slice on the bf16 pipe: the three planes of h(s-1) a wave has in registers for
-//                           the recurrence are the A operand, the head weights of its K32 group are split in three bf16
-//                           terms once per kernel, and the six leading products are shared by the two waves of a group
-//                           (three bf16 MFMAs per wave and step instead of four v_mfma_f32_16x16x4_f32, which hold the
-//                           SIMD's VALU for 32 cycles each) -- the same fp32-class product as the recurrence's own;
-//   HELEN_X3_PACKED_PLANES  the new h goes into the bf16 planes as 32-bit words: two lanes that own neighbouring hidden
-//                           units exchange half of their rows (one DPP swap per plane) and each stores two rows of the
-//                           PAIR instead of four 2-byte values -- half the LDS stores and none of the 2-byte stores'
-//                           bank conflicts (15.6 M conflict cycles per launch, profiles/r04_fp32x3_pmc_summary.json).
+// Round 5: the decoder's head slice runs on the bf16 pipe (HELEN_X3_HEAD_BF16, on by default; =0 builds round 4's form for the
+// A/B record, profiles/r05_fp32x3_levers.txt).  The three planes of h(s-1) a wave has in registers for the recurrence are the
+// A operand, the head weights of its K32 group are split in three bf16 terms once per kernel, and the six leading products
+// are shared by the two waves of a group: three bf16 MFMAs per wave and step instead of four v_mfma_f32_16x16x4_f32, which
+// hold the SIMD's VALU for 32 cycles each -- the same fp32-class product as the recurrence's own.  Decoder launch 0.475 ->
+// 0.455 ms (4,096 windows).  Also measured there and NOT taken: storing the new h into the planes as 32-bit words of two
+// neighbouring units (one DPP swap per plane, half the LDS stores, none of the 2-byte stores' 15.6 M bank-conflict
+// cycles per launch): 0.452 / 0.474 ms against 0.452 / 0.474 -- the plane stores are not on the step's critical path.
 #ifndef HELEN_X3_HEAD_BF16
 #define HELEN_X3_HEAD_BF16 1
 #endif
-#ifndef HELEN_X3_PACKED_PLANES
-#define HELEN_X3_PACKED_PLANES 1
-#endif
-__device__ __forceinline__ unsigned bf16_pair_bits(float lo, float hi) {      // v_cvt_pk_bf16_f32: lo in bits 0-15
-    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){lo, hi}, bf16x2_t));
-}
 
 __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ gi, long gi_tile_stride,
                                                      int slot0_fwd, int slot0_bwd, int T,
@@ -143,34 +135,6 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
     // this lane's 4 values: rows 4q + r of unit u.  fp32 h: float index ((u>>2)*16 + 4q + r)*4 + (u&3);
     // planes: bf16 index ((u>>3)*16 + 4q + r)*8 + (u&7) inside a 256-unit plane
     const int hoff = ((u >> 2) * kTile + 4 * q) * 4 + (u & 3);
-#if HELEN_X3_PACKED_PLANES
-    // two lanes own neighbouring hidden units (u even, u + 1): the even one stores rows 4q, 4q+1 of the pair, the odd one rows
-    // 4q+2, 4q+3, as 32-bit words (unit u in the low half).  Word offset of the first of the two rows inside a plane:
-    const int odd = j & 1;
-    const int pwoff = ((((u & ~1) >> 3) * kTile + 4 * q + 2 * odd) * 8 + ((u & ~1) & 7)) >> 1;
-    auto store_h4 = [&](int buf, const f32x4 h) {
-        float* hb = (float*)(hbuf + buf * 512);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hb[hoff + 4 * r] = h[r];
-        unsigned* pw = (unsigned*)(planes + buf * 768);
-        float x0 = h[0], x1 = h[1], x2 = h[2], x3 = h[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const unsigned p01 = bf16_pair_bits(x0, x1), p23 = bf16_pair_bits(x2, x3);
-            if (t < 2) {                                                   // what the next term has to carry
-                x0 -= __builtin_bit_cast(float, p01 << 16);
-                x1 -= __builtin_bit_cast(float, p01 & 0xffff0000u);
-                x2 -= __builtin_bit_cast(float, p23 << 16);
-                x3 -= __builtin_bit_cast(float, p23 & 0xffff0000u);
-            }
-            const unsigned send = odd ? p01 : p23;
-            const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-            const unsigned xw = odd ? recv : p01, yw = odd ? p23 : recv;   // unit u even, unit u + 1
-            pw[t * 1024 + pwoff] = __builtin_amdgcn_perm(yw, xw, 0x05040100u);        // first row: the two low halves
-            pw[t * 1024 + pwoff + 4] = __builtin_amdgcn_perm(yw, xw, 0x07060302u);    // second row: the two high halves
-        }
-    };
-#else
     const int poff = ((u >> 3) * kTile + 4 * q) * 8 + (u & 7);
     auto store_h = [&](int buf, int r, float h) {
         ((float*)(hbuf + buf * 512))[hoff + 4 * r] = h;
@@ -188,7 +152,6 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
 #pragma unroll
         for (int r = 0; r < 4; ++r) store_h(buf, r, h[r]);
     };
-#endif
 #if HELEN_X3_HEAD_BF16
     // three of the six leading products of h . W_head^T over this wave's K32 group, from the planes `at` of h
     auto head_partial = [&](const bf16x8 (&at)[3], int pb) {

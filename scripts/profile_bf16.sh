@@ -7,7 +7,7 @@ set -u
 R=$(pwd)
 O=$R/gpurun_out/bf16
 mkdir -p $O
-ARGS="--precision bf16 --batch 512 --no-cpu-baseline --no-host-path --no-margins --e2e 0"
+ARGS="--precision bf16 --batch 512 --no-cpu-baseline --no-host-path --no-margins --no-traffic --e2e 0"
 python bench.py $ARGS > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- \

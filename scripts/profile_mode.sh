@@ -10,7 +10,7 @@ O=$R/gpurun_out/${2:-prof_$P}
 B=$( [ $P = bf16 ] && echo "--batch 512" )
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-COMMON="--precision $P $B --no-cpu-baseline --no-host-path --no-margins --no-modes --e2e 0"
+COMMON="--precision $P $B --no-cpu-baseline --no-host-path --no-margins --no-modes --no-traffic --e2e 0"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- \
     python $R/bench.py --steps 16 --warmup 2 $COMMON > $O/prof.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -12,14 +12,14 @@ python bench.py > $R/gpurun_out/bench.json 2> $R/gpurun_out/bench.err
 # (the opt-in arithmetic modes are in the default line's `modes` object; scripts/profile_mode.sh profiles one of them)
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o p -- \
-    python $R/bench.py --steps 16 --warmup 2 --no-cpu-baseline --no-host-path --no-margins --no-modes --e2e 0 > $R/gpurun_out/prof.log 2>&1
+    python $R/bench.py --steps 16 --warmup 2 --no-cpu-baseline --no-host-path --no-margins --no-modes --no-traffic --e2e 0 > $R/gpurun_out/prof.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o p -- \
-        python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-path --no-margins --no-modes --e2e 0 > $R/gpurun_out/pmc_$c.log 2>&1
+        python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-path --no-margins --no-modes --no-traffic --e2e 0 > $R/gpurun_out/pmc_$c.log 2>&1
 done
 timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY \
     SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $R/gpurun_out/pmc_sq -o p -- \
-    python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-path --no-margins --no-modes --e2e 0 > $R/gpurun_out/pmc_sq.log 2>&1
+    python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-path --no-margins --no-modes --no-traffic --e2e 0 > $R/gpurun_out/pmc_sq.log 2>&1
 cd $R
 cat gpurun_out/bench.json
 find gpurun_out -name "*.csv" | head -20
