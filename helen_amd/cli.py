@@ -27,6 +27,12 @@ def add_polish_arguments(parser, threads_default):
                         help="List of gpu device ids to use for inference, e.g. 0,1,2. Default: all.")
     parser.add_argument("-c", "--callers", type=int, required=False, default=8,
                         help="Total number of callers to spawn if doing CPU inference (ignored in gpu mode).")
+    # the one option the reference does not have: the arithmetic of the gate matmuls on the MI355X
+    parser.add_argument("--precision", type=str, required=False, default=None, choices=["fp32", "bf16", "fp32x3"],
+                        help="[MI355X] gate-matmul arithmetic with -g: fp32 (default: the reference's arithmetic on the fp32 matrix\n"
+                             "cores), fp32x3 (fp32-class results from three-term bf16 splits on the bf16 matrix cores, 1.5x),\n"
+                             "bf16 (bf16 operands, fp32 accumulate and state, 6x; labels differ from fp32 at ~1e-5 of the\n"
+                             "positions of a trained network).  Default: $HELEN_PRECISION, else fp32.")
     return parser
 
 
@@ -79,6 +85,9 @@ def build_parser():
 def main(argv=None):
     parser = build_parser()
     flags, unparsed = parser.parse_known_args(argv)
+    if getattr(flags, "precision", None):
+        import os
+        os.environ["HELEN_PRECISION"] = flags.precision       # read where a rank builds its model (helen_amd/transducer.py)
     if flags.sub_command == "polish":
         from .call_consensus import polish_genome
         polish_genome(flags.image_dir, flags.model_path, flags.batch_size, flags.num_workers,

@@ -171,15 +171,15 @@ def test_gpu_polish_equals_the_reference_chain(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["bf16", "fp32x3"])
 def test_gpu_polish_reduced_precision_against_the_reference_chain(tmp_path, precision):
-    """The same command under HELEN_PRECISION=bf16 / fp32x3: labels that differ from the reference's fp32 predict() are
+    """The same command with --precision bf16 / fp32x3: labels that differ from the reference's fp32 predict() are
     counted and the FASTA's distance from the reference chain's is printed (BASELINE.json configs[3]: argmax parity is a
     reported figure there, not an identity)."""
     from edit_distance import banded_edit_distance
     gen, fixture = _fixture()
     image_dir, model, made = gen.polish_case(str(tmp_path))
     out = str(tmp_path / "out")
-    _helen(["polish", "-i", image_dir, "-m", model, "-b", "512", "-w", "2", "-t", "3", "-o", out, "-p", "polished", "-g"],
-           env={"HELEN_PRECISION": precision})
+    _helen(["polish", "-i", image_dir, "-m", model, "-b", "512", "-w", "2", "-t", "3", "-o", out, "-p", "polished", "-g",
+            "--precision", precision])
     tree, labels = _merged_tree(gen, _prediction_files(out))
     assert sorted(tree) == sorted(fixture["tree"])
     diff = _label_differences(fixture, labels)
