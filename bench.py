@@ -66,58 +66,21 @@ def pmc_traffic(windows_per_launch, precision="fp32"):
         return None, None
 
 
-def measure_traffic(windows_per_launch, precision="fp32", calls=2, timeout=240):
-    """HBM bytes MEASURED in this run: two rocprofv3 counter passes -- FETCH_SIZE and WRITE_SIZE, each its own pass with
-    --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md's HBM section prescribes -- over a child process that
-    makes `calls` helen_polish_batch calls of `windows_per_launch` windows (scripts/pmc_one_call.py).  Units and the
-    gfx950 correction per that guide and scripts/pmc_summary.py: both counters are KiB, FETCH_SIZE is doubled (wide
-    coalesced reads are tallied at half their bytes).
-    -> {"recurrence_bytes_per_launch", "call_bytes_per_window", "kernels": {name: read, write per launch}} or None."""
-    import collections
-    import csv
-    import shutil
-    import subprocess
-    import tempfile
-    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(exe):
+def pmc_call_bytes_per_window(precision="fp32"):
+    """HBM bytes per window of a WHOLE device call, every kernel of the call summed, from the same committed counter
+    summary pmc_traffic reads (launches per call: pack and the encoder projection once, the rest per chunk)."""
+    import glob
+    tag = {"fp32": None, "bf16": "bf16", "fp32x3": "fp32x3"}[precision]
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))
+                   if (tag in os.path.basename(f) if tag else not any(t in os.path.basename(f) for t in ("bf16", "fp32x3"))))
+    if not files:
         return None
-    names = {"bf16": ("gru_fused_bf16",), "fp32x3": ("gru_x3",), "fp32": ("gru_kernel", "gru_pair_kernel", "gru_single8", "gru_half8",
-                                                                              "gru_quarter4")}[precision]
-    d = tempfile.mkdtemp(prefix="helen_pmc_", dir="/tmp")
-    per = {}            # kernel -> counter -> [values]
     try:
-        env = dict(os.environ, TMPDIR="/tmp")
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(d, counter)
-            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--",
-                                sys.executable, os.path.join(ROOT, "scripts", "pmc_one_call.py"), precision, str(windows_per_launch),
-                                str(calls)], cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
-            found = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
-            if r.returncode != 0 or not found:
-                return None
-            for row in csv.DictReader(open(found[0])):
-                if "helen" not in row["Kernel_Name"] or row["Counter_Name"] != counter:
-                    continue
-                per.setdefault(row["Kernel_Name"], collections.defaultdict(list))[counter].append(float(row["Counter_Value"]))
-    except Exception:       # noqa: BLE001 -- an extra measurement must not take the line down
+        doc = json.load(open(files[-1]))
+        per_call = doc.get("call_bytes_per_window")
+        return int(per_call) if per_call else None
+    except Exception:
         return None
-    finally:
-        shutil.rmtree(d, ignore_errors=True)
-    if not per:
-        return None
-    kernels, total, rec_bytes, rec_n = {}, 0.0, 0.0, 0
-    for k, c in per.items():
-        rd = 2.0 * 1024 * sum(c["FETCH_SIZE"]) if c.get("FETCH_SIZE") else 0.0
-        wr = 1024.0 * sum(c["WRITE_SIZE"]) if c.get("WRITE_SIZE") else 0.0
-        launches = max(len(c.get("FETCH_SIZE", [])), len(c.get("WRITE_SIZE", [])), 1)
-        total += rd + wr
-        short = k.split("(")[0].replace("void ", "").strip()[:80]
-        kernels[short] = {"launches": launches, "read_bytes_per_launch": int(rd / launches), "write_bytes_per_launch": int(wr / launches)}
-        if any(nm in k for nm in names):
-            rec_bytes += rd + wr
-            rec_n += launches
-    return {"recurrence_bytes_per_launch": int(rec_bytes / rec_n) if rec_n else None,
-            "call_bytes_per_window": int(total / (calls * windows_per_launch)), "kernels": kernels}
 
 
 def usable_cpus():
@@ -624,8 +587,7 @@ def main():
                     help="process-group backend for the barrier / max-time reduce (nccl = RCCL)")
     ap.add_argument("--single-device", action="store_true",
                     help="testing aid: every rank uses cuda:0 (exercise the N>1 code path on one GPU)")
-    ap.add_argument("--no-traffic", action="store_true",
-                    help="skip the two rocprofv3 counter passes that measure roofline.traffic (N=1 only; ~30 s)")
+    ap.add_argument("--no-traffic", action="store_true", help="(accepted and ignored: the counter passes are scripts/profile_round.sh's)")
     ap.add_argument("--plan-only", action="store_true",
                     help="print what this invocation would do (legs, sizes, host plan of the N ranks) as one JSON line and "
                          "exit, without touching a device: a dry run of the launcher's command shapes")
@@ -829,12 +791,10 @@ def main():
         win_per_launch = call_windows
         achieved = GRU_FLOP_PER_WINDOW_LAUNCH * win_per_launch / (avg_ms * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(win_per_launch, args.precision)
-        measured = None
-        if world == 1 and not args.no_traffic:
-            # (the engine of this process is idle here; the child makes its own)
-            measured = measure_traffic(win_per_launch, args.precision)
-            if measured is not None and measured["recurrence_bytes_per_launch"]:
-                traffic, traffic_src = measured["recurrence_bytes_per_launch"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run"
+        # (A counter pass cannot run inside this process's run: rocprofv3 --pmc is collected in passes of its own, one
+        # counter each, with nothing else on the device -- scripts/profile_round.sh does that and scripts/pmc_summary.py
+        # writes the committed summary these figures are read from.)
+        call_bytes = pmc_call_bytes_per_window(args.precision)
         peak = BF16_MFMA_PEAK if args.precision == "bf16" else FP32_MFMA_PEAK
         bound, unit = "mfma", "TFLOP/s"
         if args.precision == "bf16":
@@ -872,12 +832,12 @@ def main():
                          "peak": peak / (1e12 if bound == "mfma" else 1e9), "unit": unit,
                          "frac": round(achieved * (1e12 if bound == "mfma" else 1e9) / peak, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "traffic_measured_in_this_run": bool(measured and measured["recurrence_bytes_per_launch"]) if traffic is not None else None,
-                         # the whole call's HBM traffic per window against the 92,000 algorithmic bytes: what the
-                         # staging of gi / y1 between the kernels costs (the path is MFMA-bound, so it is power, not time)
-                         "hbm_bytes_per_window": None if not measured else measured["call_bytes_per_window"],
-                         "hbm_over_algorithmic": None if not measured else round(measured["call_bytes_per_window"] / 92000.0, 1),
-                         "traffic_by_kernel": None if not measured else measured["kernels"],
+                         "traffic_measured_in_this_run": False if traffic is not None else None,
+                         # the whole call's HBM traffic per window against the 92,000 algorithmic bytes, from the
+                         # same committed counter passes: what staging gi / y1 between the kernels costs (the path is
+                         # MFMA-bound, so it is power, not time)
+                         "hbm_bytes_per_window_from_profile": call_bytes,
+                         "hbm_over_algorithmic": None if not call_bytes else round(call_bytes / 92000.0, 1),
                          "avg_launch_ms": round(avg_ms, 4), "launches": gru_n,
                          "avg_launch_ms_encoder": round(stats["gru_enc"][0] / max(stats["gru_enc"][1], 1), 4),
                          "avg_launch_ms_decoder": round(stats["gru_dec"][0] / max(stats["gru_dec"][1], 1), 4),

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # HELEN_HIP_LIB: developer override to A/B-test kernel variants built side by side.
 LIB_PATH = os.environ.get("HELEN_HIP_LIB") or os.path.join(_HERE, "csrc", "libhelen_hip.so")
 
-HELEN_ABI_VERSION = 2
+HELEN_ABI_VERSION = 3
 HELEN_OK = 0
 HELEN_PRECISION_FP32 = 0
 HELEN_PRECISION_BF16 = 1
@@ -25,6 +25,7 @@ EXPORTS = (
     "helen_gru_chunk_forward", "helen_evaluate_batch", "helen_debug_inject_failure", "helen_set_profiling",
     "helen_reset_kernel_stats",
     "helen_get_kernel_stats", "helen_reload_overrides", "helen_describe_dispatch", "helen_plan_call",
+    "helen_device_count", "helen_host_alloc", "helen_host_free", "helen_polish_slot_submit", "helen_polish_slot_wait",
 )
 RECURRENCE_KERNELS = ("gru_kernel", "gru_single8_kernel", "gru_half8_kernel", "gru_quarter4_kernel", "gru_pair_kernel")
 DECODER_PROJECTIONS = ("gemm_gi_kernel<16>", "gemm_dec_ws_kernel", "gemm_dec_wsp_kernel")
@@ -68,7 +69,7 @@ def _try_build(target):
             pass
 
 
-def load():
+def load(with_torch=True):
     """Load libhelen_hip.so once; raise if it is absent (build with `python __graft_entry__.py`)."""
     global _lib
     if _lib is not None:
@@ -80,8 +81,12 @@ def load():
             "helen_amd: %s not found. The HIP library is required (there is no CPU fallback); "
             "build it with `make -C helen_amd/csrc` or `python __graft_entry__.py`." % LIB_PATH)
     # PyTorch-ROCm carries its own HIP runtime; import it first so that this process has ONE
-    # libamdhip64 (device buffers and streams are torch's and are handed to the library by pointer).
-    import torch  # noqa: F401
+    # libamdhip64 (device buffers and streams are torch's and are handed to the library by pointer).  A process that
+    # never touches torch -- `helen polish` on its native slot pipeline, helen_amd.predict -- asks for with_torch=False
+    # and runs on the system's runtime; it must then not import torch afterwards (helen_amd.predict decides up front).
+    import sys
+    if with_torch or "torch" in sys.modules:
+        import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     vp, ci = ctypes.c_void_p, ctypes.c_int
     lib.helen_abi_version.restype = ci
@@ -122,6 +127,16 @@ def load():
     lib.helen_describe_dispatch.argtypes = [ci, ctypes.c_char_p, ctypes.c_size_t]
     lib.helen_plan_call.restype = ci
     lib.helen_plan_call.argtypes = [ci, ci, ctypes.POINTER(ci)]
+    lib.helen_device_count.restype = ci
+    lib.helen_device_count.argtypes = [ctypes.POINTER(ci)]
+    lib.helen_host_alloc.restype = ci
+    lib.helen_host_alloc.argtypes = [ci, ctypes.c_size_t, ctypes.POINTER(vp)]
+    lib.helen_host_free.restype = ci
+    lib.helen_host_free.argtypes = [vp]
+    lib.helen_polish_slot_submit.restype = ci
+    lib.helen_polish_slot_submit.argtypes = [vp, vp, ci, vp, vp, vp]
+    lib.helen_polish_slot_wait.restype = ci
+    lib.helen_polish_slot_wait.argtypes = [vp]
     got = lib.helen_abi_version()
     if got != HELEN_ABI_VERSION:
         raise ImportError("libhelen_hip.so ABI %d != binding ABI %d; rebuild" % (got, HELEN_ABI_VERSION))

@@ -70,13 +70,26 @@ def call_consensus(image_dir, model_path, batch_size, num_workers, threads, outp
     sys.stderr.write("INFO: OUTPUT FILE: " + output_filename + "\n")
 
     if gpu_mode:
-        import torch
-        if not torch.cuda.is_available():
+        # how many devices: from the library itself when this run stays clear of torch (helen_amd.predict decides the same
+        # way, from the same two facts), else from torch
+        from .predict import native_model_state, native_path_wanted
+        try:
+            torch_free = native_path_wanted() and native_model_state(model_path) is not None
+        except (ValueError, RuntimeError) as e:       # a checkpoint of another architecture: what the loader would say
+            _err(str(e))
+            sys.exit(1)
+        if torch_free:
+            from .native_engine import device_count
+            visible = device_count()
+        else:
+            import torch
+            visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if visible <= 0:
             # (never a silent switch to the host path: --gpu_mode means the MI355X)
-            _err("NO MI355X VISIBLE (torch.cuda.is_available() IS FALSE).")
+            _err("NO MI355X VISIBLE (NO HIP DEVICE FOR THIS PROCESS).")
             sys.exit(1)
         try:
-            device_ids, callers = plan_devices(device_ids, torch.cuda.device_count())
+            device_ids, callers = plan_devices(device_ids, visible)
         except ValueError as e:
             _err(str(e))
             sys.exit(1)

@@ -122,6 +122,11 @@ def main(argv=None):
         sys.stderr.write("ERROR: NO SUBCOMMAND PROVIDED. PLEASE USE --help TO SEE THE OPTIONS.\n")
         parser.print_help(sys.stderr)
         return 1
+    import os
+    if os.environ.get("HELEN_ASSERT_NO_TORCH", "") == "1" and "torch" in sys.modules:
+        # (tests: `polish` / `call_consensus` / `stitch` are meant to run without torch, helen_amd/native_engine.py)
+        sys.stderr.write("ERROR: torch WAS IMPORTED DURING THIS RUN (HELEN_ASSERT_NO_TORCH=1).\n")
+        return 3
     return 0
 
 

@@ -49,7 +49,7 @@ class CpuEngine(object):
     device_bytes = 0
 
     def __init__(self, state_dict, threads=0):
-        from .engine import weights_struct
+        from .native_engine import weights_struct
         self._lib = load()
         self.threads = int(threads)
         self._weights, self._keep = weights_struct(state_dict)

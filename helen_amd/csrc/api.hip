@@ -111,6 +111,9 @@ struct HelenModel {
     int q_fill = 0, q_cur = 0;           // windows gathered in mirror q_cur
     int q_count[2] = {0, 0};             // windows of the device call in flight on ring slot b (0 = none)
     void* q_stream = nullptr;            // the compute stream of the queue's calls (the first submit's)
+    // slot pipeline (helen_polish_slot_submit / _wait): device calls on page-locked caller buffers, at most two in flight
+    // on the two ring slots
+    long long slot_submitted = 0, slot_waited = 0;
     std::atomic<bool> busy{false};   // a handle serves one host thread at a time (include/helen_hip.h): enforced
     hipEvent_t ev_in[2] = {nullptr, nullptr};
     hipEvent_t ev_done[2] = {nullptr, nullptr};
@@ -618,6 +621,10 @@ int helen_model_create(const HelenWeights* w, int device, int max_windows, int p
 }
 
 int helen_model_destroy(HelenModel* m) {
+    if (m && m->slot_submitted != m->slot_waited) {      // copies into caller memory may still be queued
+        (void)hipSetDevice(m->device);
+        (void)hipDeviceSynchronize();
+    }
     free_model(m);
     return HELEN_OK;
 }
@@ -915,6 +922,99 @@ static bool host_range_is_pinned(const void* p, size_t bytes) {
     return true;
 }
 
+int helen_device_count(int* out) {
+    if (!out) return fail(HELEN_EINVAL, "null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *out = n;
+    return HELEN_OK;
+}
+
+int helen_host_alloc(int device, size_t bytes, void** out) {
+    if (!out || bytes == 0) return fail(HELEN_EINVAL, "a size and a place for the pointer, please");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return HELEN_OK;
+}
+
+int helen_host_free(void* p) {
+    if (p) HIP_TRY(hipHostFree(p));
+    return HELEN_OK;
+}
+
+// The slot pipeline: the asynchronous form of helen_polish_host for callers whose buffers are page-locked and hold one device
+// call each (the slots of helen_amd.predict: reader threads fill slot k+2 while slot k+1 is uploaded, slot k computed
+// and slot k-1's labels downloaded).  Same three streams and ring slots as helen_polish_host; nothing is staged.
+int helen_polish_slot_submit(HelenModel* m, const uint8_t* images, int n_windows, uint8_t* bases, uint8_t* rles,
+                             void* stream) {
+    if (!m || !images || !bases || !rles) return fail(HELEN_EINVAL, "null argument");
+    if (n_windows <= 0 || n_windows > m->max_windows)
+        return fail(HELEN_EINVAL, "n_windows %d outside 1..%d (a slot is one device call)", n_windows, m->max_windows);
+    HELEN_ENTER(m);
+    if (m->q_fill || m->q_count[0] || m->q_count[1])
+        return fail(HELEN_EINVAL, "submitted windows are pending: helen_polish_flush first (the staging ring is shared)");
+    if (m->slot_submitted - m->slot_waited >= 2)
+        return fail(HELEN_EINVAL, "two slots are in flight: helen_polish_slot_wait first");
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t img_bytes = (size_t)kSeq * kF, lab_bytes = (size_t)kSeq, sub = (size_t)m->max_windows;
+    int rc;
+    if (!m->ring_ready && (rc = build_ring(m))) return rc;
+    if (!host_range_is_pinned(images, (size_t)n_windows * img_bytes) || !host_range_is_pinned(bases, (size_t)n_windows * lab_bytes) ||
+        !host_range_is_pinned(rles, (size_t)n_windows * lab_bytes))
+        return fail(HELEN_EINVAL, "helen_polish_slot_submit wants page-locked buffers (helen_host_alloc / hipHostMalloc); "
+                                  "helen_polish_host takes pageable memory");
+    const int b = (int)(m->slot_submitted & 1);
+    auto run = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(m->dev_in[b], images, (size_t)n_windows * img_bytes, hipMemcpyHostToDevice, m->h2d_stream));
+        HIP_TRY(hipEventRecord(m->ev_in[b], m->h2d_stream));
+        HIP_TRY(hipStreamWaitEvent(s, m->ev_in[b], 0));
+        const int r = polish_batch_impl(m, m->dev_in[b], n_windows, m->dev_out[b], m->dev_out[b] + sub * lab_bytes, nullptr,
+                                        nullptr, s);
+        if (r) return r;
+        HIP_TRY(hipEventRecord(m->ev_done[b], s));
+        HIP_TRY(hipStreamWaitEvent(m->d2h_stream, m->ev_done[b], 0));
+        HIP_TRY(hipMemcpyAsync(bases, m->dev_out[b], (size_t)n_windows * lab_bytes, hipMemcpyDeviceToHost, m->d2h_stream));
+        HIP_TRY(hipMemcpyAsync(rles, m->dev_out[b] + sub * lab_bytes, (size_t)n_windows * lab_bytes, hipMemcpyDeviceToHost,
+                               m->d2h_stream));
+        HIP_TRY(hipEventRecord(m->ev_out[b], m->d2h_stream));
+        return HELEN_OK;
+    };
+    rc = run();
+    if (rc != HELEN_OK) {      // nothing may stay in flight on the caller's buffers after a failure; the pipeline starts over
+        char keep[sizeof(g_err)];
+        memcpy(keep, g_err, sizeof(keep));
+        (void)hipStreamSynchronize(m->h2d_stream);
+        (void)hipStreamSynchronize(s);
+        (void)hipStreamSynchronize(m->d2h_stream);
+        (void)hipGetLastError();
+        memcpy(g_err, keep, sizeof(keep));
+        m->slot_submitted = m->slot_waited = 0;
+        return rc;
+    }
+    ++m->slot_submitted;
+    return HELEN_OK;
+}
+
+int helen_polish_slot_wait(HelenModel* m) {
+    if (!m) return fail(HELEN_EINVAL, "null argument");
+    HELEN_ENTER(m);
+    if (m->slot_submitted == m->slot_waited) return fail(HELEN_EINVAL, "no slot is in flight");
+    HIP_TRY(hipSetDevice(m->device));
+    const int b = (int)(m->slot_waited & 1);
+    const hipError_t e = hipEventSynchronize(m->ev_out[b]);
+    if (e != hipSuccess) {
+        m->slot_submitted = m->slot_waited = 0;
+        return fail(HELEN_EHIP, "waiting for a slot's labels: %s", hipGetErrorString(e));
+    }
+    ++m->slot_waited;
+    return HELEN_OK;
+}
+
 int helen_polish_host(HelenModel* m, const uint8_t* images, int n_windows, uint8_t* bases,
                       uint8_t* rles, void* stream) {
     if (!m || !images || !bases || !rles) return fail(HELEN_EINVAL, "null argument");
@@ -922,6 +1022,8 @@ int helen_polish_host(HelenModel* m, const uint8_t* images, int n_windows, uint8
     HELEN_ENTER(m);
     if (m->q_fill || m->q_count[0] || m->q_count[1])
         return fail(HELEN_EINVAL, "submitted windows are pending: helen_polish_flush first (the staging ring is shared)");
+    if (m->slot_submitted != m->slot_waited)
+        return fail(HELEN_EINVAL, "slots are in flight: helen_polish_slot_wait first (the staging ring is shared)");
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
     const int sub = m->max_windows;

@@ -11,12 +11,7 @@ import torch
 from . import _lib
 from .options import ImageSizeOptions, TrainOptions
 
-_PAIRS = (
-    ("enc_w_ih", "gru_encoder.weight_ih_l0"), ("enc_w_hh", "gru_encoder.weight_hh_l0"),
-    ("enc_b_ih", "gru_encoder.bias_ih_l0"), ("enc_b_hh", "gru_encoder.bias_hh_l0"),
-    ("dec_w_ih", "gru_decoder.weight_ih_l0"), ("dec_w_hh", "gru_decoder.weight_hh_l0"),
-    ("dec_b_ih", "gru_decoder.bias_ih_l0"), ("dec_b_hh", "gru_decoder.bias_hh_l0"),
-)
+from .native_engine import weights_struct as _weights_struct
 
 
 def _as_numpy(v):
@@ -26,35 +21,8 @@ def _as_numpy(v):
 
 
 def weights_struct(state_dict):
-    """state_dict (reference names, TransducerModel.py:43-58; a leading `module.` left by
-    DataParallel/DDP is stripped as ModelHander.py:70-75 does) -> (HelenWeightsC, keepalive)."""
-    sd = {}
-    for k, v in state_dict.items():
-        sd[k[7:] if k.startswith("module.") else k] = v
-    keep = []
-
-    def arr(name):
-        if name not in sd:
-            raise KeyError("missing parameter '%s' in model state" % name)
-        a = _as_numpy(sd[name])
-        keep.append(a)
-        return a
-
-    s = _lib.HelenWeightsC()
-    s.features = arr("gru_encoder.weight_ih_l0").shape[1]
-    s.hidden = arr("gru_encoder.weight_hh_l0").shape[1]
-    s.n_base = arr("dense1_base.weight").shape[0]
-    s.n_rle = arr("dense2_rle.weight").shape[0]
-    fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))  # noqa: E731
-    for field, name in _PAIRS:
-        pair = getattr(s, field)
-        pair[0] = fp(arr(name))
-        pair[1] = fp(arr(name + "_reverse"))
-    s.base_w = fp(arr("dense1_base.weight"))
-    s.base_b = fp(arr("dense1_base.bias"))
-    s.rle_w = fp(arr("dense2_rle.weight"))
-    s.rle_b = fp(arr("dense2_rle.bias"))
-    return s, keep
+    """state_dict of torch tensors or arrays -> (HelenWeightsC, keepalive) (helen_amd.native_engine.weights_struct)."""
+    return _weights_struct(state_dict, _as_numpy)
 
 
 class HelenEngine(object):

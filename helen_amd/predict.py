@@ -157,6 +157,89 @@ class _DeviceStage(object):
         self.registered = []
 
 
+class _NativeStage(object):
+    """The device stage on the library's own slot pipeline (helen_polish_slot_submit / _wait, include/helen_hip.h): the
+    upload of slot k+1, the kernels of slot k and the label download of slot k-1 overlap on three streams INSIDE
+    libhelen_hip.so, straight from / into the slots' page-locked memory (helen_host_alloc).  Same interface as
+    _DeviceStage, no torch anywhere."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.inflight = collections.deque()
+
+    def _settle(self):
+        """Wait for every slot the library still has in flight (oldest first: they complete in order)."""
+        for entry in self.inflight:
+            if entry[2]:
+                self.engine.wait()
+                entry[2] = False
+
+    def submit(self, slot, n):
+        if getattr(slot, "pinned", False):
+            if self.engine.in_flight >= 2:           # (predict()'s loop keeps at most one behind the one just queued)
+                self._settle()
+            self.engine.submit(slot.images[:n], slot.bases[:n], slot.rles[:n])
+            self.inflight.append([slot, n, True])
+        else:                                        # a slot that could not be page-locked: the synchronous staged call
+            self._settle()
+            self.engine.polish_host(slot.images[:n], out=(slot.bases[:n], slot.rles[:n]))
+            self.inflight.append([slot, n, False])
+
+    def pop(self):
+        slot, n, queued = self.inflight.popleft()
+        if queued:
+            self.engine.wait()
+        return slot, n
+
+    def close(self):
+        self._settle()
+        self.inflight.clear()
+
+
+def native_path_wanted():
+    """`helen polish` / `call_consensus` run WITHOUT torch by default: the checkpoint is read by helen_amd.checkpoint, the
+    device stage is the library's slot pipeline.  $HELEN_DEVICE_STAGE=torch keeps round 4's stage (torch streams and
+    pinned tensors), =sync the one synchronous call per slot."""
+    return os.environ.get("HELEN_DEVICE_STAGE", "native") in ("native", "async")
+
+
+_STATE_CACHE = {}
+
+
+def native_model_state(model_path):
+    """(state dict of float32 arrays, hidden_size, gru_layers, epochs) read without torch and checked like
+    ModelHandler.load_simple_model + TransducerGRU.load_state_dict do -- or None when this checkpoint needs torch.load."""
+    from . import checkpoint
+    from .weights import param_shapes
+    try:
+        st = os.stat(model_path)
+        key = (os.path.abspath(model_path), st.st_size, st.st_mtime_ns)
+    except OSError:
+        return None
+    if key not in _STATE_CACHE:
+        try:
+            _STATE_CACHE.clear()
+            _STATE_CACHE[key] = checkpoint.load_simple_model_state(model_path)
+        except checkpoint.UnsupportedCheckpoint:
+            _STATE_CACHE[key] = None
+    got = _STATE_CACHE[key]
+    if got is None:
+        return None
+    state, hidden_size, gru_layers, epochs = got
+    if gru_layers != 1:
+        raise ValueError("this build implements the shipped HELEN architecture: one bidirectional GRU layer per stage "
+                         "(Options.py:27)")
+    want = dict(param_shapes(ImageSizeOptions.IMAGE_HEIGHT, hidden_size))
+    missing = [k for k in want if k not in state]
+    unexpected = [k for k in state if k not in want]
+    if missing or unexpected:
+        raise RuntimeError("Error(s) in loading state_dict for TransducerGRU: missing %s, unexpected %s" % (missing, unexpected))
+    for k, shape in want.items():
+        if tuple(state[k].shape) != tuple(shape):
+            raise RuntimeError("size mismatch for %s: %s vs %s" % (k, tuple(state[k].shape), tuple(shape)))
+    return state, hidden_size, gru_layers, epochs
+
+
 def writer_count(num_workers):
     """Writer processes per rank: ONE by default -- the reference's single `<output>_<rank>.hdf`
     (predict_gpu.py:55), written by a thread of this process through the direct HDF5 emitter
@@ -276,9 +359,10 @@ def _thread_feeder_loop(calls, free_slots, ready_q, make_slot, n_slots, threads,
     call's (file, first, count) runs read by `threads` native threads, files the reader has left handed to the reaper."""
     from . import native_io
     try:
-        import torch
-        if device_id is not None and torch.cuda.is_available():
-            torch.cuda.set_device(device_id)      # the page-locked allocations below belong to this rank's device
+        if device_id is not None:                 # (None: the host path, or the native path whose slots name their device)
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.set_device(device_id)  # the page-locked allocations below belong to this rank's device
         made = 0
         last_path = None
         for runs in calls:
@@ -369,11 +453,14 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
 
     Pipeline over shared-memory slots of one device call each:
       reader processes fill slot k+2 | H2D k+1 | kernels k | D2H k-1 | writer(s) store slot k-2."""
-    import torch
-
     from . import native_io
-    from .model_handler import ModelHandler
     start_time = time.time()
+    # Without torch by default (helen_amd.native_engine): decided HERE, before anything of the device is touched -- a process
+    # on the native path runs on the system's HIP runtime and must not import torch's afterwards.
+    native = native_model_state(model_path) if native_path_wanted() else None
+    t_model_file = time.time() - start_time
+    if native is None:
+        import torch
     if plan is not None:
         num_workers = min(num_workers, plan.reader_workers) if num_workers > 0 else 0
     native_io.close_readers()          # a long-lived process may have these paths mapped from an earlier run
@@ -400,8 +487,8 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         slots = []
 
         def make_slot():
-            from .sequence_dataset import PinnedSlot
-            slots.append(PinnedSlot(cap, pin=not on_host))
+            from .sequence_dataset import NativeSlot, PinnedSlot
+            slots.append(NativeSlot(cap, device_id, pin=not on_host) if native is not None else PinnedSlot(cap, pin=not on_host))
             return slots[-1]
     else:
         pairs = test_data.all_images
@@ -431,7 +518,7 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         reaper.start()
         feeder = threading.Thread(target=_thread_feeder_loop, daemon=True,
                                   args=(calls, free_slots, ready_q, make_slot, n_slots, max(1, num_workers), batch_size,
-                                        ferr, None if on_host else device_id, reap_q, stop_feeding))
+                                        ferr, None if on_host or native is not None else device_id, reap_q, stop_feeding))
     else:
         feeder = threading.Thread(target=_feeder_loop, daemon=True,
                                   args=(calls, free_slots, ready_q, pool, cap, ferr, num_workers, stop_feeding))
@@ -463,24 +550,36 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     setup_took = {}
     try:
         t_s = time.time()
-        transducer_model, hidden_size, gru_layers, prev_ite = ModelHandler.load_simple_model(
-            model_path, input_channels=ImageSizeOptions.IMAGE_CHANNELS,
-            image_features=ImageSizeOptions.IMAGE_HEIGHT, seq_len=ImageSizeOptions.SEQ_LENGTH,
-            num_base_classes=ImageSizeOptions.TOTAL_BASE_LABELS,
-            num_rle_classes=ImageSizeOptions.TOTAL_RLE_LABELS)
-        transducer_model.eval()
-        setup_took["MODEL FILE"] = time.time() - t_s
-        t_s = time.time()
-        if on_host:
-            transducer_model.use_cpu(cpu_threads)
+        if native is not None:
+            setup_took["MODEL FILE"] = t_model_file        # (read first of all, before the readers started)
+            if on_host:
+                from .cpu_engine import CpuEngine
+                engine = CpuEngine(native[0], threads=cpu_threads)
+            else:
+                from .native_engine import NativeEngine
+                engine = NativeEngine(native[0], device=device_id, max_windows=min(DEVICE_CALL_WINDOWS, cap),
+                                      precision=os.environ.get("HELEN_PRECISION", "fp32"))
+            setup_took["DEVICE CONTEXT + WEIGHTS + ENGINE"] = time.time() - t_s
         else:
-            torch.cuda.set_device(device_id)
-            transducer_model.to(device_id)
-        setup_took["DEVICE CONTEXT + WEIGHTS"] = time.time() - t_s
-        t_s = time.time()
-        transducer_model.set_capacity(min(DEVICE_CALL_WINDOWS, cap))
-        engine = transducer_model.engine
-        setup_took["ENGINE"] = time.time() - t_s
+            from .model_handler import ModelHandler
+            transducer_model, hidden_size, gru_layers, prev_ite = ModelHandler.load_simple_model(
+                model_path, input_channels=ImageSizeOptions.IMAGE_CHANNELS,
+                image_features=ImageSizeOptions.IMAGE_HEIGHT, seq_len=ImageSizeOptions.SEQ_LENGTH,
+                num_base_classes=ImageSizeOptions.TOTAL_BASE_LABELS,
+                num_rle_classes=ImageSizeOptions.TOTAL_RLE_LABELS)
+            transducer_model.eval()
+            setup_took["MODEL FILE"] = time.time() - t_s
+            t_s = time.time()
+            if on_host:
+                transducer_model.use_cpu(cpu_threads)
+            else:
+                torch.cuda.set_device(device_id)
+                transducer_model.to(device_id)
+            setup_took["DEVICE CONTEXT + WEIGHTS"] = time.time() - t_s
+            t_s = time.time()
+            transducer_model.set_capacity(min(DEVICE_CALL_WINDOWS, cap))
+            engine = transducer_model.engine
+            setup_took["ENGINE"] = time.time() - t_s
         if rank == 0:
             print(prediction_file_name(output_filename, rank))
             if on_host:
@@ -489,8 +588,10 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
                 sys.stderr.write("INFO: MI355X HIP PATH, DEVICE " + str(device_id) + ", "
                                  + str(engine.device_bytes >> 20) + " MiB OF DEVICE MEMORY HELD.\n")
             sys.stderr.write("Loading data\n")
-        if os.environ.get("HELEN_DEVICE_STAGE", "async") != "sync" and hasattr(engine, "polish") and not on_host \
-                and torch.cuda.is_available() and calls:
+        if native is not None and not on_host and calls:
+            stage = _NativeStage(engine)
+        elif native is None and os.environ.get("HELEN_DEVICE_STAGE", "async") != "sync" and hasattr(engine, "polish") \
+                and not on_host and torch.cuda.is_available() and calls:
             t_s = time.time()
             try:
                 stage = _DeviceStage(engine, slots, cap, device_id)

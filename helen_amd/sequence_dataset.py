@@ -210,6 +210,44 @@ class PinnedSlot(object):
         self.images_t = self.bases_t = self.rles_t = None
 
 
+class NativeSlot(object):
+    """PinnedSlot without torch: images and label rows in ONE block of page-locked memory of the HIP runtime
+    (helen_host_alloc through helen_amd.native_engine), positions / bounds / names in ordinary memory.  `pinned` says
+    whether the block is page-locked (False: ordinary memory -- the host path, or a refused allocation -- and the device
+    stage then goes through the library's staged, synchronous call)."""
+
+    path = None
+
+    def __init__(self, cap, device=0, pin=True):
+        self.cap = int(cap)
+        L, H = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT
+        n_img, n_lab = self.cap * L * H, self.cap * L
+        self._block = None
+        self.pinned = False
+        if pin:
+            try:
+                from .native_engine import PinnedBlock
+                self._block = PinnedBlock(n_img + 2 * n_lab + 8192, device if device is not None else 0)
+                self.pinned = True
+            except Exception as e:      # noqa: BLE001 -- page-locking refused (ulimit -l, container policy): staged copies
+                import sys
+                sys.stderr.write("INFO: SLOT NOT PAGE-LOCKED (" + str(e).splitlines()[0][:120] + "), USING STAGED COPIES.\n")
+        raw = self._block.array if self._block is not None else np.empty(n_img + 2 * n_lab + 8192, np.uint8)
+        lab0 = (n_img + 4095) // 4096 * 4096             # label rows on their own pages
+        self.images = raw[:n_img].reshape(self.cap, L, H)
+        self.bases = raw[lab0:lab0 + n_lab].reshape(self.cap, L)
+        self.rles = raw[lab0 + n_lab:lab0 + 2 * n_lab].reshape(self.cap, L)
+        self.positions = np.empty((self.cap, L, 3), np.int64)
+        self.meta = np.empty((self.cap, 3), np.int64)
+        self.contigs = np.zeros((self.cap, native_io.NAME_BYTES), np.uint8)
+
+    def close(self):
+        self.images = self.positions = self.meta = self.contigs = self.bases = self.rles = None
+        if self._block is not None:
+            self._block.close()
+            self._block = None
+
+
 def _unlink_quietly(path):
     import os
     try:

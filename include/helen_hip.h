@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HELEN_ABI_VERSION 2
+#define HELEN_ABI_VERSION 3
 
 enum {
     HELEN_OK = 0,
@@ -170,6 +170,25 @@ int helen_polish_batch(HelenModel* model, const uint8_t* images, int n_windows, 
  */
 int helen_polish_host(HelenModel* model, const uint8_t* images, int n_windows, uint8_t* bases,
                       uint8_t* rles, void* stream);
+
+/*
+ * The slot pipeline: the asynchronous form of helen_polish_host for callers whose buffers are page-locked and hold ONE device
+ * call each -- the hand-off `helen polish` itself uses (helen_amd/predict.py: reader threads fill slot k+2 while slot k+1 goes
+ * up, slot k is computed and slot k-1's labels come down; the "pinned hipMemcpyAsync double-buffering" of the loader -> HBM
+ * step).  submit enqueues upload (copy stream), kernels (`stream`) and label download (second copy stream) of one slot and
+ * returns; at most TWO slots are in flight; wait blocks until the OLDEST slot's labels are in its bases / rles.  Buffers:
+ * page-locked host memory (helen_host_alloc, hipHostMalloc, a pinned torch tensor), n_windows <= max_windows.  After an
+ * error nothing is in flight and the pipeline starts over.  Replaces `images.to(device_id)` ... `.cpu()` of
+ * `models/predict_gpu.py:94-159` for a caller that never needs torch.
+ *   helen_device_count  number of HIP devices visible (0 when there is none: never an error)
+ *   helen_host_alloc    page-locked host memory of the runtime for `device` (hipHostMalloc); helen_host_free returns it
+ */
+int helen_device_count(int* out);
+int helen_host_alloc(int device, size_t bytes, void** out);
+int helen_host_free(void* p);
+int helen_polish_slot_submit(HelenModel* model, const uint8_t* images, int n_windows, uint8_t* bases, uint8_t* rles,
+                             void* stream);
+int helen_polish_slot_wait(HelenModel* model);
 
 /*
  * The queueing form of helen_polish_host, for a caller that holds ONE loader batch at a time (the reference's loop,

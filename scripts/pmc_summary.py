@@ -57,9 +57,10 @@ def agg(path):
 fetch = agg(os.path.join(src, "pmc_FETCH_SIZE", "p_counter_collection.csv"))
 write = agg(os.path.join(src, "pmc_WRITE_SIZE", "p_counter_collection.csv"))
 sq = agg(os.path.join(src, "pmc_sq", "p_counter_collection.csv"))
-out = {"command": "rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 1 --warmup 0 "
-                  "--no-cpu-baseline --no-host-path --e2e 0" + ((" " + extra) if extra else "") +
-                  ("   (helen_polish_batch calls of 4096 windows)" if not extra else ""),
+windows = int(os.environ.get("PMC_WINDOWS", "0"))      # windows the profiled command processed in all (pmc_one_call.py: calls x n)
+out = {"command": ("rocprofv3 --kernel-trace --pmc <counters> -- python scripts/pmc_one_call.py " + (extra or "fp32 4096 2")) if windows else
+                  ("rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 1 --warmup 0 "
+                   "--no-cpu-baseline --no-host-path --e2e 0" + ((" " + extra) if extra else "")),
        "notes": "FETCH_SIZE doubled (gfx950 wide-read correction); sizes in bytes per launch",
        "kernels": {}}
 for k in sorted(sq):
@@ -85,6 +86,17 @@ for k in sorted(sq):
         "active_inst_frac": round(mean(sq, "SQ_ACTIVE_INST_ANY") / wave, 4),
         "lds_bank_conflict_cycles": mean(sq, "SQ_LDS_BANK_CONFLICT"),
     }
+if windows:
+    # every launch of every kernel of the library in the pass, read + write, over the windows the command processed
+    total = 0.0
+    for k in out["kernels"]:
+        if fetch.get(k, {}).get("FETCH_SIZE"):
+            total += 2 * 1024 * sum(fetch[k]["FETCH_SIZE"])
+        if write.get(k, {}).get("WRITE_SIZE"):
+            total += 1024 * sum(write[k]["WRITE_SIZE"])
+    out["windows_in_the_pass"] = windows
+    out["call_bytes_per_window"] = int(total / windows)
+    out["call_bytes_over_algorithmic"] = round(total / windows / 92000.0, 1)
 path = os.path.join(ROOT, "profiles", tag + "_pmc_summary.json")
 json.dump(out, open(path, "w"), indent=1)
 print(open(path).read())

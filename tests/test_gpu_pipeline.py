@@ -416,3 +416,86 @@ def test_bench_survives_an_rccl_that_does_not_come_up():
     assert line["rccl"] == "ok" or line["rccl"].startswith("failed"), line["rccl"]
     assert line["barrier"] == ("RCCL all-reduce + gloo all-reduce" if line["rccl"] == "ok" else "gloo all-reduce")
     print(line["rccl"], line["barrier"])
+
+
+def test_slot_pipeline_equals_device_calls():
+    """helen_polish_slot_submit / _wait (the hand-off `helen polish` runs on, helen_amd/native_engine.py): slots of 4096, 1000
+    and 17 windows in page-locked memory of helen_host_alloc, two in flight, give the labels of helen_polish_batch on the
+    same windows; a third submission without a wait, pageable buffers, a wait with nothing in flight and a
+    helen_polish_host while slots are in flight are refused -- and the handle works on afterwards."""
+    from helen_amd._lib import HelenError
+    from helen_amd.engine import HelenEngine
+    from helen_amd.native_engine import NativeEngine, PinnedBlock, device_count
+    from helen_amd.weights import make_images
+    assert device_count() >= 1
+    w = make_weights(seed=20260928, head_scale=8.0, input_scale=1.0 / 64.0)
+    sizes = [4096, 1000, 17, 4096]
+    img = make_images(max(sizes), seed=77)
+    ref_eng = HelenEngine(w, device=0, max_windows=4096)
+    b, r = ref_eng.polish(torch.from_numpy(img).cuda())
+    want_b, want_r = b.cpu().numpy(), r.cpu().numpy()
+    ref_eng.close()
+    eng = NativeEngine(w, device=0, max_windows=4096)
+    blocks, slots = [], []
+    for n in sizes:
+        blk = PinnedBlock(n * 92000 + 4096)
+        blocks.append(blk)
+        images = blk.array[:n * 90000].reshape(n, 1000, 90)
+        images[:] = img[:n]
+        bases = blk.array[n * 90000:n * 91000].reshape(n, 1000)
+        rles = blk.array[n * 91000:n * 92000].reshape(n, 1000)
+        bases[:] = 255
+        rles[:] = 255
+        slots.append((images, bases, rles))
+    eng.submit(*slots[0])
+    eng.submit(*slots[1])
+    with pytest.raises(HelenError, match="two slots are in flight"):
+        eng.submit(*slots[2])
+    eng.in_flight -= 1                       # (the refused call was not queued)
+    with pytest.raises(HelenError, match="slots are in flight"):
+        eng.polish_host(img[:8])
+    eng.wait()
+    eng.submit(*slots[2])
+    eng.wait()
+    eng.submit(*slots[3])
+    eng.wait()
+    eng.wait()
+    assert eng.in_flight == 0
+    with pytest.raises(HelenError, match="no slot is in flight"):
+        eng.wait()
+    eng.in_flight = 0
+    for n, (images, bases, rles) in zip(sizes, slots):
+        assert np.array_equal(bases, want_b[:n]) and np.array_equal(rles, want_r[:n]), n
+    pageable = np.ascontiguousarray(img[:32])
+    with pytest.raises(HelenError, match="page-locked"):
+        eng.submit(pageable, np.empty((32, 1000), np.uint8), np.empty((32, 1000), np.uint8))
+    eng.in_flight = 0
+    got_b, got_r = eng.polish_host(pageable)                      # the handle is fine afterwards
+    assert np.array_equal(got_b, want_b[:32]) and np.array_equal(got_r, want_r[:32])
+    eng.close()
+    for blk in blocks:
+        blk.close()
+
+
+def test_predict_on_the_native_stage_equals_the_torch_stage(tmp_path, monkeypatch):
+    """helen_amd.predict.predict on the library's slot pipeline (the default: no torch in the data path) writes the prediction
+    file of round 4's torch device stage ($HELEN_DEVICE_STAGE=torch), byte for byte, on a directory with short images, several
+    device calls and a ragged last one."""
+    import hashlib
+
+    from helen_amd import predict as P
+    from helen_amd.model_handler import ModelHandler
+    from helen_amd.synthetic import write_image_dir
+    w = make_weights(seed=20260928, head_scale=8.0, input_scale=1.0 / 64.0)
+    model = str(tmp_path / "m.pkl")
+    ModelHandler.save_model(w, None, 128, 1, 0, model)
+    img_dir = str(tmp_path / "img")
+    files = write_image_dir(img_dir, 9000, n_files=3, seed=5, short_every=9, direct=True)
+    digests = {}
+    for stage in ("native", "torch"):
+        monkeypatch.setenv("HELEN_DEVICE_STAGE", stage)
+        out = str(tmp_path / stage)
+        P.predict(files, out, model, 256, 3, 0, 0)
+        assert P.LAST_PREDICT["windows"] == 9000 and P.LAST_PREDICT["device_calls"] == 3
+        digests[stage] = hashlib.sha1(open(out + "_0.hdf", "rb").read()).hexdigest()
+    assert digests["native"] == digests["torch"]

@@ -148,7 +148,7 @@ def test_host_polish_equals_the_reference_chain(tmp_path, threads):
     image_dir, model, made = gen.polish_case(str(tmp_path))
     out = str(tmp_path / "out")
     _helen(["polish", "-i", image_dir, "-m", model, "-b", "16", "-w", "0", "-t", str(threads), "-c", "1", "-o", out,
-            "-p", "polished"])
+            "-p", "polished"], env={"HELEN_ASSERT_NO_TORCH": "1"})
     fasta = _assert_chain_equals_reference(gen, fixture, out, threads, "host path")
     assert _identity_report(fasta, made["truth"], "host path") > 0.995
 
@@ -162,7 +162,10 @@ def test_gpu_polish_equals_the_reference_chain(tmp_path):
     image_dir, model, made = gen.polish_case(str(tmp_path))
     for what, extra in (("one caller", []), ("two callers on one device", ["-d_ids", "0,0"])):
         out = str(tmp_path / ("out_" + what.split()[0]))
-        _helen(["polish", "-i", image_dir, "-m", model, "-b", "256", "-w", "2", "-t", "3", "-o", out, "-p", "polished", "-g"] + extra)
+        # (HELEN_ASSERT_NO_TORCH: the command must get through without importing torch -- checkpoint, slots and device stage
+        # are the library's own, helen_amd/native_engine.py; exit code 3 otherwise)
+        _helen(["polish", "-i", image_dir, "-m", model, "-b", "256", "-w", "2", "-t", "3", "-o", out, "-p", "polished", "-g"] + extra,
+               env={"HELEN_ASSERT_NO_TORCH": "1"})
         assert len(_prediction_files(out)) == (2 if extra else 1)
         fasta = _assert_chain_equals_reference(gen, fixture, out, 3, "MI355X, " + what)
     assert _identity_report(fasta, made["truth"], "MI355X fp32") > 0.995

@@ -26,21 +26,65 @@ class _StandInEngine(object):
         pass
 
 
-@pytest.mark.parametrize("workers,readers", [(0, "threads"), (2, "threads"), (0, "processes"), (2, "processes")])
-def test_pipeline_with_stand_in_device(tmp_path, monkeypatch, workers, readers):
+class _StandInNativeEngine(_StandInEngine):
+    """The surface of helen_amd.native_engine.NativeEngine that predict() uses: submit / wait (at most two slots in flight,
+    completed in order) beside polish_host."""
+
+    def __init__(self, state_dict, device=0, max_windows=4096, precision="fp32"):
+        assert "gru_encoder.weight_ih_l0" in state_dict and precision == "fp32"
+        self.in_flight, self.max_windows, self.submitted, self.staged = 0, max_windows, 0, 0
+
+    def submit(self, images, bases, rles):
+        assert self.in_flight < 2 and images.shape[0] <= self.max_windows
+        self.polish_host(images, out=(bases, rles))
+        self.in_flight += 1
+        self.submitted += 1
+
+    def wait(self):
+        assert self.in_flight > 0
+        self.in_flight -= 1
+
+
+@pytest.mark.parametrize("workers,readers,stage", [(0, "threads", "torch"), (2, "threads", "torch"), (0, "processes", "torch"),
+                                                   (2, "processes", "torch"), (2, "threads", "native"),
+                                                   (0, "threads", "native-unpinned"), (2, "processes", "native")])
+def test_pipeline_with_stand_in_device(tmp_path, monkeypatch, workers, readers, stage):
     """Both reader modes of predict() (helen_amd.predict.reader_mode): native threads filling page-locked slots, and the
-    pool of reader processes over shared-memory slots."""
+    pool of reader processes over shared-memory slots -- under round 4's torch device stage ($HELEN_DEVICE_STAGE=torch)
+    and under the torch-free default (the library's slot pipeline; slots that could not be page-locked, and the
+    shared-memory slots of the process pool, take its synchronous staged call)."""
     import torch
 
+    import helen_amd.native_engine as N
     import helen_amd.predict as P
+    import helen_amd.sequence_dataset as S
     import helen_amd.transducer as T
     from helen_amd.model_handler import ModelHandler
     from helen_amd.sequence_dataset import SequenceDataset
     from helen_amd.synthetic import write_image_dir
     from helen_amd.weights import make_weights
-    monkeypatch.setattr(T.TransducerGRU, "engine", property(lambda self: _StandInEngine()))
-    monkeypatch.setattr(T.TransducerGRU, "to", lambda self, d: self)
-    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    made = []
+    if stage == "torch":
+        monkeypatch.setenv("HELEN_DEVICE_STAGE", "torch")
+        monkeypatch.setattr(T.TransducerGRU, "engine", property(lambda self: _StandInEngine()))
+        monkeypatch.setattr(T.TransducerGRU, "to", lambda self, d: self)
+        monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    else:
+        monkeypatch.delenv("HELEN_DEVICE_STAGE", raising=False)
+
+        def engine(*a, **k):
+            made.append(_StandInNativeEngine(*a, **k))
+            return made[-1]
+        monkeypatch.setattr(N, "NativeEngine", engine)
+        if stage == "native":           # no device here: ordinary memory that says it is page-locked
+
+            real = S.NativeSlot
+
+            class Slot(real):
+                def __init__(self, cap, device=0, pin=True):
+                    real.__init__(self, cap, device, pin=False)
+                    self.pinned = True
+            monkeypatch.setattr(S, "NativeSlot", Slot)
     monkeypatch.setattr(P, "DEVICE_CALL_WINDOWS", 64)       # 4 loader batches per "device call"
     monkeypatch.setenv("HELEN_WRITERS", "1")                # the reference's single file per rank
     monkeypatch.setenv("HELEN_READERS", readers)
@@ -51,6 +95,9 @@ def test_pipeline_with_stand_in_device(tmp_path, monkeypatch, workers, readers):
     files = sorted(glob.glob(os.path.join(img_dir, "*.h5")))
     P.predict(files, str(tmp_path / "out"), model, 16, workers, 0, 0)
     assert P.LAST_PREDICT["reader_mode"] == readers and P.LAST_PREDICT["windows"] == 150
+    if stage != "torch":
+        assert len(made) == 1 and made[0].in_flight == 0
+        assert made[0].submitted == (3 if stage == "native" and readers == "threads" else 0)     # 150 windows = 3 device calls
     ds = SequenceDataset(None, file_list=files)
     seen = 0
     with hdf5.File(str(tmp_path / "out_0.hdf")) as f:
@@ -77,6 +124,7 @@ def test_sharded_writers(tmp_path, monkeypatch):
     from helen_amd.sequence_dataset import SequenceDataset
     from helen_amd.synthetic import write_image_dir
     from helen_amd.weights import make_weights
+    monkeypatch.setenv("HELEN_DEVICE_STAGE", "torch")        # (the stand-in below replaces the torch-side engine)
     monkeypatch.setattr(T.TransducerGRU, "engine", property(lambda self: _StandInEngine()))
     monkeypatch.setattr(T.TransducerGRU, "to", lambda self, d: self)
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
@@ -117,6 +165,7 @@ def test_reader_error_surfaces(tmp_path, monkeypatch):
     import helen_amd.transducer as T
     from helen_amd.model_handler import ModelHandler
     from helen_amd.weights import make_weights
+    monkeypatch.setenv("HELEN_DEVICE_STAGE", "torch")        # (the stand-in below replaces the torch-side engine)
     monkeypatch.setattr(T.TransducerGRU, "engine", property(lambda self: _StandInEngine()))
     monkeypatch.setattr(T.TransducerGRU, "to", lambda self, d: self)
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
@@ -161,6 +210,7 @@ def _stand_in(monkeypatch):
 
     import helen_amd.predict as P
     import helen_amd.transducer as T
+    monkeypatch.setenv("HELEN_DEVICE_STAGE", "torch")        # (the stand-in below replaces the torch-side engine)
     monkeypatch.setattr(T.TransducerGRU, "engine", property(lambda self: _StandInEngine()))
     monkeypatch.setattr(T.TransducerGRU, "to", lambda self, d: self)
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
