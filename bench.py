@@ -384,13 +384,15 @@ def trained_weights():
 
 def e2e_size(windows_per_rank, world, may_shrink, free=None):
     """What the end-to-end leg will run with: (windows per rank, bytes of RAM-backed space it needs, where it goes).
-    The default leg (no --e2e given) shrinks to what /dev/shm holds for ALL ranks, down to two device calls per rank;
-    with one rank it may go to the temp directory instead; otherwise it is skipped."""
-    from helen_amd.host_plan import SLOT_BYTES_PER_WINDOW, shm_free_bytes
+    The default leg (no --e2e given) shrinks to what may be put into /dev/shm for ALL ranks -- its free space AND half
+    of the RAM the process tree may still take (MemAvailable, memory-cgroup head-room: tmpfs pages are RAM; sizing by
+    statvfs alone took a box down in round 5) -- down to two device calls per rank; with one rank it may go to the temp
+    directory instead; otherwise it is skipped."""
+    from helen_amd.host_plan import SLOT_BYTES_PER_WINDOW, ram_backed_budget_bytes
 
     def need_bytes(per_rank):     # inputs + slots + outputs (two runs) + FASTA, all ranks, all RAM-backed
         return per_rank * world * (116000 + 2 * 16000 + 2 * 1500) + world * 5 * 4096 * SLOT_BYTES_PER_WINDOW
-    free = shm_free_bytes() if free is None else free
+    free = ram_backed_budget_bytes() if free is None else free
     n = windows_per_rank
     while may_shrink and n > 8192 and free <= need_bytes(n) * 1.1:
         n = max(8192, n - 4096)
@@ -442,22 +444,23 @@ def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_de
     from helen_amd import hdf5
     from helen_amd import predict as P
     from helen_amd.call_consensus import call_consensus, polish_genome
-    from helen_amd.host_plan import shm_free_bytes
+    from helen_amd.host_plan import ram_backed_budget_bytes
     from helen_amd.model_handler import ModelHandler
     from helen_amd.synthetic import assembly_spec, write_assembly_dir
     box = [None, windows_per_rank, 0]
     if rank == 0:
         box[1], box[2], where, free = e2e_size(windows_per_rank, world, may_shrink)
         if box[1] != windows_per_rank:
-            sys.stderr.write("INFO: /dev/shm HAS %.1f GB FREE: THE END-TO-END LEG SHRINKS TO %d WINDOWS PER RANK.\n" % (free / 1e9, box[1]))
+            sys.stderr.write("INFO: /dev/shm MAY TAKE %.1f GB (FREE SPACE, HALF OF THE AVAILABLE RAM): THE END-TO-END LEG SHRINKS TO "
+                             "%d WINDOWS PER RANK.\n" % (free / 1e9, box[1]))
         if where is not None:
             box[0] = tempfile.mkdtemp(prefix="helen_e2e_", dir="/dev/shm" if where == "/dev/shm" else None)
     if dist is not None:
         dist.broadcast_object_list(box, src=0)
     d, windows_per_rank, need = box
     if d is None:
-        return {"value": None, "skipped": "/dev/shm has %.1f GB free, the %d-rank leg needs %.1f GB"
-                                          % (shm_free_bytes() / 1e9, world, need / 1e9)} if rank == 0 else None
+        return {"value": None, "skipped": "/dev/shm may take %.1f GB, the %d-rank leg needs %.1f GB"
+                                          % (ram_backed_budget_bytes() / 1e9, world, need / 1e9)} if rank == 0 else None
     done = os.path.join(d, "done")
     try:
         img_dir = os.path.join(d, "img")

@@ -143,6 +143,47 @@ def shm_free_bytes(path="/dev/shm"):
     return 0
 
 
+def _first_int(path):
+    try:
+        with open(path) as f:
+            t = f.read().split()[0]
+        return None if t == "max" else int(t)
+    except (OSError, ValueError, IndexError):
+        return None
+
+
+def ram_available_bytes(meminfo="/proc/meminfo", cgroup_root="/sys/fs/cgroup"):
+    """RAM this process tree may still take before something is killed: MemAvailable, and the head-room of the
+    memory cgroup it runs in (version 2: memory.max - memory.current; version 1: memory.limit_in_bytes -
+    memory.usage_in_bytes), whichever is smaller.  tmpfs pages count against both -- a /dev/shm that statvfs reports
+    as all of RAM free cannot be filled (a 2-rank bench leg sized by statvfs alone took a GPU box down in round 5).
+    None when neither can be read."""
+    found = []
+    try:
+        with open(meminfo) as f:
+            for ln in f:
+                if ln.startswith("MemAvailable:"):
+                    found.append(int(ln.split()[1]) * 1024)
+                    break
+    except (OSError, ValueError):
+        pass
+    for limit, usage in (("memory.max", "memory.current"),
+                         ("memory/memory.limit_in_bytes", "memory/memory.usage_in_bytes")):
+        lim = _first_int(os.path.join(cgroup_root, limit))
+        use = _first_int(os.path.join(cgroup_root, usage))
+        if lim is not None and use is not None and lim < (1 << 60):
+            found.append(max(0, lim - use))
+    return min(found) if found else None
+
+
+def ram_backed_budget_bytes(path="/dev/shm"):
+    """What may be PUT into RAM-backed files under `path` by a run: free space of the tmpfs, and no more than half of
+    ram_available_bytes() (the other half is for the processes themselves: page-locked slots, page cache, heaps)."""
+    free = shm_free_bytes(path)
+    ram = ram_available_bytes()
+    return free if ram is None else min(free, ram // 2)
+
+
 class RankPlan(object):
     """What one rank of predict_gpu gets (picklable: it travels to the spawned process)."""
 
@@ -304,7 +345,7 @@ def plan_host(devices, num_workers, cap_windows, calls_per_rank=None, usable=Non
                     for r in rs:
                         cpus_of.pop(r)
     # RAM-backed slot budget over all ranks
-    shm_free = shm_free_bytes() if shm_free is None else shm_free
+    shm_free = ram_backed_budget_bytes() if shm_free is None else shm_free
     per_slot = int(cap_windows) * SLOT_BYTES_PER_WINDOW
     slots = 5 if calls_per_rank is None else min(5, max(1, int(calls_per_rank)))
     need = n * slots * per_slot

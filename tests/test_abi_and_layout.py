@@ -81,6 +81,30 @@ def test_product_does_not_touch_the_oracle():
                         raise AssertionError("%s references the oracle: %s" % (f, line))
 
 
+def test_every_environment_switch_is_in_the_readme_table():
+    """README.md's table of HELEN_* variables (name, default, supported / probe) and the names the code reads agree:
+    every name passed to getenv / flag_of in csrc/ and every HELEN_* read from os.environ in the package, bin/ and
+    bench.py has a row, and no row names a variable nothing reads."""
+    read = set()
+    csrc = os.path.join(ROOT, "helen_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".h", ".hip", ".cpp")):
+            read |= set(re.findall(r'(?:getenv|flag_of)\("(HELEN_[A-Z0-9_]+)"\)', open(os.path.join(csrc, f)).read()))
+    py = [os.path.join(ROOT, "bench.py")]
+    py += [os.path.join(ROOT, "bin", f) for f in os.listdir(os.path.join(ROOT, "bin"))]
+    py += [os.path.join(ROOT, "helen_amd", f) for f in os.listdir(os.path.join(ROOT, "helen_amd")) if f.endswith(".py")]
+    for f in py:
+        src = open(f).read()
+        read |= set(re.findall(r'environ(?:\.get\(|\[|\.setdefault\(|\.pop\()\s*["\'](HELEN_[A-Z0-9_]+)', src))
+        read |= set(re.findall(r'["\'](HELEN_[A-Z0-9_]+)["\']\s+(?:not\s+)?in\s+os\.environ', src))
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    table = readme[readme.index("## Environment variables"):]
+    rows = set(re.findall(r"HELEN_[A-Z0-9_]+", table))
+    assert len(read) > 20, sorted(read)
+    assert not (read - rows), "read by the code, no row in README.md: %s" % sorted(read - rows)
+    assert not (rows - read), "in README.md's table, read by nothing: %s" % sorted(rows - read)
+
+
 def test_chunk_starts_match_reference_loop():
     from helen_amd.options import chunk_starts
     assert chunk_starts() == list(range(0, 901, 50)) and len(chunk_starts()) == 19

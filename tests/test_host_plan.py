@@ -280,3 +280,47 @@ def test_eight_ranks_on_a_two_socket_node(tmp_path, monkeypatch):
     zneed = next((u for u in range(8, 400) if plan_host(list(range(8)), 16, 4096, usable=u, allowed=list(range(192)), shm_free=1 << 40,
                                                         local_cpus=local, storage=[{"deflate": 16}] * 8).as_dict()["predicted_bound"] == "device"), None)
     assert zneed == 8 * (15 + host_plan.RANK_THREADS)
+
+
+def test_ram_backed_budget_counts_ram_not_just_tmpfs_space(tmp_path, monkeypatch):
+    """A tmpfs reports (nearly) all of RAM as free space; what may be put there is bounded by the RAM the process tree
+    may still take -- MemAvailable and the memory cgroup's head-room (both cgroup versions) -- and only half of that.
+    (bench.py's multi-rank end-to-end leg, sized by statvfs alone, took a GPU box down in round 5.)"""
+    from helen_amd import host_plan
+    mi = tmp_path / "meminfo"
+    mi.write_text("MemTotal:       131072000 kB\nMemFree:  1 kB\nMemAvailable:   104857600 kB\n")       # 100 GiB
+    v2 = tmp_path / "cg2"
+    v2.mkdir()
+    (v2 / "memory.max").write_text("max\n")
+    (v2 / "memory.current").write_text("123\n")
+    assert host_plan.ram_available_bytes(str(mi), str(v2)) == 100 << 30          # "max" = no limit
+    (v2 / "memory.max").write_text("%d\n" % (64 << 30))
+    (v2 / "memory.current").write_text("%d\n" % (4 << 30))
+    assert host_plan.ram_available_bytes(str(mi), str(v2)) == 60 << 30           # the cgroup is the tighter bound
+    v1 = tmp_path / "cg1"
+    (v1 / "memory").mkdir(parents=True)
+    (v1 / "memory" / "memory.limit_in_bytes").write_text("9223372036854771712\n")   # version 1's "unlimited"
+    (v1 / "memory" / "memory.usage_in_bytes").write_text("1000\n")
+    assert host_plan.ram_available_bytes(str(mi), str(v1)) == 100 << 30
+    (v1 / "memory" / "memory.limit_in_bytes").write_text("%d\n" % (32 << 30))
+    assert host_plan.ram_available_bytes(str(mi), str(v1)) == (32 << 30) - 1000
+    assert host_plan.ram_available_bytes(str(tmp_path / "none"), str(tmp_path / "none")) is None
+    monkeypatch.setattr(host_plan, "shm_free_bytes", lambda path="/dev/shm": 126 << 30)
+    monkeypatch.setattr(host_plan, "ram_available_bytes", lambda: 100 << 30)
+    assert host_plan.ram_backed_budget_bytes() == 50 << 30
+    monkeypatch.setattr(host_plan, "shm_free_bytes", lambda path="/dev/shm": 10 << 30)
+    assert host_plan.ram_backed_budget_bytes() == 10 << 30
+    monkeypatch.setattr(host_plan, "ram_available_bytes", lambda: None)
+    assert host_plan.ram_backed_budget_bytes() == 10 << 30
+    # the bench's two-rank default leg on a 128 GB box whose /dev/shm "has" 126 GB: 300,000 windows per rank (95 GB of
+    # RAM-backed files) no longer pass; the leg shrinks to what half of the available RAM takes
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_plan", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n, need, where, free = bench.e2e_size(300000, 2, True, free=50 << 30)
+    assert where == "/dev/shm" and 8192 <= n < 300000 and need * 1.1 < 50 << 30
+    n1, need1, where1, _ = bench.e2e_size(300000, 1, True, free=50 << 30)
+    assert n1 == 300000 and where1 == "/dev/shm"
