@@ -151,6 +151,19 @@ def call_consensus(image_dir, model_path, batch_size, num_workers, threads, outp
     return streams
 
 
+def _process_age():
+    """Seconds since this process was started (fork + exec, interpreter start-up and imports included), from
+    /proc/self/stat's start time and /proc/uptime; None where /proc does not say."""
+    try:
+        with open("/proc/self/stat") as f:
+            start_ticks = int(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/uptime") as f:
+            up = float(f.read().split()[0])
+        return up - start_ticks / float(os.sysconf("SC_CLK_TCK"))
+    except (OSError, ValueError, IndexError):
+        return None
+
+
 def polish_genome(image_dir, model_path, batch_size, num_workers, threads, output_dir,
                   output_prefix, gpu_mode, device_ids, callers):
     """call_consensus into `<output_dir>/predictions_<timestamp>/`, then stitch the predictions into
@@ -182,6 +195,10 @@ def polish_genome(image_dir, model_path, batch_size, num_workers, threads, outpu
     def fmt(a, b):
         return "%d HOURS %d MINS %d SECS" % (int((b - a) // 3600), int((b - a) % 3600 // 60), int(b - a) % 60)
     sys.stderr.write("INFO: FINISHED PROCESSING.\n")
+    age = _process_age()
+    sys.stderr.write("INFO: WALL CLOCK: %sBEFORE CALL CONSENSUS %.2f S, CALL CONSENSUS %.2f S, STITCH AFTER THE LAST WINDOW %.2f S.\n"
+                     % ("" if age is None else "%.2f S SINCE THE PROCESS STARTED: " % age,
+                        0.0 if age is None else max(0.0, age - (t2 - t0)), t1 - t0, t2 - t1))
     sys.stderr.write("INFO: TOTAL TIME ELAPSED: " + fmt(t0, t2) + "\n")
     sys.stderr.write("INFO: PREDICTION TIME: " + fmt(t0, t1) + "\n")
     sys.stderr.write("INFO: STITCH TIME: " + fmt(t1, t2) + "\n")

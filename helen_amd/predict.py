@@ -39,6 +39,9 @@ DEVICE_CALL_WINDOWS = 4096
 STAGE_SECONDS = {"read_wait": 0.0, "device": 0.0, "write": 0.0}
 # what the last predict() of this process did (windows, seconds, stage seconds, reader processes, ...)
 LAST_PREDICT = {}
+# threads still handing page-locked slots of finished runs back to the runtime (see predict(): release_device)
+BACKGROUND_RELEASE = []
+
 # what the last predict_gpu() of this process did: the host plan and every rank's LAST_PREDICT
 LAST_RUN = {}
 
@@ -463,6 +466,25 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         import torch
     if plan is not None:
         num_workers = min(num_workers, plan.reader_workers) if num_workers > 0 else 0
+    # The device context and the model (0.2-0.3 s: the runtime's start-up, 15.9 GB of scratch) are created by a thread of
+    # their own from HERE, beside the indexing of the image files and the start of the readers, instead of after them:
+    # every entry of the C ABI selects the model's device itself, so the thread that creates the model need not be the
+    # one that uses it.
+    early_engine = None
+    if native is not None and cpu_threads is None:
+        early_engine = {"t0": time.time()}
+
+        def create_engine_early():
+            try:
+                from .native_engine import NativeEngine
+                cap_ = max(1, DEVICE_CALL_WINDOWS // batch_size) * batch_size
+                early_engine["engine"] = NativeEngine(native[0], device=device_id, max_windows=min(DEVICE_CALL_WINDOWS, cap_),
+                                                      precision=os.environ.get("HELEN_PRECISION", "fp32"))
+            except BaseException as e:          # noqa: BLE001 -- raised where the engine is needed
+                early_engine["error"] = e
+            early_engine["took"] = time.time() - early_engine["t0"]
+        early_engine["thread"] = threading.Thread(target=create_engine_early, daemon=True)
+        early_engine["thread"].start()
     native_io.close_readers()          # a long-lived process may have these paths mapped from an earlier run
     _remove_stale_outputs(output_filename, rank)
     writers = writer_count(num_workers)
@@ -556,10 +578,14 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
                 from .cpu_engine import CpuEngine
                 engine = CpuEngine(native[0], threads=cpu_threads)
             else:
-                from .native_engine import NativeEngine
-                engine = NativeEngine(native[0], device=device_id, max_windows=min(DEVICE_CALL_WINDOWS, cap),
-                                      precision=os.environ.get("HELEN_PRECISION", "fp32"))
-            setup_took["DEVICE CONTEXT + WEIGHTS + ENGINE"] = time.time() - t_s
+                early_engine["thread"].join()
+                if "error" in early_engine:
+                    raise early_engine["error"]
+                engine = early_engine.pop("engine")
+                setup_took["DEVICE CONTEXT + WEIGHTS + ENGINE (BESIDE THE INDEXING) %.2f, WAITED" % early_engine["took"]] = \
+                    time.time() - t_s
+            if on_host:
+                setup_took["ENGINE"] = time.time() - t_s
         else:
             from .model_handler import ModelHandler
             transducer_model, hidden_size, gru_layers, prev_ite = ModelHandler.load_simple_model(
@@ -661,8 +687,21 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
             took["DEVICE MEMORY"] = time.time() - t
             writer_done.wait()          # the writer reads labels and positions out of the slots
             t = time.time()
+            # Page-locked slots of this process (1.9 GB; the runtime takes 0.05 s to let go of each) are released
+            # BEHIND the caller's back: nobody waits for them -- `polish` goes on to the joins and the FASTA, a command
+            # ends (helen_amd.cli.leave) -- and a caller that must know joins BACKGROUND_RELEASE.  Slots that are files
+            # (reader processes) are removed here and now.
+            later = [sl for sl in slots if not hasattr(sl, "path") or sl.path is None]
             for sl in slots:
-                sl.close()
+                if sl not in later:
+                    sl.close()
+            if later:
+                def free_slots_later(them=later):
+                    for sl in them:
+                        sl.close()
+                th = threading.Thread(target=free_slots_later, daemon=True)
+                BACKGROUND_RELEASE[:] = [x for x in BACKGROUND_RELEASE if x.is_alive()] + [th]
+                th.start()
             took["SLOTS"] = time.time() - t
 
         def release_readers():

@@ -20,6 +20,7 @@ A region whose images do not arrive back to back (possible only in a hand-made i
 region's images consecutively) is decoded from the finished prediction file instead, like perform_stitch does.
 """
 import bisect
+import operator
 import concurrent.futures
 import os
 import pickle
@@ -55,6 +56,7 @@ class RegionStream(object):
         self.carry = None          # the newest region, still growing: [key, [(chunk id, positions, bases, rles), ...]]
         self.placed = {}           # contig -> (start, end) of its decoded regions, sorted
         self.joins = {}            # (left bytes, right bytes) -> (score, pos_a, pos_b)
+        self.pair_joins = {}       # (contig, start a, end a, start b, end b) -> (score, pos_a, pos_b): the same results by REGION
         self.pool = concurrent.futures.ThreadPoolExecutor(self.threads) if native_io.available() else None
         self.pending = []
         self.seconds = {"decode": 0.0, "joins_submitted": 0, "regions": 0, "from_file": 0}
@@ -179,7 +181,7 @@ class RegionStream(object):
                 ov += int(ov * StitchOptions.BASE_ERROR_RATE)
                 sa, sb = self.regions.get((contig,) + a), self.regions.get((contig,) + b)
                 if sa and sb:
-                    jobs.append((sa[-ov:], sb[:ov]))
+                    jobs.append((sa[-ov:], sb[:ov], (contig,) + a + b))
 
         for key, seq in zip(keys, seqs):
             self.regions[key] = seq
@@ -214,13 +216,14 @@ class RegionStream(object):
         if self.carry is not None:
             self._close_carry()
         for fut in self.pending:
-            for left, right, res in fut.result():
+            for left, right, res, pair in fut.result():
                 self.joins[(left, right)] = res
+                self.pair_joins[pair] = res
         self.pending = []
         if self.pool is not None:
             self.pool.shutdown()
             self.pool = None
-        return StreamResult(self.file, self.regions, self.joins, dict(self.seconds))
+        return StreamResult(self.file, self.regions, self.joins, dict(self.seconds), self.pair_joins)
 
 
 def _string_order_once(ids, seen):
@@ -235,11 +238,11 @@ def _string_order_once(ids, seen):
 
 
 def _align_jobs(jobs):
-    """[(left, right)] -> [(left, right, (score, pos_a, pos_b))] through helen_ssw_join_batch (one native call)."""
-    blob = b"".join(x for pair in jobs for x in pair)
+    """[(left, right, pair)] -> [(left, right, (score, pos_a, pos_b), pair)] through helen_ssw_join_batch (one native call)."""
+    blob = b"".join(x for job in jobs for x in job[:2])
     l_off, l_len, r_off, r_len = [], [], [], []
     at = 0
-    for left, right in jobs:
+    for left, right, _ in jobs:
         l_off.append(at)
         l_len.append(len(left))
         at += len(left)
@@ -249,19 +252,23 @@ def _align_jobs(jobs):
     out = native_io.ssw_join_batch(blob, l_off, l_len, r_off, r_len, StitchOptions.MATCH_PENALTY,
                                    StitchOptions.MISMATCH_PENALTY, StitchOptions.GAP_PENALTY,
                                    StitchOptions.GAP_EXTEND_PENALTY, StitchOptions.OVERLAP_THRESHOLD).tolist()
-    return [(left, right, tuple(res)) for (left, right), res in zip(jobs, out)]
+    return [(left, right, tuple(res), pair) for (left, right, pair), res in zip(jobs, out)]
 
 
 class StreamResult(object):
     """What one rank's RegionStream hands the final pass; travels between processes as a file (save / load)."""
 
-    def __init__(self, file, regions, joins, stats):
+    def __init__(self, file, regions, joins, stats, pair_joins=None):
         self.file, self.regions, self.joins, self.stats = file, regions, joins, stats
+        # the joins by region pair.  A pair's result was computed from the two regions' sequences as they are in
+        # `regions` (a sequence never changes once it is there), so it is valid for exactly those
+        self.pair_joins = {} if pair_joins is None else pair_joins
 
     def save(self, directory=None):
         fd, path = tempfile.mkstemp(prefix="helen_stream_%d_" % os.getpid(), suffix=".pkl", dir=directory)
         with os.fdopen(fd, "wb") as f:
-            pickle.dump((self.file, self.regions, self.joins, self.stats), f, protocol=pickle.HIGHEST_PROTOCOL)
+            pickle.dump((self.file, self.regions, self.joins, self.stats, self.pair_joins), f,
+                        protocol=pickle.HIGHEST_PROTOCOL)
         return path
 
     @staticmethod
@@ -285,7 +292,101 @@ def spill_directory():
     return None
 
 
-def finish_stitch(results, input_directory, output_path, output_prefix, threads):
+def _joined_from_slices(contig, rows, pair_joins):
+    """The sequence of a contig as SLICES of its regions' sequences, when every join of the contig is an ordinary one
+    whose result is in the table -- or None, and the caller goes through the reference's procedure join by join.
+
+    `rows` = [(path, name, start, end, sequence)] in (start, end) order.  alignment_stitch (Stitch.py:96-190) keeps, of
+    a join with alignment positions (pos_a, pos_b) over an overlap of `ov` bases, the running sequence up to
+    len - ov + pos_a and the next sequence from pos_b on.  If the last `ov` bases of the running sequence are the left
+    region's own (it kept at least that much after ITS left join) and the first `ov` bases of whatever the right
+    region heads (the region itself, or the partial sequence of the run it starts: Stitch.py:257-301 stitches runs of
+    regions first and the runs to each other afterwards) are the right region's own, then the two strings aligned are
+    the two regions' tail and head -- the pair the stream has aligned already -- whatever the runs are, and the contig is
+    region 0 [0 : e0] + region 1 [s1 : e1] + ...  Both conditions are checked for every region; gaps between
+    neighbours (the ten-N filler and its warning) are taken along; anything else -- a region without a sequence, a pair
+    that was never aligned, an alignment without a score or without an anchor, sequences of ten bases or fewer, two
+    regions of one span -- leaves the contig to the general procedure."""
+    m = len(rows)
+    rate = StitchOptions.BASE_ERROR_RATE
+    seqs = [e[4] for e in rows]
+    if None in seqs:
+        return None
+    lens = [len(q) for q in seqs]
+    if min(lens) <= 10:
+        return None
+    starts = [e[2] for e in rows]
+    ends = [e[3] for e in rows]
+    start_cut = [0] * m
+    end_cut = list(lens)
+    need_tail = [0] * m           # bases of its own that region i must still hold at its end (the overlap of its right join)
+    need_head = [0] * m           # ... and at its start (the overlap of its left join)
+    gaps = []
+    get = pair_joins.get
+    i = 0
+    for a0, a1, b0, b1, n in zip(starts, ends, starts[1:], ends[1:], lens):
+        if b0 < a1:
+            res = get((contig, a0, a1, b0, b1))
+            if res is None or res[0] == 0 or res[1] < 0 or res[2] < 0 or (a0 == b0 and a1 == b1):
+                return None
+            ov = a1 - b0
+            ov += int(ov * rate)
+            end_cut[i] = n - ov + res[1]
+            start_cut[i + 1] = res[2]
+            need_tail[i] = ov
+            need_head[i + 1] = ov
+        else:
+            gaps.append(i + 1)
+        i += 1
+    for n, s0, e0, t, h in zip(lens, start_cut, end_cut, need_tail, need_head):
+        if s0 > n - t or e0 < h or e0 <= s0:
+            return None
+    pieces = [memoryview(q)[s0:e0] for q, s0, e0 in zip(seqs, start_cut, end_cut)]
+    total = sum(end_cut) - sum(start_cut) + 10 * len(gaps)
+    warnings = []
+    fill = b'N' * 10
+    for g in reversed(gaps):
+        pieces.insert(g, fill)
+    for g in gaps:
+        warnings.append("WARNING: NO OVERLAP IN CHUNKS:  " + str(contig) + " " + str(starts[g]) + " " + str(ends[g - 1]) + "\n")
+    return pieces, total, warnings
+
+
+def _align_unseen_neighbours(per_contig, joins, pair_joins, threads):
+    """Neighbours that no stream has seen side by side -- the regions of a contig whose images were dealt to several
+    ranks (MarginPolish writes a contig's regions into whichever thread's file; CallConsensusInterface.py:138-145 deals
+    the files round-robin) -- are aligned here, all of them at once on `threads` worker threads, BEFORE the serial join
+    pass, instead of one by one inside it.  `per_contig` = {contig: rows in (start, end) order}; fills `joins` (by the two
+    strings) and `pair_joins` (by the two spans).  -> number of alignments made."""
+    rate = StitchOptions.BASE_ERROR_RATE
+    jobs = []
+    for contig, rows in per_contig.items():
+        for (_, _, a0, a1, sa), (_, _, b0, b1, sb) in zip(rows, rows[1:]):
+            if b0 < a1 and sa and sb:
+                pair = (contig, a0, a1, b0, b1)
+                if pair_joins is not None and pair in pair_joins:
+                    continue
+                ov = a1 - b0
+                ov += int(ov * rate)
+                left, right = sa[-ov:], sb[:ov]
+                known = joins.get((left, right))
+                if known is None:
+                    jobs.append((left, right, pair))
+                elif pair_joins is not None and (a0, a1) != (b0, b1):
+                    pair_joins[pair] = known
+    if not jobs or not native_io.available():
+        return 0
+    per = max(8, -(-len(jobs) // (4 * max(1, threads))))
+    with concurrent.futures.ThreadPoolExecutor(max(1, threads)) as pool:
+        for done in pool.map(_align_jobs, [jobs[lo:lo + per] for lo in range(0, len(jobs), per)]):
+            for left, right, res, pair in done:
+                joins[(left, right)] = res
+                if pair_joins is not None and pair[1:3] != pair[3:5]:
+                    pair_joins[pair] = res
+    return len(jobs)
+
+
+def finish_stitch(results, input_directory, output_path, output_prefix, threads, fast=True):
     """perform_stitch (StitchInterface.py:40-106) from the streams of the run that has just written `input_directory`:
     the same contig order, region order, runs and joins -- and the same FASTA -- with the regions' sequences and most of
     the overlap alignments already there.  `results` = one StreamResult per prediction file of the directory."""
@@ -295,42 +396,80 @@ def finish_stitch(results, input_directory, output_path, output_prefix, threads)
     if missing or len(files) != len(by_file):
         raise RuntimeError("the prediction directory and the streamed regions do not match (%s): run `helen stitch` on %s"
                            % (missing[:2], input_directory))
-    joins = {}
+    joins, pair_joins = {}, {}
     for r in results:
         joins.update(r.joins)
-    # regions per contig: files in the directory's listing order, a file's regions in NAME order (StitchInterface.py:84-95)
+        if fast:
+            pair_joins.update(getattr(r, "pair_joins", None) or {})
+    # regions per contig: files in the directory's listing order, then (start, end) -- the order perform_stitch gives a
+    # contig's regions (StitchInterface.py:84-95 lists a file's regions by name, Stitch.py:262 sorts by (start, end), the
+    # sort is stable, and one file holds a span once: only the order of the FILES decides between equal spans)
     per_contig = {}
     for path in files:
-        r = by_file[os.path.abspath(path)]
-        named = {}
-        for (contig, start, end), seq in r.regions.items():
-            named.setdefault(contig, []).append(("%s-%d-%d" % (contig, start, end), start, end, seq))
-        for contig, rows in named.items():
-            rows.sort(key=lambda e: e[0])
-            per_contig.setdefault(contig, []).extend((path,) + row for row in rows)
+        for (contig, start, end), seq in by_file[os.path.abspath(path)].regions.items():
+            per_contig.setdefault(contig, []).append((path, None, start, end, seq))
+    by_span = operator.itemgetter(2, 3)
+    for rows in per_contig.values():
+        rows.sort(key=by_span)
+    late = _align_unseen_neighbours(per_contig, joins, pair_joins if fast else None, threads)
     output_dir = file_manager.handle_output_directory(output_path)
     output_filename = os.path.join(output_dir, output_prefix + '.fa')
     sys.stderr.write("INFO: OUTPUT FILE: " + output_filename + "\n")
     contigs = sorted(per_contig)
     hits = [0, 0]
+    sliced = 0
 
     def aligner(left, right):
         got = joins.get((left, right))
         hits[0 if got is not None else 1] += 1
         return got
 
-    with open(output_filename, 'wb') as fasta:
+    # the FASTA is written by a thread of its own (a contig is tens of megabytes; the write releases the interpreter
+    # lock) while the next contig is being joined
+    import queue
+    import threading
+    to_write = queue.Queue(maxsize=4)
+    write_error = []
+
+    def write_loop(fasta):
+        while True:
+            item = to_write.get()
+            if item is None:
+                return
+            if write_error:
+                continue
+            try:
+                fasta.write(b"".join(item))
+            except BaseException as e:          # noqa: BLE001 -- raised by the caller's thread below
+                write_error.append(e)
+
+    fasta = open(output_filename, 'wb')
+    writer = threading.Thread(target=write_loop, args=(fasta,), daemon=True)
+    writer.start()
+    try:
         for i, contig in enumerate(contigs):
             prefix = "{:04d}/{:04d}:".format(i, len(contigs))
             sys.stderr.write("INFO: " + prefix + " PROCESSING CONTIG: " + contig + "\n")
-            key_list = sorted(per_contig[contig], key=lambda e: (e[2], e[3]))
+            key_list = per_contig[contig]
+            quick = _joined_from_slices(contig, key_list, pair_joins) if pair_joins else None
+            if quick is not None:
+                pieces, total, warnings = quick
+                for w in warnings:
+                    sys.stderr.write(w)
+                hits[0] += len(key_list) - 1 - len(warnings)
+                sliced += 1
+                sys.stderr.write("INFO: " + prefix + " FINISHED PROCESSING " + contig
+                                 + ", POLISHED SEQUENCE LENGTH: " + str(total) + ".\n")
+                if total > 0:
+                    to_write.put([b'>' + contig.encode() + b"\n"] + pieces + [b"\n"])
+                continue
             n = max(StitchOptions.MIN_SEQUENCE_REQUIRED_FOR_MULTITHREADING, int(len(key_list) / threads) + 1)
             partial = []
             for lo in range(0, len(key_list), n):                       # FileManager.chunks
                 chunk = []
                 for path, name, start, end, seq in key_list[lo:lo + n]:
                     if seq is None:
-                        seq = native_io.region_sequence(path, contig, name, as_bytes=True)
+                        seq = native_io.region_sequence(path, contig, "%s-%d-%d" % (contig, start, end), as_bytes=True)
                     chunk.append((contig, start, end, seq))
                 chunk.sort(key=lambda e: (e[1], e[2]))
                 c, s, e, running = _alignment_stitch(chunk, aligner)
@@ -340,9 +479,16 @@ def finish_stitch(results, input_directory, output_path, output_prefix, threads)
             sys.stderr.write("INFO: " + prefix + " FINISHED PROCESSING " + contig
                              + ", POLISHED SEQUENCE LENGTH: " + str(len(sequence)) + ".\n")
             if len(sequence) > 0:
-                fasta.write(b'>' + contig.encode() + b"\n")
-                fasta.write(sequence)
-                fasta.write(b"\n")
+                to_write.put((b'>' + contig.encode() + b"\n", sequence, b"\n"))
+    finally:
+        to_write.put(None)
+        writer.join()
+        fasta.close()
+    if write_error:
+        raise write_error[0]
     sys.stderr.write("INFO: STITCH PIPELINED BEHIND INFERENCE: %d JOINS FROM THE TABLE, %d ALIGNED NOW, %d REGION(S) READ BACK "
-                     "FROM THE FILES.\n" % (hits[0], hits[1], sum(r.stats.get("from_file", 0) for r in results)))
+                     "FROM THE FILES; %d OF %d CONTIG(S) ASSEMBLED FROM REGION SLICES%s.\n"
+                     % (hits[0], hits[1], sum(r.stats.get("from_file", 0) for r in results), sliced, len(contigs),
+                        "" if not late else "; %d JOIN(S) BETWEEN REGIONS OF DIFFERENT STREAMS ALIGNED ON %d THREAD(S) FIRST"
+                        % (late, threads)))
     return output_filename

@@ -39,10 +39,10 @@ def main():
                                env=dict(os.environ, HELEN_STITCH_PIPELINE=mode), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                text=True)
             dt = time.time() - t0
-            info = [ln for ln in r.stderr.splitlines() if ln.startswith("INFO") and ("WINDOWS IN" in ln or "PIPELINED" in ln or "TIME" in ln)]
+            info = [ln for ln in r.stderr.splitlines() if ln.startswith("INFO") and ("WINDOWS IN" in ln or "PIPELINED" in ln or "TIME" in ln or "WALL CLOCK" in ln)]
             print("HELEN_STITCH_PIPELINE=%s rc %d: polish wall %.2f s = %.0f windows/s (FASTA %d bytes)"
                   % (mode, r.returncode, dt, n / dt, os.path.getsize(os.path.join(out, "asm.fa")) if r.returncode == 0 else -1))
-            print("\n".join("    " + ln for ln in info[-6:]))
+            print("\n".join("    " + ln for ln in info[-7:]))
             if r.returncode != 0:
                 print(r.stderr[-3000:])
         a, b = (open(os.path.join(d, "out" + m, "asm.fa"), "rb").read() for m in "10")

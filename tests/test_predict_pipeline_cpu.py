@@ -408,7 +408,7 @@ def test_helen_commands_run_through_their_entry_points(tmp_path):
         import tomli as toml_reader
     with open(os.path.join(root, "pyproject.toml"), "rb") as f:
         scripts = toml_reader.load(f)["project"]["scripts"]
-    assert scripts == {"helen": "helen_amd.cli:main", "helen_train": "helen_amd.cli:train_main"}
+    assert scripts == {"helen": "helen_amd.cli:entry", "helen_train": "helen_amd.cli:train_entry"}
     import importlib
     for target in scripts.values():                      # the declared entry points resolve to callables
         mod, fn = target.split(":")

@@ -131,6 +131,9 @@ def test_streamed_stitch_equals_the_two_phase_stitch(tmp_path, seed, batch, thre
     got = finish_stitch(results, str(pred), str(tmp_path / "streamed"), "asm", threads)
     a, b = open(want, "rb").read(), open(got, "rb").read()
     assert a == b and len(a) > 5000
+    # ... and with every contig taken through the general procedure (no assembly from region slices)
+    slow = finish_stitch(results, str(pred), str(tmp_path / "streamed_general"), "asm", threads, fast=False)
+    assert open(slow, "rb").read() == a
     err = capfd.readouterr().err
     from_file = sum(r.stats["from_file"] for r in results)
     assert "JOINS FROM THE TABLE" in err
@@ -204,3 +207,131 @@ def test_join_batch_equals_single_alignments():
             assert (pa, pb) == get_confident_positions(al), (a, b, al.cigar_string)
             anchored += pa >= 0
     assert anchored >= 20
+
+
+@pytest.mark.parametrize("seed,threads,batch,n_streams", [(11, 1, 5, 1), (12, 4, 64, 1), (13, 16, 3, 1), (14, 4, 9, 3)])
+def test_contigs_assembled_from_region_slices(tmp_path, seed, threads, batch, n_streams, capfd):
+    """Ordinary assemblies -- regions of 700-1,200 called bases that agree with their neighbours over 100-300 of them, a
+    few mismatches in the overlaps, one hole -- are put together from slices of the regions' sequences (every join of a
+    contig already in the pair table, helen_amd.stitch_stream._joined_from_slices) instead of join by join: the FASTA
+    must be perform_stitch's, for any number of stitch threads (= any cut of a contig into runs), and the report must say
+    that the short way was taken."""
+    from helen_amd.data_store import DataStore
+    from helen_amd.stitch import perform_stitch
+    from helen_amd.stitch_stream import RegionStream, finish_stitch
+    rng = random.Random(seed)
+    pred = tmp_path / "pred"
+    pred.mkdir()
+    windows = []
+    for c in range(4):
+        contig = "chr%d" % c
+        length = rng.randrange(9000, 16000)
+        truth = [rng.randrange(1, 5) for _ in range(length)]
+        start, k = 0, 0
+        while start < length - 300:
+            end = min(length, start + rng.randrange(700, 1000))
+            pos = np.full((1000, 3), -1, np.int64)
+            n = end - start
+            pos[:n, 0] = np.arange(start, end)
+            pos[:n, 1:] = 0
+            b = np.zeros(1000, np.uint8)
+            r = np.zeros(1000, np.uint8)
+            b[:n] = truth[start:end]
+            r[:n] = [1 + (rng.random() < 0.2) for _ in range(n)]
+            for _ in range(3):                               # a few disagreements with the neighbour
+                b[rng.randrange(n)] = rng.randrange(1, 5)
+            windows.append((contig, start, end, 0, pos, b, r))
+            step = (end - start) - rng.randrange(100, 300)
+            if c == 2 and k == 4:
+                step = (end - start) + 40                     # a hole: ten Ns and a warning
+            start += step
+            k += 1
+    # one stream per rank; with several, a contig's regions are dealt to them in turn (MarginPolish writes a contig's
+    # regions into whichever thread's file, and the files are dealt to the ranks): most neighbours never meet in a stream
+    results = []
+    for k in range(n_streams):
+        mine = windows[k::n_streams]
+        path = str(pred / ("p_%d.hdf" % k))
+        store = DataStore(path, "w")
+        stream = RegionStream(path, threads=2)
+        for lo in range(0, len(mine), batch):
+            contigs, meta, pos, b, r = _arrays(mine[lo:lo + batch])
+            store.write_batch(contigs, meta, pos, b, r)
+            stream.feed(contigs, meta, pos, b, r)
+        store.close()
+        results.append(stream.finish())
+    if n_streams == 1:
+        assert len(results[0].pair_joins) >= len(windows) - 4 - 1
+    want = perform_stitch(str(pred), str(tmp_path / "two_phase"), "asm", threads)
+    capfd.readouterr()
+    got = finish_stitch(results, str(pred), str(tmp_path / "streamed"), "asm", threads)
+    err = capfd.readouterr().err
+    a = open(want, "rb").read()
+    assert open(got, "rb").read() == a and a.count(b">") == 4 and b"N" * 10 in a
+    assert "4 OF 4 CONTIG(S) ASSEMBLED FROM REGION SLICES" in err and "0 ALIGNED NOW" in err, err[-400:]
+    assert err.count("WARNING: NO OVERLAP IN CHUNKS") == 1
+    assert ("BETWEEN REGIONS OF DIFFERENT STREAMS ALIGNED ON %d THREAD(S) FIRST" % threads in err) == (n_streams > 1)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_region_slices_fuzz(tmp_path, seed):
+    """The short way of finish_stitch on assemblies that are ALMOST ordinary: region lengths from 12 bases to 1,000,
+    overlaps from 5 bases to longer than the shorter neighbour (nested regions), overlaps that disagree in a fifth of
+    their bases (alignments without an anchor), empty regions, holes.  Whatever mixture of contigs goes the short way
+    and the general way, for 1, 3 and 16 stitch threads the FASTA is perform_stitch's."""
+    from helen_amd.data_store import DataStore
+    from helen_amd.stitch import perform_stitch
+    from helen_amd.stitch_stream import RegionStream, finish_stitch
+    rng = random.Random(1000 + seed)
+    pred = tmp_path / "pred"
+    pred.mkdir()
+    path = str(pred / "p_0.hdf")
+    store = DataStore(path, "w")
+    stream = RegionStream(path, threads=2)
+    windows = []
+    for c in range(rng.randrange(2, 6)):
+        contig = "c%d" % c
+        length = rng.randrange(1500, 6000)
+        truth = [rng.randrange(1, 5) for _ in range(length)]
+        p_odd = rng.choice([0.0, 0.0, 0.03, 0.15])             # how often a region of this contig is not ordinary
+        start = 0
+        while start < length - 50:
+            odd = rng.random() < p_odd
+            span = rng.choice([12, 60, 300, 700, 1000]) if odd else rng.randrange(500, 1000)
+            end = min(length, start + span)
+            n = end - start
+            pos = np.full((1000, 3), -1, np.int64)
+            pos[:n, 0] = np.arange(start, end)
+            pos[:n, 1:] = 0
+            b = np.zeros(1000, np.uint8)
+            r = np.zeros(1000, np.uint8)
+            b[:n] = truth[start:end]
+            r[:n] = [1 + (rng.random() < 0.3) for _ in range(n)]
+            if odd and rng.random() < 0.3:
+                for j in range(n):                             # a noisy region: its overlaps will not anchor
+                    if rng.random() < 0.2:
+                        b[j] = rng.randrange(1, 5)
+            elif rng.random() < 0.5:
+                for _ in range(rng.randrange(1, 6)):           # a few disagreements with the neighbours
+                    b[rng.randrange(n)] = rng.randrange(1, 5)
+            if odd and rng.random() < 0.1:
+                b[:n] = 0                                      # an empty region
+                r[:n] = 0
+            windows.append((contig, start, end, 0, pos, b, r))
+            if end == length:
+                break
+            ov = rng.choice([5, 20, 150, 400, 1200]) if odd else rng.randrange(60, 300)
+            step = n - ov
+            if odd and rng.random() < 0.2:
+                step = n + rng.randrange(1, 200)               # a hole
+            start += max(3, step)
+    for lo in range(0, len(windows), 7):
+        contigs, meta, pos, b, r = _arrays(windows[lo:lo + 7])
+        store.write_batch(contigs, meta, pos, b, r)
+        stream.feed(contigs, meta, pos, b, r)
+    store.close()
+    res = stream.finish()
+    for threads in (1, 3, 16):
+        want = perform_stitch(str(pred), str(tmp_path / ("two_phase%d" % threads)), "asm", threads)
+        got = finish_stitch([res], str(pred), str(tmp_path / ("streamed%d" % threads)), "asm", threads)
+        assert open(got, "rb").read() == open(want, "rb").read(), (seed, threads)
