@@ -146,6 +146,8 @@ def call_consensus(image_dir, model_path, batch_size, num_workers, threads, outp
         if vet is not None:
             vet["thread"].join()
     if vet is not None and vet["error"] is not None:
+        if hasattr(streams, "abort"):
+            streams.abort()
         raise vet["error"]
     sys.stderr.write("INFO: PREDICTION GENERATED SUCCESSFULLY.\n")
     return streams
@@ -186,7 +188,10 @@ def polish_genome(image_dir, model_path, batch_size, num_workers, threads, outpu
     t1 = time.time()
     sys.stderr.write("INFO: STITCH STARTING\n")
     print(prediction_dir)
-    if streams is not None:
+    if streams is not None and hasattr(streams, "export_spec"):
+        # several ranks: collector processes hold the regions and have joined them (helen_amd.stitch_collect)
+        streams.finish(output_dir, output_prefix)
+    elif streams is not None:
         stitch_stream.finish_stitch(streams, prediction_dir, output_dir, output_prefix, threads)
     else:
         perform_stitch(prediction_dir, output_dir, output_prefix, threads)

@@ -447,7 +447,7 @@ LAST_STREAM = [None]
 
 
 def predict(test_file, output_filename, model_path, batch_size, num_workers, rank, device_id, plan=None, cpu_threads=None,
-            stitch_threads=None):
+            stitch_threads=None, stitch_export=None):
     """Run inference over the image files `test_file` (a list) on device `device_id` and write
     `<output_filename>_<rank>.hdf` (predict_gpu.py:38-179).  `plan` (helen_amd.host_plan.RankPlan, from
     predict_gpu) caps the reader processes at what the host grants this rank and names its slots.
@@ -532,7 +532,11 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     if stitch_threads is not None and writers == 1:
         from . import stitch_stream
         if stitch_stream.enabled():
-            stream = stitch_stream.RegionStream(prediction_file_name(output_filename, rank), stitch_threads)
+            export = None
+            if stitch_export is not None:       # a multi-rank run: the regions go to the collectors (helen_amd.stitch_collect)
+                from .stitch_collect import RegionExport
+                export = RegionExport(stitch_export[0], rank, stitch_export[1])
+            stream = stitch_stream.RegionStream(prediction_file_name(output_filename, rank), stitch_threads, export=export)
             sq = queue.Queue()
     if mode == "threads":
         reap_q = queue.Queue()
@@ -773,7 +777,8 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
 
 def _setup_cpu(rank, total_callers, args, all_input_files, result_q=None):
     """One caller of a run without --gpu_mode (predict_cpu.py:177-195; no process group is created: it was never used)."""
-    output_filepath, model_path, batch_size, num_workers, threads, stitch_threads = args
+    output_filepath, model_path, batch_size, num_workers, threads, stitch_threads = args[:6]
+    stitch_export = args[6] if len(args) > 6 else None
     if result_q is not None:
         import signal
 
@@ -785,7 +790,7 @@ def _setup_cpu(rank, total_callers, args, all_input_files, result_q=None):
         except OSError:
             pass
     predict(all_input_files[rank], output_filepath, model_path, batch_size, num_workers, rank, None, cpu_threads=threads,
-            stitch_threads=stitch_threads)
+            stitch_threads=stitch_threads, stitch_export=stitch_export)
     if result_q is not None:
         result_q.put((rank, _rank_report()))
 
@@ -817,12 +822,54 @@ def _collect_streams(in_process, rank_infos):
     return [StreamResult.load(p) for p in paths]
 
 
+def _start_collectors(output_filepath, total_callers, stitch_threads):
+    """`polish` over several ranks: the collector processes that take the ranks' regions (helen_amd.stitch_collect), or
+    None (no stitch behind this run)."""
+    if stitch_threads is None:
+        return None
+    from . import stitch_stream
+    if not stitch_stream.enabled():
+        return None
+    from .stitch_collect import CollectorRun
+    return CollectorRun([prediction_file_name(output_filepath, r) for r in range(total_callers)], stitch_threads).start()
+
+
+def _streams_of_run(collectors, results, failed, total_callers, what):
+    """What a multi-rank run hands `polish`: the collectors (they hold the regions), the ranks' own streams (a run without
+    collectors), or None; raises when a rank failed."""
+    if failed:
+        if collectors is not None:
+            collectors.abort()
+        for r in results.values():
+            p = r.pop("stream_file", None)
+            if p is not None:
+                try:
+                    os.unlink(p)
+                except OSError:
+                    pass
+        raise RuntimeError("prediction process(es) failed: " + ", ".join(
+            "rank %d exit %s" % f for f in failed) + "; the other %s were terminated" % what)
+    if collectors is not None:
+        for r in results.values():                     # (the ranks' stubs: statistics only)
+            p = r.pop("stream_file", None)
+            if p is not None:
+                try:
+                    os.unlink(p)
+                except OSError:
+                    pass
+        if len(results) != total_callers:
+            collectors.abort()
+            return None
+        return collectors
+    return _collect_streams(False, [results[r] for r in sorted(results)]) if len(results) == total_callers else None
+
+
 def predict_cpu(file_chunks, output_filepath, model_path, batch_size, total_callers, threads, num_workers,
                 stitch_threads=None):
     """`callers` processes, each over its own file list with `threads` threads, each writing `<output>_<rank>.hdf`
     (models/predict_cpu.py:198-248).  The engine is libhelen_cpu.so (no ONNX export: the .pkl is all it needs); a failing
     caller takes the others down, as mp.spawn(join=True) does (:245-248)."""
-    args = (output_filepath, model_path, batch_size, num_workers, max(1, int(threads)), stitch_threads)
+    args = (output_filepath, model_path, batch_size, num_workers, max(1, int(threads)), stitch_threads, None)
     LAST_RUN.clear()
     LAST_RUN.update({"host_plan": None, "ranks": []})
     t0 = time.time()
@@ -831,18 +878,23 @@ def predict_cpu(file_chunks, output_filepath, model_path, batch_size, total_call
         LAST_RUN["ranks"] = [dict(LAST_PREDICT)]
         LAST_RUN["seconds"] = round(time.time() - t0, 3)
         return _collect_streams(True, None)
-    results, failed = run_ranks(_setup_cpu, [(r, total_callers, args, file_chunks) for r in range(total_callers)])
+    collectors = _start_collectors(output_filepath, total_callers, stitch_threads)
+    if collectors is not None:
+        args = args[:5] + (max(1, int(stitch_threads) // total_callers), collectors.export_spec())
+    try:
+        results, failed = run_ranks(_setup_cpu, [(r, total_callers, args, file_chunks) for r in range(total_callers)])
+    except BaseException:
+        if collectors is not None:
+            collectors.abort()
+        raise
     LAST_RUN["ranks"] = [results[r] for r in sorted(results)]
     LAST_RUN["seconds"] = round(time.time() - t0, 3)
-    streams = _collect_streams(False, LAST_RUN["ranks"]) if len(results) == total_callers else None
-    if failed:
-        raise RuntimeError("prediction process(es) failed: " + ", ".join(
-            "rank %d exit %s" % f for f in failed) + "; the other callers were terminated")
-    return streams
+    return _streams_of_run(collectors, results, failed, total_callers, "callers")
 
 
 def _setup(rank, total_callers, args, all_input_files, all_devices, plans=None, result_q=None):
-    output_filepath, model_path, batch_size, num_workers, stitch_threads = args
+    output_filepath, model_path, batch_size, num_workers, stitch_threads = args[:5]
+    stitch_export = args[5] if len(args) > 5 else None
     plan = plans[rank] if plans is not None else None
     if result_q is not None:
         # a spawned rank: SIGTERM from the parent (a sibling failed) must unwind through predict()'s tear-down --
@@ -859,7 +911,7 @@ def _setup(rank, total_callers, args, all_input_files, all_devices, plans=None, 
     from .host_plan import apply_rank_plan
     apply_rank_plan(plan)
     predict(all_input_files[rank], output_filepath, model_path, batch_size, num_workers, rank,
-            all_devices[rank], plan=plan, stitch_threads=stitch_threads)
+            all_devices[rank], plan=plan, stitch_threads=stitch_threads, stitch_export=stitch_export)
     if result_q is not None:
         result_q.put((rank, _rank_report()))
 
@@ -949,6 +1001,7 @@ def predict_gpu(file_chunks, output_filepath, model_path, batch_size, total_call
     Before anything starts the host is budgeted over all ranks (helen_amd.host_plan): reader processes per rank
     from the usable CPUs, NUMA pinning of each rank to its GPU's node, one RAM-backed slot budget."""
     from .host_plan import plan_host, storage_of_files
+    total_stitch_threads = stitch_threads
     if stitch_threads is not None:          # `polish`: each rank gets its share of the stitch threads
         stitch_threads = max(1, int(stitch_threads) // max(1, total_callers))
     args = (output_filepath, model_path, batch_size, num_workers, stitch_threads)
@@ -964,13 +1017,17 @@ def predict_gpu(file_chunks, output_filepath, model_path, batch_size, total_call
         LAST_RUN["ranks"] = [dict(LAST_PREDICT)]
         LAST_RUN["seconds"] = round(time.time() - t0, 3)
         return _collect_streams(True, None)
-    results, failed = run_ranks(_setup, [(r, total_callers, args, file_chunks, devices, host.ranks)
-                                         for r in range(total_callers)],
-                                [rp.slot_prefix for rp in host.ranks])
+    collectors = _start_collectors(output_filepath, total_callers, total_stitch_threads)
+    if collectors is not None:
+        args = args + (collectors.export_spec(),)
+    try:
+        results, failed = run_ranks(_setup, [(r, total_callers, args, file_chunks, devices, host.ranks)
+                                             for r in range(total_callers)],
+                                    [rp.slot_prefix for rp in host.ranks])
+    except BaseException:
+        if collectors is not None:
+            collectors.abort()
+        raise
     LAST_RUN["ranks"] = [results[r] for r in sorted(results)]
     LAST_RUN["seconds"] = round(time.time() - t0, 3)
-    streams = _collect_streams(False, LAST_RUN["ranks"]) if len(results) == total_callers else None
-    if failed:
-        raise RuntimeError("prediction process(es) failed: " + ", ".join(
-            "rank %d exit %s" % f for f in failed) + "; the other ranks were terminated")
-    return streams
+    return _streams_of_run(collectors, results, failed, total_callers, "ranks")

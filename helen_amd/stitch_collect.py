@@ -1,0 +1,348 @@
+"""Stitch behind a MULTI-RANK inference: collector processes that take the ranks' regions as they are decoded.
+
+With one rank, `helen polish` decodes regions and aligns neighbours in the rank itself while its device works
+(helen_amd.stitch_stream).  With one rank per GPU that is not enough.  The reference deals the image FILES to the ranks
+(CallConsensusInterface.py:138-145) and MarginPolish writes a contig's regions into whichever thread's file, so the two
+neighbours of most joins are decoded by different ranks; and eight ranks finish eight times the regions in the same
+time.  Left to the end of the run, the parent would load every rank's sequences (gigabytes), align most joins and walk
+every region in one interpreter: on a whole genome that tail is twice the device time.
+
+So the work is sharded by CONTIG instead.  The parent starts W collector processes before the ranks.  A rank only
+decodes: its RegionStream writes each region -- (contig, start, end, sequence) -- as one record into the append-only file
+of the collector that owns the contig (crc32 of the name mod W; files under /dev/shm, one per (rank, collector)).  A
+collector follows its R files while the ranks run, keeps the regions per rank (the order of the prediction FILES decides
+between regions of one span, as in perform_stitch), and runs the same neighbour speculation as a single rank's stream, on
+its share of the `-t` threads -- over the regions of ALL ranks, so neighbours from different ranks meet here.  When every
+rank has written its end marker the collector joins its contigs (helen_amd.stitch_stream.assemble_contigs: slices where
+every join is ordinary, the reference's own order otherwise) into a part file with an index, and the parent copies the
+parts into the FASTA in sorted contig order.  What is serial after the last window is that copy.
+
+The FASTA is perform_stitch's (tests/test_stitch_collect.py: the same adversarial streams as the single-rank tests, dealt
+over several ranks and collectors; tests/test_polish_chain.py runs the command with two callers).
+"""
+import json
+import multiprocessing as mp
+import os
+import struct
+import sys
+import time
+import zlib
+
+_HEADER = struct.Struct("<IqqI")
+_NO_SEQUENCE = 0xFFFFFFFF          # seq_len of a record that says "decode this region from the prediction file"
+_END = 0xFFFFFFFF                  # contig_len of the record that ends a rank's file
+
+
+def bucket_of(contig, buckets):
+    return zlib.crc32(contig.encode()) % buckets
+
+
+def _path(prefix, rank, bucket):
+    return "%s_%d_%d.bin" % (prefix, rank, bucket)
+
+
+class RegionExport(object):
+    """The rank's side: records appended to one file per collector.  The files exist before any rank starts (the parent
+    creates them), so a collector never waits for a name to appear."""
+
+    def __init__(self, prefix, rank, buckets):
+        self.buckets = buckets
+        self.fds = [os.open(_path(prefix, rank, w), os.O_WRONLY | os.O_APPEND) for w in range(buckets)]
+
+    def _send(self, per_bucket):
+        for w, parts in per_bucket.items():
+            data = b"".join(parts)
+            view = memoryview(data)
+            while len(view):
+                view = view[os.write(self.fds[w], view):]
+
+    def write(self, keys, seqs):
+        per_bucket = {}
+        for (contig, start, end), seq in zip(keys, seqs):
+            name = contig.encode()
+            parts = per_bucket.setdefault(bucket_of(contig, self.buckets), [])
+            parts.append(_HEADER.pack(len(name), start, end, len(seq)))
+            parts.append(name)
+            parts.append(seq)
+        self._send(per_bucket)
+
+    def from_file(self, key):
+        name = key[0].encode()
+        self._send({bucket_of(key[0], self.buckets): [_HEADER.pack(len(name), key[1], key[2], _NO_SEQUENCE), name]})
+
+    def close(self):
+        """The end marker: this rank has decoded its last region (and closed its prediction file)."""
+        for fd in self.fds:
+            os.write(fd, _HEADER.pack(_END, 0, 0, 0))
+            os.close(fd)
+        self.fds = []
+
+    def abandon(self):
+        """A failed rank: no end marker (the parent takes the collectors down)."""
+        for fd in self.fds:
+            os.close(fd)
+        self.fds = []
+
+
+class _Follower(object):
+    """One rank's file as the collector reads it: whatever has been appended since the last look, cut into records."""
+
+    def __init__(self, path):
+        self.fd = os.open(path, os.O_RDONLY)
+        self.rest = b""
+        self.ended = False
+
+    def poll(self):
+        """-> ([(key, sequence or None)], bytes read)."""
+        chunks = []
+        got = 0
+        while True:
+            data = os.read(self.fd, 1 << 24)
+            if not data:
+                break
+            chunks.append(data)
+            got += len(data)
+            if got >= 1 << 26:
+                break
+        if not chunks:
+            return [], 0
+        buf = self.rest + b"".join(chunks)
+        out, at, n = [], 0, len(buf)
+        size = _HEADER.size
+        while at + size <= n:
+            name_len, start, end, seq_len = _HEADER.unpack_from(buf, at)
+            if name_len == _END:
+                self.ended = True
+                at = n
+                break
+            body = name_len + (0 if seq_len == _NO_SEQUENCE else seq_len)
+            if at + size + body > n:
+                break
+            name = buf[at + size:at + size + name_len].decode()
+            seq = None if seq_len == _NO_SEQUENCE else buf[at + size + name_len:at + size + body]
+            out.append(((name, start, end), seq))
+            at += size + body
+        self.rest = buf[at:]
+        return out, got
+
+    def close(self):
+        os.close(self.fd)
+
+
+def _collector_main(bucket, buckets, prefix, prediction_files, threads, run_threads, part_path, result_q):
+    """A collector process: follow the ranks' files of this bucket, speculate joins, assemble the bucket's contigs."""
+    import signal
+
+    def on_term(signum, frame):
+        raise SystemExit(143)
+    signal.signal(signal.SIGTERM, on_term)
+    from . import stitch_stream
+    ranks = len(prediction_files)
+    followers = [_Follower(_path(prefix, r, bucket)) for r in range(ranks)]
+    # ONE stream over the regions of all ranks (neighbours by position, joins on this collector's threads) ...
+    stream = stitch_stream.RegionStream(prediction_files[0], threads)
+    # ... and the regions per rank, for the order between regions of one span and for the regions to read back
+    per_rank = [{} for _ in range(ranks)]
+    t0 = time.time()
+    busy = 0.0
+    from_file = 0
+    while not all(f.ended for f in followers):
+        progressed = False
+        for r, f in enumerate(followers):
+            if f.ended:
+                continue
+            records, got = f.poll()
+            if not got:
+                continue
+            progressed = True
+            t1 = time.time()
+            keys, seqs = [], []
+            for key, seq in records:
+                if seq is None:
+                    per_rank[r][key] = None
+                    if stream.regions.get(key, b"") is not None:
+                        stream.regions[key] = None
+                    from_file += 1
+                    continue
+                per_rank[r][key] = seq
+                if key in stream.regions:
+                    continue                    # a second rank holds a region of this span: the join pass sorts it out
+                keys.append(key)
+                seqs.append(seq)
+            if keys:
+                stream.accept_sequences(keys, seqs)
+            busy += time.time() - t1
+        if not progressed:
+            time.sleep(0.01)
+    t_last = time.time()
+    for f in followers:
+        f.close()
+    result = stream.finish()
+    t_joined = time.time()
+    index = []
+    writer = stitch_stream.FastaWriter(part_path)
+    offset = [0]
+
+    def emit(contig, pieces):
+        n = sum(len(p) for p in pieces)
+        index.append((contig, offset[0], n))
+        offset[0] += n
+        writer.put(pieces)
+    try:
+        by_file = {os.path.abspath(p): per_rank[r] for r, p in enumerate(prediction_files)}
+        stats = stitch_stream.assemble_contigs(prediction_files, by_file, result.joins, result.pair_joins, threads, emit,
+                                               run_threads=run_threads, quiet=True)
+    finally:
+        writer.close()
+    stats.update({"bucket": bucket, "regions": sum(len(d) for d in per_rank), "from_file": from_file,
+                  "joins_submitted": result.stats.get("joins_submitted", 0), "index": index,
+                  "seconds": {"following": round(t_last - t0, 3), "accepting": round(busy, 3),
+                              "joins_after_the_last_record": round(t_joined - t_last, 3),
+                              "assembly": round(time.time() - t_joined, 3)}})
+    result_q.put((bucket, stats))
+
+
+def collectors_for(threads):
+    """How many collector processes a run with `-t threads` starts: one per four threads, eight at most."""
+    return max(1, min(8, int(threads) // 4))
+
+
+class CollectorRun(object):
+    """The parent's handle: start() before the ranks, finish() after them (-> the FASTA), abort() when a rank failed."""
+
+    def __init__(self, prediction_files, threads, directory=None):
+        from .stitch_stream import spill_directory
+        self.files = [os.path.abspath(p) for p in prediction_files]
+        self.threads = max(1, int(threads))
+        self.buckets = collectors_for(self.threads)
+        d = directory or spill_directory() or os.path.dirname(self.files[0])
+        self.prefix = os.path.join(d, "helen_regions_%d_%x" % (os.getpid(), int(time.time() * 1e6) & 0xFFFFFFFF))
+        self.parts = [self.prefix + "_part%d.fa" % w for w in range(self.buckets)]
+        self.procs = []
+        self.result_q = None
+        self.stats = None
+
+    def export_spec(self):
+        """What a rank needs to write its regions: (prefix, buckets)."""
+        return (self.prefix, self.buckets)
+
+    def start(self):
+        for r in range(len(self.files)):
+            for w in range(self.buckets):
+                open(_path(self.prefix, r, w), "wb").close()
+        ctx = mp.get_context("spawn")
+        self.result_q = ctx.Queue()
+        share = max(1, self.threads // self.buckets)
+        for w in range(self.buckets):
+            p = ctx.Process(target=_collector_main, args=(w, self.buckets, self.prefix, self.files, share, self.threads,
+                                                          self.parts[w], self.result_q), daemon=True)
+            p.start()
+            self.procs.append(p)
+        return self
+
+    def _cleanup(self):
+        for r in range(len(self.files)):
+            for w in range(self.buckets):
+                try:
+                    os.unlink(_path(self.prefix, r, w))
+                except OSError:
+                    pass
+        for p in self.parts:
+            try:
+                os.unlink(p)
+            except OSError:
+                pass
+
+    def abort(self):
+        for p in self.procs:
+            if p.is_alive():
+                p.terminate()
+        for p in self.procs:
+            p.join(5.0)
+            if p.is_alive():
+                p.kill()
+                p.join()
+        self.procs = []
+        self._cleanup()
+
+    def finish(self, output_path, output_prefix):
+        """Wait for the collectors (the ranks have written their end markers) and copy their parts into
+        `<output_path>/<output_prefix>.fa` in sorted contig order.  -> the FASTA's path."""
+        import queue
+
+        from . import file_manager
+        from .stitch_stream import report_line
+        t0 = time.time()
+        got = {}
+        try:
+            while len(got) < self.buckets:
+                try:
+                    w, stats = self.result_q.get(timeout=0.2)
+                    got[w] = stats
+                except queue.Empty:
+                    dead = [p for p in self.procs if not p.is_alive() and p.exitcode not in (0, None)]
+                    if dead:
+                        raise RuntimeError("a stitch collector exited with %s: the prediction files are complete, run "
+                                           "`helen stitch` on them" % dead[0].exitcode)
+            for p in self.procs:
+                p.join()
+            t_collected = time.time()
+            output_dir = file_manager.handle_output_directory(output_path)
+            output_filename = os.path.join(output_dir, output_prefix + '.fa')
+            sys.stderr.write("INFO: OUTPUT FILE: " + output_filename + "\n")
+            where = {}
+            for w, stats in got.items():
+                for contig, offset, n in stats["index"]:
+                    where[contig] = (w, offset, n)
+            sources = {}
+            with open(output_filename, "wb") as out:
+                for contig in sorted(where):
+                    w, offset, n = where[contig]
+                    if w not in sources:
+                        sources[w] = open(self.parts[w], "rb")
+                    _copy_range(sources[w], out, offset, n)
+            for f in sources.values():
+                f.close()
+        finally:
+            self.abort()
+        total = {"from_table": 0, "aligned_now": 0, "sliced": 0, "contigs": 0, "late": 0}
+        for stats in got.values():
+            for k in total:
+                total[k] += stats[k]
+        sys.stderr.write(report_line(total, sum(s["from_file"] for s in got.values()), self.threads))
+        sys.stderr.write("INFO: %d STITCH COLLECTOR(S) OVER %d RANK(S): %d REGION(S); AFTER THE LAST REGION: JOINS %.2f S, "
+                         "ASSEMBLY %.2f S (THE SLOWEST), FASTA COPY %.2f S.\n"
+                         % (self.buckets, len(self.files), sum(s["regions"] for s in got.values()),
+                            max(s["seconds"]["joins_after_the_last_record"] for s in got.values()),
+                            max(s["seconds"]["assembly"] for s in got.values()), time.time() - t_collected))
+        self.stats = {"collectors": self.buckets, "per_collector": [dict(got[w], index=len(got[w]["index"])) for w in sorted(got)],
+                      "wait_seconds": round(t_collected - t0, 3), "copy_seconds": round(time.time() - t_collected, 3)}
+        return output_filename
+
+    def describe(self):
+        return json.dumps(self.stats)
+
+
+def _copy_range(src, dst, offset, n):
+    """n bytes of `src` from `offset` on to the end of `dst` (both ordinary files): in the kernel where it can."""
+    dst.flush()
+    done = 0
+    try:
+        while done < n:
+            k = os.copy_file_range(src.fileno(), dst.fileno(), n - done, offset + done)
+            if k <= 0:
+                break
+            done += k
+    except (AttributeError, OSError):
+        pass
+    if done < n:
+        dst.seek(0, os.SEEK_END)
+        src.seek(offset + done)
+        while done < n:
+            data = src.read(min(1 << 24, n - done))
+            if not data:
+                raise RuntimeError("a stitch collector's part file is shorter than its index says")
+            dst.write(data)
+            done += len(data)
+    else:
+        dst.seek(0, os.SEEK_END)

@@ -47,7 +47,10 @@ class RegionStream(object):
     feed() is called from one thread, in the order the images are written; finish() after the last one.  `threads`
     worker threads run the speculative overlap alignments (native, the interpreter lock released)."""
 
-    def __init__(self, prediction_file, threads=1, decode_threads=None):
+    def __init__(self, prediction_file, threads=1, decode_threads=None, export=None):
+        # export = a helen_amd.stitch_collect.RegionExport: this stream only DECODES, every region goes to the collector
+        # process that owns its contig (a multi-rank run), which aligns and joins
+        self.export = export
         self.file = os.path.abspath(prediction_file)
         self.threads = max(1, int(threads))
         self.decode_threads = max(1, min(4, self.threads)) if decode_threads is None else decode_threads
@@ -57,7 +60,7 @@ class RegionStream(object):
         self.placed = {}           # contig -> (start, end) of its decoded regions, sorted
         self.joins = {}            # (left bytes, right bytes) -> (score, pos_a, pos_b)
         self.pair_joins = {}       # (contig, start a, end a, start b, end b) -> (score, pos_a, pos_b): the same results by REGION
-        self.pool = concurrent.futures.ThreadPoolExecutor(self.threads) if native_io.available() else None
+        self.pool = concurrent.futures.ThreadPoolExecutor(self.threads) if native_io.available() and export is None else None
         self.pending = []
         self.seconds = {"decode": 0.0, "joins_submitted": 0, "regions": 0, "from_file": 0}
 
@@ -138,6 +141,8 @@ class RegionStream(object):
     def _from_file(self, key):
         self.regions[key] = None
         self.seconds["from_file"] += 1
+        if self.export is not None:
+            self.export.from_file(key)
 
     def _decode_segments(self, keys, seg_first, seg_end, meta, positions, bases, rles):
         if not keys:
@@ -170,7 +175,17 @@ class RegionStream(object):
         neighbours that stitch will most likely make to the alignment workers."""
         blob = blob.tobytes()
         off = off.tolist()
-        seqs = [blob[off[k]:off[k + 1]] for k in range(len(keys))]
+        self.accept_sequences(keys, [blob[off[k]:off[k + 1]] for k in range(len(keys))])
+
+    def accept_sequences(self, keys, seqs):
+        """Regions with their sequences (bytes), in stream order (also the entry of a collector process, which receives
+        them from the ranks: helen_amd.stitch_collect)."""
+        if self.export is not None:
+            self.export.write(keys, seqs)
+            for key in keys:
+                self.regions[key] = b""          # seen, and not with this process
+            self.seconds["regions"] += len(keys)
+            return
         jobs = []            # (left string, right string)
 
         def join(a, b):
@@ -205,6 +220,9 @@ class RegionStream(object):
     # ---- the end of the stream ----
     def abort(self):
         """The run failed: drop what is queued, let the workers go."""
+        if self.export is not None:
+            self.export.abandon()
+            self.export = None
         if self.pool is not None:
             self.pool.shutdown(wait=False, cancel_futures=True)
             self.pool = None
@@ -223,6 +241,10 @@ class RegionStream(object):
         if self.pool is not None:
             self.pool.shutdown()
             self.pool = None
+        if self.export is not None:
+            self.export.close()                  # the end marker: the collectors may finish
+            self.export = None
+            return StreamResult(self.file, {}, {}, dict(self.seconds, exported=True), {})
         return StreamResult(self.file, self.regions, self.joins, dict(self.seconds), self.pair_joins)
 
 
@@ -386,6 +408,120 @@ def _align_unseen_neighbours(per_contig, joins, pair_joins, threads):
     return len(jobs)
 
 
+def assemble_contigs(files, by_file, joins, pair_joins, threads, emit, fast=True, run_threads=None, quiet=False):
+    """The join pass shared by finish_stitch and the collectors of a multi-rank run (helen_amd.stitch_collect): every
+    contig of the streams `by_file` = {absolute path of a prediction file: its regions {(contig, start, end): sequence
+    or None}}, `files` = those paths in the directory's listing order, in sorted contig order, handed to
+    `emit(contig, pieces)` as a list of bytes-like pieces (header line and newline included; nothing for an empty
+    sequence).  `threads` worker threads align what no stream has aligned; `run_threads` (default `threads`) is the
+    thread count of the reference's run formula (Stitch.py:268-270: a contig is stitched in runs of
+    max(2, regions // threads + 1) regions).  -> statistics."""
+    run_threads = threads if run_threads is None else run_threads
+    if not fast:
+        pair_joins = {}
+    # regions per contig: files in the directory's listing order, then (start, end) -- the order perform_stitch gives a
+    # contig's regions (StitchInterface.py:84-95 lists a file's regions by name, Stitch.py:262 sorts by (start, end), the
+    # sort is stable, and one file holds a span once: only the order of the FILES decides between equal spans)
+    per_contig = {}
+    for path in files:
+        for (contig, start, end), seq in by_file[os.path.abspath(path)].items():
+            per_contig.setdefault(contig, []).append((path, None, start, end, seq))
+    by_span = operator.itemgetter(2, 3)
+    for rows in per_contig.values():
+        rows.sort(key=by_span)
+    late = _align_unseen_neighbours(per_contig, joins, pair_joins if fast else None, threads)
+    contigs = sorted(per_contig)
+    hits = [0, 0]
+    sliced = 0
+
+    def aligner(left, right):
+        got = joins.get((left, right))
+        hits[0 if got is not None else 1] += 1
+        return got
+
+    def say(text):
+        if not quiet:
+            sys.stderr.write(text)
+
+    for i, contig in enumerate(contigs):
+        prefix = "{:04d}/{:04d}:".format(i, len(contigs))
+        say("INFO: " + prefix + " PROCESSING CONTIG: " + contig + "\n")
+        key_list = per_contig[contig]
+        quick = _joined_from_slices(contig, key_list, pair_joins) if pair_joins else None
+        if quick is not None:
+            pieces, total, warnings = quick
+            for w in warnings:
+                sys.stderr.write(w)
+            hits[0] += len(key_list) - 1 - len(warnings)
+            sliced += 1
+            say("INFO: " + prefix + " FINISHED PROCESSING " + contig + ", POLISHED SEQUENCE LENGTH: " + str(total) + ".\n")
+            if total > 0:
+                emit(contig, [b'>' + contig.encode() + b"\n"] + pieces + [b"\n"])
+            continue
+        n = max(StitchOptions.MIN_SEQUENCE_REQUIRED_FOR_MULTITHREADING, int(len(key_list) / run_threads) + 1)
+        partial = []
+        for lo in range(0, len(key_list), n):                       # FileManager.chunks
+            chunk = []
+            for path, name, start, end, seq in key_list[lo:lo + n]:
+                if seq is None:
+                    seq = native_io.region_sequence(path, contig, "%s-%d-%d" % (contig, start, end), as_bytes=True)
+                chunk.append((contig, start, end, seq))
+            chunk.sort(key=lambda e: (e[1], e[2]))
+            c, s, e, running = _alignment_stitch(chunk, aligner)
+            partial.append((c, s, e, bytes(running)))
+        partial.sort(key=lambda e: (e[1], e[2]))
+        sequence = _alignment_stitch(partial, aligner)[3] if partial else b""
+        say("INFO: " + prefix + " FINISHED PROCESSING " + contig + ", POLISHED SEQUENCE LENGTH: " + str(len(sequence)) + ".\n")
+        if len(sequence) > 0:
+            emit(contig, [b'>' + contig.encode() + b"\n", sequence, b"\n"])
+    return {"from_table": hits[0], "aligned_now": hits[1], "sliced": sliced, "contigs": len(contigs), "late": late}
+
+
+def report_line(stats, from_file, threads):
+    return ("INFO: STITCH PIPELINED BEHIND INFERENCE: %d JOINS FROM THE TABLE, %d ALIGNED NOW, %d REGION(S) READ BACK "
+            "FROM THE FILES; %d OF %d CONTIG(S) ASSEMBLED FROM REGION SLICES%s.\n"
+            % (stats["from_table"], stats["aligned_now"], from_file, stats["sliced"], stats["contigs"],
+               "" if not stats["late"] else "; %d JOIN(S) BETWEEN REGIONS OF DIFFERENT STREAMS ALIGNED ON %d THREAD(S) FIRST"
+               % (stats["late"], threads)))
+
+
+class FastaWriter(object):
+    """The FASTA written by a thread of its own (a contig is tens of megabytes; the write releases the interpreter lock)
+    while the next contig is being joined.  put(pieces); close() joins the thread and raises what it met."""
+
+    def __init__(self, path):
+        import queue
+        import threading
+        self.q = queue.Queue(maxsize=4)
+        self.error = []
+        self.file = open(path, 'wb')
+        self.offset = 0
+        self.thread = threading.Thread(target=self._loop, daemon=True)
+        self.thread.start()
+
+    def _loop(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            if self.error:
+                continue
+            try:
+                self.file.write(b"".join(item))
+            except BaseException as e:          # noqa: BLE001 -- raised by close()
+                self.error.append(e)
+
+    def put(self, pieces):
+        self.q.put(pieces)
+
+    def close(self):
+        self.q.put(None)
+        self.thread.join()
+        self.file.close()
+        if self.error:
+            raise self.error[0]
+
+
 def finish_stitch(results, input_directory, output_path, output_prefix, threads, fast=True):
     """perform_stitch (StitchInterface.py:40-106) from the streams of the run that has just written `input_directory`:
     the same contig order, region order, runs and joins -- and the same FASTA -- with the regions' sequences and most of
@@ -401,94 +537,14 @@ def finish_stitch(results, input_directory, output_path, output_prefix, threads,
         joins.update(r.joins)
         if fast:
             pair_joins.update(getattr(r, "pair_joins", None) or {})
-    # regions per contig: files in the directory's listing order, then (start, end) -- the order perform_stitch gives a
-    # contig's regions (StitchInterface.py:84-95 lists a file's regions by name, Stitch.py:262 sorts by (start, end), the
-    # sort is stable, and one file holds a span once: only the order of the FILES decides between equal spans)
-    per_contig = {}
-    for path in files:
-        for (contig, start, end), seq in by_file[os.path.abspath(path)].regions.items():
-            per_contig.setdefault(contig, []).append((path, None, start, end, seq))
-    by_span = operator.itemgetter(2, 3)
-    for rows in per_contig.values():
-        rows.sort(key=by_span)
-    late = _align_unseen_neighbours(per_contig, joins, pair_joins if fast else None, threads)
     output_dir = file_manager.handle_output_directory(output_path)
     output_filename = os.path.join(output_dir, output_prefix + '.fa')
     sys.stderr.write("INFO: OUTPUT FILE: " + output_filename + "\n")
-    contigs = sorted(per_contig)
-    hits = [0, 0]
-    sliced = 0
-
-    def aligner(left, right):
-        got = joins.get((left, right))
-        hits[0 if got is not None else 1] += 1
-        return got
-
-    # the FASTA is written by a thread of its own (a contig is tens of megabytes; the write releases the interpreter
-    # lock) while the next contig is being joined
-    import queue
-    import threading
-    to_write = queue.Queue(maxsize=4)
-    write_error = []
-
-    def write_loop(fasta):
-        while True:
-            item = to_write.get()
-            if item is None:
-                return
-            if write_error:
-                continue
-            try:
-                fasta.write(b"".join(item))
-            except BaseException as e:          # noqa: BLE001 -- raised by the caller's thread below
-                write_error.append(e)
-
-    fasta = open(output_filename, 'wb')
-    writer = threading.Thread(target=write_loop, args=(fasta,), daemon=True)
-    writer.start()
+    fasta = FastaWriter(output_filename)
     try:
-        for i, contig in enumerate(contigs):
-            prefix = "{:04d}/{:04d}:".format(i, len(contigs))
-            sys.stderr.write("INFO: " + prefix + " PROCESSING CONTIG: " + contig + "\n")
-            key_list = per_contig[contig]
-            quick = _joined_from_slices(contig, key_list, pair_joins) if pair_joins else None
-            if quick is not None:
-                pieces, total, warnings = quick
-                for w in warnings:
-                    sys.stderr.write(w)
-                hits[0] += len(key_list) - 1 - len(warnings)
-                sliced += 1
-                sys.stderr.write("INFO: " + prefix + " FINISHED PROCESSING " + contig
-                                 + ", POLISHED SEQUENCE LENGTH: " + str(total) + ".\n")
-                if total > 0:
-                    to_write.put([b'>' + contig.encode() + b"\n"] + pieces + [b"\n"])
-                continue
-            n = max(StitchOptions.MIN_SEQUENCE_REQUIRED_FOR_MULTITHREADING, int(len(key_list) / threads) + 1)
-            partial = []
-            for lo in range(0, len(key_list), n):                       # FileManager.chunks
-                chunk = []
-                for path, name, start, end, seq in key_list[lo:lo + n]:
-                    if seq is None:
-                        seq = native_io.region_sequence(path, contig, "%s-%d-%d" % (contig, start, end), as_bytes=True)
-                    chunk.append((contig, start, end, seq))
-                chunk.sort(key=lambda e: (e[1], e[2]))
-                c, s, e, running = _alignment_stitch(chunk, aligner)
-                partial.append((c, s, e, bytes(running)))
-            partial.sort(key=lambda e: (e[1], e[2]))
-            sequence = _alignment_stitch(partial, aligner)[3] if partial else b""
-            sys.stderr.write("INFO: " + prefix + " FINISHED PROCESSING " + contig
-                             + ", POLISHED SEQUENCE LENGTH: " + str(len(sequence)) + ".\n")
-            if len(sequence) > 0:
-                to_write.put((b'>' + contig.encode() + b"\n", sequence, b"\n"))
+        stats = assemble_contigs(files, {k: r.regions for k, r in by_file.items()}, joins, pair_joins, threads,
+                                 lambda contig, pieces: fasta.put(pieces), fast=fast)
     finally:
-        to_write.put(None)
-        writer.join()
         fasta.close()
-    if write_error:
-        raise write_error[0]
-    sys.stderr.write("INFO: STITCH PIPELINED BEHIND INFERENCE: %d JOINS FROM THE TABLE, %d ALIGNED NOW, %d REGION(S) READ BACK "
-                     "FROM THE FILES; %d OF %d CONTIG(S) ASSEMBLED FROM REGION SLICES%s.\n"
-                     % (hits[0], hits[1], sum(r.stats.get("from_file", 0) for r in results), sliced, len(contigs),
-                        "" if not late else "; %d JOIN(S) BETWEEN REGIONS OF DIFFERENT STREAMS ALIGNED ON %d THREAD(S) FIRST"
-                        % (late, threads)))
+    sys.stderr.write(report_line(stats, sum(r.stats.get("from_file", 0) for r in results), threads))
     return output_filename
