@@ -136,6 +136,8 @@ def _collector_main(bucket, buckets, prefix, prediction_files, threads, run_thre
     def on_term(signum, frame):
         raise SystemExit(143)
     signal.signal(signal.SIGTERM, on_term)
+    import gc
+    gc.disable()        # millions of tuples and byte strings, no cycles: the collector's generations only cost time here
     from . import stitch_stream
     ranks = len(prediction_files)
     followers = [_Follower(_path(prefix, r, bucket)) for r in range(ranks)]
@@ -190,15 +192,23 @@ def _collector_main(bucket, buckets, prefix, prediction_files, threads, run_thre
         writer.put(pieces)
     try:
         by_file = {os.path.abspath(p): per_rank[r] for r, p in enumerate(prediction_files)}
-        stats = stitch_stream.assemble_contigs(prediction_files, by_file, result.joins, result.pair_joins, threads, emit,
+        # between regions of one span the order of the FILES decides, and that is the directory's listing order
+        # (StitchInterface.py:35-36 takes os.listdir as it comes) -- not the order of the ranks
+        listing = [p for p in stitch_stream.get_file_paths_from_directory(os.path.dirname(prediction_files[0]))]
+        if sorted(os.path.abspath(p) for p in listing) != sorted(by_file):
+            raise RuntimeError("the prediction directory holds other files than this run's (%s): run `helen stitch` on it"
+                               % sorted(set(os.path.abspath(p) for p in listing) ^ set(by_file))[:2])
+        stats = stitch_stream.assemble_contigs(listing, by_file, result.joins, result.pair_joins, threads, emit,
                                                run_threads=run_threads, quiet=True)
+        t_assembled = time.time()
     finally:
         writer.close()
     stats.update({"bucket": bucket, "regions": sum(len(d) for d in per_rank), "from_file": from_file,
                   "joins_submitted": result.stats.get("joins_submitted", 0), "index": index,
                   "seconds": {"following": round(t_last - t0, 3), "accepting": round(busy, 3),
                               "joins_after_the_last_record": round(t_joined - t_last, 3),
-                              "assembly": round(time.time() - t_joined, 3)}})
+                              "assembly": round(time.time() - t_joined, 3),
+                              "of_which_waiting_for_the_part_file": round(time.time() - t_assembled, 3)}})
     result_q.put((bucket, stats))
 
 

@@ -541,10 +541,15 @@ def finish_stitch(results, input_directory, output_path, output_prefix, threads,
     output_filename = os.path.join(output_dir, output_prefix + '.fa')
     sys.stderr.write("INFO: OUTPUT FILE: " + output_filename + "\n")
     fasta = FastaWriter(output_filename)
+    import gc
+    was_enabled = gc.isenabled()
+    gc.disable()        # hundreds of thousands of tuples and slices, no cycles: generation scans would be a third of the pass
     try:
         stats = assemble_contigs(files, {k: r.regions for k, r in by_file.items()}, joins, pair_joins, threads,
                                  lambda contig, pieces: fasta.put(pieces), fast=fast)
     finally:
         fasta.close()
+        if was_enabled:
+            gc.enable()
     sys.stderr.write(report_line(stats, sum(r.stats.get("from_file", 0) for r in results), threads))
     return output_filename

@@ -140,15 +140,20 @@ def test_assembly_generator_is_deterministic_and_writers_agree(tmp_path):
     assert len(c.regions) == 13 and c.truth() == a["truth"]["ctgA"]        # 14 regions, one left out
 
 
-@pytest.mark.parametrize("threads", [3])
-def test_host_polish_equals_the_reference_chain(tmp_path, threads):
+@pytest.mark.parametrize("threads,callers", [(3, 1), (3, 2)])
+def test_host_polish_equals_the_reference_chain(tmp_path, threads, callers):
     """`helen polish` WITHOUT --gpu_mode (the product's host engine, libhelen_cpu.so) on the simulated assembly: the
-    prediction file and the FASTA of the reference's own predict + perform_stitch, byte for byte."""
+    prediction file and the FASTA of the reference's own predict + perform_stitch, byte for byte.  With two callers
+    (two processes, two prediction files) the regions travel to a stitch collector process while the callers run
+    (helen_amd/stitch_collect.py) -- the path of a multi-GPU `polish`."""
     gen, fixture = _fixture()
     image_dir, model, made = gen.polish_case(str(tmp_path))
     out = str(tmp_path / "out")
-    _helen(["polish", "-i", image_dir, "-m", model, "-b", "16", "-w", "0", "-t", str(threads), "-c", "1", "-o", out,
-            "-p", "polished"], env={"HELEN_ASSERT_NO_TORCH": "1"})
+    r = _helen(["polish", "-i", image_dir, "-m", model, "-b", "16", "-w", "0", "-t", str(threads), "-c", str(callers), "-o", out,
+                "-p", "polished"], env={"HELEN_ASSERT_NO_TORCH": "1"})
+    assert len(_prediction_files(out)) == callers
+    if callers > 1 and r is not None:
+        assert "STITCH COLLECTOR(S) OVER 2 RANK(S)" in r.stderr, r.stderr[-600:]
     fasta = _assert_chain_equals_reference(gen, fixture, out, threads, "host path")
     assert _identity_report(fasta, made["truth"], "host path") > 0.995
 
