@@ -148,7 +148,10 @@ def _collector_main(bucket, buckets, prefix, prediction_files, threads, run_thre
     t0 = time.time()
     busy = 0.0
     from_file = 0
+    parent = os.getppid()
     while not all(f.ended for f in followers):
+        if os.getppid() != parent:              # the run's parent is gone (killed): nobody will ever write the end markers
+            raise SystemExit(1)
         progressed = False
         for r, f in enumerate(followers):
             if f.ended:
