@@ -390,8 +390,8 @@ def e2e_size(windows_per_rank, world, may_shrink, free=None):
     directory instead; otherwise it is skipped."""
     from helen_amd.host_plan import SLOT_BYTES_PER_WINDOW, ram_backed_budget_bytes
 
-    def need_bytes(per_rank):     # inputs + slots + outputs (two runs) + FASTA, all ranks, all RAM-backed
-        return per_rank * world * (116000 + 2 * 16000 + 2 * 1500) + world * 5 * 4096 * SLOT_BYTES_PER_WINDOW
+    def need_bytes(per_rank):     # inputs + slots + outputs (three runs) + FASTAs, all ranks, all RAM-backed
+        return per_rank * world * (116000 + 3 * 16000 + 3 * 1500) + world * 5 * 4096 * SLOT_BYTES_PER_WINDOW
     free = ram_backed_budget_bytes() if free is None else free
     n = windows_per_rank
     while may_shrink and n > 8192 and free <= need_bytes(n) * 1.1:
@@ -522,6 +522,27 @@ def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_de
                     same = x == y
                     if not x:
                         break
+        # ... and the COMMAND as a user starts it (one rank only: with several, the command would compete with this bench's
+        # own ranks for their devices): `bin/helen polish -g` in a process of its own, from exec to exit -- interpreter
+        # start, imports, device context, inference, stitch, FASTA, exit
+        command = None
+        if world == 1:
+            import subprocess
+            cmd = [sys.executable, os.path.join(ROOT, "bin", "helen"), "polish", "-i", img_dir, "-m", model, "-b", str(batch),
+                   "-w", str(workers), "-t", str(threads), "-o", os.path.join(d, "cmd"), "-p", "asm", "-g"]
+            t0 = time.time()
+            r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            dt_cmd = time.time() - t0
+            fasta3 = os.path.join(d, "cmd", "asm.fa")
+            ok = r.returncode == 0 and os.path.isfile(fasta3) and os.path.getsize(fasta3) == os.path.getsize(fasta)
+            if ok:
+                with open(fasta, "rb") as a, open(fasta3, "rb") as b:
+                    ok = a.read() == b.read()
+            clock = [ln for ln in r.stderr.splitlines() if "WALL CLOCK" in ln]
+            command = {"what": "bin/helen polish -i <dir> -m <model> -b %d -w %d -t %d -g, a process of its own, exec to exit"
+                               % (batch, workers, threads),
+                       "seconds": round(dt_cmd, 3), "windows_per_s": round(total / dt_cmd, 1), "returncode": r.returncode,
+                       "fasta_equals_two_phase": bool(ok), "wall_clock_line": clock[-1][6:] if clock else None}
         plan = run.get("host_plan", {})
         # the same run without its fixed costs: every rank's windows over the slowest rank's loop time (first slot
         # submitted .. last labels back; process start-up, model load, page-locking, file close and tear-down excluded)
@@ -554,6 +575,7 @@ def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_de
                            "fasta_equals_two_phase": bool(same),
                            "per_rank": [{k: r.get(k) for k in ("rank", "windows", "seconds", "stage_seconds", "stitch_stream")}
                                         for r in polish_run.get("ranks", [])]},
+                "polish_command": command,
                 "what": "call_consensus(image_dir -> one prediction HDF5 per rank) over %d rank(s) incl. host "
                         "budgeting, process start-up, model load and close; %d synthetic windows per rank written in "
                         "%.1f s to %s" % (world, windows_per_rank, t_write, os.path.dirname(d))}

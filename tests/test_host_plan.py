@@ -322,5 +322,5 @@ def test_ram_backed_budget_counts_ram_not_just_tmpfs_space(tmp_path, monkeypatch
     spec.loader.exec_module(bench)
     n, need, where, free = bench.e2e_size(300000, 2, True, free=50 << 30)
     assert where == "/dev/shm" and 8192 <= n < 300000 and need * 1.1 < 50 << 30
-    n1, need1, where1, _ = bench.e2e_size(300000, 1, True, free=50 << 30)
+    n1, need1, where1, _ = bench.e2e_size(300000, 1, True, free=64 << 30)
     assert n1 == 300000 and where1 == "/dev/shm"

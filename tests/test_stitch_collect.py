@@ -76,7 +76,7 @@ def _deal(windows, ranks, how, rng):
 
 
 @pytest.mark.parametrize("seed,ranks,threads,how", [(1, 2, 1, "blocks"), (2, 3, 4, "scatter"), (3, 2, 16, "scatter"),
-                                                    (4, 4, 9, "contigs"), (5, 3, 32, "blocks")])
+                                                    (4, 4, 9, "contigs"), (5, 3, 32, "blocks"), (6, 11, 8, "scatter")])
 def test_collectors_write_the_fasta_of_the_two_phase_stitch(tmp_path, seed, ranks, threads, how, capfd):
     from helen_amd.data_store import DataStore
     from helen_amd.stitch import perform_stitch
@@ -85,7 +85,11 @@ def test_collectors_write_the_fasta_of_the_two_phase_stitch(tmp_path, seed, rank
     rng = random.Random(seed)
     pred = tmp_path / "pred"
     pred.mkdir()
-    dealt = _deal(_windows(rng, n_contigs=5), ranks, how, rng)
+    # (eleven ranks: p_10.hdf sorts before p_2.hdf and os.listdir sorts nothing -- between regions of one span the
+    # directory's listing order decides, as in perform_stitch, not the rank order)
+    dealt = _deal(_windows(rng, n_contigs=5 if ranks < 10 else 8), ranks, how, rng)
+    for r in range(ranks):
+        assert dealt[r], "rank %d got nothing (perform_stitch refuses an empty prediction file)" % r
     files = [str(pred / ("p_%d.hdf" % r)) for r in range(ranks)]
     run = CollectorRun(files, threads, directory=str(tmp_path)).start()
     assert run.buckets == collectors_for(threads) == max(1, min(8, threads // 4))
