@@ -822,10 +822,11 @@ def _collect_streams(in_process, rank_infos):
     return [StreamResult.load(p) for p in paths]
 
 
-def _start_collectors(output_filepath, total_callers, stitch_threads):
+def _start_collectors(output_filepath, total_callers, stitch_threads, num_workers):
     """`polish` over several ranks: the collector processes that take the ranks' regions (helen_amd.stitch_collect), or
-    None (no stitch behind this run)."""
-    if stitch_threads is None:
+    None (no stitch behind this run: `call_consensus` alone, $HELEN_STITCH_PIPELINE=0, or a pool of writer processes --
+    a rank streams its regions only beside the one-file writer, and a collector waits for every rank's end marker)."""
+    if stitch_threads is None or writer_count(num_workers) != 1:
         return None
     from . import stitch_stream
     if not stitch_stream.enabled():
@@ -878,7 +879,7 @@ def predict_cpu(file_chunks, output_filepath, model_path, batch_size, total_call
         LAST_RUN["ranks"] = [dict(LAST_PREDICT)]
         LAST_RUN["seconds"] = round(time.time() - t0, 3)
         return _collect_streams(True, None)
-    collectors = _start_collectors(output_filepath, total_callers, stitch_threads)
+    collectors = _start_collectors(output_filepath, total_callers, stitch_threads, num_workers)
     if collectors is not None:
         args = args[:5] + (max(1, int(stitch_threads) // total_callers), collectors.export_spec())
     try:
@@ -1017,7 +1018,7 @@ def predict_gpu(file_chunks, output_filepath, model_path, batch_size, total_call
         LAST_RUN["ranks"] = [dict(LAST_PREDICT)]
         LAST_RUN["seconds"] = round(time.time() - t0, 3)
         return _collect_streams(True, None)
-    collectors = _start_collectors(output_filepath, total_callers, total_stitch_threads)
+    collectors = _start_collectors(output_filepath, total_callers, total_stitch_threads, num_workers)
     if collectors is not None:
         args = args + (collectors.export_spec(),)
     try:

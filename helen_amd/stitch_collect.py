@@ -297,6 +297,9 @@ class CollectorRun(object):
                     if dead:
                         raise RuntimeError("a stitch collector exited with %s: the prediction files are complete, run "
                                            "`helen stitch` on them" % dead[0].exitcode)
+                    if time.time() - t0 > 3600.0:       # (every rank has ended by now: an hour is not a backlog)
+                        raise RuntimeError("the stitch collectors did not finish: the prediction files are complete, run "
+                                           "`helen stitch` on them")
             for p in self.procs:
                 p.join()
             t_collected = time.time()
