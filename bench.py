@@ -574,7 +574,10 @@ def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_de
                            "seconds": round(dt_polish, 3), "predict_seconds": polish_run.get("seconds"),
                            "fasta_equals_two_phase": bool(same),
                            "per_rank": [{k: r.get(k) for k in ("rank", "windows", "seconds", "stage_seconds", "stitch_stream")}
-                                        for r in polish_run.get("ranks", [])]},
+                                        for r in polish_run.get("ranks", [])],
+                           # several ranks: the stitch collector processes (helen_amd/stitch_collect.py) -- regions, joins
+                           # and seconds per collector, the parent's wait for them and its copy of their parts
+                           "stitch_collectors": polish_run.get("stitch_collectors")},
                 "polish_command": command,
                 "what": "call_consensus(image_dir -> one prediction HDF5 per rank) over %d rank(s) incl. host "
                         "budgeting, process start-up, model load and close; %d synthetic windows per rank written in "

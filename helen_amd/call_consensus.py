@@ -191,6 +191,8 @@ def polish_genome(image_dir, model_path, batch_size, num_workers, threads, outpu
     if streams is not None and hasattr(streams, "export_spec"):
         # several ranks: collector processes hold the regions and have joined them (helen_amd.stitch_collect)
         streams.finish(output_dir, output_prefix)
+        from . import predict as _predict
+        _predict.LAST_RUN["stitch_collectors"] = streams.stats      # (what each collector did, for reports)
     elif streams is not None:
         stitch_stream.finish_stitch(streams, prediction_dir, output_dir, output_prefix, threads)
     else:

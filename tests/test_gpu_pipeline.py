@@ -375,6 +375,10 @@ def test_bench_two_ranks_end_to_end_line():
     # the whole `polish` of the same directory, stitch pipelined behind the inference: the FASTA of the two-phase stitch
     assert e["polish"]["fasta_equals_two_phase"] is True and e["polish_seconds"] > 0
     assert all(r_["stitch_stream"]["regions"] * 3 == r_["windows"] for r_ in e["polish"]["per_rank"]), e["polish"]
+    # two ranks: their regions went to stitch collector processes while they ran (helen_amd/stitch_collect.py)
+    sc = e["polish"]["stitch_collectors"]
+    assert sc["collectors"] >= 1 and sum(c["regions"] for c in sc["per_collector"]) * 3 == e["windows"], sc
+    assert all(c["aligned_now"] == 0 for c in sc["per_collector"]), sc       # every join was aligned behind the inference
     assert e["value"] > 0 and e["usable_cpus"] >= 1 and e["predicted_host_ceiling"] > 0
     assert line["barrier"] == "gloo all-reduce" and line["rccl"].startswith("not used"), line["rccl"]
     print(json.dumps(e))
@@ -396,6 +400,7 @@ def test_bench_eight_ranks_end_to_end_line():
     assert e["output_files"] == ["p_%d.hdf" % k for k in range(8)] and len(e["per_rank"]) == 8
     assert all(r_["windows"] * 8 == e["windows"] and r_["reader_workers"] >= 1 for r_ in e["per_rank"])
     assert e["polish"]["fasta_equals_two_phase"] is True
+    assert sum(c["regions"] for c in e["polish"]["stitch_collectors"]["per_collector"]) * 3 == e["windows"]
     assert sum(e["reader_workers_per_rank"]) + 2 * 8 <= max(e["usable_cpus"], 3 * 8)       # the host budget holds
     assert e["predicted_bound"] in ("device", "host readers")
     print(json.dumps({k: e[k] for k in ("value", "usable_cpus", "reader_workers_per_rank", "predicted_bound")}))
