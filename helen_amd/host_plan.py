@@ -283,8 +283,14 @@ class HostPlan(object):
             out.write("INFO: HOST PLAN: " + n + "\n")
 
 
+# `polish`: what the stitch stage behind the inference costs the host per rank at the device's rate (measured on the GPU
+# box's host, 81 k windows/s = 27 k regions/s per MI355X): region decode 0.65 of a CPU in the rank, overlap alignments
+# 70 us each = 1.9 CPUs (in the rank itself with one rank, in the collector processes with several)
+STITCH_CPUS_PER_RANK = 2.5
+
+
 def plan_host(devices, num_workers, cap_windows, calls_per_rank=None, usable=None, allowed=None, shm_free=None,
-              local_cpus=None, token=None, storage=None):
+              local_cpus=None, token=None, storage=None, stitch=False):
     """The plan for `len(devices)` ranks.
 
     * reader processes per rank = min(requested `-w`, (usable CPUs - RANK_THREADS x ranks) // ranks), at least 1 when
@@ -310,6 +316,13 @@ def plan_host(devices, num_workers, cap_windows, calls_per_rank=None, usable=Non
         workers = budget
         notes.append("%d READER PROCESSES PER RANK REQUESTED, %d GRANTED: %d USABLE CPUS FOR %d RANK(S) OF %d OWN "
                      "THREADS EACH" % (requested, workers, usable, n, RANK_THREADS))
+    if stitch:
+        want = n * (min(workers, 2) + RANK_THREADS + STITCH_CPUS_PER_RANK)
+        if want > usable:
+            notes.append("STITCH RUNS BEHIND THE INFERENCE AND WANTS ABOUT %.1f CPUS PER RANK AT THE DEVICE'S RATE (REGION DECODE, "
+                         "OVERLAP ALIGNMENTS): %d RANK(S) WITH THEIR READERS AND WRITERS WANT %.0f, %d ARE USABLE -- THE RUN "
+                         "WILL BE HOST-BOUND BY ITS STITCH STAGE, NOT BY ITS READERS"
+                         % (STITCH_CPUS_PER_RANK, n, want, usable))
     # NUMA pinning
     pin = os.environ.get("HELEN_PIN", "1") != "0" and n > 1
     cpus_of, node_of = {}, {}

@@ -1008,7 +1008,8 @@ def predict_gpu(file_chunks, output_filepath, model_path, batch_size, total_call
     args = (output_filepath, model_path, batch_size, num_workers, stitch_threads)
     group = max(1, DEVICE_CALL_WINDOWS // batch_size)
     host = plan_host(list(devices[:total_callers]), num_workers, group * batch_size,
-                     storage=[storage_of_files(file_chunks[r]) for r in range(total_callers)])
+                     storage=[storage_of_files(file_chunks[r]) for r in range(total_callers)],
+                     stitch=total_stitch_threads is not None)
     host.describe()
     LAST_RUN.clear()
     LAST_RUN.update({"host_plan": host.as_dict(), "ranks": []})

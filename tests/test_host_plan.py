@@ -324,3 +324,19 @@ def test_ram_backed_budget_counts_ram_not_just_tmpfs_space(tmp_path, monkeypatch
     assert where == "/dev/shm" and 8192 <= n < 300000 and need * 1.1 < 50 << 30
     n1, need1, where1, _ = bench.e2e_size(300000, 1, True, free=64 << 30)
     assert n1 == 300000 and where1 == "/dev/shm"
+
+
+def test_the_plan_prices_the_stitch_stage_of_polish():
+    """`polish` runs stitch behind the inference: region decode and overlap alignments want ~2.5 CPUs per rank at the
+    device's rate.  Eight ranks under a 16-CPU grant are told so before they start; under 192 CPUs nothing is said."""
+    from helen_amd import host_plan
+    lookup = lambda d: (None, [])
+    small = host_plan.plan_host(list(range(8)), 8, 4096, usable=16, allowed=list(range(16)), shm_free=1 << 40,
+                                local_cpus=lookup, stitch=True)
+    assert any("HOST-BOUND BY ITS STITCH STAGE" in n for n in small.notes), small.notes
+    large = host_plan.plan_host(list(range(8)), 8, 4096, usable=192, allowed=list(range(192)), shm_free=1 << 40,
+                                local_cpus=lookup, stitch=True)
+    assert not any("STITCH" in n for n in large.notes), large.notes
+    plain = host_plan.plan_host(list(range(8)), 8, 4096, usable=16, allowed=list(range(16)), shm_free=1 << 40,
+                                local_cpus=lookup)
+    assert not any("STITCH" in n for n in plain.notes)
