@@ -799,8 +799,9 @@ def _rank_report():
     """What a spawned rank sends its parent: LAST_PREDICT, with the stitch stage's regions parked in a file."""
     info = dict(LAST_PREDICT)
     if LAST_STREAM[0] is not None:
-        from .stitch_stream import spill_directory
-        info["stream_file"] = LAST_STREAM[0].save(spill_directory())
+        if not LAST_STREAM[0].stats.get("exported"):      # (exported: the collectors have the regions, helen_amd.stitch_collect)
+            from .stitch_stream import spill_directory
+            info["stream_file"] = LAST_STREAM[0].save(spill_directory())
         LAST_STREAM[0] = None
     return info
 
