@@ -114,7 +114,7 @@ def test_large_groups_and_every_name_length(tmp_path):
         assert f.keys("mid/empty") == [] and int(f.read("mid/answer")) == 42
         assert f.keys("mid/many") == want                        # complete, and in strcmp order
         rng = np.random.default_rng(1)
-        for i in list(rng.integers(0, n, 3000)) + [0, 1, n - 1, n - 2]:
+        for i in list(rng.integers(0, n, 400)) + [0, 1, n - 1, n - 2]:
             name = str(i) + chr(ord("a") + i % 26) * (i % 9)
             assert int(f.read("mid/many/" + name)) == 3 * int(i) - 7, name      # by-name lookup through the B-tree
         assert ("mid/many/" + "nope") not in f and ("mid/many/" + want[-1] + "z") not in f
