@@ -111,6 +111,64 @@ def cpu_baseline(batch, seconds_target=12.0):
                       "8-window blocks, %d threads = usable CPUs under the cgroup quota), %.1f s" % (n, threads, dt)}
 
 
+def torch_eager_baseline(batch, seconds_target=10.0):
+    """What the reference's arithmetic library does on this box's host cores: torch.nn.GRU + Linear of the reference's
+    architecture (TransducerModel.py:43-58) driven by the reference's loop (predict_gpu.py:99-159: 19 chunks of 100
+    positions at stride 50, hidden carried, softmax, zero-pad-add, argmax) at the loader batch, eager, fp32, on the CPU with
+    every usable thread -- a RESTATEMENT written here (the reference's modules cannot travel to this box and its CLI's
+    CPU path is an ONNX Runtime session, which this image does not have); checked against the oracle's labels on the
+    sample's first windows.  The closest this box can come to "the reference CPU path on the same cores"."""
+    import numpy as np
+    import torch
+
+    import oracle
+    from helen_amd.weights import make_images, make_weights
+    threads = usable_cpus()
+    torch.set_num_threads(threads)
+    w = make_weights(input_scale=1.0 / 64.0)
+    enc = torch.nn.GRU(90, 128, num_layers=1, bidirectional=True, batch_first=True)
+    dec = torch.nn.GRU(256, 128, num_layers=1, bidirectional=True, batch_first=True)
+    base, rle = torch.nn.Linear(256, 5), torch.nn.Linear(256, 11)
+    with torch.no_grad():
+        for mod, prefix in ((enc, "gru_encoder."), (dec, "gru_decoder."), (base, "dense1_base."), (rle, "dense2_rle.")):
+            for name, par in mod.named_parameters():
+                par.copy_(torch.from_numpy(w[prefix + name]))
+
+    def polish(images):                       # uint8 [n, 1000, 90] -> labels, batch by batch
+        out_b, out_r = [], []
+        with torch.no_grad():
+            for lo in range(0, images.shape[0], batch):
+                x = torch.from_numpy(images[lo:lo + batch]).float()
+                hidden = torch.zeros(2, x.shape[0], 128)
+                acc_b = torch.zeros(x.shape[0], 1000, 5)
+                acc_r = torch.zeros(x.shape[0], 1000, 11)
+                for i in range(0, 901, 50):
+                    y1, h1 = enc(x[:, i:i + 100], hidden)
+                    y2, hidden = dec(y1, h1)
+                    acc_b[:, i:i + 100] += torch.softmax(base(y2), dim=2)
+                    acc_r[:, i:i + 100] += torch.softmax(rle(y2), dim=2)
+                out_b.append(acc_b.argmax(dim=2).numpy().astype(np.uint8))
+                out_r.append(acc_r.argmax(dim=2).numpy().astype(np.uint8))
+        return np.concatenate(out_b), np.concatenate(out_r)
+
+    probe = make_images(min(batch, 64), seed=5)
+    t0 = time.time()
+    pb, pr = polish(probe)
+    rate = probe.shape[0] / (time.time() - t0)
+    ref = oracle.polish_batch(w, probe[:8])
+    differ = int((pb[:8] != ref["bases"]).sum() + (pr[:8] != ref["rles"]).sum())
+    n = int(min(max(rate * seconds_target, 64), 4 * batch))
+    n = n // batch * batch if n >= batch else n // 8 * 8      # whole loader batches, or one short one on a slow host
+    img = make_images(n, seed=6)
+    t0 = time.time()
+    polish(img)
+    dt = time.time() - t0
+    return {"value": round(n / dt, 2), "unit": "windows/s", "cores": threads, "kind": "port",
+            "sample": "%d uniform-random windows at batch %d through torch %s nn.GRU / Linear eager on the CPU (a restatement of "
+                      "TransducerModel.py:43-79 + predict_gpu.py:99-159), %d threads, %.1f s" % (n, batch, torch.__version__, threads, dt),
+            "labels_differing_from_the_oracle_on_8_windows": differ}
+
+
 def host_mode(seconds_target=8.0):
     """The product's OWN path for runs without --gpu_mode (helen_amd/csrc/cpu_path.cpp through helen_amd/cpu_engine.py: not
     the oracle), on a bounded sample with every usable thread: what `helen polish` without -g does per caller."""
@@ -902,6 +960,10 @@ def main():
                     out["modes"][prec] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B)
+            try:
+                out["cpu_baseline_torch_eager"] = torch_eager_baseline(B)
+            except Exception as e:          # noqa: BLE001 -- an extra leg must not take the headline down with it
+                out["cpu_baseline_torch_eager"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
             try:
                 out["host_mode"] = host_mode()
             except Exception as e:          # noqa: BLE001 -- an extra leg must not take the headline down with it
