@@ -325,6 +325,54 @@ Best striped(const int8_t* ref, bool backwards, int n, const int8_t* read, int m
     return striped_pass(ref, backwards, n, read, m, gap_open, gap_ext, mat, lanes, bias, terminate);
 }
 
+// Does the 8-bit pass certainly saturate?  It reports 255 (and the caller turns to the 16-bit pass) as soon as a
+// column's maximum + bias reaches 255; a cell at the end of a gap-free run of k equal bases holds at least k * match
+// whatever E and F are (H = max(diagonal, E, F), saturating), so ONE common substring of need = ceil((255 - bias) /
+// match) real bases (63 with stitch's 4 / 6) settles it -- and two overlapping ends of neighbouring regions nearly
+// always have one.  Found by indexing the reference's 16-mers (2 bits a base: one 32-bit word) and extending the hits of
+// every 16th 16-mer of the query... of every (need - 15)th at most, so that no run of `need` is stepped over.
+bool surely_saturates(const int8_t* ref, int n, const int8_t* read, int m, int match, int bias) {
+    if (match <= 0) return false;
+    const int need = (255 - bias + match - 1) / match;
+    constexpr int K = 16;
+    if (need < K || n < need || m < need) return false;
+    thread_local std::vector<int> head;            // open hash of the reference's K-mers: first position + chain
+    thread_local std::vector<int> next;
+    constexpr int kBuckets = 1024;
+    head.assign(kBuckets, -1);
+    next.assign((size_t)n, -1);
+    auto bucket = [](uint32_t w) { return (int)((w * 2654435761u) >> 22); };
+    uint32_t w = 0;
+    int valid = 0;
+    for (int i = 0; i < n; ++i) {
+        if (ref[i] > 3) { valid = 0; continue; }
+        w = (w << 2) | (uint32_t)ref[i];
+        if (++valid >= K) {
+            const int b = bucket(w), at = i - K + 1;
+            next[at] = head[b];
+            head[b] = at;
+        }
+    }
+    const int step = need - K + 1;                 // a run of `need` holds a K-mer starting at a multiple of `step`
+    for (int q = 0; q + K <= m; q += step) {
+        uint32_t v = 0;
+        bool ok = true;
+        for (int k = 0; k < K; ++k) {
+            if (read[q + k] > 3) { ok = false; break; }
+            v = (v << 2) | (uint32_t)read[q + k];
+        }
+        if (!ok) continue;
+        for (int at = head[bucket(v)]; at >= 0; at = next[at]) {
+            if (memcmp(ref + at, read + q, K) != 0) continue;
+            int lo = 0, hi = K;                    // extend the hit both ways over equal real bases
+            while (at - lo > 0 && q - lo > 0 && ref[at - lo - 1] == read[q - lo - 1] && ref[at - lo - 1] <= 3) ++lo;
+            while (at + hi < n && q + hi < m && ref[at + hi] == read[q + hi] && ref[at + hi] <= 3) ++hi;
+            if (lo + hi >= need) return true;
+        }
+    }
+    return false;
+}
+
 struct Op {
     char op;
     int len;
@@ -449,7 +497,12 @@ int helen_ssw_align(const char* ref_seq, int ref_len, const char* query_seq, int
     // 8-bit pass first; the 16-bit pass replaces it when the score saturates
     const int bias = mismatch;  // |most negative matrix entry|
     int lanes = 16;
-    Best fwd = striped(ref.data(), false, ref_len, read.data(), query_len, gap_open, gap_extend, mat, 16, bias, -1);
+    Best fwd;
+    // (a pass whose result is known to be "saturated" is not run: an eighth of a typical join's time)
+    if (surely_saturates(ref.data(), ref_len, read.data(), query_len, match, bias))
+        fwd.score = 255;
+    else
+        fwd = striped(ref.data(), false, ref_len, read.data(), query_len, gap_open, gap_extend, mat, 16, bias, -1);
     if (fwd.score == 255) {
         lanes = 8;
         fwd = striped(ref.data(), false, ref_len, read.data(), query_len, gap_open, gap_extend, mat, 8, 0, -1);
