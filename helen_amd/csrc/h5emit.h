@@ -59,10 +59,25 @@ class File {
 
     // ---- datasets ----
     // integer dataset of `rank` dims with contiguous layout; returns the object header address
+    // `fill(dst)` writes the `bytes` of the dataset straight into the file buffer (a conversion need not pass through
+    // a buffer of its own); data == nullptr selects it
+    template <class Fill>
+    uint64_t dataset_filled(Fill&& fill, size_t bytes, int elem_size, bool is_signed, int rank, const uint64_t* dims) {
+        align8();
+        const uint64_t addr = tell();
+        const size_t at = buf_.size();
+        buf_.resize(at + bytes);
+        fill(buf_.data() + at);
+        if (buf_.size() >= kFlush) flush();
+        return dataset_header(addr, bytes, elem_size, is_signed, rank, dims);
+    }
     uint64_t dataset(const void* data, size_t bytes, int elem_size, bool is_signed, int rank, const uint64_t* dims) {
         align8();
         const uint64_t addr = tell();
         put(data, bytes);
+        return dataset_header(addr, bytes, elem_size, is_signed, rank, dims);
+    }
+    uint64_t dataset_header(uint64_t addr, size_t bytes, int elem_size, bool is_signed, int rank, const uint64_t* dims) {
         align8();
         const uint64_t hdr = tell();
         const size_t msgs = (8 + 8 + 8 * rank) + (8 + 16) + (8 + 8) + (8 + 24);

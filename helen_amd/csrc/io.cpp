@@ -28,6 +28,7 @@
 #include <string>
 #include <thread>
 #include <type_traits>
+#include <unordered_set>
 #include <vector>
 
 namespace {
@@ -462,8 +463,8 @@ struct Writer {
     hid_t file = -1;
     hid_t lcpl = -1, dcpl = -1;
     hid_t space_pos = -1, space_lab = -1, space_scalar = -1;
-    std::set<std::string> regions;   // DataStore.py:115  meta['predictions_contig']
-    std::set<std::string> images;    // DataStore.py:123  meta['predictions']
+    std::unordered_set<std::string> regions;   // DataStore.py:115  meta['predictions_contig']
+    std::unordered_set<std::string> images;    // DataStore.py:123  meta['predictions']
     std::vector<uint32_t> pos32;
     // direct emitter (h5emit.h): the default; $HELEN_IO_WRITER=libhdf5 selects the library path above
     h5emit::File* fast = nullptr;
@@ -1102,10 +1103,14 @@ int helen_io_write_predictions_sel(void* handle, int n_sel, const int32_t* sel, 
             }
             if (w->images.insert(contig + prefix + suffix).second) {
                 const int64_t* p = positions + (size_t)i * kSeq * 3;
-                for (int k = 0; k < kSeq * 3; ++k) w->pos32[k] = (uint32_t)p[k];
                 const uint64_t dp[2] = {(uint64_t)kSeq, 3}, dl[1] = {(uint64_t)kSeq};
                 std::vector<h5emit::Child> kids(3);
-                kids[0] = {"position", w->fast->dataset(w->pos32.data(), (size_t)kSeq * 12, 4, false, 2, dp)};
+                // int64 -> uint32 (a -1 padding row wraps to 4294967295, DataStore.py:128) straight into the file buffer
+                kids[0] = {"position", w->fast->dataset_filled([p](uint8_t* dst) {
+                               typedef uint32_t unaligned_u32 __attribute__((aligned(1), may_alias));
+                               unaligned_u32* q = (unaligned_u32*)dst;      // (aligned in the FILE, not in memory)
+                               for (int k = 0; k < kSeq * 3; ++k) q[k] = (uint32_t)p[k];
+                           }, (size_t)kSeq * 12, 4, false, 2, dp)};
                 kids[1] = {"bases", w->fast->dataset(bases + (size_t)i * kSeq, kSeq, 1, false, 1, dl)};
                 kids[2] = {"rles", w->fast->dataset(rles + (size_t)i * kSeq, kSeq, 1, false, 1, dl)};
                 reg.kids.push_back({suffix, w->fast->group(kids)});
@@ -1420,6 +1425,7 @@ long long helen_io_decode_regions(int n_regions, const int32_t* first, const int
     std::atomic<bool> bad{false};
     auto work = [&]() {
         std::vector<Item> acc, img, merged;
+        std::string local;
         static const char kDecode[5] = {0, 'A', 'C', 'G', 'T'};
         for (;;) {
             const int r = next.fetch_add(1);
@@ -1445,15 +1451,20 @@ long long helen_io_decode_regions(int n_regions, const int32_t* first, const int
                     acc.swap(merged);
                 }
             }
-            std::string& seq = seqs[(size_t)r];
+            // (built in this thread's own string and moved into place: neighbouring elements of `seqs` share cache lines,
+            // and a string that grows there is written to by every append)
             size_t need = 0;
             for (const Item& x : acc) need += x.rle;
-            seq.reserve(need);
+            local.resize(need);
+            char* at = &local[0];
             for (size_t k = 0; k < acc.size(); ++k) {
                 if (k > 0 && same(acc[k], acc[k - 1])) continue;                    // first writer wins
                 const char ch = acc[k].base < 5 ? kDecode[acc[k].base] : 0;
-                if (ch) seq.append((size_t)acc[k].rle, ch);
+                if (!ch) continue;
+                for (int c = acc[k].rle; c > 0; --c) *at++ = ch;
             }
+            local.resize((size_t)(at - local.data()));
+            seqs[(size_t)r] = local;
         }
     };
     const int T = std::max(1, std::min(threads, n_regions));

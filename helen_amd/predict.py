@@ -46,9 +46,27 @@ BACKGROUND_RELEASE = []
 LAST_RUN = {}
 
 
-def _writer_loop(wq, store, free_slots, err, sq=None):
-    """Writer thread: labels of one device call -> prediction HDF5, then recycle the slot -- or, when `polish` stitches
-    behind the inference (`sq`), pass it on to the stitch stage, which recycles it."""
+class _SlotRelease(object):
+    """A slot goes back to the readers when EVERY stage that reads its labels is done with it: the writer alone, or --
+    `polish` -- the writer and the stitch stage, which work on the same slot side by side (both only read it)."""
+
+    def __init__(self, free_slots, stages):
+        self.free_slots, self.stages = free_slots, stages
+        self.lock = threading.Lock()
+        self.left = {}
+
+    def done(self, slot):
+        with self.lock:
+            left = self.left.get(id(slot), self.stages) - 1
+            if left > 0:
+                self.left[id(slot)] = left
+                return
+            self.left.pop(id(slot), None)
+        self.free_slots.put(slot)
+
+
+def _writer_loop(wq, store, release, err):
+    """Writer thread: labels of one device call -> prediction HDF5, then the slot is this stage's no longer."""
     try:
         while True:
             item = wq.get()
@@ -58,21 +76,15 @@ def _writer_loop(wq, store, free_slots, err, sq=None):
             t0 = time.time()
             store.write_batch(slot.contigs[:n], slot.meta[:n], slot.positions[:n], bases, rles)
             STAGE_SECONDS["write"] += time.time() - t0
-            if sq is not None:
-                sq.put(item)
-            else:
-                free_slots.put(slot)
+            release.done(slot)
     except Exception as e:  # surfaced by the caller
         err.append(e)
-        free_slots.put(None)
-    finally:
-        if sq is not None:
-            sq.put(None)
+        release.free_slots.put(None)
 
 
-def _stitch_loop(sq, stream, free_slots, err):
-    """Stitch stage of `polish` (helen_amd.stitch_stream): the regions whose images the writer has just stored are decoded
-    from the slot's label buffers and their overlap alignments handed to worker threads; then the slot is recycled."""
+def _stitch_loop(sq, stream, release, err):
+    """Stitch stage of `polish` (helen_amd.stitch_stream): the regions of a device call are decoded from the slot's label
+    buffers -- beside the writer, which stores the same labels -- and their overlap alignments handed to worker threads."""
     failed = False
     while True:
         item = sq.get()
@@ -87,8 +99,8 @@ def _stitch_loop(sq, stream, free_slots, err):
             except Exception as e:  # surfaced by the caller; the slots keep circulating so that nothing hangs
                 failed = True
                 err.append(e)
-                free_slots.put(None)
-        free_slots.put(slot)
+                release.free_slots.put(None)
+        release.done(slot)
 
 
 class _DeviceStage(object):
@@ -551,12 +563,12 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     for k in STAGE_SECONDS:
         STAGE_SECONDS[k] = 0.0
     if writers == 1:
-        writer = threading.Thread(target=_writer_loop, args=(wq, prediction_data_file, free_slots, werr, sq),
-                                  daemon=True)
+        release = _SlotRelease(free_slots, 2 if stream is not None else 1)
+        writer = threading.Thread(target=_writer_loop, args=(wq, prediction_data_file, release, werr), daemon=True)
         writer.start()
         writer_pool = None
         if stream is not None:
-            stitcher = threading.Thread(target=_stitch_loop, args=(sq, stream, free_slots, werr), daemon=True)
+            stitcher = threading.Thread(target=_stitch_loop, args=(sq, stream, release, werr), daemon=True)
             stitcher.start()
     else:
         writer_pool = _WriterPool(output_filename, rank, writers, free_slots, werr)
@@ -566,7 +578,10 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
 
     def to_writer(slot, n):
         if writer_pool is None:
-            wq.put((slot, n, slot.bases[:n], slot.rles[:n]))
+            item = (slot, n, slot.bases[:n], slot.rles[:n])
+            wq.put(item)
+            if sq is not None:
+                sq.put(item)
         else:
             writer_pool.submit(slot, n)
 
@@ -717,6 +732,8 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
             side.append(threading.Thread(target=release_readers, daemon=True))
         if writer_pool is None:
             wq.put(None)
+            if sq is not None:
+                sq.put(None)
         for t in side:
             t.start()
         t_side = time.time()

@@ -53,7 +53,7 @@ class RegionStream(object):
         self.export = export
         self.file = os.path.abspath(prediction_file)
         self.threads = max(1, int(threads))
-        self.decode_threads = max(1, min(4, self.threads)) if decode_threads is None else decode_threads
+        self.decode_threads = max(1, min(8, self.threads)) if decode_threads is None else decode_threads
         self.regions = {}          # (contig, start, end) -> sequence bytes, or None = take it from the file
         self.written = {}          # (contig, start, end) -> set of chunk ids the writer has stored for it
         self.carry = None          # the newest region, still growing: [key, [(chunk id, positions, bases, rles), ...]]
@@ -186,30 +186,44 @@ class RegionStream(object):
                 self.regions[key] = b""          # seen, and not with this process
             self.seconds["regions"] += len(keys)
             return
-        jobs = []            # (left string, right string)
+        jobs = []            # (left string, right string, the pair)
+        regions, placed_of, rate = self.regions, self.placed, StitchOptions.BASE_ERROR_RATE
 
-        def join(a, b):
+        def join(contig, a, b):
             # stitch joins the regions of a contig in (start, end) order; what it aligns is the last / first
             # `end(a) - start(b)` bases of the two (Stitch.py:141-147)
             if b[0] < a[1]:
                 ov = a[1] - b[0]
-                ov += int(ov * StitchOptions.BASE_ERROR_RATE)
-                sa, sb = self.regions.get((contig,) + a), self.regions.get((contig,) + b)
+                ov += int(ov * rate)
+                sa, sb = regions.get((contig,) + a), regions.get((contig,) + b)
                 if sa and sb:
                     jobs.append((sa[-ov:], sb[:ov], (contig,) + a + b))
 
         for key, seq in zip(keys, seqs):
-            self.regions[key] = seq
+            regions[key] = seq
             contig, span = key[0], key[1:]
-            placed = self.placed.setdefault(contig, [])
+            placed = placed_of.get(contig)
+            if placed is None:
+                placed = placed_of[contig] = []
             # the region's neighbours by POSITION among the regions decoded so far (images come in name order, which is
             # position order only between starts of the same number of digits)
-            i = len(placed) if not placed or placed[-1] < span else bisect.bisect_left(placed, span)
+            if not placed or placed[-1] < span:          # the ordinary case: the next region along the contig
+                if placed:
+                    a = placed[-1]
+                    if span[0] < a[1] and seq:
+                        sa = regions.get((contig,) + a)
+                        if sa:
+                            ov = a[1] - span[0]
+                            ov += int(ov * rate)
+                            jobs.append((sa[-ov:], seq[:ov], (contig,) + a + span))
+                placed.append(span)
+                continue
+            i = bisect.bisect_left(placed, span)
             placed.insert(i, span)
             if i > 0:
-                join(placed[i - 1], span)
+                join(contig, placed[i - 1], span)
             if i + 1 < len(placed):
-                join(span, placed[i + 1])
+                join(contig, span, placed[i + 1])
         self.seconds["regions"] += len(keys)
         if jobs and self.pool is not None:
             self.seconds["joins_submitted"] += len(jobs)
