@@ -21,10 +21,15 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <deque>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -44,18 +49,20 @@ struct Child {
 class File {
    public:
     ~File() {
+        stop_flushers();
         if (fd_ >= 0) ::close(fd_);
     }
     bool open(const char* path) {
         fd_ = ::open(path, O_CREAT | O_TRUNC | O_WRONLY, 0644);
         if (fd_ < 0) return false;
+        for (int t = 0; t < kFlushers; ++t) flushers_.emplace_back([this]() { flusher_loop(); });
         buf_.reserve(kFlush + (1 << 20));
         // room for the superblock (96 bytes), written last
         buf_.assign(kDataStart, 0);
         base_ = 0;
         return true;
     }
-    bool ok() const { return fd_ >= 0 && !failed_; }
+    bool ok() const { return fd_ >= 0 && !failed_.load(); }
 
     // ---- datasets ----
     // integer dataset of `rank` dims with contiguous layout; returns the object header address
@@ -214,6 +221,7 @@ class File {
         align8();
         const uint64_t eof = tell();
         flush();
+        stop_flushers();             // every piece is in the file (or failed_ says otherwise)
         uint8_t sb[96];
         size_t o = 0;
         auto w8 = [&](uint8_t v) { sb[o++] = v; };
@@ -226,7 +234,7 @@ class File {
         w16(kLeafK); w16(kInternalK); w32(0);
         w64(0); w64(kUndef); w64(eof); w64(kUndef);
         w64(0); w64(root_header); w32(1); w32(0); w64(root_btree); w64(root_heap);
-        bool good = !failed_ && ::pwrite(fd_, sb, sizeof(sb), 0) == (ssize_t)sizeof(sb);
+        bool good = !failed_.load() && ::pwrite(fd_, sb, sizeof(sb), 0) == (ssize_t)sizeof(sb);
         good = (::close(fd_) == 0) && good;
         fd_ = -1;
         return good;
@@ -235,21 +243,95 @@ class File {
    private:
     static constexpr size_t kFlush = 8 << 20;
     static constexpr size_t kDataStart = 2048;
+    // A full buffer goes to the file BEHIND the caller: the kernel's copy into the page cache (or a RAM-backed file's
+    // pages) is as long as the formatting of the next buffer, and two pieces of a file can be copied at once.  Pieces
+    // are written with pwrite at their own offsets, so their order does not matter; at most kInFlight wait or are
+    // being written (the caller blocks beyond that); finish() writes the superblock after the last piece is in.
+    static constexpr int kFlushers = 2;
+    static constexpr size_t kInFlight = 3;
     int fd_ = -1;
-    bool failed_ = false;
+    std::atomic<bool> failed_{false};
     std::vector<uint8_t> buf_;
     uint64_t base_ = 0;   // file offset of buf_[0]
+    struct Piece {
+        std::vector<uint8_t> bytes;
+        uint64_t offset;
+    };
+    std::vector<std::thread> flushers_;
+    std::mutex mutex_;
+    std::condition_variable work_, room_;
+    std::deque<Piece> queue_;
+    std::vector<std::vector<uint8_t>> spare_;
+    size_t in_flight_ = 0;
+    bool stopping_ = false;
 
     uint64_t tell() const { return base_ + buf_.size(); }
-    void flush() {
-        size_t done = 0;
-        while (done < buf_.size() && !failed_) {
-            const ssize_t n = ::write(fd_, buf_.data() + done, buf_.size() - done);
-            if (n <= 0) failed_ = true;
-            else done += (size_t)n;
+    void flusher_loop() {
+        for (;;) {
+            Piece piece;
+            {
+                std::unique_lock<std::mutex> lock(mutex_);
+                work_.wait(lock, [this]() { return stopping_ || !queue_.empty(); });
+                if (queue_.empty()) return;
+                piece = std::move(queue_.front());
+                queue_.pop_front();
+            }
+            size_t done = 0;
+            while (done < piece.bytes.size() && !failed_.load()) {
+                const ssize_t n = ::pwrite(fd_, piece.bytes.data() + done, piece.bytes.size() - done,
+                                           (off_t)(piece.offset + done));
+                if (n <= 0) failed_.store(true);
+                else done += (size_t)n;
+            }
+            {
+                std::lock_guard<std::mutex> lock(mutex_);
+                piece.bytes.clear();
+                spare_.push_back(std::move(piece.bytes));
+                --in_flight_;
+            }
+            room_.notify_all();
         }
-        base_ += buf_.size();
+    }
+    void stop_flushers() {
+        {
+            std::unique_lock<std::mutex> lock(mutex_);
+            room_.wait(lock, [this]() { return in_flight_ == 0; });
+            stopping_ = true;
+        }
+        work_.notify_all();
+        for (auto& t : flushers_) t.join();
+        flushers_.clear();
+        stopping_ = false;
+    }
+    void flush() {
+        if (buf_.empty()) return;
+        if (flushers_.empty()) {            // (after finish() has stopped them: nothing writes then)
+            size_t done = 0;
+            while (done < buf_.size() && !failed_.load()) {
+                const ssize_t n = ::pwrite(fd_, buf_.data() + done, buf_.size() - done, (off_t)(base_ + done));
+                if (n <= 0) failed_.store(true);
+                else done += (size_t)n;
+            }
+            base_ += buf_.size();
+            buf_.clear();
+            return;
+        }
+        std::vector<uint8_t> next;
+        {
+            std::unique_lock<std::mutex> lock(mutex_);
+            room_.wait(lock, [this]() { return in_flight_ < kInFlight; });
+            if (!spare_.empty()) {
+                next = std::move(spare_.back());
+                spare_.pop_back();
+            }
+            ++in_flight_;
+            queue_.push_back(Piece{std::move(buf_), base_});
+            base_ += queue_.back().bytes.size();
+        }
+        work_.notify_one();
+        buf_ = std::move(next);
         buf_.clear();
+        buf_.reserve(kFlush + (1 << 20));
     }
     void put(const void* p, size_t n) {
         const uint8_t* b = (const uint8_t*)p;

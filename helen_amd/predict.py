@@ -777,11 +777,13 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         "cpus_pinned": None if plan is None or not plan.cpus else len(plan.cpus),
         "numa_node": None if plan is None else plan.numa_node})
     if rank == 0:
-        sys.stderr.write("INFO: %d WINDOWS IN %.1f SECS (WAITING FOR READERS %.1f, DEVICE %.1f, WRITER BUSY %.1f; "
+        sys.stderr.write("INFO: %d WINDOWS IN %.1f SECS (WAITING FOR READERS %.1f, DEVICE %.1f, WRITER BUSY %.1f%s; "
                          "MODEL + ENGINE SET-UP %.1f [%s], FLUSH + CLOSE %.1f = LAST SLOTS %.2f + FILE CLOSE %.2f + "
                          "RELEASE %.2f [%s]).\n"
                          % (total_windows, time.time() - start_time, STAGE_SECONDS["read_wait"],
-                            STAGE_SECONDS["device"], STAGE_SECONDS["write"], t_setup - start_time,
+                            STAGE_SECONDS["device"], STAGE_SECONDS["write"],
+                            "" if stream is None else ", STITCH STAGE BUSY %.1f" % STAGE_SECONDS.get("stitch", 0.0),
+                            t_setup - start_time,
                             ", ".join("%s %.2f" % kv for kv in setup_took.items()),
                             time.time() - t_loop_end, t_drained - t_side, t_closed - t_drained,
                             time.time() - t_closed,
