@@ -601,6 +601,28 @@ def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_de
                                % (batch, workers, threads),
                        "seconds": round(dt_cmd, 3), "windows_per_s": round(total / dt_cmd, 1), "returncode": r.returncode,
                        "fasta_equals_two_phase": bool(ok), "wall_clock_line": clock[-1][6:] if clock else None}
+            # the same command in the two opt-in arithmetic modes: there the device is 1.5x / 6x faster and the HOST stages
+            # (readers, writer, stitch) set the pace; the FASTA is compared with the fp32 one byte for byte (fp32x3: equal
+            # on this assembly; bf16: labels differ at ~1e-5 of the positions)
+            command["modes"] = {}
+            for prec in ("fp32x3", "bf16"):
+                out_dir = os.path.join(d, "cmd_" + prec)
+                t0 = time.time()
+                r2 = subprocess.run(cmd[:cmd.index("-o") + 1] + [out_dir] + cmd[cmd.index("-o") + 2:] + ["--precision", prec],
+                                    cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                dt2 = time.time() - t0
+                f2 = os.path.join(out_dir, "asm.fa")
+                same2 = None
+                if r2.returncode == 0 and os.path.isfile(f2):
+                    same2 = os.path.getsize(f2) == os.path.getsize(fasta)
+                    if same2:
+                        with open(fasta, "rb") as a, open(f2, "rb") as b:
+                            same2 = a.read() == b.read()
+                busy = [ln for ln in r2.stderr.splitlines() if "WINDOWS IN" in ln]
+                command["modes"][prec] = {"seconds": round(dt2, 3), "windows_per_s": round(total / dt2, 1),
+                                          "returncode": r2.returncode, "fasta_equals_fp32": same2,
+                                          "stages": busy[-1][6:busy[-1].index(";")] + ")" if busy and ";" in busy[-1] else None}
+                shutil.rmtree(out_dir, ignore_errors=True)
         plan = run.get("host_plan", {})
         # the same run without its fixed costs: every rank's windows over the slowest rank's loop time (first slot
         # submitted .. last labels back; process start-up, model load, page-locking, file close and tear-down excluded)
