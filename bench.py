@@ -448,8 +448,8 @@ def e2e_size(windows_per_rank, world, may_shrink, free=None):
     directory instead; otherwise it is skipped."""
     from helen_amd.host_plan import SLOT_BYTES_PER_WINDOW, ram_backed_budget_bytes
 
-    def need_bytes(per_rank):     # inputs + slots + outputs (three runs) + FASTAs, all ranks, all RAM-backed
-        return per_rank * world * (116000 + 3 * 16000 + 3 * 1500) + world * 5 * 4096 * SLOT_BYTES_PER_WINDOW
+    def need_bytes(per_rank):     # inputs + slots + outputs (four runs at a time) + FASTAs, all ranks, all RAM-backed
+        return per_rank * world * (116000 + 4 * 16000 + 4 * 1500) + world * 5 * 4096 * SLOT_BYTES_PER_WINDOW
     free = ram_backed_budget_bytes() if free is None else free
     n = windows_per_rank
     while may_shrink and n > 8192 and free <= need_bytes(n) * 1.1:
