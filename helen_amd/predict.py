@@ -13,7 +13,7 @@ No process group is created (the reference's gloo group is never used on this pa
 The prediction file is the reference's single `<output>_<rank>.hdf` per rank, written by one thread through the
 direct HDF5 emitter of libhelen_io.so (helen_amd/csrc/h5emit.h): libhdf5 itself spends ~100 us creating the
 group and three small datasets of a window (8-14 k windows/s per process against ~81 k windows/s of device
-throughput), the emitter writes the same objects at ~100 k windows/s.  $HELEN_WRITERS=W > 1 opts into the
+throughput), the emitter writes the same objects at ~170 k windows/s.  $HELEN_WRITERS=W > 1 opts into the
 round-1 pool of W writer processes: writer 0 keeps `<output>_<rank>.hdf`, writer k > 0 writes
 `<output>_<rank>_w<k>.hdf`, all chunks of one region go to the same file, a writer without regions leaves no
 file, and stitch takes every `*.hdf` of the directory (StitchInterface.py:35-36).
@@ -258,7 +258,7 @@ def native_model_state(model_path):
 def writer_count(num_workers):
     """Writer processes per rank: ONE by default -- the reference's single `<output>_<rank>.hdf`
     (predict_gpu.py:55), written by a thread of this process through the direct HDF5 emitter
-    (helen_amd/csrc/h5emit.h: ~100 k windows/s, above the device's 81 k).  $HELEN_WRITERS=N > 1 opts into the
+    (helen_amd/csrc/h5emit.h: ~170 k windows/s, above the device's 81 k).  $HELEN_WRITERS=N > 1 opts into the
     round-1 pool of N writer processes and `<output>_<rank>_w<k>.hdf` shards (useful only with
     HELEN_IO_WRITER=libhdf5, whose ~8 k windows/s per process were the reason for the pool)."""
     env = os.environ.get("HELEN_WRITERS")
