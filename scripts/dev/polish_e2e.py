@@ -1,7 +1,7 @@
 """Developer probe (GPU box): `bin/helen polish -g` on a simulated assembly of ~N images (helen_amd.synthetic, the trained
 network of tests/golden/trained_synth.npz), wall-clocked as a user sees it: process start, imports, device context,
 call_consensus, stitch (pipelined behind the inference; HELEN_STITCH_PIPELINE=0 for the two phases of round 4).
-    python scripts/dev/polish_e2e.py [N=300000] [threads=16] [repeats=2]"""
+    python scripts/dev/polish_e2e.py [N=300000] [threads=16] [repeats=2] [extra arguments of the command, e.g. "-d_ids 0,0"]"""
 import os
 import shutil
 import subprocess
@@ -21,6 +21,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300000
     threads = sys.argv[2] if len(sys.argv) > 2 else "16"
     repeats = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    extra = sys.argv[4].split() if len(sys.argv) > 4 else []
     d = tempfile.mkdtemp(prefix="helen_polish_", dir="/dev/shm")
     try:
         model = os.path.join(d, "model.pkl")
@@ -35,11 +36,11 @@ def main():
             shutil.rmtree(out, ignore_errors=True)
             t0 = time.time()
             r = subprocess.run([os.path.join(ROOT, "bin", "helen"), "polish", "-i", os.path.join(d, "img"), "-m", model, "-b", "256",
-                                "-w", "8", "-t", threads, "-o", out, "-p", "asm", "-g"], cwd=ROOT,
+                                "-w", "8", "-t", threads, "-o", out, "-p", "asm", "-g"] + extra, cwd=ROOT,
                                env=dict(os.environ, HELEN_STITCH_PIPELINE=mode), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                text=True)
             dt = time.time() - t0
-            info = [ln for ln in r.stderr.splitlines() if ln.startswith("INFO") and ("WINDOWS IN" in ln or "PIPELINED" in ln or "TIME" in ln or "WALL CLOCK" in ln)]
+            info = [ln for ln in r.stderr.splitlines() if ln.startswith("INFO") and ("WINDOWS IN" in ln or "PIPELINED" in ln or "TIME" in ln or "WALL CLOCK" in ln or "COLLECTOR" in ln or "HOST PLAN" in ln)]
             print("HELEN_STITCH_PIPELINE=%s rc %d: polish wall %.2f s = %.0f windows/s (FASTA %d bytes)"
                   % (mode, r.returncode, dt, n / dt, os.path.getsize(os.path.join(out, "asm.fa")) if r.returncode == 0 else -1))
             print("\n".join("    " + ln for ln in info[-7:]))
