@@ -1,7 +1,8 @@
 """Developer probe (GPU box): `bin/helen polish -g` on a simulated assembly of ~N images (helen_amd.synthetic, the trained
 network of tests/golden/trained_synth.npz), wall-clocked as a user sees it: process start, imports, device context,
 call_consensus, stitch (pipelined behind the inference; HELEN_STITCH_PIPELINE=0 for the two phases of round 4).
-    python scripts/dev/polish_e2e.py [N=300000] [threads=16] [repeats=2] [extra arguments of the command, e.g. "-d_ids 0,0"]"""
+    python scripts/dev/polish_e2e.py [N=300000] [threads=16] [repeats=2] [extra arguments of the command, e.g. "-d_ids 0,0"]
+        [blocks=1: every contig's regions cut into that many runs dealt over the 16 files, as MarginPolish scatters them]"""
 import os
 import shutil
 import subprocess
@@ -22,13 +23,16 @@ def main():
     threads = sys.argv[2] if len(sys.argv) > 2 else "16"
     repeats = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     extra = sys.argv[4].split() if len(sys.argv) > 4 else []
+    blocks = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     d = tempfile.mkdtemp(prefix="helen_polish_", dir="/dev/shm")
     try:
         model = os.path.join(d, "model.pkl")
         z = np.load(os.path.join(ROOT, "tests", "golden", "trained_synth.npz"))
         ModelHandler.save_model({k: z[k] for k in z.files if not k.startswith("_")}, None, 128, 1, 0, model)
         t0 = time.time()
-        made = write_assembly_dir(os.path.join(d, "img"), assembly_spec(n, 16), 16, direct=True, processes=8)
+        spec = assembly_spec(n, 16)
+        made = write_assembly_dir(os.path.join(d, "img"), spec, 16, direct=True, processes=8,
+                                  blocks=[blocks] * len(spec) if blocks > 1 else None)
         n = made["windows"]
         print("inputs (%d images, %d regions) written in %.1f s" % (n, made["regions"], time.time() - t0), flush=True)
         for mode in ["1"] * repeats + ["0"]:
