@@ -257,7 +257,7 @@ def contig_windows(contig, bank, lo=0, hi=None):
 def _write_assembly_files(args):
     directory, spec, n_files, seed, blocks, direct, only = args
     made = write_assembly_dir(directory, spec, n_files, seed, blocks, direct, only_files=only)
-    return made["files"], made["windows"], made["regions"], made["windows_per_file"]
+    return made["files"], made["windows"], made["regions"], made["windows_per_file"], made["regions_per_file"]
 
 
 def assembly_spec(windows, n_files, contigs_per_file=2, region_positions=2400, overlap=200, name="chr%02d_sim"):
@@ -286,16 +286,19 @@ def write_assembly_dir(directory, spec, n_files=1, seed=20260929, blocks=None, d
         todo = sorted(range(n_files) if only_files is None else only_files)
         with concurrent.futures.ProcessPoolExecutor(min(processes, len(todo)), mp_context=mp.get_context("spawn")) as ex:
             parts = list(ex.map(_write_assembly_files, [(directory, spec, n_files, seed, blocks, direct, [fi]) for fi in todo]))
-        counts = [0] * n_files
+        counts, region_counts = [0] * n_files, [0] * n_files
         for fi, p in zip(todo, parts):
             counts[fi] = p[3][fi]
-        return {"files": [f for p in parts for f in p[0]], "windows": sum(p[1] for p in parts),
-                "regions": sum(p[2] for p in parts), "truth": None, "windows_per_file": counts}
+            region_counts[fi] = p[4][fi]
+        # (a worker renders every contig that touches its file: its own totals count those contigs whole)
+        return {"files": [f for p in parts for f in p[0]], "windows": sum(counts), "regions": sum(region_counts), "truth": None,
+                "windows_per_file": counts, "regions_per_file": region_counts}
     bank = _noise_bank()
     # which file a block goes to depends only on the blocks before it: block j -> file j % n_files
     paths = [os.path.join(directory, "assembly_images_%04d.h5" % fi) for fi in range(n_files)]
     mine = set(range(n_files)) if only_files is None else set(only_files)
     per_file = [[] for _ in range(n_files)]     # (contig, first image, end image)
+    regions_per_file = [0] * n_files
     truth, j, windows, regions = {}, 0, 0, 0
     for k, (name, n, kw) in enumerate(spec):
         targets = [(j + b) % n_files for b in range(blocks[k])]
@@ -315,6 +318,7 @@ def write_assembly_dir(directory, spec, n_files=1, seed=20260929, blocks=None, d
             lo, hi = int(np.searchsorted(region_of, r_lo)), int(np.searchsorted(region_of, r_hi))
             if hi > lo and targets[b] in mine:
                 per_file[targets[b]].append((contig, lo, hi))
+                regions_per_file[targets[b]] += r_hi - r_lo
     counts = []
     for fi in range(n_files):
         counts.append(sum(hi - lo for _, lo, hi in per_file[fi]))
@@ -329,7 +333,7 @@ def write_assembly_dir(directory, spec, n_files=1, seed=20260929, blocks=None, d
         else:
             _write_windows(paths[fi], names, *cat)
     return {"files": [p for fi, p in enumerate(paths) if per_file[fi] and fi in mine], "windows": windows, "regions": regions,
-            "truth": truth if only_files is None else None, "windows_per_file": counts}
+            "truth": truth if only_files is None else None, "windows_per_file": counts, "regions_per_file": regions_per_file}
 
 
 def _write_windows(path, names, starts, ends, chunks, lengths, images, positions):
