@@ -75,18 +75,27 @@ class RegionStream(object):
         if n == 0:
             return
         contigs = np.asarray(contigs)
-        # (a name ends at its first NUL; what follows in the slot's row may be left over from a longer name)
-        contigs = contigs * (np.cumsum(contigs == 0, axis=1, dtype=np.int32) == 0)
+        # (a name ends at its first NUL; what follows in the slot's row may be left over from a longer name: only the
+        # columns up to the longest name of this call are looked at, with every row's tail behind its NUL zeroed)
+        is_nul = contigs == 0
+        length = np.where(is_nul.any(axis=1), is_nul.argmax(axis=1), contigs.shape[1])
+        width = int(length.max()) + 1 if n else 1
+        names = contigs[:, :width] * (np.arange(width)[None, :] < length[:, None])
         # runs of consecutive images of one region
         change = np.ones(n, bool)
         if n > 1:
             change[1:] = (meta[1:, 0] != meta[:-1, 0]) | (meta[1:, 1] != meta[:-1, 1]) | \
-                np.any(contigs[1:] != contigs[:-1], axis=1)
+                np.any(names[1:] != names[:-1], axis=1)
         seg_first = np.flatnonzero(change)
         seg_end = np.append(seg_first[1:], n)
         keys = []
-        for a in seg_first.tolist():
-            keys.append((bytes(contigs[a]).split(b"\0", 1)[0].decode(), int(meta[a, 0]), int(meta[a, 1])))
+        starts, ends = meta[seg_first, 0].tolist(), meta[seg_first, 1].tolist()
+        last_row, last_name = None, None
+        for a, cs, ce in zip(seg_first.tolist(), starts, ends):
+            row = names[a].tobytes()
+            if row != last_row:                       # (consecutive regions nearly always share their contig)
+                last_row, last_name = row, row[:int(length[a])].decode()
+            keys.append((last_name, cs, ce))
         # a region that shows up in two separate runs of this call (its images are not back to back): from the file
         count = {}
         for k in keys:
