@@ -239,7 +239,32 @@ class CollectorRun(object):
         """What a rank needs to write its regions: (prefix, buckets)."""
         return (self.prefix, self.buckets)
 
+    @staticmethod
+    def sweep(directory):
+        """Record and part files a KILLED run left behind (their names carry the parent's pid: gone = stale)."""
+        try:
+            names = os.listdir(directory)
+        except OSError:
+            return 0
+        removed = 0
+        for name in names:
+            if not name.startswith("helen_regions_"):
+                continue
+            try:
+                pid = int(name.split("_")[2])
+            except (IndexError, ValueError):
+                continue
+            if pid == os.getpid() or os.path.exists("/proc/%d" % pid):
+                continue
+            try:
+                os.unlink(os.path.join(directory, name))
+                removed += 1
+            except OSError:
+                pass
+        return removed
+
     def start(self):
+        self.sweep(os.path.dirname(self.prefix))
         for r in range(len(self.files)):
             for w in range(self.buckets):
                 open(_path(self.prefix, r, w), "wb").close()

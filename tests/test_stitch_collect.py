@@ -124,3 +124,17 @@ def test_a_failed_run_leaves_nothing_behind(tmp_path):
     assert all(p.is_alive() for p in run.procs)
     run.abort()
     assert run.procs == [] and [f for f in os.listdir(str(tmp_path)) if f.startswith("helen_regions_")] == []
+
+
+def test_what_a_killed_run_left_behind_is_swept(tmp_path):
+    """Record files carry the parent's pid; the next run removes those whose process is gone, and no others."""
+    from helen_amd.stitch_collect import CollectorRun
+    dead = 2 ** 22 + 12345                                       # (beyond pid_max of this machine: nobody)
+    assert not os.path.exists("/proc/%d" % dead)
+    stale = [tmp_path / ("helen_regions_%d_abc_0_0.bin" % dead), tmp_path / ("helen_regions_%d_abc_part0.fa" % dead)]
+    alive = tmp_path / ("helen_regions_%d_abc_0_0.bin" % os.getppid())
+    other = tmp_path / "helen_slot_1_2_3"
+    for f in stale + [alive, other]:
+        f.write_bytes(b"x")
+    assert CollectorRun.sweep(str(tmp_path)) == 2
+    assert not any(f.exists() for f in stale) and alive.exists() and other.exists()
