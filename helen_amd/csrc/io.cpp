@@ -767,6 +767,8 @@ int helen_io_read_image_range(const char* path, long long first, int count, uint
 /* How a file's images are stored, from its first image (a MarginPolish run writes all of them alike): out[0] = 0 the direct
  * scanner reads the file, 1 libhdf5 has to; out[1] = layout class of `image` (0 compact, 1 contiguous, 2 chunked, -1 not
  * inspected); out[2] = number of filters; out[3] = 1 if deflate is among them.  Returns 1 if the file has no images. */
+int helen_io_fast_inflate(void) { return h5scan::fast_inflate().ok ? 1 : 0; }
+
 int helen_io_image_storage(const char* path, int* out) {
     out[0] = 0;
     out[1] = -1;

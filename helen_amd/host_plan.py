@@ -27,7 +27,15 @@ READER_WINDOWS_PER_S = 30000.0
 # the direct scanner does not take costs libhdf5's six object opens per window (3.2-12.6 k from its one thread per
 # process).  The plan prices a run with the storage class it FINDS (the first image of every file:
 # helen_amd.native_io.image_storage).
+# Round 5: deflated chunks go through libdeflate where the system has it (helen_amd/csrc/h5scan.h; profiles/
+# r05_reader_variants.txt: 13.7-16.5 k windows/s from one thread, 100-124 k from eight on pileup-like pixels).
 READER_RATE = {"contiguous": 65000.0, "chunked": 50000.0, "deflate": 5600.0, "libhdf5": 5000.0}
+try:
+    from . import native_io as _native_io
+    if _native_io.fast_inflate():
+        READER_RATE["deflate"] = 12500.0
+except Exception:          # noqa: BLE001 -- no native library: the zlib figure stands
+    pass
 DEVICE_WINDOWS_PER_S = 81000.0
 WRITER_WINDOWS_PER_S = 100000.0
 RANK_THREADS = 2            # the rank's own busy threads: device stage + writer (feeder and release threads sleep)

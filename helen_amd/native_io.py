@@ -379,6 +379,14 @@ def region_sequence(path, contig, region, as_bytes=False):
         return buf.raw[:n] if as_bytes else buf.raw[:n].decode()
 
 
+def fast_inflate():
+    """Are deflated chunks inflated through libdeflate (helen_io_fast_inflate)?  False without the native library."""
+    if not available():
+        return False
+    lib = load()
+    return bool(lib.helen_io_fast_inflate()) if hasattr(lib, "helen_io_fast_inflate") else False
+
+
 def decode_regions(first, rows, positions, bases, rles, threads=1):
     """Sequences of regions whose images are in memory (helen_io_decode_regions): region r = windows
     rows[first[r]:first[r + 1]] of positions int64 [*, 1000, 3] / bases, rles uint8 [*, 1000], listed in the string order

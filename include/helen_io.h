@@ -73,6 +73,8 @@ void helen_io_forget_images(const char* path);
  * out[1] = layout class of `image` (0 compact, 1 contiguous, 2 chunked; -1 not inspected); out[2] = number of filters;
  * out[3] = 1 if deflate is among them.  Returns 1 if the file has no images.  (helen_amd.host_plan prices a run with it.) */
 int helen_io_image_storage(const char* path, int* out);
+/* 1 when deflated chunks are inflated through libdeflate (found at run time; 2-3 x zlib's rate), 0 when through zlib. */
+int helen_io_fast_inflate(void);
 
 /* The loader of `helen_train test` (`models/dataloader.py:48-61`): image uint8 [1000, 90], label_base and
  * label_run_length uint8 [1000] of `n` images of one file, exactly as stored (that loader does not pad: any other
