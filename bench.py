@@ -36,6 +36,15 @@ FLOP_PER_WINDOW = 1772441600.0        # 932,864 FLOP/step x 100 st
 # also carry the heads' product (8,192 FLOP per timestep).  Averaged over the encoder and
 # decoder launches, which the timing below also averages.
 GRU_FLOP_PER_WINDOW_LAUNCH = 100 * 2 * 2.0 * 384 * 128 + 100 * 8192 / 2.0
+# SURVEY.md 8d's matmul FLOPs per GRU timestep, both directions, by where a call spends them
+ENC_PROJ_FLOP_STEP = 2 * 2.0 * 384 * 90       # x_t . W_ih^T, encoder
+ENC_REC_FLOP_STEP = 2 * 2.0 * 384 * 128       # h . W_hh^T, encoder
+DEC_PROJ_FLOP_STEP = 2 * 2.0 * 384 * 256      # y1_t . W_ih^T, decoder
+DEC_REC_FLOP_STEP = 2 * 2.0 * 384 * 128       # h . W_hh^T, decoder
+HEADS_FLOP_STEP = 2.0 * 256 * 16              # [h_fwd | h_bwd] . [W_base ; W_rle]^T
+# one fused bf16 layer launch (projection + recurrence; the decoder's also the heads), averaged over the two layers
+BF16_LAYER_FLOP_PER_WINDOW_LAUNCH = 100 * (ENC_PROJ_FLOP_STEP + ENC_REC_FLOP_STEP + DEC_PROJ_FLOP_STEP + DEC_REC_FLOP_STEP
+                                           + HEADS_FLOP_STEP) / 2.0
 FP32_MFMA_PEAK = 157.3e12             # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 BF16_MFMA_PEAK = 2.5e15               # MI355X_MICROARCH.md: bf16 MFMA, dense
 
@@ -81,6 +90,46 @@ def pmc_call_bytes_per_window(precision="fp32"):
         return int(per_call) if per_call else None
     except Exception:
         return None
+
+
+def kernel_table(all_stats, calls, call_windows, precision, ms_per_step):
+    """`roofline.kernels`: every kernel class of a device call with its share of a step and its own roofline fraction,
+    from HIP events around EVERY launch of `calls` extra (untimed-for-the-headline) calls on the launch stream.
+    Algorithmic FLOPs per window and launch are SURVEY.md 8d's, split by where the call spends them; `pipe` is the matrix
+    pipe the class's kernels issue to in this precision."""
+    enc_all = 1000 * ENC_PROJ_FLOP_STEP                 # the encoder projection is computed ONCE for all 1000 positions
+    if precision == "bf16":
+        flop = {"gru_enc": 100 * (ENC_PROJ_FLOP_STEP + ENC_REC_FLOP_STEP),
+                "gru_dec": 100 * (DEC_PROJ_FLOP_STEP + DEC_REC_FLOP_STEP + HEADS_FLOP_STEP)}
+        peak, pipe = BF16_MFMA_PEAK, "bf16 MFMA (v_mfma_f32_16x16x32_bf16 / 32x32x16), fp32 accumulate"
+    else:
+        flop = {"gemm_enc": enc_all, "gru_enc": 100 * ENC_REC_FLOP_STEP, "gemm_dec": 100 * DEC_PROJ_FLOP_STEP,
+                "gru_dec": 100 * (DEC_REC_FLOP_STEP + HEADS_FLOP_STEP)}
+        if precision == "fp32x3":
+            peak, pipe = X3_MFMA_PEAK, "bf16 MFMA, 6 products of 3-term splits per fp32 product (peak = bf16 / 6)"
+        else:
+            peak, pipe = FP32_MFMA_PEAK, "fp32 MFMA (v_mfma_f32_16x16x4_f32 / 4x4x1)"
+    hbm_bytes = {"pack": 90000.0 + 96 * 4 * 1000.0}     # uint8 image in, K-padded fp32 operand tiles out (fp32 mode)
+    rows = []
+    for name, (ms, n) in all_stats.items():
+        if n == 0:
+            continue
+        avg = ms / n
+        per_step = ms / calls
+        row = {"class": name, "launches_per_call": round(n / float(calls), 2), "avg_launch_ms": round(avg, 4),
+               "ms_per_step": round(per_step, 3), "share_of_step": round(per_step / ms_per_step, 4)}
+        if name in flop:
+            tf = flop[name] * call_windows / (avg * 1e-3) / 1e12
+            row.update({"bound": "mfma", "pipe": pipe, "flop_per_window_launch": flop[name], "achieved_TFLOPs": round(tf, 1),
+                        "frac": round(tf * 1e12 / peak, 4)})
+        elif name in hbm_bytes and precision == "fp32":
+            gb = hbm_bytes[name] * call_windows / (avg * 1e-3) / 1e9
+            row.update({"bound": "hbm", "achieved_GBps": round(gb, 1), "frac": round(gb / 8000.0, 4)})
+        else:
+            row.update({"bound": "latency" if name == "heads" else "hbm", "frac": None})
+        rows.append(row)
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows
 
 
 def usable_cpus():
@@ -373,12 +422,19 @@ def mode_report(precision, batch, coalesce, images, dev, fp32_labels, steps=8, w
         torch.cuda.synchronize(dev)
         elapsed = time.perf_counter() - t0
         stats = eng.kernel_stats()
+        eng.set_profiling(list(_lib.KERNEL_CLASSES))          # every class, launch by launch, outside the timed region
+        run(1)
+        torch.cuda.synchronize(dev)
+        eng.reset_kernel_stats()
+        run(4)
+        torch.cuda.synchronize(dev)
+        all_stats = eng.kernel_stats()
         eng.set_profiling([])
         value = steps * call_windows / elapsed
         n_l = stats["gru_enc"][1] + stats["gru_dec"][1]
         avg_ms = (stats["gru_enc"][0] + stats["gru_dec"][0]) / max(n_l, 1)
         if precision == "bf16":
-            peak, flop = BF16_MFMA_PEAK, 100 * 2 * 384 * 2 * ((90 + 128) + (256 + 128) + 16) / 2.0
+            peak, flop = BF16_MFMA_PEAK, BF16_LAYER_FLOP_PER_WINDOW_LAUNCH
             kernel = ("gru_fused_bf16_* (projection + recurrence per layer, bf16 MFMA, fp32 accumulate / state / gates); "
                       "peak = dense bf16 MFMA")
         else:
@@ -400,6 +456,7 @@ def mode_report(precision, batch, coalesce, images, dev, fp32_labels, steps=8, w
                             "avg_launch_ms_decoder": round(stats["gru_dec"][0] / max(stats["gru_dec"][1], 1), 4),
                             "launches": n_l, "traffic": traffic, "traffic_source": traffic_src,
                             "path_frac": round(value * FLOP_PER_WINDOW / peak, 4),
+                            "kernels": kernel_table(all_stats, 4, call_windows, precision, elapsed * 1e3 / steps),
                             "path_frac_of_fp32_mfma_peak": round(value * FLOP_PER_WINDOW / FP32_MFMA_PEAK, 4)},
                "label_identity": {"base": round(same_b, 6), "rle": round(same_r, 6), "windows": k,
                                   "against": "the fp32 path's labels of the same windows (the headline run above)"}}
@@ -440,21 +497,48 @@ def trained_weights():
     return {k: np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files if not k.startswith("_")}
 
 
-def e2e_size(windows_per_rank, world, may_shrink, free=None):
-    """What the end-to-end leg will run with: (windows per rank, bytes of RAM-backed space it needs, where it goes).
-    The default leg (no --e2e given) shrinks to what may be put into /dev/shm for ALL ranks -- its free space AND half
-    of the RAM the process tree may still take (MemAvailable, memory-cgroup head-room: tmpfs pages are RAM; sizing by
-    statvfs alone took a box down in round 5) -- down to two device calls per rank; with one rank it may go to the temp
-    directory instead; otherwise it is skipped."""
-    from helen_amd.host_plan import SLOT_BYTES_PER_WINDOW, ram_backed_budget_bytes
+# what the end-to-end leg costs in RAM besides its RAM-backed files, measured on the GPU box with scripts/dev/watch_box.sh
+# (profiles/r06_scale_single_device.json, N = 2): the input generator's worker processes hold a whole file each while they
+# render it -- 5.3 GB per worker at 18,750 windows per file = 2.5 x the file's image + position bytes, 85 GB over 16 workers
+# -- and a bench rank keeps ~6 GB (device context, heaps, page-locked host-path buffers) while it waits for rank 0
+E2E_GENERATOR_TRANSIENT = 3.0 * 114152      # bytes of worker RSS per window of the file being rendered (2.5 measured)
+E2E_RANK_RESIDENT_BYTES = 8 << 30           # per bench rank (6 GB measured)
+E2E_RAM_FRACTION = 0.8                      # of what the process tree may still take (MemAvailable / cgroup head-room)
+
+
+def e2e_generator_processes(world, cpus=None):
+    """Worker processes PER RANK of the synthetic-input generation."""
+    return max(1, min(8, (usable_cpus() if cpus is None else cpus) // world))
+
+
+def e2e_size(windows_per_rank, world, may_shrink, free=None, ram=None, cpus=None):
+    """What the end-to-end leg will run with: (windows per rank, bytes of RAM-backed space it needs, where it goes, the
+    tmpfs budget).  The default leg (no --e2e given) shrinks -- down to two device calls per rank -- until BOTH hold:
+    its RAM-backed files fit the tmpfs budget (`free`: /dev/shm's free space and no more than half of the RAM the process
+    tree may still take), and files + the generator workers' transient memory + the bench ranks' own resident memory
+    fit 0.8 of that RAM (`ram`; None = unknown, not checked).  Round 5 sized the leg by statvfs alone and lost a box at
+    N = 2; sizing it by the tmpfs budget alone leaves N = 8 on a 300 GiB cgroup at 160 GB of files + 85 GB of generator
+    workers + 8 x 6 GB of ranks + the 8 call_consensus processes' slots: over the limit.  With one rank the
+    leg may go to the temp directory instead of /dev/shm; otherwise it is skipped."""
+    from helen_amd.host_plan import SLOT_BYTES_PER_WINDOW, ram_available_bytes, ram_backed_budget_bytes
 
     def need_bytes(per_rank):     # inputs + slots + outputs (four runs at a time) + FASTAs, all ranks, all RAM-backed
         return per_rank * world * (116000 + 4 * 16000 + 4 * 1500) + world * 5 * 4096 * SLOT_BYTES_PER_WINDOW
-    free = ram_backed_budget_bytes() if free is None else free
+
+    def ram_bytes(per_rank):
+        workers = world * e2e_generator_processes(world, cpus)
+        return (need_bytes(per_rank) + workers * (per_rank / float(E2E_FILES_PER_RANK)) * E2E_GENERATOR_TRANSIENT
+                + world * E2E_RANK_RESIDENT_BYTES)
+    if free is None:
+        free = ram_backed_budget_bytes()
+        ram = ram_available_bytes() if ram is None else ram
+
+    def fits(per_rank):
+        return free > need_bytes(per_rank) * 1.1 and (ram is None or ram_bytes(per_rank) <= E2E_RAM_FRACTION * ram)
     n = windows_per_rank
-    while may_shrink and n > 8192 and free <= need_bytes(n) * 1.1:
+    while may_shrink and n > 8192 and not fits(n):
         n = max(8192, n - 4096)
-    where = "/dev/shm" if free > need_bytes(n) * 1.1 else ("tmp" if world == 1 else None)
+    where = "/dev/shm" if fits(n) else ("tmp" if world == 1 else None)
     return n, need_bytes(n), where, free
 
 
@@ -478,7 +562,7 @@ def plan_only(args, rank, world):
         host = plan_host(list(range(world)), args.e2e_workers, 4096)
         out["end_to_end"] = {"windows_per_rank_asked": e2e_windows, "windows_per_rank": n, "shrunk": n != e2e_windows,
                              "ram_bytes_needed": need, "shm_free_bytes": free, "directory": where, "image_files": n_files,
-                             "contigs": len(spec), "generation_processes_per_rank": max(1, min(8, usable_cpus() // world)),
+                             "contigs": len(spec), "generation_processes_per_rank": e2e_generator_processes(world),
                              "stitch_threads": max(1, min(16, usable_cpus())), "host_plan": host.as_dict()}
     return out
 
@@ -506,6 +590,15 @@ def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_de
     from helen_amd.model_handler import ModelHandler
     from helen_amd.synthetic import assembly_spec, write_assembly_dir
     box = [None, windows_per_rank, 0]
+    # this rank's page-locked host-path buffers are still cached by torch's host allocator (3.3 GB): give them back
+    import gc
+    gc.collect()
+    try:
+        import torch
+        torch.cuda.empty_cache()
+        getattr(torch._C, "_host_emptyCache", lambda: None)()
+    except Exception:           # noqa: BLE001 -- housekeeping only
+        pass
     if rank == 0:
         box[1], box[2], where, free = e2e_size(windows_per_rank, world, may_shrink)
         if box[1] != windows_per_rank:
@@ -530,7 +623,7 @@ def end_to_end(windows_per_rank, workers, batch, weights, rank, world, single_de
         try:
             # file fi goes to caller fi % world (round-robin over the sorted list): this rank writes its own
             write_assembly_dir(img_dir, spec, n_files, direct=True, only_files=[fi for fi in range(n_files) if fi % world == rank],
-                               processes=max(1, min(8, usable_cpus() // world)))
+                               processes=e2e_generator_processes(world))
         except Exception as e:          # noqa: BLE001 -- agreed on by all ranks below
             write_error = "%s: %s" % (type(e).__name__, e)
         t_write = time.time() - t0
@@ -847,6 +940,17 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     stats = eng.kernel_stats()
+    # every kernel class of the call, bracketed launch by launch on the same stream, over a few extra calls OUTSIDE the timed
+    # region (events around all 77 launches of a call would cost the headline ~0.3 %): `roofline.kernels`
+    from helen_amd._lib import KERNEL_CLASSES
+    table_calls = 4
+    eng.set_profiling(list(KERNEL_CLASSES))
+    run(2)
+    torch.cuda.synchronize(dev)
+    eng.reset_kernel_stats()
+    run(table_calls)
+    torch.cuda.synchronize(dev)
+    all_stats = eng.kernel_stats()
     eng.set_profiling([])
     my_elapsed = elapsed
 
@@ -908,7 +1012,7 @@ def main():
         if args.precision == "bf16":
             # the fused layer kernels do projection + recurrence (+ the decoder's head partials): count a
             # layer launch's algorithmic matmul FLOPs, averaged over the encoder and decoder launches
-            flop = 100 * 2 * 384 * 2 * ((90 + 128) + (256 + 128) + 16) / 2.0
+            flop = BF16_LAYER_FLOP_PER_WINDOW_LAUNCH
             achieved = flop * win_per_launch / (avg_ms * 1e-3) / 1e12
         out = {
             "metric": "pileup windows/sec (batch 256, 1000-pos)",
@@ -950,7 +1054,8 @@ def main():
                          "avg_launch_ms_encoder": round(stats["gru_enc"][0] / max(stats["gru_enc"][1], 1), 4),
                          "avg_launch_ms_decoder": round(stats["gru_dec"][0] / max(stats["gru_dec"][1], 1), 4),
                          "path_frac": round(value / world * FLOP_PER_WINDOW /
-                                            (BF16_MFMA_PEAK if args.precision == "bf16" else FP32_MFMA_PEAK), 4)},
+                                            (BF16_MFMA_PEAK if args.precision == "bf16" else FP32_MFMA_PEAK), 4),
+                         "kernels": kernel_table(all_stats, table_calls, call_windows, args.precision, my_elapsed * 1e3 / args.steps)},
         }
         if args.precision != "fp32":
             out["precision_check"] = precision_check(eng, args.precision, images, dev)

@@ -5,15 +5,9 @@
 
 #include "kernels_fused_bf16.h"
 
-#ifndef HELEN_BF16_IL_PARKED       // K32 groups of the decoder's W_ih kept in LDS instead of registers (24 KiB each): none needed
 #define HELEN_BF16_IL_PARKED 0
-#endif
-#ifndef HELEN_BF16_IL_ADEPTH       // A fragments in flight (4 registers each)
 #define HELEN_BF16_IL_ADEPTH(dec) ((dec) ? 5 : 7)
-#endif
-#ifndef HELEN_BF16_IL_LEAD         // gate slots ahead of the first MFMA of a region
 #define HELEN_BF16_IL_LEAD(dec) ((dec) ? 6 : 1)
-#endif
 
 #define HELEN_PIN(x) asm volatile("" : "+v"(x))
 
@@ -194,10 +188,6 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
 #pragma unroll
     for (int x = 0; x < 2; ++x) Pr[x] = Pz[x] = Pn[x] = Pg[x] = splat4(0.f);
 
-#ifdef HELEN_BIL_TIMING   // developer probe: where a wave's cycles go
-    long long tk[3] = {0, 0, 0};
-    long long tlast = __builtin_readcyclecounter();
-#endif
     constexpr int NIN = 3 * MI, NHEAD = DEC ? 2 : 0, NREC = 12;
     constexpr int NM = NIN + NHEAD + NREC;            // MFMAs of one M phase: the step's input part, head slice of h(s-1), recurrent part
     constexpr int NS = 40;                            // gate slots
@@ -245,11 +235,7 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
         // front of the fragments -- so that hipcc's waits for them cannot drain the prefetch ring -- they measured SLOWER:
         // decoder 0.480 against 0.468 ms, encoder 0.345 against 0.335, profiles/r04_bf16_own.txt.)
         f32x4 hd = splat4(0.f);
-#ifdef HELEN_BIL_HEADNOLOAD       // (timing probe: the head's MFMAs on a register constant)
-        hd = splat4(bn);
-#else
         if (DEC && has_prev) hd = hx[v * 64 + lane];
-#endif
         __builtin_amdgcn_sched_barrier(0);
         static_for<AD>([&](auto F) __attribute__((always_inline)) { fetch_a(F); });
         // fragment f has arrived when at most min(NF - 1 - f, AD - 1) younger fetches are outstanding
@@ -303,7 +289,6 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
         bf16x8 ha;
         auto head_item = [&](auto E) __attribute__((always_inline)) {
             constexpr int e = decltype(E)::value;
-#ifndef HELEN_BIL_NOHEAD
             if (has_prev) {
                 if constexpr (e == 0) {
                     ha = head_split_h(hd);
@@ -313,7 +298,6 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
                 }
                 HELEN_PIN(pl);
             }
-#endif
         };
         auto mfma_item = [&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
@@ -357,22 +341,12 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
         static_for<(NM + kLead > NS ? NM + kLead : NS)>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
             __builtin_amdgcn_sched_barrier(0);
-#ifndef HELEN_BIL_NOMFMA     // (timing probes: results are garbage)
             if constexpr (i >= kLead && i - kLead < NM) mfma_item(std::integral_constant<int, (i >= kLead ? i - kLead : 0)>{});
-#endif
             __builtin_amdgcn_sched_barrier(0);
-#ifndef HELEN_BIL_NOGATES
             if constexpr (i < NS) gate_slot(I);
-#endif
         });
         __builtin_amdgcn_sched_barrier(0);
         ring_rd[x] = ring_rd[x] == (RD - 1u) * MI * 1024u ? 0u : ring_rd[x] + MI * 1024u;
-#ifdef HELEN_BIL_NOGATES
-        static_for<4>([&](auto C) { hn[decltype(C)::value] = gr[decltype(C)::value] + gz[decltype(C)::value] + gnn[decltype(C)::value] + ggn[decltype(C)::value]; });
-#endif
-#ifdef HELEN_BIL_NOMFMA
-        ar = az = gnx = ahn = splat4(bn);
-#endif
         if constexpr (gates) {     // new h of tile o -> LDS (fp32 state / layer output, bf16 plane)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -398,21 +372,12 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
             }
             y_next[x] += 128 * 16;
         }
-#ifdef HELEN_BIL_TIMING
-        { __builtin_amdgcn_sched_barrier(0); long long now_ = __builtin_readcyclecounter(); tk[0] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
-#endif
         if (issued == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (issued == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifdef HELEN_BIL_TIMING
-        { __builtin_amdgcn_sched_barrier(0); long long now_ = __builtin_readcyclecounter(); tk[1] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
-#endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-#ifdef HELEN_BIL_TIMING
-        { __builtin_amdgcn_sched_barrier(0); long long now_ = __builtin_readcyclecounter(); tk[2] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
-#endif
         __builtin_amdgcn_sched_barrier(0);
     };
     using I0 = std::integral_constant<int, 0>;
@@ -441,11 +406,6 @@ __global__ __launch_bounds__(512, 1) void gru_fused_bf16_il_kernel(
         region(I1{}, I1{}, I0{}, Yes{}, Yes{}, s + 1, s + 1);
     }
     for (; s < T; ++s) step(No{}, s);
-#ifdef HELEN_BIL_TIMING
-    if (blockIdx.x == 0 && lane == 0)
-        printf("bf16 il %s dir %d wave %d: cycles per region  stream %lld  waits %lld  barrier %lld\n", DEC ? "dec" : "enc", dir, v,
-               tk[0] / (2 * T), tk[1] / (2 * T), tk[2] / (2 * T));
-#endif
     // the gates of tile 1's last step (nothing left to interleave them with), into buffer T & 1
     {
         const int last = T & 1;

@@ -22,18 +22,10 @@ namespace helen {
 // npos-1-pos for direction 1.
 // ------------------------------------------------------------------------------------------------
 // waves per projection workgroup; 8 / HELEN_GEMM_WAVES workgroups (grid.z) cover the 48 column tiles
-#ifndef HELEN_GEMM_WAVES
 #define HELEN_GEMM_WAVES 1   // measured at 10 positions per wave: 1 -> 1.164 ms, 2 -> 1.180, 4 -> 1.215 per decoder launch
-#endif
-#ifndef HELEN_GEMM_P
 #define HELEN_GEMM_P 10  // positions per wave of the streaming-weights projection (4: 1.21 ms, 5: 1.19, 10: 1.18 per decoder launch)
-#endif
-#ifndef HELEN_GEMM_N
 #define HELEN_GEMM_N 6   // column tiles per wave (48 / N wave slots per position group)
-#endif
-#ifndef HELEN_GEMM_DEPTH
 #define HELEN_GEMM_DEPTH 2   // operand groups in flight, including the one being multiplied
-#endif
 template <int MG, bool REV_A>
 __global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_kernel(const f32x4* __restrict__ A, long a_tile_stride,
                                                       const f32x4* __restrict__ Wp,
@@ -127,9 +119,7 @@ __global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_kernel(const f3
 //   LDS-DMA into a 2-deep ring, 384 MFMAs per wave per barrier, and the 16 output stores of a stage stay
 //   in flight across the next barrier.  Two workgroups per CU.
 // ------------------------------------------------------------------------------------------------
-#ifndef HELEN_WS_PB
 #define HELEN_WS_PB 4
-#endif
 __global__ __launch_bounds__(256, 2) void gemm_enc_ws_kernel(const f32x4* __restrict__ A, long a_tile_stride,
                                                              const f32x4* __restrict__ Wp,
                                                              const float* __restrict__ bias,
@@ -224,12 +214,10 @@ __global__ __launch_bounds__(256, 2) void gemm_enc_ws_kernel(const f32x4* __rest
 //   Same MFMA order per accumulator as gemm_gi_kernel<16, true> (m ascending, e ascending): bit-identical gi.
 //   Grid: the two directions of a tile sit on one XCD (ids b, b + 8) so that y1 comes from HBM once.
 // ------------------------------------------------------------------------------------------------
-#ifndef HELEN_DWS_PB
 #define HELEN_DWS_PB 4
-#endif
 constexpr int kDecWsLdsF4 = 2 * HELEN_DWS_PB * 16 * 64;   // 2 x PB x 16 KiB
-// (the body is a device function over one (tile, direction) and a caller-provided LDS block of kDecWsLdsF4 float4:
-// gemm_dec_ws_kernel below is one call per workgroup; polish_persistent_kernel calls it per chunk and tile)
+// (the body is a device function over one (tile, direction) and a caller-provided LDS block of kDecWsLdsF4 float4;
+// gemm_dec_ws_kernel below is one call per workgroup)
 __device__ __forceinline__ void gemm_dec_ws_body(f32x4* __restrict__ smem, const int tile, const int dir,
                                                  const f32x4* __restrict__ A, long a_tile_stride,
                                                  const f32x4* __restrict__ Wp,
@@ -352,9 +340,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dec_wsp_kernel(const f32x4* __res
 //   6 output stores (the 3 MB of gi per window are what this kernel mostly does).  Two waves per SIMD.
 //   Same MFMA order per accumulator as gemm_gi_kernel<6, false> / gemm_enc_ws_kernel: bit-identical gi.
 // ------------------------------------------------------------------------------------------------
-#ifndef HELEN_EWS8_PB
 #define HELEN_EWS8_PB 8
-#endif
 // (the body over one tile and positions [p0, p1): gemm_enc_ws8_kernel takes all of a tile's positions, gemm_enc_ws8p_kernel
 // cuts them into runs for small calls)
 __device__ __forceinline__ void gemm_enc_ws8_body(f32x4* __restrict__ smem, const int tile, const f32x4* __restrict__ A,

@@ -92,25 +92,6 @@ __device__ __forceinline__ f32x4 gru_cell4(f32x4 ar, f32x4 az, f32x4 an, f32x4 g
     return f32x4{lo.x, lo.y, hi.x, hi.y};
 }
 
-// The same four cells on SCALAR instructions (the same IEEE operations per component: same bits).  Beside bf16 MFMAs a
-// packed fp32 instruction costs a SIMD 16 cycles where two scalar ones cost 2 x 4.7 (scripts/ubench/bf16_mfma_valu_overlap.hip):
-// probe form for the bf16 layer kernels (-DHELEN_BP_SCALAR_GATES).  The empty asm keeps the SLP vectoriser from packing them again.
-__device__ __forceinline__ float gru_cell1_scalar(float sr, float sz, float an, float gn, float hp) {
-    float er = __builtin_amdgcn_exp2f(sr * -1.4426950408889634f);
-    float ez = __builtin_amdgcn_exp2f(sz * -1.4426950408889634f);
-    asm volatile("" : "+v"(er), "+v"(ez));
-    const float rg = __builtin_amdgcn_rcpf(1.0f + er);
-    const float zg = __builtin_amdgcn_rcpf(1.0f + ez);
-    float pre = __builtin_fmaf(rg, an, gn);
-    asm volatile("" : "+v"(pre));
-    const float ng = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre * 2.8853900817779268f)), 1.0f);
-    return __builtin_fmaf(zg, hp - ng, ng);
-}
-__device__ __forceinline__ f32x4 gru_cell4_scalar(f32x4 sr, f32x4 sz, f32x4 an, f32x4 gn, const float (&hp)[4]) {
-    return f32x4{gru_cell1_scalar(sr.x, sz.x, an.x, gn.x, hp[0]), gru_cell1_scalar(sr.y, sz.y, an.y, gn.y, hp[1]),
-                 gru_cell1_scalar(sr.z, sz.z, an.z, gn.z, hp[2]), gru_cell1_scalar(sr.w, sz.w, an.w, gn.w, hp[3])};
-}
-
 constexpr int kGruLdsF4 = 2 * 512 + 4 * 384 + 4 * 512;  // h[2] | gi[4 waves] | W tile 5[4 waves]
 
 template <bool DEC>
@@ -206,13 +187,6 @@ __global__ __launch_bounds__(256, 2) void gru_kernel(const f32x4* __restrict__ g
     }
     f32x4* y_p = y + (size_t)tile * y_tile_stride + (size_t)dir * (kHidDirStride / 4);
 
-#ifdef HELEN_GRU_TIMING
-    long long tk[7] = {0, 0, 0, 0, 0, 0, 0};
-#define HELEN_TICK(i) { __builtin_amdgcn_sched_barrier(0); long long now_ = __builtin_readcyclecounter(); tk[i] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
-    long long tlast = __builtin_readcyclecounter();
-#else
-#define HELEN_TICK(i)
-#endif
     for (int s = 0; s < T; ++s) {
         const int cur = s & 1;
         const f32x4* hb = hbuf + cur * 512 + lane;
@@ -251,7 +225,6 @@ __global__ __launch_bounds__(256, 2) void gru_kernel(const f32x4* __restrict__ g
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef HELEN_GRU_MMA
-        HELEN_TICK(0)
         // gate pre-activations of this step (DMA'd during the previous step), then refill the slot
         // VMEM queue of this wave, oldest first: 6 gi DMAs (issued last step), 2 y stores (issued
         // after last step's barrier).  vmcnt(2) = the DMAs have landed; the stores may still fly.
@@ -263,14 +236,11 @@ __global__ __launch_bounds__(256, 2) void gru_kernel(const f32x4* __restrict__ g
             asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        HELEN_TICK(5)
         f32x4 G[6];
 #pragma unroll
         for (int n = 0; n < 6; ++n) G[n] = gbuf[n * 64 + lane];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        HELEN_TICK(6)
         if (s + 1 < T) dma_gi(slot0 + s + 1);
-        HELEN_TICK(1)
 
         float* hw = (float*)(hbuf + (cur ^ 1) * 512);
 #pragma unroll
@@ -282,12 +252,10 @@ __global__ __launch_bounds__(256, 2) void gru_kernel(const f32x4* __restrict__ g
                 hw[hoff[hh] + 4 * r] = hn[r];
             }
         }
-        HELEN_TICK(2)
         // raw barrier: only LDS traffic has to be drained, the gi DMA stays in flight across it
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        HELEN_TICK(3)
         if (DEC) {
             if (s > 0) head_store(s - 1);
         } else {
@@ -297,19 +265,12 @@ __global__ __launch_bounds__(256, 2) void gru_kernel(const f32x4* __restrict__ g
             yo[tid] = hn4[tid];
             yo[tid + 256] = hn4[tid + 256];
         }
-        HELEN_TICK(4)
     }
     if (DEC) {   // the last step's logits
         head_partial(T & 1, (T - 1) & 1);
         __syncthreads();
         head_store(T - 1);
     }
-#ifdef HELEN_GRU_TIMING
-    if (tile == 0 && lane == 0) {
-        printf("gru dir %d wave %d: cycles/step  mfma %lld  vmwait %lld  Gread %lld  dma-issue %lld  gates %lld  barrier %lld  ycopy %lld\n",
-               dir, w, tk[0] / T, tk[5] / T, tk[6] / T, tk[1] / T, tk[2] / T, tk[3] / T, tk[4] / T);
-    }
-#endif
     const f32x4* hl = hbuf + (T & 1) * 512;
     hid_p[tid] = hl[tid];
     hid_p[tid + 256] = hl[tid + 256];

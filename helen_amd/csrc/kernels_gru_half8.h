@@ -33,15 +33,7 @@ namespace helen {
 // 16x16x4, partials to LDS, added in the same order by one wave: the same logits bit for bit.
 // grid (2 x tiles, 2 directions), 256 threads.
 // ------------------------------------------------------------------------------------------------
-#ifdef HELEN_H8_TIMING   // developer probe: where a wave's cycles go (results unchanged; -DHELEN_H8_NOGI: no gi traffic)
-#define HELEN_H8_TICKS long long tk[4] = {0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
-#define HELEN_H8_TICK(i) { __builtin_amdgcn_sched_barrier(0); const long long now_ = __builtin_readcyclecounter(); tk[i] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
-#define HELEN_H8_REPORT(name) if (blockIdx.x == 0 && lane == 0) printf("%s %s dir %d wave %d: cycles per step  mfma stream %lld  stores + gates + lds writes %lld  lgkm wait + barrier %lld  A reload issue %lld\n", name, DEC ? "dec" : "enc", dir, w, tk[0] / T, tk[1] / T, tk[2] / T, tk[3] / T);
-#else
-#define HELEN_H8_TICKS
-#define HELEN_H8_TICK(i)
 #define HELEN_H8_REPORT(name)
-#endif
 
 template <int N, typename F>
 __device__ __forceinline__ void half8_for(F&& f) {   // f(integral_constant<0>) ... f(integral_constant<N-1>)
@@ -163,14 +155,11 @@ __global__ __launch_bounds__(256, 1) void gru_half8_kernel(const f32x4* __restri
         }
         return hp;
     };
-    HELEN_H8_TICKS
     auto step = [&](auto CUR, int s) __attribute__((always_inline)) {
         constexpr int cur = decltype(CUR)::value;
         const bool has_prev = s > 0, has_prev2 = s > 1, has_next = s + 1 < T;
         f32x4 acc[3], yv = splat4(0.f), hd = splat4(0.f), hp = splat4(0.f);
-#ifndef HELEN_H8_NOGI
         if (has_next) load_gi(cur ^ 1);
-#endif
         if (!DEC && has_prev) yv = hbuf[cur * 256 + tid];
         // (DEC: the head product of h(s-1) rides in the stream, one MFMA per k of its sixteen; at s = 0 it multiplies the
         // initial state and nobody takes the result)
@@ -190,7 +179,6 @@ __global__ __launch_bounds__(256, 1) void gru_half8_kernel(const f32x4* __restri
         // (no branch inside the MFMA stream: hipcc sinks the part of a chain that sits in front of one into the block
         // behind it -- that chain's MFMAs then run back to back, two wait states each)
         __builtin_amdgcn_sched_barrier(0);
-        HELEN_H8_TICK(0)
         if (!DEC && has_prev) {
             *(f32x4*)(y_next + in_block(tile16)) = yv;
             y_next += kYStride * 4;
@@ -211,15 +199,12 @@ __global__ __launch_bounds__(256, 1) void gru_half8_kernel(const f32x4* __restri
             hw[hoff + 4 * r] = hn[r];
         }
         if (DEC && has_prev) part[(((s - 1) & 1) * 8 + 2 * w + slH) * 32 + wgH * 16 + 4 * pH + j] = hp;
-        HELEN_H8_TICK(1)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        HELEN_H8_TICK(2)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) A4[g4] = abuf[(cur ^ 1) * 256 + g4 * 64 + lane];
         __builtin_amdgcn_sched_barrier(0);
-        HELEN_H8_TICK(3)
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -376,14 +361,11 @@ __global__ __launch_bounds__(256, 1) void gru_quarter4_kernel(const f32x4* __res
         }
         return hp;
     };
-    HELEN_H8_TICKS
     auto step = [&](auto CUR, int s) __attribute__((always_inline)) {
         constexpr int cur = decltype(CUR)::value;
         const bool has_prev = s > 0, has_prev2 = s > 1, has_next = s + 1 < T;
         f32x4 arz = splat4(0.f), an = bnv, yv = splat4(0.f), hd = splat4(0.f), hp = splat4(0.f);
-#ifndef HELEN_H8_NOGI
         if (has_next) load_gi(cur ^ 1);
-#endif
         if (!DEC && has_prev && mover) yv = hbuf[cur * 128 + tid];
         if (DEC) hd = hbuf[cur * 128 + (4 * (4 * (w & 1) + slH) + pH) * 4 + j];
         half8_for<128>([&](auto TT) __attribute__((always_inline)) {
@@ -395,7 +377,6 @@ __global__ __launch_bounds__(256, 1) void gru_quarter4_kernel(const f32x4* __res
                 hp = __builtin_amdgcn_mfma_f32_4x4x1f32(hd[(t - 16) >> 2], HB[t - 16], hp, 2, (t - 16) & 3, 0);
         });
         __builtin_amdgcn_sched_barrier(0);   // (no branch inside the MFMA stream: see gru_half8_kernel)
-        HELEN_H8_TICK(0)
         if (!DEC && has_prev) {
             if (mover) *(f32x4*)(y_next + in_block(tile16)) = yv;
             y_next += kYStride * 4;
@@ -430,15 +411,12 @@ __global__ __launch_bounds__(256, 1) void gru_quarter4_kernel(const f32x4* __res
             }
         }
         if (DEC && has_prev && w < 2) part[(((s - 1) & 1) * 8 + 4 * w + slH) * 16 + 4 * pH + j] = hp;
-        HELEN_H8_TICK(1)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        HELEN_H8_TICK(2)
         A4[0] = abuf[(cur ^ 1) * 128 + lane];
         A4[1] = abuf[(cur ^ 1) * 128 + 64 + lane];
         __builtin_amdgcn_sched_barrier(0);
-        HELEN_H8_TICK(3)
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;

@@ -41,8 +41,7 @@ constexpr int kPairHF4 = 2 * 2 * 512;        // h[tile x][buffer][512]
 constexpr int kPairPF4 = 2 * 2 * 8 * 64;     // head partials [tile x][parity][wave][64]
 
 // The body is a device function over (tile pair, direction) and a caller-provided LDS block of kPairHF4 (+ kPairPF4)
-// float4: gru_pair_kernel below is one call per workgroup; polish_persistent_kernel (kernels_persistent.h) calls it
-// once per chunk and layer from its loop.
+// float4; gru_pair_kernel below is one call per workgroup.
 template <bool DEC>
 __device__ __forceinline__ void gru_pair_body(f32x4* __restrict__ smem, const int pair_index, const int dir,
                                               const f32x4* __restrict__ gi, long gi_tile_stride,
@@ -97,11 +96,7 @@ __device__ __forceinline__ void gru_pair_body(f32x4* __restrict__ smem, const in
     // gate results (windows 4q..4q+3 of one unit) then go to 64 different banks per ds_write_b32 instead of 16
     // (unswizzled, the four lanes j, j+4, j+8, j+12 of a 16-lane group hit the same bank: 4-way conflicts on every
     // write, 9.9 M conflict cycles per launch).  Readers fetch whole 16-byte entries: they only pick another one.
-#ifdef HELEN_PAIR_NOSWZ
-    const int slane = lane, stid = tid;
-#else
     const int slane = (lane & 48) | (j ^ q), stid = (tid & ~15) | ((tid & 15) ^ ((tid >> 4) & 3));
-#endif
 
     // this wave's gi fragments (gate g = column tile 8g + v) of each tile's next step, in registers
     f32x4 G[2][3];
@@ -115,9 +110,6 @@ __device__ __forceinline__ void gru_pair_body(f32x4* __restrict__ smem, const in
 #pragma unroll
     for (int x = 0; x < 2; ++x) hbuf[x * 1024 + stid] = *(const f32x4*)(hid_s[x] + tid16);
     load_gi(0);
-#ifdef HELEN_PAIR_NOLOAD   // timing probe: both tiles' first gi, never reloaded
-    load_gi(1);
-#endif
     __syncthreads();
 
     float hprev[2][4];
@@ -125,11 +117,7 @@ __device__ __forceinline__ void gru_pair_body(f32x4* __restrict__ smem, const in
     int hoff[4];   // float offset of (window 4q + r, unit u) in an h buffer
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-#ifdef HELEN_PAIR_NOSWZ
-        hoff[r] = ((u >> 2) * kTile + 4 * q + r) * 4 + (u & 3);
-#else
         hoff[r] = ((u >> 2) * kTile + 4 * q + (r ^ (j >> 2))) * 4 + (u & 3);
-#endif
     }
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -143,13 +131,6 @@ __device__ __forceinline__ void gru_pair_body(f32x4* __restrict__ smem, const in
         return (((ps[0] + ps[64]) + (ps[128] + ps[192])) + (ps[256] + ps[320])) + (ps[384] + ps[448]);
     };
 
-#ifdef HELEN_PAIR_TIMING   // developer probe: where a wave's cycles go
-    long long tk[3] = {0, 0, 0};
-#define HELEN_PAIR_TICK(i) { __builtin_amdgcn_sched_barrier(0); long long now_ = __builtin_readcyclecounter(); tk[i] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
-    long long tlast = __builtin_readcyclecounter();
-#else
-#define HELEN_PAIR_TICK(i)
-#endif
     // One half-step: MFMA phase and gate math of tile X at step s (CUR = s & 1 at compile time so that every LDS
     // address is a lane offset + immediate).  `so` = newest step of the OTHER tile o.  STEADY = the caller
     // guarantees 2 <= s and s + 2 <= T - 1... i.e. every "is there a previous / next step" question is a
@@ -168,9 +149,7 @@ __device__ __forceinline__ void gru_pair_body(f32x4* __restrict__ smem, const in
         f32x4 acc[3], a[3], yv = splat4(0.f), hd = splat4(0.f), hp = splat4(0.f);
         a[0] = a_pref;
         a[1] = hb[1 * 64];
-#ifndef HELEN_PAIR_NOLOAD   // (timing probe: no gi traffic, results are garbage)
         if (has_next_o) load_gi(o);                              // tile o's registers were consumed in G(o, so)
-#endif
         if (!DEC && has_prev) yv = hx[stid];                      // h_x(s-1) is the layer output of slot s-1
         if (DEC && has_prev) hd = hb[v * 64];                    // ... or feeds the heads: this wave's k-slice
 #pragma unroll
@@ -182,11 +161,7 @@ __device__ __forceinline__ void gru_pair_body(f32x4* __restrict__ smem, const in
             for (int e = 0; e < 2; ++e)
 #pragma unroll
                 for (int g = 0; g < 3; ++g)   // the first MFMA of a chain takes its initial value as the C operand
-#ifdef HELEN_PAIR_SEED   // probe: r / z chains start from gi instead of adding it in the gates
-                    acc[g] = mfma4(a[m % 3][e], W[g][m][e], (m | e) ? acc[g] : g < 2 ? G[x][g] : bnv);
-#else
                     acc[g] = mfma4(a[m % 3][e], W[g][m][e], (m | e) ? acc[g] : g < 2 ? splat4(0.f) : bnv);
-#endif
             __builtin_amdgcn_sched_barrier(0);
             if (m + 2 < 8) a[(m + 2) % 3] = hb[(m + 2) * 64];
             __builtin_amdgcn_sched_barrier(0);
@@ -200,9 +175,7 @@ __device__ __forceinline__ void gru_pair_body(f32x4* __restrict__ smem, const in
                 for (int e = 0; e < 4; ++e) hp = mfma4(hd[e], Bh[e], hp);
             }
             if (m == 2 && !DEC && has_prev) {
-#ifndef HELEN_PAIR_NOSTORE   // (timing probe)
                 *(f32x4*)(y_next[x] + in_block(tid16)) = yv;
-#endif
                 y_next[x] += kYStride * 4;
             }
         }
@@ -213,21 +186,13 @@ __device__ __forceinline__ void gru_pair_body(f32x4* __restrict__ smem, const in
             if (v == ((s - 2) & 3)) *(f32x4*)(pl_next[x] + in_block(lane16)) = sum_partials(x, s & 1);
             pl_next[x] += 128 * 16;
         }
-        HELEN_PAIR_TICK(0)
         // every wave is through M(x,s); the h_o(so) written in the previous half-step's G becomes visible
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        HELEN_PAIR_TICK(1)
         a_pref = hbuf[(o * 2 + ocur) * 512 + slane];              // next phase: M(o, so+1) starts on h_o(so)
         __builtin_amdgcn_sched_barrier(0);
-#ifdef HELEN_PAIR_NOGATES   // timing probe: MFMA phase + barrier only (results are garbage)
-        const f32x4 hn = acc[0] + acc[1] + acc[2] + G[x][0] + G[x][1] + G[x][2];
-#elif defined(HELEN_PAIR_SEED)
-        const f32x4 hn = gru_cell4(acc[0], acc[1], acc[2], G[x][2], hprev[x]);
-#else
         const f32x4 hn = gru_cell4(acc[0], acc[1], acc[2], G[x][0], G[x][1], G[x][2], hprev[x]);
-#endif
         float* hw = (float*)(hbuf + (x * 2 + (cur ^ 1)) * 512);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -236,7 +201,6 @@ __device__ __forceinline__ void gru_pair_body(f32x4* __restrict__ smem, const in
         }
         if (DEC && has_prev) (part + ((x * 2 + ((s - 1) & 1)) * 8 + v) * 64)[lane] = hp;
         __builtin_amdgcn_sched_barrier(0);
-        HELEN_PAIR_TICK(2)
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -260,11 +224,6 @@ __device__ __forceinline__ void gru_pair_body(f32x4* __restrict__ smem, const in
         half_step(I1{}, I1{}, Yes{}, s + 1);
     }
     for (; s < T; ++s) step(No{}, s);                     // the last one or two steps: no step s+1 to feed
-#ifdef HELEN_PAIR_TIMING
-    if (pair_index == 0 && lane == 0)
-        printf("pair %s dir %d wave %d: cycles per half-step  mfma phase %lld  barrier %lld  gates %lld\n", DEC ? "dec" : "enc",
-               dir, v, tk[0] / (2 * T), tk[1] / (2 * T), tk[2] / (2 * T));
-#endif
     __syncthreads();
     const int last = T & 1;   // buffer of h(T-1)
     if (DEC) {

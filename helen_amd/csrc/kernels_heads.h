@@ -65,9 +65,7 @@ __device__ __forceinline__ int group16_argmax(float v, int idx) {
     return idx;
 }
 
-#ifndef HELEN_HEADS_SPAN
 #define HELEN_HEADS_SPAN 10
-#endif
 constexpr int kHeadsSpan = HELEN_HEADS_SPAN;  // positions per workgroup; divides kJump so a group never straddles halves
 
 // The 16 logits of 16 windows at chunk position t: the decoder recurrences already multiplied each
@@ -100,8 +98,8 @@ __device__ __forceinline__ f32x4 heads_softmax(f32x4 logit, bool isb) {
 typedef uint8_t HeadsLabels[2][kTile][kHeadsSpan];   // LDS staging of one (tile, position group): labels written as rows
 
 // The body is a device function over one (tile, group of kHeadsSpan positions) for 256 threads `tid` and their LDS
-// staging block: heads_kernel below is one call per workgroup; polish_persistent_kernel runs two such groups of 256
-// threads side by side (all of them reach the one __syncthreads inside; `valid` = false computes nothing).
+// staging block; heads_kernel below is one call per workgroup (all threads reach the one __syncthreads inside;
+// `valid` = false computes nothing).
 __device__ __forceinline__ void heads_body(
     HeadsLabels& lab, const int tid, const int tile, const int t0, const bool valid,
     const f32x4* __restrict__ plogit, long pl_tile_stride,
@@ -177,88 +175,6 @@ __device__ __forceinline__ void heads_body(
         if (window < n_windows && tl < span) {
             uint8_t* out = kind ? rles : bases;
             out[(size_t)window * kSeq + chunk * kJump + t0 + tl] = lab[kind][win][tl];
-        }
-    }
-}
-
-// heads_body's work for HALF a chunk (positions half * 50 .. + 49) of up to two tiles, by a whole 512-thread workgroup:
-// what polish_persistent_kernel runs between a pair's hand-off B and the next chunk.  The phase is pure latency (two
-// 1 KiB loads, a few shuffles, stores per position), so every wave takes positions of its own, four at a time with
-// their loads issued together; heads_body's ten-position groups, two at a time, took 90 us per chunk here against
-// 33 us for the whole chip in heads_kernel.  Same per-position arithmetic (heads_softmax, first-maximum argmax), same
-// `pending` slots: same bits.  `lab` = 2 tiles x 2 kinds x 16 windows x 50 positions of LDS.
-constexpr int kHeadsHalfLdsBytes = 2 * 2 * kTile * kJump;
-#ifndef HELEN_HEADS_HALF_U
-#define HELEN_HEADS_HALF_U 4
-#endif
-__device__ __forceinline__ void heads_half_body(
-    uint8_t* __restrict__ lab, const int tid, const int tile0, const int tile1, const int half,
-    const f32x4* __restrict__ plogit, long pl_tile_stride, const float* __restrict__ bhd, int chunk, int T,
-    int n_windows, f32x4* __restrict__ pending, uint8_t* __restrict__ bases, uint8_t* __restrict__ rles,
-    float* __restrict__ acc_base, float* __restrict__ acc_rle) {
-    const int lane = tid & 63;
-    const int v = tid >> 6;
-    const int j = lane & 15;
-    const int q = lane >> 4;
-    const bool isb = j < kNB;
-    const float bias = bhd[j];
-    const bool park = (half == 1) && (chunk < kChunks - 1);
-    const bool add_prev = (half == 0) && (chunk > 0);
-    const int ntile = tile1 == tile0 ? 1 : 2;
-    const int nitems = ntile * kJump;
-    constexpr int U = HELEN_HEADS_HALF_U;   // items per wave in flight (their loads are issued together)
-    for (int i0 = v * U; i0 < nitems; i0 += 8 * U) {
-        f32x4 lg[U], pv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = min(i0 + u, nitems - 1);
-            const int tile = i / kJump ? tile1 : tile0;
-            const int t = half * kJump + i % kJump;
-            lg[u] = head_logits(plogit, pl_tile_stride, tile, t, T, bias, lane);
-            pv[u] = splat4(0.f);
-            if (add_prev) pv[u] = pending[(((size_t)tile * 2 + ((chunk - 1) & 1)) * kJump + t) * 64 + lane];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u;
-            if (i >= nitems) break;
-            const int which = i / kJump, tl = i % kJump;
-            const int tile = which ? tile1 : tile0;
-            const int t = half * kJump + tl;
-            f32x4 p = heads_softmax(lg[u], isb);
-            if (park) {
-                pending[(((size_t)tile * 2 + (chunk & 1)) * kJump + (t - kJump)) * 64 + lane] = p;
-                continue;
-            }
-            if (add_prev) p += pv[u];
-            const int pos = chunk * kJump + t;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int window = tile * kTile + 4 * q + r;
-                if (window < n_windows) {
-                    if (acc_base != nullptr && isb) acc_base[((size_t)window * kSeq + pos) * kNB + j] = p[r];
-                    if (acc_rle != nullptr && !isb) acc_rle[((size_t)window * kSeq + pos) * kNR + (j - kNB)] = p[r];
-                }
-                const int ib = group16_argmax(isb ? p[r] : -1.f, isb ? j : 99);
-                const int ir = group16_argmax(isb ? -1.f : p[r], isb ? 99 : j);
-                if (j == 0) {
-                    lab[((which * 2 + 0) * kTile + 4 * q + r) * kJump + tl] = (uint8_t)ib;
-                    lab[((which * 2 + 1) * kTile + 4 * q + r) * kJump + tl] = (uint8_t)(ir - kNB);
-                }
-            }
-        }
-    }
-    if (park) return;      // (uniform over the workgroup)
-    __syncthreads();
-    // labels as rows: 2 x 2 x 16 rows of 50 bytes, two bytes per thread and trip
-    for (int g = tid; g < ntile * 2 * kTile * (kJump / 2); g += 512) {
-        const int row = g / (kJump / 2), tl = 2 * (g % (kJump / 2));
-        const int which = row / (2 * kTile), kind = (row / kTile) & 1, win = row % kTile;
-        const int window = (which ? tile1 : tile0) * kTile + win;
-        if (window < n_windows) {
-            uint8_t* out = (kind ? rles : bases) + (size_t)window * kSeq + chunk * kJump + half * kJump + tl;
-            const uint8_t* src = lab + ((which * 2 + kind) * kTile + win) * kJump + tl;
-            *(uint16_t*)out = *(const uint16_t*)src;      // (window * 1000 + 50 c + 50 half + even tl: 2-byte aligned)
         }
     }
 }

@@ -34,17 +34,13 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short b) {
     return __builtin_bit_cast(float, (unsigned)b << 16);
 }
 
-// Round 5: the decoder's head slice runs on the bf16 pipe (HELEN_X3_HEAD_BF16, on by default; =0 builds round 4's form for the
-// A/B record, profiles/r05_fp32x3_levers.txt).  The three planes of h(s-1) a wave has in registers for the recurrence are the
+// The decoder's head slice runs on the bf16 pipe (A/B record: profiles/r05_fp32x3_levers.txt).  The three planes of h(s-1) a wave has in registers for the recurrence are the
 // A operand, the head weights of its K32 group are split in three bf16 terms once per kernel, and the six leading products
 // are shared by the two waves of a group: three bf16 MFMAs per wave and step instead of four v_mfma_f32_16x16x4_f32, which
 // hold the SIMD's VALU for 32 cycles each -- the same fp32-class product as the recurrence's own.  Decoder launch 0.475 ->
 // 0.455 ms (4,096 windows).  Also measured there and NOT taken: storing the new h into the planes as 32-bit words of two
 // neighbouring units (one DPP swap per plane, half the LDS stores, none of the 2-byte stores' 15.6 M bank-conflict
 // cycles per launch): 0.452 / 0.474 ms against 0.452 / 0.474 -- the plane stores are not on the step's critical path.
-#ifndef HELEN_X3_HEAD_BF16
-#define HELEN_X3_HEAD_BF16 1
-#endif
 
 __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ gi, long gi_tile_stride,
                                                      int slot0_fwd, int slot0_bwd, int T,
@@ -93,7 +89,6 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
                 for (int t = 0; t < 3; ++t) W[g][M][t] = wp[((g * 4 + M) * 3 + t) * 64];
     }
     const float bn = bhn[dir * kH + u];
-#if HELEN_X3_HEAD_BF16
     // decoder: the head weights of K32 group Mv = v & 3 as a B operand in three bf16 terms: k = dir*128 + 32 Mv + 8q + e,
     // class j.  Waves v and v + 4 share the group: v < 4 takes the three small products, v >= 4 the three large ones.
     const int Mv = v & 3;
@@ -117,10 +112,6 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
             Bh3[t] = __builtin_bit_cast(bf16x8, uint4{tb[t][0] | (unsigned)tb[t][1] << 16, tb[t][2] | (unsigned)tb[t][3] << 16,
                                                        tb[t][4] | (unsigned)tb[t][5] << 16, tb[t][6] | (unsigned)tb[t][7] << 16});
     }
-#else
-    f32x4 Bh = splat4(0.f);   // decoder: head weights for k = dir*128 + 16v + 4q + e, class j
-    if (dec) Bh = Whd[(dir * 8 + v) * 64 + lane];
-#endif
 
     const f32x4* gi_p = gi + (size_t)tile * gi_tile_stride + (size_t)dir * (kNTile * 64) + v * 64 + lane;
     constexpr long kPosStride = 2 * kNTile * 64;
@@ -152,7 +143,6 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
 #pragma unroll
         for (int r = 0; r < 4; ++r) store_h(buf, r, h[r]);
     };
-#if HELEN_X3_HEAD_BF16
     // three of the six leading products of h . W_head^T over this wave's K32 group, from the planes `at` of h
     auto head_partial = [&](const bf16x8 (&at)[3], int pb) {
         f32x4 pl = splat4(0.f);
@@ -167,15 +157,6 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
         }
         (part + (pb * 8 + v) * 64)[lane] = pl;
     };
-#else
-    auto head_partial = [&](int hb, int pb) {   // h in hbuf[hb]: wave v's k-slice is one fp32 A fragment
-        const f32x4 a = (hbuf + hb * 512)[v * 64 + lane];
-        f32x4 pl = splat4(0.f);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pl = mfma4(a[e], Bh[e], pl);
-        (part + (pb * 8 + v) * 64)[lane] = pl;
-    };
-#endif
     auto head_store = [&](int slot) {           // one wave adds the eight slices in wave order
         if (v != (slot & 7)) return;
         const f32x4* pp = part + (slot & 1) * 8 * 64 + lane;
@@ -195,10 +176,6 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
     for (int r = 0; r < 4; ++r) hprev[r] = ((const float*)hbuf)[hoff + 4 * r];
     store_h4(0, f32x4{hprev[0], hprev[1], hprev[2], hprev[3]});     // planes of h0 (fp32 copy rewritten in place)
     __syncthreads();
-#ifdef HELEN_GRU_TIMING
-    long long tk[7] = {0, 0, 0, 0, 0, 0, 0};
-    long long tlast = __builtin_readcyclecounter();
-#endif
     for (int s = 0; s < T; ++s) {
         const int cur = s & 1;
         const bf16x8* pa = (const bf16x8*)(planes + cur * 768) + lane;
@@ -206,16 +183,11 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
         acc[0] = splat4(0.f);
         acc[1] = splat4(0.f);
         acc[2] = splat4(bn);
-#if !HELEN_X3_HEAD_BF16
-        if (dec && s > 0) head_partial(cur, (s - 1) & 1);    // h(s-1) sits in hbuf[cur] since the last barrier
-#endif
 #pragma unroll
         for (int M = 0; M < 4; ++M) {
             const bf16x8 a1 = pa[0 * 256 + M * 64], a2 = pa[1 * 256 + M * 64], a3 = pa[2 * 256 + M * 64];
             const bf16x8 at[3] = {a1, a2, a3};
-#if HELEN_X3_HEAD_BF16
             if (dec && s > 0 && M == Mv) head_partial(at, (s - 1) & 1);   // the planes of h(s-1) are this step's A operand
-#endif
             constexpr int TA[6] = {0, 2, 1, 0, 1, 0};   // six leading products, smallest first;
             constexpr int TB[6] = {2, 0, 1, 1, 0, 0};   // product index outermost: 3 accumulators rotate
 #pragma unroll
@@ -224,39 +196,26 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
                 for (int g = 0; g < 3; ++g)
                     acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[TA[k]], W[g][M][TB[k]], acc[g], 0, 0, 0);
         }
-        HELEN_TICK(0)
-#ifdef HELEN_GRU_TIMING
-        asm volatile("s_nop 0" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]));
-        HELEN_TICK(1)
-#endif
         // VMEM queue, oldest first: the 3 gi DMAs of this step (issued in the previous one), then that
         // step's output stores -- encoder: at least one per wave; decoder: one, by wave (s-2) mod 8 only
         if (!dec || (s >= 2 && v == ((s - 2) & 7)))
             asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        HELEN_TICK(2)
         f32x4 G[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) G[g] = gbuf[g * 64 + lane];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (s + 1 < T) dma_gi(slot0 + s + 1);
         {   // four cells as two packed pairs (gru_cell4)
-#ifdef HELEN_BP_SCALAR_GATES
-            const f32x4 hn4 = gru_cell4_scalar(acc[0] + G[0], acc[1] + G[1], acc[2], G[2], hprev);
-#else
             const f32x4 hn4 = gru_cell4(acc[0], acc[1], acc[2], G[0], G[1], G[2], hprev);
-#endif
 #pragma unroll
             for (int r = 0; r < 4; ++r) hprev[r] = hn4[r];
             store_h4(cur ^ 1, hn4);
         }
-        HELEN_TICK(3)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        HELEN_TICK(4)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        HELEN_TICK(5)
         if (dec) {
             if (s > 0) head_store(s - 1);
         } else {   // 768 units of 16 B per (tile, slot, dir)
@@ -266,19 +225,10 @@ __global__ __launch_bounds__(512) void gru_x3_kernel(const f32x4* __restrict__ g
             if (tid < 256) po[512 + tid] = ps[512 + tid];
         }
     }
-#ifdef HELEN_GRU_TIMING
-    if (blockIdx.x == 0 && lane == 0 && (v == 0 || v == 5))
-        printf("gru_x3 dir %d wave %d: cycles/step  mfma-issue %lld  mfma-drain %lld  vmwait %lld  G+gates+stores %lld  lgkm %lld  barrier %lld  (output in mfma-issue)\n",
-               dir, v, tk[0] / T, tk[1] / T, tk[2] / T, tk[3] / T, tk[4] / T, tk[5] / T);
-#endif
     if (dec) {   // the last step's logits
-#if HELEN_X3_HEAD_BF16
         const bf16x8* pl = (const bf16x8*)(planes + (T & 1) * 768) + lane + Mv * 64;
         const bf16x8 at[3] = {pl[0], pl[256], pl[512]};
         head_partial(at, (T - 1) & 1);
-#else
-        head_partial(T & 1, (T - 1) & 1);
-#endif
         __syncthreads();
         head_store(T - 1);
     }

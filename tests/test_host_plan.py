@@ -327,6 +327,19 @@ def test_ram_backed_budget_counts_ram_not_just_tmpfs_space(tmp_path, monkeypatch
     assert where == "/dev/shm" and 8192 <= n < 300000 and need * 1.1 < 50 << 30
     n1, need1, where1, _ = bench.e2e_size(300000, 1, True, free=64 << 30)
     assert n1 == 300000 and where1 == "/dev/shm"
+    # round 6: the GPU box's own numbers (300 GiB memory cgroup, 16 CPUs; tmpfs budget = half of it).  The files alone would
+    # fit that budget at N = 8 with ~100 k windows per rank; together with the generator workers' transient memory and the
+    # ranks' resident memory the leg must stay under 0.8 of the RAM, and N = 1, 2 must not shrink at all
+    ram = 300 << 30
+    sizes = {w: bench.e2e_size(300000, w, True, free=ram // 2, ram=ram, cpus=16) for w in (1, 2, 4, 8)}
+    assert sizes[1][0] == 300000 and sizes[2][0] == 300000
+    assert 8192 <= sizes[8][0] < sizes[4][0] < 300000
+    for w, (n, need, where, _) in sizes.items():
+        workers = w * bench.e2e_generator_processes(w, 16)
+        total = need + workers * n / 16.0 * bench.E2E_GENERATOR_TRANSIENT + w * bench.E2E_RANK_RESIDENT_BYTES
+        assert where == "/dev/shm" and total <= 0.8 * ram, (w, n, total)
+    # RAM unknown (no meminfo, no cgroup): only the tmpfs budget decides
+    assert bench.e2e_size(300000, 8, True, free=1 << 40)[0] == 300000
 
 
 def test_the_plan_prices_the_stitch_stage_of_polish():
