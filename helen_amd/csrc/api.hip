@@ -499,6 +499,12 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
         if ((rc = upload(m, &m->whp_enc, pack_w_hh(w->enc_w_hh)))) return rc;
         if ((rc = upload(m, &m->whp_dec, pack_w_hh(w->dec_w_hh)))) return rc;
     }
+    if (precision == HELEN_PRECISION_FP32 && m->overrides.enc_exact != 0) {
+        // the encoder projection of the polish entry points: pileup counts are exact in bf16 and W_ih is exactly three
+        // bf16 terms, so x.w = x.w1 + x.w2 + x.w3 with every partial product exact and fp32 accumulation (launch_front)
+        if ((rc = upload(m, &m->w3i_enc, pack_w_ih_x3(w->enc_w_ih, kF)))) return rc;
+        if ((rc = dev_alloc(m, &m->xb, (size_t)m->max_tiles * kSeq * 192))) return rc;
+    }
     if (precision == HELEN_PRECISION_FP32X3) {
         if ((rc = upload(m, &m->w3h_enc, pack_w_hh_x3(w->enc_w_hh)))) return rc;
         if ((rc = upload(m, &m->w3h_dec, pack_w_hh_x3(w->dec_w_hh)))) return rc;
@@ -671,15 +677,17 @@ int helen_plan_call(int cus, int tiles, int* out) {
 // uint8 windows -> operand tiles -> encoder input projection for all 1000 positions (overlapping chunks
 // share it) -> zero initial hidden (predict_gpu.py:97-99): everything before the chunk loop.
 static int launch_front(HelenModel* m, hipStream_t s, const uint8_t* images, int n_windows, int tiles) {
-    if (m->precision == HELEN_PRECISION_FP32X3 || m->precision == HELEN_PRECISION_BF16) {
+    if (m->xb) {
         // pileup counts are exact in bf16: pack them straight into A fragments; three exact products per w
-        // (fp32x3) or the one product with w rounded to bf16 (bf16)
+        // (fp32 and fp32x3: W_ih in three bf16 terms, fp32 accumulation) or the one product with w rounded to bf16 (bf16)
         LAUNCH(HELEN_K_PACK, pack_images_x3_kernel, dim3((kSeq * 192 + 255) / 256, tiles), dim3(256), images,
                n_windows, kSeq, m->xb);
-        const dim3 egrid(3 * ((tiles + 7) / 8 * 8));
-        if (m->precision == HELEN_PRECISION_FP32X3)
-            LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_x3_kernel<3>, egrid, dim3(512), m->xb, (long)kSeq * 192,
-                   (const f32x4*)m->w3i_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, kSeq, tiles);
+        if (m->precision != HELEN_PRECISION_BF16) {
+            const ExactEncoderPlan e = plan_exact_encoder(tiles, kSeq, m->cus);
+            LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_x3_kernel<3>, dim3(e.parts * 3 * ((tiles + 7) / 8 * 8)), dim3(512), m->xb,
+                   (long)kSeq * 192, (const f32x4*)m->w3i_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, kSeq, tiles, e.parts,
+                   e.run);
+        }
         // (bf16: the projection is fused into the recurrence, gru_fused_bf16_kernel reads xb directly)
     } else {
         // uint8 -> fp32 operand tiles (predict_gpu.py:97)
@@ -712,12 +720,13 @@ static int polish_range(HelenModel* m, hipStream_t s, const uint8_t* images, int
 // are taken at launch).
 struct TileWindow {
     HelenModel* m;
-    f32x4 *xa, *gi_enc, *gi_dec, *y1, *hid, *plogit, *pending;
+    f32x4 *xa, *xb, *gi_enc, *gi_dec, *y1, *hid, *plogit, *pending;
     TileWindow(HelenModel* model, int tile0)
-        : m(model), xa(m->xa), gi_enc(m->gi_enc), gi_dec(m->gi_dec), y1(m->y1), hid(m->hid), plogit(m->plogit),
+        : m(model), xa(m->xa), xb(m->xb), gi_enc(m->gi_enc), gi_dec(m->gi_dec), y1(m->y1), hid(m->hid), plogit(m->plogit),
           pending(m->pending) {
         const size_t t = (size_t)tile0;
         if (m->xa) m->xa += t * kXaTileStride;
+        if (m->xb) m->xb += t * kSeq * 192;
         if (m->gi_enc) m->gi_enc += t * kGiEncTileStride;
         if (m->gi_dec) m->gi_dec += t * kGiDecTileStride;
         if (m->y1) m->y1 += t * kYTileStride;
@@ -726,7 +735,7 @@ struct TileWindow {
         m->pending += t * 2 * kJump * 64;
     }
     ~TileWindow() {
-        m->xa = xa; m->gi_enc = gi_enc; m->gi_dec = gi_dec; m->y1 = y1; m->hid = hid; m->plogit = plogit;
+        m->xa = xa; m->xb = xb; m->gi_enc = gi_enc; m->gi_dec = gi_dec; m->y1 = y1; m->hid = hid; m->plogit = plogit;
         m->pending = pending;
     }
 };

@@ -54,6 +54,7 @@ struct Overrides {
     int enc_ws8 = -1, enc_ws8p = -1, enc_ws8p_parts = 0;
     int split = -1, split_at = 0;
     int bf16_pair = -1;
+    int enc_exact = -1;                         // fp32: 0 = the polish entry points project the encoder input on the fp32 matrix pipe
     int host_lock = -1;                         // helen_polish_host: 0 never page-lock caller memory, 1 ranges that own their pages, 2 all
     bool verbose = false;
 };
@@ -76,6 +77,7 @@ inline Overrides read_overrides() {
     o.split = flag_of("HELEN_SPLIT");
     if (const char* n = getenv("HELEN_SPLIT_AT")) o.split_at = atoi(n);
     o.bf16_pair = flag_of("HELEN_BF16_PAIR");
+    o.enc_exact = flag_of("HELEN_ENC_EXACT");
     // exactly none | own | all ("0" = none); anything else is ignored: a typo must not re-open the in-place page-locking
     if (const char* hl = getenv("HELEN_HOST_LOCK")) {
         if (!strcmp(hl, "none") || !strcmp(hl, "0")) o.host_lock = 0;
@@ -161,6 +163,22 @@ inline EncoderPlan plan_encoder(int tiles, int npos, int cus, const Overrides& o
     } else {
         p.kind = kEncStreaming;
     }
+    return p;
+}
+
+// The exact-product encoder projection (gemm_enc_x3_kernel, the polish entry points of the fp32 and fp32x3 modes): three
+// (tile, column set) workgroups per tile; a call with fewer of them than CUs cuts the positions into runs of whole stages.
+struct ExactEncoderPlan {
+    int parts = 1, run = 0;
+};
+inline ExactEncoderPlan plan_exact_encoder(int tiles, int npos, int cus) {
+    ExactEncoderPlan p;
+    const int wgs = 3 * ((tiles + 7) / 8 * 8);
+    int want = cus / wgs;
+    want = want < 1 ? 1 : want;
+    const int per = (npos + want - 1) / want;
+    p.run = (per + kEncStagePositions - 1) / kEncStagePositions * kEncStagePositions;
+    p.parts = (npos + p.run - 1) / p.run;
     return p;
 }
 

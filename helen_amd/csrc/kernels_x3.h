@@ -402,19 +402,26 @@ __global__ __launch_bounds__(512) void gemm_enc_x3_kernel(const f32x4* __restric
                                                           const f32x4* __restrict__ W3e,
                                                           const float* __restrict__ bias,
                                                           f32x4* __restrict__ gi, long gi_tile_stride,
-                                                          int npos, int ntiles) {
+                                                          int npos, int ntiles, int parts, int run) {
     constexpr int PB = 8, ROWS = PB * 3;    // rows of 1 KiB per stage: (position, group)
     __shared__ f32x4 smem[2 * ROWS * 64];   // 48 KiB
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // 1-D grid of 3 * roundup8(ntiles) ids.  Workgroups go round-robin over the 8 XCDs (id % 8): the three
+    // 1-D grid of parts * 3 * roundup8(ntiles) ids.  Workgroups go round-robin over the 8 XCDs (id % 8): the three
     // column sets of a tile get consecutive local slots of ONE XCD, so its A stream is fetched from HBM
-    // once and served from that XCD's L2 to the other two.
-    const int local = blockIdx.x >> 3;
+    // once and served from that XCD's L2 to the other two.  A call that does not fill the chip with (tile, column set)
+    // workgroups cuts the positions into `parts` runs of `run` (whole stages): every output element is still ONE
+    // accumulator chain over the same MFMAs in the same order, so the partition never changes a bit.
+    const int per_part = 3 * ((ntiles + 7) / 8 * 8);
+    const int part = (int)blockIdx.x / per_part;
+    const int id = (int)blockIdx.x % per_part;
+    const int local = id >> 3;
     const int set = local % 3;
-    const int tile = (local / 3) * 8 + (blockIdx.x & 7);
+    const int tile = (local / 3) * 8 + (id & 7);
     if (tile >= ntiles) return;
+    const int g_lo = part * run / PB;                       // stages of this run: positions part*run .. min(+run, npos) - 1
+    const int p_hi = min(npos, (part + 1) * run);
     const int gt0 = 16 * set + 2 * w;
     const int dir = gt0 / kNTile;
     const int nt = gt0 % kNTile;
@@ -437,17 +444,17 @@ __global__ __launch_bounds__(512) void gemm_enc_x3_kernel(const f32x4* __restric
 #pragma unroll
         for (int i = 0; i < ROWS / 8; ++i) {
             const int r = w + 8 * i;
-            const int pc = min(PB * g + r / 3, npos - 1);
+            const int pc = min(PB * g + r / 3, p_hi - 1);
             const f32x4* src = xp + (size_t)pc * 192 + (r % 3) * 64;
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                              (void __attribute__((address_space(3)))*)(dst + r * 64), 16, 0, 0);
         }
     };
-    const int ng = (npos + PB - 1) / PB;
-    stage(0, 0);
-    for (int g = 0; g < ng; ++g) {
+    const int ng = (p_hi + PB - 1) / PB;
+    stage(g_lo, g_lo & 1);
+    for (int g = g_lo; g < ng; ++g) {
         // VMEM queue, oldest first: 3 DMA rows of group g, then 16 output stores of group g-1
-        if (g == 0)
+        if (g == g_lo)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(512) void gemm_enc_x3_kernel(const f32x4* __restric
         for (int p = 0; p < PB; ++p) {
             // every stage issues exactly 16 stores per lane (counted above): out-of-range positions of the
             // last stage rewrite the last valid one with identical values
-            const int pos = min(PB * g + p, npos - 1);
+            const int pos = min(PB * g + p, p_hi - 1);
             const int slot = dir ? (npos - 1 - pos) : pos;
             f32x4* o = gi + (size_t)tile * gi_tile_stride + ((size_t)slot * 2 + dir) * (kNTile * 64) + nt * 64 + lane;
             o[0] = acc[p][0];
