@@ -166,6 +166,24 @@ def _process_age():
         return None
 
 
+def _report_ranks(run):
+    """Several ranks: one line per rank with its stage times (rank 0 alone prints the long line while it runs), and the
+    resident-memory high-water marks of the parent, the ranks and the stitch collectors."""
+    from .host_plan import peak_rss_mb
+    ranks = run.get("ranks") or []
+    if len(ranks) > 1:
+        for r in ranks:
+            st = r.get("stage_seconds") or {}
+            sys.stderr.write("INFO: RANK %s: %s WINDOWS IN %.1f SECS (WAITING FOR READERS %.1f, DEVICE %.1f, WRITER BUSY %.1f, "
+                             "STITCH STAGE BUSY %.1f), %s READER(S).\n"
+                             % (r.get("rank"), r.get("windows"), r.get("seconds") or 0.0, st.get("read_wait", 0.0), st.get("device", 0.0),
+                                st.get("write", 0.0), st.get("stitch", 0.0), r.get("reader_workers")))
+    collectors = (run.get("stitch_collectors") or {}).get("per_collector") or []
+    sys.stderr.write("INFO: PEAK RESIDENT MEMORY (MB): PARENT %s, RANKS %s%s.\n"
+                     % (peak_rss_mb(), [r.get("peak_rss_mb") for r in ranks],
+                        ", STITCH COLLECTORS %s" % [c.get("peak_rss_mb") for c in collectors] if collectors else ""))
+
+
 def polish_genome(image_dir, model_path, batch_size, num_workers, threads, output_dir,
                   output_prefix, gpu_mode, device_ids, callers):
     """call_consensus into `<output_dir>/predictions_<timestamp>/`, then stitch the predictions into
@@ -188,14 +206,25 @@ def polish_genome(image_dir, model_path, batch_size, num_workers, threads, outpu
     t1 = time.time()
     sys.stderr.write("INFO: STITCH STARTING\n")
     print(prediction_dir)
-    if streams is not None and hasattr(streams, "export_spec"):
-        # several ranks: collector processes hold the regions and have joined them (helen_amd.stitch_collect)
-        streams.finish(output_dir, output_prefix)
-        from . import predict as _predict
-        _predict.LAST_RUN["stitch_collectors"] = streams.stats      # (what each collector did, for reports)
-    elif streams is not None:
-        stitch_stream.finish_stitch(streams, prediction_dir, output_dir, output_prefix, threads)
-    else:
+    from . import predict as _predict
+    if streams is not None:
+        # the pipelined stitch is an optimisation of this command, never a way to lose its result: the prediction files
+        # are complete at this point, and whatever goes wrong with the regions parked beside the run (a collector died,
+        # the spill directory filled up) the FASTA comes from them in a second phase, as `helen stitch` would make it
+        try:
+            if hasattr(streams, "export_spec"):
+                # several ranks: collector processes hold the regions and have joined them (helen_amd.stitch_collect)
+                streams.finish(output_dir, output_prefix)
+                _predict.LAST_RUN["stitch_collectors"] = streams.stats      # (what each collector did, for reports)
+            else:
+                stitch_stream.finish_stitch(streams, prediction_dir, output_dir, output_prefix, threads)
+        except Exception as e:          # noqa: BLE001 -- reported; the second phase takes over
+            sys.stderr.write("WARNING: THE PIPELINED STITCH DID NOT FINISH (%s: %s): STITCHING THE PREDICTION FILES INSTEAD.\n"
+                             % (type(e).__name__, e))
+            if hasattr(streams, "abort"):
+                streams.abort()
+            streams = None
+    if streams is None:
         perform_stitch(prediction_dir, output_dir, output_prefix, threads)
     t2 = time.time()
 
@@ -206,6 +235,7 @@ def polish_genome(image_dir, model_path, batch_size, num_workers, threads, outpu
     sys.stderr.write("INFO: WALL CLOCK: %sBEFORE CALL CONSENSUS %.2f S, CALL CONSENSUS %.2f S, STITCH AFTER THE LAST WINDOW %.2f S.\n"
                      % ("" if age is None else "%.2f S SINCE THE PROCESS STARTED: " % age,
                         0.0 if age is None else max(0.0, age - (t2 - t0)), t1 - t0, t2 - t1))
+    _report_ranks(_predict.LAST_RUN)
     sys.stderr.write("INFO: TOTAL TIME ELAPSED: " + fmt(t0, t2) + "\n")
     sys.stderr.write("INFO: PREDICTION TIME: " + fmt(t0, t1) + "\n")
     sys.stderr.write("INFO: STITCH TIME: " + fmt(t1, t2) + "\n")

@@ -43,9 +43,18 @@ def _rebuild_tensor(storage, storage_offset, size, stride, *unused):
     """torch._utils._rebuild_tensor_v2: a strided view of a flat storage, made contiguous."""
     size, stride = tuple(size), tuple(stride)
     if len(size) == 0:
+        if not 0 <= int(storage_offset) < len(storage):
+            raise UnsupportedCheckpoint("a scalar of the checkpoint lies outside its storage: the file is truncated or corrupt")
         return storage[storage_offset:storage_offset + 1].reshape(()).copy()
     if any(n == 0 for n in size):
         return np.zeros(size, storage.dtype)
+    # a truncated or corrupt file must not become an out-of-bounds view (garbage weights or a fault): the pickled
+    # geometry is checked against the storage it claims to view
+    storage_offset = int(storage_offset)
+    if (len(size) != len(stride) or storage_offset < 0 or any(int(n) < 0 for n in size) or any(int(st) < 0 for st in stride)
+            or storage_offset + sum((int(n) - 1) * int(st) for n, st in zip(size, stride)) >= len(storage)):
+        raise UnsupportedCheckpoint("a tensor of the checkpoint (offset %s, size %s, stride %s) does not fit its storage of %d "
+                                    "elements: the file is truncated or corrupt" % (storage_offset, size, stride, len(storage)))
     view = np.lib.stride_tricks.as_strided(storage[storage_offset:], shape=size,
                                            strides=tuple(s * storage.dtype.itemsize for s in stride))
     return np.ascontiguousarray(view)

@@ -192,7 +192,7 @@ def _test_on_host(data_filepath, batch_size, transducer_model, num_workers, num_
     # a host engine of its own from the model's parameters: the caller's model object is left as it was (a later
     # test(..., gpu_mode=True) or forward() on it must not find itself on the host path)
     from .cpu_engine import CpuEngine
-    engine = CpuEngine({k: v.numpy() for k, v in transducer_model.state_dict().items()}, threads=threads)
+    engine = CpuEngine({k: v.detach().cpu().numpy() for k, v in transducer_model.state_dict().items()}, threads=threads)
     base_cm = np.zeros((num_base_classes, num_base_classes), np.int64)
     rle_cm = np.zeros((num_rle_classes, num_rle_classes), np.int64)
     sys.stderr.write("Test starting (host path, %d threads)\n" % threads)

@@ -184,6 +184,18 @@ def ram_available_bytes(meminfo="/proc/meminfo", cgroup_root="/sys/fs/cgroup"):
     return min(found) if found else None
 
 
+def peak_rss_mb(status="/proc/self/status"):
+    """High-water mark of this process's resident set (VmHWM) in MB, or None where /proc does not say."""
+    try:
+        with open(status) as f:
+            for ln in f:
+                if ln.startswith("VmHWM:"):
+                    return int(ln.split()[1]) // 1024
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+
+
 def ram_backed_budget_bytes(path="/dev/shm"):
     """What may be PUT into RAM-backed files under `path` by a run: free space of the tmpfs, and no more than half of
     ram_available_bytes() (the other half is for the processes themselves: page-locked slots, page cache, heaps)."""

@@ -28,6 +28,7 @@ import time
 
 
 from .data_store import DataStore
+from .host_plan import peak_rss_mb
 from .options import ImageSizeOptions
 from .prediction_writer import prediction_file_name, writer_of_region, writer_process  # noqa: F401
 from .sequence_dataset import SequenceDataset, SharedSlot, fill_shared
@@ -84,7 +85,10 @@ def _writer_loop(wq, store, release, err):
 
 def _stitch_loop(sq, stream, release, err):
     """Stitch stage of `polish` (helen_amd.stitch_stream): the regions of a device call are decoded from the slot's label
-    buffers -- beside the writer, which stores the same labels -- and their overlap alignments handed to worker threads."""
+    buffers -- beside the writer, which stores the same labels -- and their overlap alignments handed to worker threads.
+    A failure here (a full spill directory, a dead collector's pipe) is the stitch stage's own: `err` takes it, the stage
+    stops decoding, the slots keep circulating and the inference finishes its prediction file -- `polish` then stitches
+    that file in a second phase (helen_amd.call_consensus.polish_genome)."""
     failed = False
     while True:
         item = sq.get()
@@ -96,10 +100,11 @@ def _stitch_loop(sq, stream, release, err):
                 t0 = time.time()
                 stream.feed(slot.contigs[:n], slot.meta[:n], slot.positions[:n], bases, rles)
                 STAGE_SECONDS["stitch"] = STAGE_SECONDS.get("stitch", 0.0) + time.time() - t0
-            except Exception as e:  # surfaced by the caller; the slots keep circulating so that nothing hangs
+            except Exception as e:      # noqa: BLE001 -- reported; the run goes on without its pipelined stitch
                 failed = True
                 err.append(e)
-                release.free_slots.put(None)
+                sys.stderr.write("WARNING: THE STITCH STAGE BEHIND THE INFERENCE STOPPED (%s: %s); THE PREDICTION FILE IS "
+                                 "UNAFFECTED AND WILL BE STITCHED AFTER THE RUN.\n" % (type(e).__name__, e))
         release.done(slot)
 
 
@@ -183,17 +188,31 @@ class _NativeStage(object):
         self.inflight = collections.deque()
 
     def _settle(self):
-        """Wait for every slot the library still has in flight (oldest first: they complete in order)."""
+        """Wait for every slot the library still has in flight (oldest first: they complete in order).  A failed submit or
+        wait resets the library's pipeline: nothing is in flight any more, whatever this side had counted."""
         for entry in self.inflight:
             if entry[2]:
-                self.engine.wait()
                 entry[2] = False
+                try:
+                    self.engine.wait()
+                except Exception:
+                    self._forget()
+                    raise
+
+    def _forget(self):
+        for entry in self.inflight:
+            entry[2] = False
+        self.engine.in_flight = 0
 
     def submit(self, slot, n):
         if getattr(slot, "pinned", False):
             if self.engine.in_flight >= 2:           # (predict()'s loop keeps at most one behind the one just queued)
                 self._settle()
-            self.engine.submit(slot.images[:n], slot.bases[:n], slot.rles[:n])
+            try:
+                self.engine.submit(slot.images[:n], slot.bases[:n], slot.rles[:n])
+            except Exception:
+                self._forget()
+                raise
             self.inflight.append([slot, n, True])
         else:                                        # a slot that could not be page-locked: the synchronous staged call
             self._settle()
@@ -203,11 +222,19 @@ class _NativeStage(object):
     def pop(self):
         slot, n, queued = self.inflight.popleft()
         if queued:
-            self.engine.wait()
+            try:
+                self.engine.wait()
+            except Exception:
+                self._forget()
+                raise
         return slot, n
 
     def close(self):
-        self._settle()
+        """Tear-down: never raises (a run that failed in the device stage is released here, from a thread of its own)."""
+        try:
+            self._settle()
+        except Exception:       # noqa: BLE001 -- the failure has been reported where it happened
+            pass
         self.inflight.clear()
 
 
@@ -458,6 +485,21 @@ def _remove_stale_outputs(output_filename, rank):
 LAST_STREAM = [None]
 
 
+def _discard_early_engine(early_engine):
+    """Set-up failed after the early engine thread was started: wait for it and release what it made."""
+    if not early_engine:
+        return
+    t = early_engine.get("thread")
+    if t is not None:
+        t.join()
+    eng = early_engine.pop("engine", None)
+    if eng is not None:
+        try:
+            eng.close()
+        except Exception:       # noqa: BLE001 -- already failing: the first error is the one to report
+            pass
+
+
 def predict(test_file, output_filename, model_path, batch_size, num_workers, rank, device_id, plan=None, cpu_threads=None,
             stitch_threads=None, stitch_export=None):
     """Run inference over the image files `test_file` (a list) on device `device_id` and write
@@ -497,94 +539,100 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
             early_engine["took"] = time.time() - early_engine["t0"]
         early_engine["thread"] = threading.Thread(target=create_engine_early, daemon=True)
         early_engine["thread"].start()
-    native_io.close_readers()          # a long-lived process may have these paths mapped from an earlier run
-    _remove_stale_outputs(output_filename, rank)
-    writers = writer_count(num_workers)
-    prediction_data_file = DataStore(prediction_file_name(output_filename, rank), mode="w") \
-        if writers == 1 else None
-    on_host = cpu_threads is not None
-    group = 1 if on_host else max(1, DEVICE_CALL_WINDOWS // batch_size)       # loader batches per engine call
-    cap = group * batch_size
+    # (everything up to the try block of the loop below is set-up that can fail -- a bad image file, an unwritable output:
+    # the early engine's thread and its device model must not outlive such a failure in a long-lived process)
+    try:
+        native_io.close_readers()          # a long-lived process may have these paths mapped from an earlier run
+        _remove_stale_outputs(output_filename, rank)
+        writers = writer_count(num_workers)
+        prediction_data_file = DataStore(prediction_file_name(output_filename, rank), mode="w") \
+            if writers == 1 else None
+        on_host = cpu_threads is not None
+        group = 1 if on_host else max(1, DEVICE_CALL_WINDOWS // batch_size)       # loader batches per engine call
+        cap = group * batch_size
 
-    # Readers and writers first: their processes start (and the first slots fill) while the model is
-    # loaded and the device context is created below.
-    test_data = SequenceDataset(image_directory=None, file_list=test_file)
-    total_windows = len(test_data)
-    total_batches = -(-total_windows // batch_size)
-    mode = reader_mode(test_data.runs, num_workers, writers)
-    free_slots, ready_q, wq = queue.Queue(), queue.Queue(maxsize=2), queue.Queue()
-    pool = None
-    if mode == "threads":
-        calls = test_data.call_runs(cap)
-        # reader filling | H2D | kernels | D2H | writer: five slots keep every stage busy
-        n_slots = min(plan.slots if plan is not None else 5, max(1, len(calls)))
-        slots = []
+        # Readers and writers first: their processes start (and the first slots fill) while the model is
+        # loaded and the device context is created below.
+        test_data = SequenceDataset(image_directory=None, file_list=test_file)
+        total_windows = len(test_data)
+        total_batches = -(-total_windows // batch_size)
+        mode = reader_mode(test_data.runs, num_workers, writers)
+        free_slots, ready_q, wq = queue.Queue(), queue.Queue(maxsize=2), queue.Queue()
+        pool = None
+        if mode == "threads":
+            calls = test_data.call_runs(cap)
+            # reader filling | H2D | kernels | D2H | writer: five slots keep every stage busy
+            n_slots = min(plan.slots if plan is not None else 5, max(1, len(calls)))
+            slots = []
 
-        def make_slot():
-            from .sequence_dataset import NativeSlot, PinnedSlot
-            slots.append(NativeSlot(cap, device_id, pin=not on_host) if native is not None else PinnedSlot(cap, pin=not on_host))
-            return slots[-1]
-    else:
-        pairs = test_data.all_images
-        batches = [pairs[i:i + batch_size] for i in range(0, len(pairs), batch_size)]   # sequential,
-        calls = [batches[i:i + group] for i in range(0, len(batches), group)]           # short last batch
-        n_slots = min(plan.slots if plan is not None else 5, max(1, len(calls)))
-        slots = [SharedSlot(cap, prefix=plan.slot_prefix if plan is not None else "helen_slot_") for _ in range(n_slots)]
-        for sl in slots:
-            free_slots.put(sl)
-        if num_workers > 0 and calls:
-            import concurrent.futures as cf
-            pool = cf.ProcessPoolExecutor(num_workers, mp_context=mp.get_context("spawn"))
-    ferr, werr = [], []
-    reaper = None
-    stop_feeding = threading.Event()
-    # `polish`: stitch runs behind the inference (stitch_threads = its -t); only with the one-file writer of this process
-    stream = sq = stitcher = None
-    LAST_STREAM[0] = None
-    if stitch_threads is not None and writers == 1:
-        from . import stitch_stream
-        if stitch_stream.enabled():
-            export = None
-            if stitch_export is not None:       # a multi-rank run: the regions go to the collectors (helen_amd.stitch_collect)
-                from .stitch_collect import RegionExport
-                export = RegionExport(stitch_export[0], rank, stitch_export[1])
-            stream = stitch_stream.RegionStream(prediction_file_name(output_filename, rank), stitch_threads, export=export)
-            sq = queue.Queue()
-    if mode == "threads":
-        reap_q = queue.Queue()
-        reaper = threading.Thread(target=_reaper_loop, args=(reap_q,), daemon=True)
-        reaper.start()
-        feeder = threading.Thread(target=_thread_feeder_loop, daemon=True,
-                                  args=(calls, free_slots, ready_q, make_slot, n_slots, max(1, num_workers), batch_size,
-                                        ferr, None if on_host or native is not None else device_id, reap_q, stop_feeding))
-    else:
-        feeder = threading.Thread(target=_feeder_loop, daemon=True,
-                                  args=(calls, free_slots, ready_q, pool, cap, ferr, num_workers, stop_feeding))
-    for k in STAGE_SECONDS:
-        STAGE_SECONDS[k] = 0.0
-    if writers == 1:
-        release = _SlotRelease(free_slots, 2 if stream is not None else 1)
-        writer = threading.Thread(target=_writer_loop, args=(wq, prediction_data_file, release, werr), daemon=True)
-        writer.start()
-        writer_pool = None
-        if stream is not None:
-            stitcher = threading.Thread(target=_stitch_loop, args=(sq, stream, release, werr), daemon=True)
-            stitcher.start()
-    else:
-        writer_pool = _WriterPool(output_filename, rank, writers, free_slots, werr)
-    feeder.start()
-
-    stage = engine = None
-
-    def to_writer(slot, n):
-        if writer_pool is None:
-            item = (slot, n, slot.bases[:n], slot.rles[:n])
-            wq.put(item)
-            if sq is not None:
-                sq.put(item)
+            def make_slot():
+                from .sequence_dataset import NativeSlot, PinnedSlot
+                slots.append(NativeSlot(cap, device_id, pin=not on_host) if native is not None else PinnedSlot(cap, pin=not on_host))
+                return slots[-1]
         else:
-            writer_pool.submit(slot, n)
+            pairs = test_data.all_images
+            batches = [pairs[i:i + batch_size] for i in range(0, len(pairs), batch_size)]   # sequential,
+            calls = [batches[i:i + group] for i in range(0, len(batches), group)]           # short last batch
+            n_slots = min(plan.slots if plan is not None else 5, max(1, len(calls)))
+            slots = [SharedSlot(cap, prefix=plan.slot_prefix if plan is not None else "helen_slot_") for _ in range(n_slots)]
+            for sl in slots:
+                free_slots.put(sl)
+            if num_workers > 0 and calls:
+                import concurrent.futures as cf
+                pool = cf.ProcessPoolExecutor(num_workers, mp_context=mp.get_context("spawn"))
+        ferr, werr, serr = [], [], []          # failures of the feeder, of the writer, and of the stitch stage (its own: not fatal)
+        reaper = None
+        stop_feeding = threading.Event()
+        # `polish`: stitch runs behind the inference (stitch_threads = its -t); only with the one-file writer of this process
+        stream = sq = stitcher = None
+        LAST_STREAM[0] = None
+        if stitch_threads is not None and writers == 1:
+            from . import stitch_stream
+            if stitch_stream.enabled():
+                export = None
+                if stitch_export is not None:       # a multi-rank run: the regions go to the collectors (helen_amd.stitch_collect)
+                    from .stitch_collect import RegionExport
+                    export = RegionExport(stitch_export[0], rank, stitch_export[1])
+                stream = stitch_stream.RegionStream(prediction_file_name(output_filename, rank), stitch_threads, export=export)
+                sq = queue.Queue()
+        if mode == "threads":
+            reap_q = queue.Queue()
+            reaper = threading.Thread(target=_reaper_loop, args=(reap_q,), daemon=True)
+            reaper.start()
+            feeder = threading.Thread(target=_thread_feeder_loop, daemon=True,
+                                      args=(calls, free_slots, ready_q, make_slot, n_slots, max(1, num_workers), batch_size,
+                                            ferr, None if on_host or native is not None else device_id, reap_q, stop_feeding))
+        else:
+            feeder = threading.Thread(target=_feeder_loop, daemon=True,
+                                      args=(calls, free_slots, ready_q, pool, cap, ferr, num_workers, stop_feeding))
+        for k in STAGE_SECONDS:
+            STAGE_SECONDS[k] = 0.0
+        if writers == 1:
+            release = _SlotRelease(free_slots, 2 if stream is not None else 1)
+            writer = threading.Thread(target=_writer_loop, args=(wq, prediction_data_file, release, werr), daemon=True)
+            writer.start()
+            writer_pool = None
+            if stream is not None:
+                stitcher = threading.Thread(target=_stitch_loop, args=(sq, stream, release, serr), daemon=True)
+                stitcher.start()
+        else:
+            writer_pool = _WriterPool(output_filename, rank, writers, free_slots, werr)
+        feeder.start()
 
+        stage = engine = None
+
+        def to_writer(slot, n):
+            if writer_pool is None:
+                item = (slot, n, slot.bases[:n], slot.rles[:n])
+                wq.put(item)
+                if sq is not None:
+                    sq.put(item)
+            else:
+                writer_pool.submit(slot, n)
+
+    except BaseException:
+        _discard_early_engine(early_engine)
+        raise
     through_library = 0
     t_setup = t_loop_end = start_time
     batch_iterator = 0
@@ -763,9 +811,21 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
     if close_error is not None:
         raise close_error
     stitch_wait = 0.0
+    stitch_failed = None
+    if stream is not None and serr:
+        stream.abort()
+        stitch_failed = "%s: %s" % (type(serr[0]).__name__, serr[0])
+        stream = None
     if stream is not None:
         t_s = time.time()
-        LAST_STREAM[0] = stream.finish()        # the overlap alignments still queued with the worker threads
+        try:
+            LAST_STREAM[0] = stream.finish()        # the overlap alignments still queued with the worker threads
+        except Exception as e:      # noqa: BLE001 -- the stitch stage's own failure: the prediction file is complete
+            stream.abort()
+            stitch_failed = "%s: %s" % (type(e).__name__, e)
+            sys.stderr.write("WARNING: THE STITCH STAGE BEHIND THE INFERENCE FAILED AT ITS END (%s); THE PREDICTION FILE IS "
+                             "UNAFFECTED AND WILL BE STITCHED AFTER THE RUN.\n" % stitch_failed)
+            stream = None
         stitch_wait = time.time() - t_s
     LAST_PREDICT.clear()
     LAST_PREDICT.update({
@@ -774,6 +834,7 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         "setup_seconds": round(t_setup - start_time, 3), "close_seconds": round(time.time() - t_loop_end, 3),
         "reader_workers": num_workers, "reader_mode": mode, "slots": n_slots, "device_calls": len(calls),
         "stitch_stream": None if stream is None else dict(LAST_STREAM[0].stats, wait_seconds=round(stitch_wait, 3)),
+        "stitch_failed": stitch_failed, "peak_rss_mb": peak_rss_mb(),
         "cpus_pinned": None if plan is None or not plan.cpus else len(plan.cpus),
         "numa_node": None if plan is None else plan.numa_node})
     if rank == 0:
@@ -820,7 +881,8 @@ def _rank_report():
     if LAST_STREAM[0] is not None:
         if not LAST_STREAM[0].stats.get("exported"):      # (exported: the collectors have the regions, helen_amd.stitch_collect)
             from .stitch_stream import spill_directory
-            info["stream_file"] = LAST_STREAM[0].save(spill_directory())
+            size = sum(len(v) for v in LAST_STREAM[0].regions.values() if v is not None)
+            info["stream_file"] = LAST_STREAM[0].save(spill_directory(size) or os.path.dirname(os.path.abspath(LAST_STREAM[0].file)))
         LAST_STREAM[0] = None
     return info
 
@@ -842,7 +904,7 @@ def _collect_streams(in_process, rank_infos):
     return [StreamResult.load(p) for p in paths]
 
 
-def _start_collectors(output_filepath, total_callers, stitch_threads, num_workers):
+def _start_collectors(output_filepath, total_callers, stitch_threads, num_workers, file_chunks=None):
     """`polish` over several ranks: the collector processes that take the ranks' regions (helen_amd.stitch_collect), or
     None (no stitch behind this run: `call_consensus` alone, $HELEN_STITCH_PIPELINE=0, or a pool of writer processes --
     a rank streams its regions only beside the one-file writer, and a collector waits for every rank's end marker)."""
@@ -852,7 +914,17 @@ def _start_collectors(output_filepath, total_callers, stitch_threads, num_worker
     if not stitch_stream.enabled():
         return None
     from .stitch_collect import CollectorRun
-    return CollectorRun([prediction_file_name(output_filepath, r) for r in range(total_callers)], stitch_threads).start()
+    # two bytes per window position parked between ranks and collectors; a window is at most 114 KB of an image file
+    # (fewer when the file is deflated: the floor of spill_directory and the run-time fallback cover that)
+    expected = 0
+    for chunk in file_chunks or []:
+        for path in chunk:
+            try:
+                expected += os.path.getsize(path) // 114000 * 2 * ImageSizeOptions.SEQ_LENGTH
+            except OSError:
+                pass
+    return CollectorRun([prediction_file_name(output_filepath, r) for r in range(total_callers)], stitch_threads,
+                        expected_bytes=expected).start()
 
 
 def _streams_of_run(collectors, results, failed, total_callers, what):
@@ -870,6 +942,20 @@ def _streams_of_run(collectors, results, failed, total_callers, what):
                     pass
         raise RuntimeError("prediction process(es) failed: " + ", ".join(
             "rank %d exit %s" % f for f in failed) + "; the other %s were terminated" % what)
+    stopped = sorted(r for r, info in results.items() if info.get("stitch_failed"))
+    if stopped:         # a rank's stitch stage stopped (its prediction file is complete): no pipelined result for this run
+        sys.stderr.write("WARNING: THE STITCH STAGE OF RANK(S) %s STOPPED (%s): STITCHING THE PREDICTION FILES AFTER THE RUN INSTEAD.\n"
+                         % (", ".join(str(r) for r in stopped), results[stopped[0]]["stitch_failed"]))
+        if collectors is not None:
+            collectors.abort()
+        for r in results.values():
+            p = r.pop("stream_file", None)
+            if p is not None:
+                try:
+                    os.unlink(p)
+                except OSError:
+                    pass
+        return None
     if collectors is not None:
         for r in results.values():                     # (the ranks' stubs: statistics only)
             p = r.pop("stream_file", None)
@@ -899,7 +985,7 @@ def predict_cpu(file_chunks, output_filepath, model_path, batch_size, total_call
         LAST_RUN["ranks"] = [dict(LAST_PREDICT)]
         LAST_RUN["seconds"] = round(time.time() - t0, 3)
         return _collect_streams(True, None)
-    collectors = _start_collectors(output_filepath, total_callers, stitch_threads, num_workers)
+    collectors = _start_collectors(output_filepath, total_callers, stitch_threads, num_workers, file_chunks)
     if collectors is not None:
         args = args[:5] + (max(1, int(stitch_threads) // total_callers), collectors.export_spec())
     try:
@@ -1039,7 +1125,7 @@ def predict_gpu(file_chunks, output_filepath, model_path, batch_size, total_call
         LAST_RUN["ranks"] = [dict(LAST_PREDICT)]
         LAST_RUN["seconds"] = round(time.time() - t0, 3)
         return _collect_streams(True, None)
-    collectors = _start_collectors(output_filepath, total_callers, total_stitch_threads, num_workers)
+    collectors = _start_collectors(output_filepath, total_callers, total_stitch_threads, num_workers, file_chunks)
     if collectors is not None:
         args = args + (collectors.export_spec(),)
     try:

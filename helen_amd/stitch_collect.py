@@ -84,13 +84,35 @@ class RegionExport(object):
         self.fds = []
 
 
+_FALLOC_FL_KEEP_SIZE, _FALLOC_FL_PUNCH_HOLE = 1, 2
+_libc = [None]
+
+
+def _punch_hole(fd, length):
+    """Give the pages of bytes [0, length) of a record file back (tmpfs pages are RAM): the records are in the collector's
+    heap by now.  Best effort -- a file system without hole punching keeps them until the run's directory goes."""
+    try:
+        if _libc[0] is None:
+            import ctypes
+            lib = ctypes.CDLL(None, use_errno=True)
+            lib.fallocate.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_longlong]
+            lib.fallocate.restype = ctypes.c_int
+            _libc[0] = lib
+        return _libc[0].fallocate(fd, _FALLOC_FL_PUNCH_HOLE | _FALLOC_FL_KEEP_SIZE, 0, length) == 0
+    except (OSError, AttributeError):
+        _libc[0] = False
+        return False
+
+
 class _Follower(object):
     """One rank's file as the collector reads it: whatever has been appended since the last look, cut into records."""
 
     def __init__(self, path):
-        self.fd = os.open(path, os.O_RDONLY)
+        self.fd = os.open(path, os.O_RDWR)
         self.rest = b""
         self.ended = False
+        self.read_bytes = 0
+        self.punched = 0
 
     def poll(self):
         """-> ([(key, sequence or None)], bytes read)."""
@@ -106,6 +128,11 @@ class _Follower(object):
                 break
         if not chunks:
             return [], 0
+        self.read_bytes += got
+        if _libc[0] is not False and self.read_bytes - self.punched >= 1 << 26:     # every 64 MiB, whole pages
+            upto = self.read_bytes & ~4095
+            if _punch_hole(self.fd, upto):
+                self.punched = upto
         buf = self.rest + b"".join(chunks)
         out, at, n = [], 0, len(buf)
         size = _HEADER.size
@@ -206,7 +233,8 @@ def _collector_main(bucket, buckets, prefix, prediction_files, threads, run_thre
         t_assembled = time.time()
     finally:
         writer.close()
-    stats.update({"bucket": bucket, "regions": sum(len(d) for d in per_rank), "from_file": from_file,
+    from .host_plan import peak_rss_mb
+    stats.update({"bucket": bucket, "regions": sum(len(d) for d in per_rank), "from_file": from_file, "peak_rss_mb": peak_rss_mb(),
                   "joins_submitted": result.stats.get("joins_submitted", 0), "index": index,
                   "seconds": {"following": round(t_last - t0, 3), "accepting": round(busy, 3),
                               "joins_after_the_last_record": round(t_joined - t_last, 3),
@@ -223,13 +251,28 @@ def collectors_for(threads):
 class CollectorRun(object):
     """The parent's handle: start() before the ranks, finish() after them (-> the FASTA), abort() when a rank failed."""
 
-    def __init__(self, prediction_files, threads, directory=None):
+    def __init__(self, prediction_files, threads, directory=None, expected_bytes=0):
+        """`expected_bytes`: what the run will park between ranks and collectors -- the called sequences once as records
+        (given back page by page as the collectors read them) and once as part files, about two bytes per window position.
+        The files go to a directory of this run's own (removed with the run) under /dev/shm when that may take them
+        (helen_amd.stitch_stream.spill_directory: free space and half of the available RAM, at least 1 GiB -- Docker's
+        default 64 MB /dev/shm is never used), under the prediction directory otherwise."""
+        import tempfile
+
         from .stitch_stream import spill_directory
         self.files = [os.path.abspath(p) for p in prediction_files]
         self.threads = max(1, int(threads))
         self.buckets = collectors_for(self.threads)
-        d = directory or spill_directory() or os.path.dirname(self.files[0])
-        self.prefix = os.path.join(d, "helen_regions_%d_%x" % (os.getpid(), int(time.time() * 1e6) & 0xFFFFFFFF))
+        parent = directory or spill_directory(expected_bytes) or os.path.dirname(self.files[0])
+        self.sweep(parent)
+        self.directory = tempfile.mkdtemp(prefix="helen_regions_", dir=parent)
+        self.lock = open(os.path.join(self.directory, "lock"), "w")
+        try:
+            import fcntl
+            fcntl.flock(self.lock, fcntl.LOCK_EX | fcntl.LOCK_NB)       # held while the run lives: sweep() leaves it alone
+        except (ImportError, OSError):
+            pass
+        self.prefix = os.path.join(self.directory, "r")
         self.parts = [self.prefix + "_part%d.fa" % w for w in range(self.buckets)]
         self.procs = []
         self.result_q = None
@@ -240,31 +283,33 @@ class CollectorRun(object):
         return (self.prefix, self.buckets)
 
     @staticmethod
-    def sweep(directory):
-        """Record and part files a KILLED run left behind (their names carry the parent's pid: gone = stale)."""
+    def sweep(parent, min_age_seconds=600.0):
+        """Directories a KILLED run left behind under `parent`: provably stale only -- nobody holds the run's lock (a live
+        run does, whatever PID namespace it is in: containers sharing /dev/shm) and nothing in it changed for ten minutes."""
+        import shutil
         try:
-            names = os.listdir(directory)
+            names = os.listdir(parent)
         except OSError:
             return 0
         removed = 0
         for name in names:
-            if not name.startswith("helen_regions_"):
+            d = os.path.join(parent, name)
+            if not name.startswith("helen_regions_") or not os.path.isdir(d):
                 continue
             try:
-                pid = int(name.split("_")[2])
-            except (IndexError, ValueError):
+                newest = max([os.stat(d).st_mtime] + [os.stat(os.path.join(d, n)).st_mtime for n in os.listdir(d)])
+                if time.time() - newest < min_age_seconds:
+                    continue
+                with open(os.path.join(d, "lock"), "a") as lock:
+                    import fcntl
+                    fcntl.flock(lock, fcntl.LOCK_EX | fcntl.LOCK_NB)    # raises while the run lives
+                    shutil.rmtree(d, ignore_errors=True)
+                    removed += 1
+            except (OSError, ImportError):
                 continue
-            if pid == os.getpid() or os.path.exists("/proc/%d" % pid):
-                continue
-            try:
-                os.unlink(os.path.join(directory, name))
-                removed += 1
-            except OSError:
-                pass
         return removed
 
     def start(self):
-        self.sweep(os.path.dirname(self.prefix))
         for r in range(len(self.files)):
             for w in range(self.buckets):
                 open(_path(self.prefix, r, w), "wb").close()
@@ -290,6 +335,12 @@ class CollectorRun(object):
                 os.unlink(p)
             except OSError:
                 pass
+        import shutil
+        try:
+            self.lock.close()
+        except OSError:
+            pass
+        shutil.rmtree(self.directory, ignore_errors=True)
 
     def abort(self):
         for p in self.procs:
@@ -356,7 +407,8 @@ class CollectorRun(object):
                          % (self.buckets, len(self.files), sum(s["regions"] for s in got.values()),
                             max(s["seconds"]["joins_after_the_last_record"] for s in got.values()),
                             max(s["seconds"]["assembly"] for s in got.values()), time.time() - t_collected))
-        self.stats = {"collectors": self.buckets, "per_collector": [dict(got[w], index=len(got[w]["index"])) for w in sorted(got)],
+        self.stats = {"collectors": self.buckets, "directory": os.path.dirname(self.directory),
+                      "per_collector": [dict(got[w], index=len(got[w]["index"])) for w in sorted(got)],
                       "wait_seconds": round(t_collected - t0, 3), "copy_seconds": round(time.time() - t_collected, 3)}
         return output_filename
 

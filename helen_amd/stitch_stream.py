@@ -41,6 +41,9 @@ def enabled():
     return os.environ.get("HELEN_STITCH_PIPELINE", "1") != "0" and native_io.available()
 
 
+_INJECT_FAILURE = [None]
+
+
 class RegionStream(object):
     """The regions of ONE prediction file (one rank), decoded as the writer stage delivers their images.
 
@@ -74,6 +77,12 @@ class RegionStream(object):
         n = int(meta.shape[0])
         if n == 0:
             return
+        if _INJECT_FAILURE[0] is None:      # test hook: the second feed of a stream fails as a full spill directory would
+            _INJECT_FAILURE[0] = os.environ.get("HELEN_DEBUG_HOOKS") == "1" and os.environ.get("HELEN_DEBUG_STITCH_FAIL") == "1"
+        if _INJECT_FAILURE[0]:
+            self._feeds = getattr(self, "_feeds", 0) + 1
+            if self._feeds == 2:
+                raise OSError(28, "No space left on device (injected by HELEN_DEBUG_STITCH_FAIL)")
         contigs = np.asarray(contigs)
         # (a name ends at its first NUL; what follows in the slot's row may be left over from a longer name: only the
         # columns up to the longest name of this call are looked at, with every row's tail behind its NUL zeroed)
@@ -330,10 +339,18 @@ class StreamResult(object):
         return out
 
 
-def spill_directory():
+SPILL_FLOOR_BYTES = 1 << 30     # a RAM-backed directory that may not take this much is not used (Docker's default /dev/shm: 64 MB)
+
+
+def spill_directory(expected_bytes=0):
+    """Where a run parks region sequences between its processes: /dev/shm when it may take what is expected -- its free
+    space AND half of the RAM the process tree may still claim (helen_amd.host_plan.ram_backed_budget_bytes: tmpfs pages are
+    RAM) -- with a floor of 1 GiB; None otherwise (the caller uses the prediction directory)."""
+    from .host_plan import ram_backed_budget_bytes
     for d in ("/dev/shm",):
         if os.path.isdir(d) and os.access(d, os.W_OK):
-            return d
+            if ram_backed_budget_bytes(d) >= max(SPILL_FLOOR_BYTES, int(1.2 * expected_bytes)):
+                return d
     return None
 
 

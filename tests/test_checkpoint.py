@@ -80,6 +80,20 @@ def test_checkpoint_reader_refuses_what_it_does_not_know(tmp_path):
         checkpoint.load(r)
 
 
+def test_tensor_geometry_is_checked_against_the_storage():
+    """A pickled (offset, size, stride) that does not fit its storage -- a truncated or corrupt file -- is refused instead of
+    becoming an out-of-bounds strided view."""
+    from helen_amd import checkpoint
+    storage = np.arange(12, dtype=np.float32)
+    ok = checkpoint._rebuild_tensor(storage, 2, (2, 5), (5, 1))
+    assert ok.shape == (2, 5) and ok[0, 0] == 2 and ok[1, 4] == 11
+    assert checkpoint._rebuild_tensor(storage, 0, (3, 4), (1, 3)).tolist() == storage.reshape(4, 3).T.tolist()
+    for offset, size, stride in ((3, (2, 5), (5, 1)), (0, (13,), (1,)), (0, (2, 2), (100, 1)), (-1, (2,), (1,)), (0, (2,), (-1,)),
+                                 (0, (2, 2), (1,)), (12, (), ())):
+        with pytest.raises(checkpoint.UnsupportedCheckpoint):
+            checkpoint._rebuild_tensor(storage, offset, size, stride)
+
+
 def test_checkpoint_reader_does_not_import_torch(tmp_path):
     path, _ = _checkpoint(tmp_path, False)
     code = ("import sys; sys.path.insert(0, %r); from helen_amd import checkpoint; s = checkpoint.load_simple_model_state(%r); "

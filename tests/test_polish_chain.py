@@ -158,6 +158,22 @@ def test_host_polish_equals_the_reference_chain(tmp_path, threads, callers):
     assert _identity_report(fasta, made["truth"], "host path") > 0.995
 
 
+@pytest.mark.parametrize("callers", [1, 2])
+def test_a_failing_stitch_stage_does_not_fail_polish(tmp_path, callers):
+    """The stitch stage behind the inference is an optimisation: when it stops (a full spill directory -- injected here
+    at the second device call of every caller) the prediction files are still written whole, the command says so, stitches
+    them in a second phase and exits 0 with the same FASTA."""
+    gen, fixture = _fixture()
+    image_dir, model, made = gen.polish_case(str(tmp_path))
+    out = str(tmp_path / "out")
+    r = _helen(["polish", "-i", image_dir, "-m", model, "-b", "16", "-w", "0", "-t", "3", "-c", str(callers), "-o", out,
+                "-p", "polished"], env={"HELEN_DEBUG_HOOKS": "1", "HELEN_DEBUG_STITCH_FAIL": "1"})
+    assert "THE STITCH STAGE BEHIND THE INFERENCE STOPPED" in r.stderr, r.stderr[-1500:]
+    assert "No space left on device (injected" in r.stderr
+    assert len(_prediction_files(out)) == callers
+    _assert_chain_equals_reference(gen, fixture, out, 3, "host path, stitch stage stopped")
+
+
 @pytest.mark.gpu
 def test_gpu_polish_equals_the_reference_chain(tmp_path):
     """`helen polish -g` on the MI355X, the command a user types: same prediction tree and labels as the reference's

@@ -2,6 +2,7 @@
 processes sharded by contig; the FASTA must be the one `perform_stitch` writes from the finished prediction files --
 whatever the number of ranks, collectors and threads, and however the regions of a contig are dealt over the ranks."""
 import os
+import time
 import random
 import sys
 
@@ -127,14 +128,80 @@ def test_a_failed_run_leaves_nothing_behind(tmp_path):
 
 
 def test_what_a_killed_run_left_behind_is_swept(tmp_path):
-    """Record files carry the parent's pid; the next run removes those whose process is gone, and no others."""
+    """A run's record and part files live in a directory of its own whose lock file the parent holds (flock) while it
+    lives.  The next run removes only what is provably stale: nobody holds the lock AND nothing changed for ten minutes --
+    a live run in another PID namespace that shares /dev/shm (containers with --ipc=host) holds its lock and is left alone."""
+    import fcntl
     from helen_amd.stitch_collect import CollectorRun
-    dead = 2 ** 22 + 12345                                       # (beyond pid_max of this machine: nobody)
-    assert not os.path.exists("/proc/%d" % dead)
-    stale = [tmp_path / ("helen_regions_%d_abc_0_0.bin" % dead), tmp_path / ("helen_regions_%d_abc_part0.fa" % dead)]
-    alive = tmp_path / ("helen_regions_%d_abc_0_0.bin" % os.getppid())
+    old = time.time() - 3600
+
+    def make(name, locked, aged):
+        d = tmp_path / name
+        d.mkdir()
+        (d / "r_0_0.bin").write_bytes(b"x")
+        lock = open(str(d / "lock"), "w")
+        if aged:
+            for f in (d / "r_0_0.bin", d / "lock", d):
+                os.utime(str(f), (old, old))
+        if locked:
+            fcntl.flock(lock, fcntl.LOCK_EX | fcntl.LOCK_NB)
+            return lock
+        lock.close()
+        return None
+    held = make("helen_regions_live", True, True)              # old but its parent lives
+    make("helen_regions_fresh", False, False)                  # nobody holds it, but it changed a moment ago
+    make("helen_regions_stale", False, True)
     other = tmp_path / "helen_slot_1_2_3"
-    for f in stale + [alive, other]:
-        f.write_bytes(b"x")
-    assert CollectorRun.sweep(str(tmp_path)) == 2
-    assert not any(f.exists() for f in stale) and alive.exists() and other.exists()
+    other.write_bytes(b"x")
+    assert CollectorRun.sweep(str(tmp_path)) == 1
+    assert sorted(n for n in os.listdir(str(tmp_path))) == ["helen_regions_fresh", "helen_regions_live", "helen_slot_1_2_3"]
+    held.close()
+
+
+def test_the_spill_goes_to_ram_only_when_it_fits(tmp_path, monkeypatch):
+    """The collectors' files are RAM when they sit under /dev/shm: the directory is chosen against what the run may still
+    take (free space of the tmpfs, half of the available RAM), with a floor of 1 GiB -- Docker's default 64 MB /dev/shm is
+    never used; otherwise the files go beside the prediction files."""
+    from helen_amd import host_plan, stitch_stream
+    from helen_amd.stitch_collect import CollectorRun
+    monkeypatch.setattr(host_plan, "shm_free_bytes", lambda path="/dev/shm": 64 << 20)
+    monkeypatch.setattr(host_plan, "ram_available_bytes", lambda: 256 << 30)
+    assert stitch_stream.spill_directory(0) is None
+    files = [str(tmp_path / "pred" / "p_0.hdf"), str(tmp_path / "pred" / "p_1.hdf")]
+    os.makedirs(str(tmp_path / "pred"))
+    run = CollectorRun(files, 4, expected_bytes=10 << 20)
+    try:
+        assert os.path.dirname(run.directory) == str(tmp_path / "pred")
+    finally:
+        run.abort()
+    assert os.listdir(str(tmp_path / "pred")) == []
+    monkeypatch.setattr(host_plan, "shm_free_bytes", lambda path="/dev/shm": 200 << 30)
+    if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK):
+        assert stitch_stream.spill_directory(6 << 30) == "/dev/shm"
+        assert stitch_stream.spill_directory(120 << 30) is None         # more than half of the available RAM
+
+
+def test_consumed_records_are_given_back(tmp_path):
+    """A collector punches the pages of what it has read out of a rank's record file (tmpfs pages are RAM): the file keeps
+    its size, its blocks go."""
+    from helen_amd.stitch_collect import _Follower, _HEADER
+    path = str(tmp_path / "r_0_0.bin")
+    rec = _HEADER.pack(4, 0, 1000, 1000) + b"ctgA" + b"A" * 1000
+    n = (96 << 20) // len(rec)
+    with open(path, "wb") as f:
+        f.write(rec * n)
+    before = os.stat(path).st_blocks
+    fo = _Follower(path)
+    total = 0
+    while True:
+        records, got = fo.poll()
+        if not got:
+            break
+        total += len(records)
+        assert all(k == ("ctgA", 0, 1000) and len(sq) == 1000 for k, sq in records)
+    fo.close()
+    assert total == n
+    after = os.stat(path)
+    assert after.st_size == n * len(rec)
+    if fo.punched:                                           # (a file system without hole punching: nothing to check)
+        assert after.st_blocks < before // 2, (before, after.st_blocks)
