@@ -255,8 +255,8 @@ def contig_windows(contig, bank, lo=0, hi=None):
 
 
 def _write_assembly_files(args):
-    directory, spec, n_files, seed, blocks, direct, only = args
-    made = write_assembly_dir(directory, spec, n_files, seed, blocks, direct, only_files=only)
+    directory, spec, n_files, seed, blocks, direct, only, gzip = args
+    made = write_assembly_dir(directory, spec, n_files, seed, blocks, direct, only_files=only, gzip=gzip)
     return made["files"], made["windows"], made["regions"], made["windows_per_file"], made["regions_per_file"]
 
 
@@ -269,13 +269,14 @@ def assembly_spec(windows, n_files, contigs_per_file=2, region_positions=2400, o
     return [(name % k, positions, {"region_positions": region_positions, "overlap": overlap}) for k in range(n_contigs)]
 
 
-def write_assembly_dir(directory, spec, n_files=1, seed=20260929, blocks=None, direct=False, only_files=None, processes=0):
+def write_assembly_dir(directory, spec, n_files=1, seed=20260929, blocks=None, direct=False, only_files=None, processes=0, gzip=None):
     """A directory of MarginPolish-shaped image files for the simulated assembly `spec` (see assembly_contigs).  Each
     contig's regions are cut into blocks[k] (default 1) runs of consecutive regions; the blocks, in contig order, go to
     the files round-robin -- all images of a region share a file, a contig may span several.  Images are named
     <contig>-<contig_start>-<contig_end>-<feature_chunk_idx>.  direct=True writes through the emitter of libhelen_io.so
     (the benchmark's 300 k-window inputs in seconds) instead of libhdf5; only_files = the file indices this caller writes
-    (several ranks of a benchmark each write their share); processes = N > 1 writes the files in N worker processes.
+    (several ranks of a benchmark each write their share); processes = N > 1 writes the files in N worker processes;
+    gzip = 1..9 (with direct=False) stores image and position chunked and deflated, as an h5py writer with compression="gzip".
     -> {"files": [paths], "windows": total images, "regions": total, "truth": {contig: sequence} (None when only_files is given),
         "windows_per_file": [...]}"""
     os.makedirs(directory, exist_ok=True)
@@ -285,7 +286,7 @@ def write_assembly_dir(directory, spec, n_files=1, seed=20260929, blocks=None, d
         import multiprocessing as mp
         todo = sorted(range(n_files) if only_files is None else only_files)
         with concurrent.futures.ProcessPoolExecutor(min(processes, len(todo)), mp_context=mp.get_context("spawn")) as ex:
-            parts = list(ex.map(_write_assembly_files, [(directory, spec, n_files, seed, blocks, direct, [fi]) for fi in todo]))
+            parts = list(ex.map(_write_assembly_files, [(directory, spec, n_files, seed, blocks, direct, [fi], gzip) for fi in todo]))
         counts, region_counts = [0] * n_files, [0] * n_files
         for fi, p in zip(todo, parts):
             counts[fi] = p[3][fi]
@@ -331,12 +332,12 @@ def write_assembly_dir(directory, spec, n_files=1, seed=20260929, blocks=None, d
             from . import native_io
             native_io.emit_image_windows(paths[fi], names, *cat)
         else:
-            _write_windows(paths[fi], names, *cat)
+            _write_windows(paths[fi], names, *cat, gzip=gzip)
     return {"files": [p for fi, p in enumerate(paths) if per_file[fi] and fi in mine], "windows": windows, "regions": regions,
             "truth": truth if only_files is None else None, "windows_per_file": counts, "regions_per_file": regions_per_file}
 
 
-def _write_windows(path, names, starts, ends, chunks, lengths, images, positions):
+def _write_windows(path, names, starts, ends, chunks, lengths, images, positions, gzip=None):
     with hdf5.File(path, "w") as f:
         for i, contig in enumerate(names):
             L = int(lengths[i])
@@ -345,8 +346,8 @@ def _write_windows(path, names, starts, ends, chunks, lengths, images, positions
             f.write(base + "contig_start", np.array([starts[i]], np.int64))
             f.write(base + "contig_end", np.array([ends[i]], np.int64))
             f.write(base + "feature_chunk_idx", np.array([chunks[i]], np.int64))
-            f.write(base + "image", images[i, :L], np.uint8)
-            f.write(base + "position", positions[i, :L], np.int64)
+            f.write(base + "image", images[i, :L], np.uint8, chunks=(min(256, L), images.shape[2]) if gzip else None, gzip=gzip)
+            f.write(base + "position", positions[i, :L], np.int64, chunks=(L, 3) if gzip else None, gzip=gzip)
 
 
 # the simulated assembly of the chained `polish` parity fixture (tests/golden/make_golden_polish.py): three contigs in
