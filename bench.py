@@ -109,7 +109,10 @@ def kernel_table(all_stats, calls, call_windows, precision, ms_per_step):
             peak, pipe = X3_MFMA_PEAK, "bf16 MFMA, 6 products of 3-term splits per fp32 product (peak = bf16 / 6)"
         else:
             peak, pipe = FP32_MFMA_PEAK, "fp32 MFMA (v_mfma_f32_16x16x4_f32 / 4x4x1)"
-    hbm_bytes = {"pack": 90000.0 + 96 * 4 * 1000.0}     # uint8 image in, K-padded fp32 operand tiles out (fp32 mode)
+    # HBM-bound classes (fp32 / fp32x3): pack = uint8 image in, bf16 A fragments out (K padded to 96); the encoder projection
+    # runs on the bf16 pipe with exact products (counts are one bf16 term, W_ih three: 3 MFMAs per 32 k, fp32 accumulation)
+    # and is bound by its fp32 output stream: 192 KB of fragments in, 2 x 384 x 1000 x 4 B of gi out per window
+    hbm_bytes = {"pack": 90000.0 + 96 * 2 * 1000.0, "gemm_enc": 96 * 2 * 1000.0 + 2 * 384 * 1000 * 4.0}
     rows = []
     for name, (ms, n) in all_stats.items():
         if n == 0:
@@ -118,13 +121,18 @@ def kernel_table(all_stats, calls, call_windows, precision, ms_per_step):
         per_step = ms / calls
         row = {"class": name, "launches_per_call": round(n / float(calls), 2), "avg_launch_ms": round(avg, 4),
                "ms_per_step": round(per_step, 3), "share_of_step": round(per_step / ms_per_step, 4)}
-        if name in flop:
+        if name in hbm_bytes and precision != "bf16":
+            gb = hbm_bytes[name] * call_windows / (avg * 1e-3) / 1e9
+            row.update({"bound": "hbm", "achieved_GBps": round(gb, 1), "frac": round(gb / 8000.0, 4)})
+            if name in flop:
+                tf = flop[name] * call_windows / (avg * 1e-3) / 1e12
+                row.update({"pipe": "bf16 MFMA, exact products: pileup counts (one bf16 term) x W_ih in three bf16 terms, fp32 accumulate",
+                            "flop_per_window_launch": flop[name], "achieved_TFLOPs": round(tf, 1),
+                            "frac_of_fp32_mfma_peak": round(tf * 1e12 / FP32_MFMA_PEAK, 4)})
+        elif name in flop:
             tf = flop[name] * call_windows / (avg * 1e-3) / 1e12
             row.update({"bound": "mfma", "pipe": pipe, "flop_per_window_launch": flop[name], "achieved_TFLOPs": round(tf, 1),
                         "frac": round(tf * 1e12 / peak, 4)})
-        elif name in hbm_bytes and precision == "fp32":
-            gb = hbm_bytes[name] * call_windows / (avg * 1e-3) / 1e9
-            row.update({"bound": "hbm", "achieved_GBps": round(gb, 1), "frac": round(gb / 8000.0, 4)})
         else:
             row.update({"bound": "latency" if name == "heads" else "hbm", "frac": None})
         rows.append(row)

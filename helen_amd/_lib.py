@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # HELEN_HIP_LIB: developer override to A/B-test kernel variants built side by side.
 LIB_PATH = os.environ.get("HELEN_HIP_LIB") or os.path.join(_HERE, "csrc", "libhelen_hip.so")
 
-HELEN_ABI_VERSION = 3
+HELEN_ABI_VERSION = 4
 HELEN_OK = 0
 HELEN_PRECISION_FP32 = 0
 HELEN_PRECISION_BF16 = 1
@@ -29,7 +29,7 @@ EXPORTS = (
 )
 RECURRENCE_KERNELS = ("gru_kernel", "gru_single8_kernel", "gru_half8_kernel", "gru_quarter4_kernel", "gru_pair_kernel")
 DECODER_PROJECTIONS = ("gemm_gi_kernel<16>", "gemm_dec_ws_kernel", "gemm_dec_wsp_kernel")
-ENCODER_PROJECTIONS = ("gemm_gi_kernel<6>", "gemm_enc_ws_kernel", "gemm_enc_ws8_kernel", "gemm_enc_ws8p_kernel")
+ENCODER_PROJECTIONS = ("gemm_enc_x3_kernel",)        # polish entry points: exact bf16 products, fp32 accumulation
 
 _f32p = ctypes.POINTER(ctypes.c_float)
 

@@ -22,7 +22,7 @@
 
 using namespace helen;
 
-static_assert(kDecStagePositions == HELEN_DWS_PB && kEncStagePositions == HELEN_EWS8_PB, "dispatch.h's stage sizes are the kernels'");
+static_assert(kDecStagePositions == HELEN_DWS_PB, "dispatch.h's stage sizes are the kernels'");
 
 namespace {
 
@@ -141,7 +141,7 @@ struct BusyGuard {
     BusyGuard guard_(m);                                                                           \
     if (!guard_.ok) return fail(HELEN_EINVAL, "handle is in use by another thread (one thread per handle)")
 
-constexpr long kXaTileStride = (long)kSeq * (kXaStride / 4);        // float4
+constexpr long kXaTileStride = (long)kWin * (kXaStride / 4);        // float4: the operator entry's fp32 operand tiles (one chunk)
 constexpr long kGiEncTileStride = (long)kSeq * (kGiStride / 4);
 constexpr long kGiDecTileStride = (long)kWin * (kGiStride / 4);
 constexpr long kYTileStride = (long)kWin * (kYStride / 4);
@@ -320,27 +320,11 @@ unsigned gemm_grid(int npos, int tiles, int positions_per_wave = HELEN_GEMM_P) {
     return (unsigned)((units + 7) / 8 * 8) * ((2 * kNTile / HELEN_GEMM_N) / HELEN_GEMM_WAVES);
 }
 
-// Encoder input projection: which of the four kernels (all the same gi bit for bit) is dispatch.h's plan_encoder.
+// Encoder input projection of the OPERATOR entry (helen_gru_chunk_forward: x is arbitrary fp32, at most kWin positions):
+// fp32 MFMA, streaming weights.  The polish entry points take exact bf16 products instead (launch_front).
 void launch_enc_gemm(HelenModel* m, hipStream_t s, int tiles, int npos) {
-    const EncoderPlan e = plan_encoder(tiles, npos, m->cus, m->overrides);
-    switch (e.kind) {
-        case kEncTile:          // one long workgroup per tile, one per CU: wants whole rounds of tiles
-            LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_ws8_kernel, dim3(tiles), dim3(512), m->xa, kXaTileStride, m->wp_enc,
-                   m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles);
-            break;
-        case kEncTileRuns:      // a small call: a tile's positions cut into runs, about one workgroup per CU
-            LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_ws8p_kernel, dim3(tiles * e.parts), dim3(512), m->xa, kXaTileStride, m->wp_enc,
-                   m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles, e.parts, e.run);
-            break;
-        case kEncSets:          // one workgroup per (tile, column set)
-            LAUNCH(HELEN_K_GEMM_ENC, gemm_enc_ws_kernel, dim3(3 * ((tiles + 7) / 8 * 8)), dim3(256), m->xa,
-                   kXaTileStride, m->wp_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles);
-            break;
-        default:
-            LAUNCH(HELEN_K_GEMM_ENC, (gemm_gi_kernel<kFPad / 16, false>), dim3(gemm_grid(npos, tiles)),
-                   dim3(HELEN_GEMM_WAVES * 64), m->xa, kXaTileStride, m->wp_enc, m->bias_enc, m->gi_enc, kGiEncTileStride,
-                   npos, tiles);
-    }
+    LAUNCH(HELEN_K_GEMM_ENC, (gemm_gi_kernel<kFPad / 16, false>), dim3(gemm_grid(npos, tiles)), dim3(HELEN_GEMM_WAVES * 64), m->xa,
+           kXaTileStride, m->wp_enc, m->bias_enc, m->gi_enc, kGiEncTileStride, npos, tiles);
 }
 
 // One TransducerGRU.forward over `tiles` tiles whose encoder pre-activations are already in
@@ -499,7 +483,7 @@ int create_impl(const HelenWeights* w, int device, int max_windows, int precisio
         if ((rc = upload(m, &m->whp_enc, pack_w_hh(w->enc_w_hh)))) return rc;
         if ((rc = upload(m, &m->whp_dec, pack_w_hh(w->dec_w_hh)))) return rc;
     }
-    if (precision == HELEN_PRECISION_FP32 && m->overrides.enc_exact != 0) {
+    if (precision == HELEN_PRECISION_FP32) {
         // the encoder projection of the polish entry points: pileup counts are exact in bf16 and W_ih is exactly three
         // bf16 terms, so x.w = x.w1 + x.w2 + x.w3 with every partial product exact and fp32 accumulation (launch_front)
         if ((rc = upload(m, &m->w3i_enc, pack_w_ih_x3(w->enc_w_ih, kF)))) return rc;
@@ -661,13 +645,13 @@ int helen_plan_call(int cus, int tiles, int* out) {
     const Overrides o = read_overrides();
     const CallPlan c = plan_call(tiles, cus, true, o);
     const ChunkPlan k = plan_chunk(tiles, kWin, cus, o);
-    const EncoderPlan e = plan_encoder(tiles, kSeq, cus, o);
+    const ExactEncoderPlan e = plan_exact_encoder(tiles, kSeq, cus);
     out[0] = c.split ? 1 : 0;
     out[1] = c.first_group;
     out[2] = (int)k.recurrence;
     out[3] = (int)k.decoder;
     out[4] = k.dec_parts;
-    out[5] = (int)e.kind;
+    out[5] = 0;                 // (one encoder projection kernel: gemm_enc_x3_kernel)
     out[6] = e.parts;
     out[7] = bf16_pair_pays(tiles, cus, o) ? 1 : 0;
     return HELEN_OK;
@@ -677,7 +661,7 @@ int helen_plan_call(int cus, int tiles, int* out) {
 // uint8 windows -> operand tiles -> encoder input projection for all 1000 positions (overlapping chunks
 // share it) -> zero initial hidden (predict_gpu.py:97-99): everything before the chunk loop.
 static int launch_front(HelenModel* m, hipStream_t s, const uint8_t* images, int n_windows, int tiles) {
-    if (m->xb) {
+    {
         // pileup counts are exact in bf16: pack them straight into A fragments; three exact products per w
         // (fp32 and fp32x3: W_ih in three bf16 terms, fp32 accumulation) or the one product with w rounded to bf16 (bf16)
         LAUNCH(HELEN_K_PACK, pack_images_x3_kernel, dim3((kSeq * 192 + 255) / 256, tiles), dim3(256), images,
@@ -689,11 +673,6 @@ static int launch_front(HelenModel* m, hipStream_t s, const uint8_t* images, int
                    e.run);
         }
         // (bf16: the projection is fused into the recurrence, gru_fused_bf16_kernel reads xb directly)
-    } else {
-        // uint8 -> fp32 operand tiles (predict_gpu.py:97)
-        LAUNCH(HELEN_K_PACK, pack_images_kernel, dim3((kSeq * (kXaStride / 4) + 255) / 256, tiles),
-               dim3(256), images, n_windows, kSeq, m->xa);
-        launch_enc_gemm(m, s, tiles, kSeq);
     }
     // zero initial hidden per batch (predict_gpu.py:99)
     HIP_TRY(hipMemsetAsync(m->hid, 0, (size_t)tiles * kHidStride * sizeof(float), s));

@@ -3,7 +3,7 @@
 // Every stage of the fp32 path has several kernels that give the same bits (same MFMA order per accumulator, same gate
 // cell: tests/test_gpu_scale.py), so the choice is pure scheduling: how many workgroups a launch has against how many
 // CUs the device has.  This header is the whole of that decision -- plain C++, no HIP, no globals: plan_chunk /
-// plan_encoder / plan_call map (tiles, CUs) to kernels, describe_dispatch prints the table for a device, and the
+// plan_exact_encoder / plan_call map (tiles, CUs) to kernels, describe_dispatch prints the table for a device, and the
 // environment overrides (A/B probes and tests) are read ONCE, by read_overrides at helen_model_create (or again through
 // helen_reload_overrides), never per call.  helen_describe_dispatch (C ABI) runs it dry for any CU count.
 #pragma once
@@ -26,13 +26,6 @@ enum DecoderProjection {
     kDecStationary,           // gemm_dec_ws_kernel: one workgroup per (tile, direction), weights in registers
     kDecStationaryRuns,       // gemm_dec_wsp_kernel: the same with a (tile, direction)'s positions cut into runs
 };
-enum EncoderProjection {
-    kEncStreaming = 0,        // gemm_gi_kernel<6, false>
-    kEncSets,                 // gemm_enc_ws_kernel: three column-set workgroups per tile
-    kEncTile,                 // gemm_enc_ws8_kernel: one workgroup per tile
-    kEncTileRuns,             // gemm_enc_ws8p_kernel: the same with a tile's positions cut into runs
-};
-
 inline const char* name_of(RecurrenceKernel k) {
     static const char* n[] = {"gru_kernel", "gru_single8_kernel", "gru_half8_kernel", "gru_quarter4_kernel", "gru_pair_kernel"};
     return n[k];
@@ -41,20 +34,13 @@ inline const char* name_of(DecoderProjection k) {
     static const char* n[] = {"gemm_gi_kernel<16>", "gemm_dec_ws_kernel", "gemm_dec_wsp_kernel"};
     return n[k];
 }
-inline const char* name_of(EncoderProjection k) {
-    static const char* n[] = {"gemm_gi_kernel<6>", "gemm_enc_ws_kernel", "gemm_enc_ws8_kernel", "gemm_enc_ws8p_kernel"};
-    return n[k];
-}
-
 // -1 = not forced.  HELEN_<NAME>=0 / 1 forces a choice off / on whatever the size (A/B probes; every forced choice still
 // gives the same bits).
 struct Overrides {
     int gru_pair = -1, gru_single8 = -1, gru_half8 = -1, gru_quarter4 = -1;
     int dec_ws = -1, dec_wsp = -1, dec_wsp_parts = 0;
-    int enc_ws8 = -1, enc_ws8p = -1, enc_ws8p_parts = 0;
     int split = -1, split_at = 0;
     int bf16_pair = -1;
-    int enc_exact = -1;                         // fp32: 0 = the polish entry points project the encoder input on the fp32 matrix pipe
     int host_lock = -1;                         // helen_polish_host: 0 never page-lock caller memory, 1 ranges that own their pages, 2 all
     bool verbose = false;
 };
@@ -71,13 +57,9 @@ inline Overrides read_overrides() {
     o.dec_ws = flag_of("HELEN_DEC_WS");
     o.dec_wsp = flag_of("HELEN_DEC_WSP");
     if (const char* n = getenv("HELEN_DEC_WSP_PARTS")) o.dec_wsp_parts = atoi(n);
-    o.enc_ws8 = flag_of("HELEN_ENC_WS8");
-    o.enc_ws8p = flag_of("HELEN_ENC_WS8P");
-    if (const char* n = getenv("HELEN_ENC_WS8P_PARTS")) o.enc_ws8p_parts = atoi(n);
     o.split = flag_of("HELEN_SPLIT");
     if (const char* n = getenv("HELEN_SPLIT_AT")) o.split_at = atoi(n);
     o.bf16_pair = flag_of("HELEN_BF16_PAIR");
-    o.enc_exact = flag_of("HELEN_ENC_EXACT");
     // exactly none | own | all ("0" = none); anything else is ignored: a typo must not re-open the in-place page-locking
     if (const char* hl = getenv("HELEN_HOST_LOCK")) {
         if (!strcmp(hl, "none") || !strcmp(hl, "0")) o.host_lock = 0;
@@ -90,16 +72,12 @@ inline Overrides read_overrides() {
 }
 
 constexpr int kDecStagePositions = 4;    // HELEN_DWS_PB: positions per stage of gemm_dec_ws(p)_kernel
-constexpr int kEncStagePositions = 8;    // HELEN_EWS8_PB: positions per stage of gemm_enc_ws8(p)_kernel
+constexpr int kEncStagePositions = 8;    // positions per stage of gemm_enc_x3_kernel
 
 struct ChunkPlan {
     RecurrenceKernel recurrence;
     DecoderProjection decoder;
     int dec_parts = 0, dec_run = 0;      // kDecStationaryRuns: runs per (tile, direction), positions per run (whole stages)
-};
-struct EncoderPlan {
-    EncoderProjection kind;
-    int parts = 0, run = 0;              // kEncTileRuns
 };
 struct CallPlan {
     bool split = false;                  // two tile groups on two internal streams
@@ -144,28 +122,6 @@ inline ChunkPlan plan_chunk(int tiles, int T, int cus, const Overrides& o) {
     return p;
 }
 
-inline EncoderPlan plan_encoder(int tiles, int npos, int cus, const Overrides& o) {
-    EncoderPlan p;
-    const int rounds = (tiles + cus - 1) / cus;
-    const bool tile_kernel = o.enc_ws8 >= 0 ? o.enc_ws8 == 1
-                                            : (tiles > cus / 2 && rounds * cus - tiles <= cus / 8) || (rounds == 1 && 3 * tiles > 2 * cus);
-    if (tile_kernel) {
-        p.kind = kEncTile;
-    } else if (o.enc_ws8p != 0 && (o.enc_ws8p == 1 || 4 * tiles <= cus)) {
-        int want = o.enc_ws8p_parts > 0 ? o.enc_ws8p_parts : cus / tiles;
-        want = want < 1 ? 1 : want;
-        const int per = (npos + want - 1) / want;
-        p.run = (per + kEncStagePositions - 1) / kEncStagePositions * kEncStagePositions;
-        p.parts = (npos + p.run - 1) / p.run;
-        p.kind = kEncTileRuns;
-    } else if (2 * 3 * tiles >= 3 * cus) {      // 1.5 workgroups per CU at three column-set workgroups per tile
-        p.kind = kEncSets;
-    } else {
-        p.kind = kEncStreaming;
-    }
-    return p;
-}
-
 // The exact-product encoder projection (gemm_enc_x3_kernel, the polish entry points of the fp32 and fp32x3 modes): three
 // (tile, column set) workgroups per tile; a call with fewer of them than CUs cuts the positions into runs of whole stages.
 struct ExactEncoderPlan {
@@ -205,7 +161,7 @@ inline std::string describe_dispatch(int cus, const Overrides& o, int max_tiles 
     std::string out;
     char line[512];
     snprintf(line, sizeof(line), "dispatch for %d CUs (tiles of 16 windows; every row gives the same bits)\n"
-             "%-12s %-22s %-26s %-28s %s\n", cus, "tiles", "recurrences", "decoder projection", "encoder projection", "call as");
+             "%-12s %-22s %-26s %-36s %s\n", cus, "tiles", "recurrences", "decoder projection", "encoder projection (exact products)", "call as");
     out += line;
     auto row = [&](int tiles) {
         const CallPlan c = plan_call(tiles, cus, true, o);
@@ -216,10 +172,11 @@ inline std::string describe_dispatch(int cus, const Overrides& o, int max_tiles 
             return std::string("-|-|-|") + buf;
         }
         const ChunkPlan k = plan_chunk(tiles, 100, cus, o);
-        const EncoderPlan e = plan_encoder(tiles, 1000, cus, o);
-        snprintf(buf, sizeof(buf), "%s|%s%s|%s%s|one sequence", name_of(k.recurrence), name_of(k.decoder),
-                 k.decoder == kDecStationaryRuns ? " (position runs)" : "", name_of(e.kind),
-                 e.kind == kEncTileRuns ? " (position runs)" : "");
+        const ExactEncoderPlan e = plan_exact_encoder(tiles, 1000, cus);
+        char enc[64];
+        snprintf(enc, sizeof(enc), e.parts > 1 ? "gemm_enc_x3_kernel (%d position runs)" : "gemm_enc_x3_kernel", e.parts);
+        snprintf(buf, sizeof(buf), "%s|%s%s|%s|one sequence", name_of(k.recurrence), name_of(k.decoder),
+                 k.decoder == kDecStationaryRuns ? " (position runs)" : "", enc);
         return std::string(buf);
     };
     int start = 1;
@@ -236,7 +193,7 @@ inline std::string describe_dispatch(int cus, const Overrides& o, int max_tiles 
             }
             char range[32];
             snprintf(range, sizeof(range), start == t - 1 ? "%d" : "%d-%d", start, t - 1);
-            snprintf(line, sizeof(line), "%-12s %-22s %-26s %-28s %s\n", range, cols[0].c_str(), cols[1].c_str(), cols[2].c_str(),
+            snprintf(line, sizeof(line), "%-12s %-22s %-26s %-36s %s\n", range, cols[0].c_str(), cols[1].c_str(), cols[2].c_str(),
                      cols[3].c_str());
             out += line;
             start = t;

@@ -1,4 +1,6 @@
-// kernels_gemm.h -- fp32 input projections: gemm_gi_kernel (streaming weights) and gemm_enc_ws_kernel (weight-stationary)
+// kernels_gemm.h -- fp32 input projections: gemm_gi_kernel (streaming weights; the operator entry's encoder projection and the
+// decoder's fine-grained form) and gemm_dec_ws(p)_kernel (weight-stationary decoder projection).  The polish entry points
+// project the encoder input with exact bf16 products instead (gemm_enc_x3_kernel, kernels_x3.h).
 #pragma once
 #include "kernels_common.h"
 
@@ -104,97 +106,6 @@ __global__ __launch_bounds__(HELEN_GEMM_WAVES * 64) void gemm_gi_kernel(const f3
             const int slot = dir ? (npos - 1 - (pos0 + p)) : (pos0 + p);
             f32x4* o = gi + (size_t)tile * gi_tile_stride +
                        ((size_t)slot * 2 + dir) * (kNTile * 64) + nt0 * 64 + lane;
-#pragma unroll
-            for (int n = 0; n < N; ++n) o[n * 64] = acc[p][n];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Encoder input projection, weight-stationary (fp32 MFMA): gi = X . W_ih^T + bias for all `npos` positions.
-//   K is only 96, so a wave can hold its whole slice of W_ih in registers: 4 column tiles x 6 groups =
-//   96 registers, loaded once.  Workgroup = 4 waves = one third of the 48 column tiles; grid = 3 column
-//   sets x tiles, enumerated so that the three sets of a tile run on one XCD (its xa stream comes from HBM
-//   once).  Only the activations move: a stage is 4 positions (24 KiB of KB16 fragments) brought in by
-//   LDS-DMA into a 2-deep ring, 384 MFMAs per wave per barrier, and the 16 output stores of a stage stay
-//   in flight across the next barrier.  Two workgroups per CU.
-// ------------------------------------------------------------------------------------------------
-#define HELEN_WS_PB 4
-__global__ __launch_bounds__(256, 2) void gemm_enc_ws_kernel(const f32x4* __restrict__ A, long a_tile_stride,
-                                                             const f32x4* __restrict__ Wp,
-                                                             const float* __restrict__ bias,
-                                                             f32x4* __restrict__ gi, long gi_tile_stride,
-                                                             int npos, int ntiles) {
-    constexpr int MG = kFPad / 16;          // 6 operand groups of 16 k
-    constexpr int PB = HELEN_WS_PB, N = 4;
-    constexpr int ROWS = PB * MG;           // 24 rows of 1 KiB per stage
-    __shared__ f32x4 smem[2 * ROWS * 64];   // 48 KiB
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int local = blockIdx.x >> 3;
-    const int set = local % 3;
-    const int tile = (local / 3) * 8 + (blockIdx.x & 7);
-    if (tile >= ntiles) return;
-    const int gt0 = 16 * set + N * w;       // first of this wave's global column tiles (dir*24 + nt)
-    const int dir = gt0 / kNTile;
-    const int nt0 = gt0 % kNTile;
-    f32x4 B[N][MG];
-#pragma unroll
-    for (int n = 0; n < N; ++n)
-#pragma unroll
-        for (int m = 0; m < MG; ++m) B[n][m] = Wp[(size_t)((gt0 + n) * MG + m) * 64 + lane];
-    float bs[N];
-#pragma unroll
-    for (int n = 0; n < N; ++n) bs[n] = bias[dir * kG + (nt0 + n) * 16 + (lane & 15)];
-    const f32x4* ap = A + (size_t)tile * a_tile_stride + lane;
-    auto stage = [&](int g, int b) {        // positions 4g..4g+3: row r = p*6 + m, 6 rows per wave
-        f32x4* dst = smem + b * (ROWS * 64);
-#pragma unroll
-        for (int i = 0; i < ROWS / 4; ++i) {
-            const int r = w + 4 * i;
-            const int pc = min(PB * g + r / MG, npos - 1);
-            const f32x4* src = ap + (size_t)pc * (MG * 64) + (r % MG) * 64;
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
-                                             (void __attribute__((address_space(3)))*)(dst + r * 64), 16, 0, 0);
-        }
-    };
-    const int ng = (npos + PB - 1) / PB;
-    stage(0, 0);
-    for (int g = 0; g < ng; ++g) {
-        // VMEM queue, oldest first: 6 DMA rows of group g, then the 16 output stores of group g-1
-        if (g == 0)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PB * N) : "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (g + 1 < ng) stage(g + 1, (g + 1) & 1);
-        const f32x4* L = smem + (g & 1) * (ROWS * 64) + lane;
-        f32x4 acc[PB][N];
-#pragma unroll
-        for (int p = 0; p < PB; ++p)
-#pragma unroll
-            for (int n = 0; n < N; ++n) acc[p][n] = splat4(bs[n]);
-#pragma unroll
-        for (int m = 0; m < MG; ++m) {
-            f32x4 a[PB];
-#pragma unroll
-            for (int p = 0; p < PB; ++p) a[p] = L[(p * MG + m) * 64];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int p = 0; p < PB; ++p)
-#pragma unroll
-                    for (int n = 0; n < N; ++n) acc[p][n] = mfma4(a[p][e], B[n][m][e], acc[p][n]);
-        }
-#pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            // exactly 16 stores per lane per stage (counted above): positions past the end of the last
-            // stage rewrite the last valid one with identical values
-            const int pos = min(PB * g + p, npos - 1);
-            const int slot = dir ? (npos - 1 - pos) : pos;
-            f32x4* o = gi + (size_t)tile * gi_tile_stride + ((size_t)slot * 2 + dir) * (kNTile * 64) + nt0 * 64 + lane;
 #pragma unroll
             for (int n = 0; n < N; ++n) o[n * 64] = acc[p][n];
         }
@@ -328,120 +239,6 @@ __global__ __launch_bounds__(512, 1) void gemm_dec_wsp_kernel(const f32x4* __res
     if (tile >= ntiles) return;
     const int p0 = part * run;
     gemm_dec_ws_body(smem, tile, dir, A, a_tile_stride, Wp, bias, gi, gi_tile_stride, npos, p0, min(p0 + run, npos));
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Encoder input projection, weight-stationary, one workgroup per tile (fp32 MFMA, K = 96 of which 90 are features).
-//   8 waves x 6 column tiles = all 48 column tiles of both directions; a wave's W_ih slice is 6 tiles x 6 k-groups
-//   = 144 registers, loaded once.  A stage is PB = 8 positions (6 KiB each) in a 2-deep LDS-DMA ring, read by all
-//   eight waves: the packed image is fetched ONCE per tile (gemm_enc_ws_kernel's three column-set workgroups per tile
-//   fetch it three times, 2.2x in HBM traffic after L2).  Per position and wave 144 MFMAs against 6 LDS reads and
-//   6 output stores (the 3 MB of gi per window are what this kernel mostly does).  Two waves per SIMD.
-//   Same MFMA order per accumulator as gemm_gi_kernel<6, false> / gemm_enc_ws_kernel: bit-identical gi.
-// ------------------------------------------------------------------------------------------------
-#define HELEN_EWS8_PB 8
-// (the body over one tile and positions [p0, p1): gemm_enc_ws8_kernel takes all of a tile's positions, gemm_enc_ws8p_kernel
-// cuts them into runs for small calls)
-__device__ __forceinline__ void gemm_enc_ws8_body(f32x4* __restrict__ smem, const int tile, const f32x4* __restrict__ A,
-                                                  long a_tile_stride, const f32x4* __restrict__ Wp,
-                                                  const float* __restrict__ bias, f32x4* __restrict__ gi,
-                                                  long gi_tile_stride, int npos, int p0, int p1) {
-    constexpr int MG = kFPad / 16, PB = HELEN_EWS8_PB, N = 6;
-    constexpr int ROWS = PB * MG;            // 1 KiB rows per stage
-    constexpr int RPW = ROWS / 8;            // rows a wave brings in per stage
-    static_assert(ROWS % 8 == 0, "stage rows must split over 8 waves");
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int gt0 = N * v;                   // first of this wave's global column tiles (dir*24 + nt)
-    const int dir = gt0 / kNTile;
-    const int nt0 = gt0 % kNTile;
-    f32x4 B[N][MG];
-#pragma unroll
-    for (int n = 0; n < N; ++n)
-#pragma unroll
-        for (int m = 0; m < MG; ++m) B[n][m] = Wp[(size_t)((gt0 + n) * MG + m) * 64 + lane];
-    f32x4 bsv[N];
-#pragma unroll
-    for (int n = 0; n < N; ++n) bsv[n] = splat4(bias[dir * kG + (nt0 + n) * 16 + (lane & 15)]);
-    const unsigned lane16 = (unsigned)lane * 16u;
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(char*)smem;
-    const char* a_tile = (const char*)(A + (size_t)tile * a_tile_stride);
-    char* o_tile = (char*)(gi + (size_t)tile * gi_tile_stride + (size_t)dir * (kNTile * 64) + nt0 * 64);
-    auto stage_rows = [&](int g, int b, int i0, int i1) {   // row r = p*6 + m of stage g; wave v: rows v, v+8, ...
-#pragma unroll
-        for (int i = i0; i < i1; ++i) {
-            const int r = v + 8 * i;
-            const int pc = min(p0 + PB * g + r / MG, p1 - 1);
-            dma_row_to_lds(lds0 + (unsigned)((b * ROWS + r) * 1024), a_tile + ((size_t)pc * MG + r % MG) * 1024, lane16);
-        }
-    };
-    const int ng = (p1 - p0 + PB - 1) / PB;
-    stage_rows(0, 0, 0, RPW);
-    for (int g = 0; g < ng; ++g) {
-        // VMEM queue, oldest first: ... the DMA rows of stage g (issued before the last positions' MFMAs of stage
-        // g-1), then the N output stores of the last position of stage g-1
-        if (g == 0)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const f32x4* L = smem + (g & 1) * (ROWS * 64) + lane;
-#pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            // the next stage's rows, spread over the first positions (a row per position until they are out)
-            if (g + 1 < ng && p < RPW) stage_rows(g + 1, (g + 1) & 1, p, p + 1);
-            f32x4 acc[N], a[2];
-            a[0] = L[(p * MG) * 64];
-#pragma unroll
-            for (int m = 0; m < MG; ++m) {
-                if (m + 1 < MG) a[(m + 1) & 1] = L[(p * MG + m + 1) * 64];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int n = 0; n < N; ++n) acc[n] = mfma4(a[m & 1][e], B[n][m][e], (m | e) ? acc[n] : bsv[n]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // exactly N stores per lane per position (counted above): positions past the end of the last stage
-            // rewrite the last valid one with identical values
-            const int pos = min(p0 + PB * g + p, p1 - 1);
-            const int slot = dir ? (npos - 1 - pos) : pos;
-            char* o = o_tile + (size_t)slot * (2 * kNTile * 64 * 16) + in_block(lane16);
-#pragma unroll
-            for (int n = 0; n < N; ++n) *(f32x4*)(o + n * 1024) = acc[n];
-        }
-    }
-}
-
-
-constexpr int kEncWs8LdsF4 = 2 * HELEN_EWS8_PB * (kFPad / 16) * 64;   // 2 x PB x 6 KiB
-
-__global__ __launch_bounds__(512, 1) void gemm_enc_ws8_kernel(const f32x4* __restrict__ A, long a_tile_stride,
-                                                              const f32x4* __restrict__ Wp,
-                                                              const float* __restrict__ bias,
-                                                              f32x4* __restrict__ gi, long gi_tile_stride,
-                                                              int npos, int ntiles) {
-    __shared__ f32x4 smem[kEncWs8LdsF4];
-    const int tile = blockIdx.x;
-    if (tile >= ntiles) return;
-    gemm_enc_ws8_body(smem, tile, A, a_tile_stride, Wp, bias, gi, gi_tile_stride, npos, 0, npos);
-}
-
-// For calls of fewer tiles than half the CUs: a tile's positions in `parts` runs of `run` positions (whole stages), one
-// workgroup each (see gemm_dec_wsp_kernel).  grid (tiles x parts), tile = blockIdx.x / parts.
-__global__ __launch_bounds__(512, 1) void gemm_enc_ws8p_kernel(const f32x4* __restrict__ A, long a_tile_stride,
-                                                               const f32x4* __restrict__ Wp,
-                                                               const float* __restrict__ bias,
-                                                               f32x4* __restrict__ gi, long gi_tile_stride,
-                                                               int npos, int ntiles, int parts, int run) {
-    __shared__ f32x4 smem[kEncWs8LdsF4];
-    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
-    if (tile >= ntiles) return;
-    const int p0 = part * run;
-    gemm_enc_ws8_body(smem, tile, A, a_tile_stride, Wp, bias, gi, gi_tile_stride, npos, p0, min(p0 + run, npos));
 }
 
 }  // namespace helen

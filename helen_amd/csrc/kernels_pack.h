@@ -4,34 +4,11 @@
 
 namespace helen {
 
-// ------------------------------------------------------------------------------------------------
-// pack: uint8 pileup windows [n, 1000, F] -> KB16 fp32 operand tiles xa[tile][pos][kb 24][16][4].
-// Fuses the reference's host-side `images.type(torch.FloatTensor)` (predict_gpu.py:97); rows of
-// windows past n_windows and features past F are zero.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_images_kernel(const uint8_t* __restrict__ img,
-                                                          int n_windows, int npos,
-                                                          f32x4* __restrict__ xa) {
-    const int tile = blockIdx.y;
-    const int g = blockIdx.x * 256 + threadIdx.x;  // (pos, kb, i), i fastest
-    const int per_pos = (kFPad / 4) * kTile;        // 384 float4 per (tile, pos)
-    if (g >= npos * per_pos) return;
-    const int i = g & 15;
-    const int kb = (g >> 4) % (kFPad / 4);
-    const int pos = g / per_pos;
-    const int window = tile * kTile + i;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (window < n_windows && kb * 4 < kF) {
-        const uint8_t* p = img + ((size_t)window * npos + pos) * kF + kb * 4;
-        // the last group of a row holds k = 88, 89 only: never read past the row (and the buffer)
-        const uint32_t w = kb * 4 + 4 <= kF ? *(const u32_a2*)p : (uint32_t) * (const u16_a2*)p;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (float)((w >> (8 * e)) & 0xffu);
-    }
-    xa[((size_t)tile * npos + pos) * per_pos + kb * kTile + i] = v;
-}
+// (uint8 pileup windows go straight to bf16 A fragments: pack_images_x3_kernel, kernels_x3.h -- the reference's host-side
+// `images.type(torch.FloatTensor)` of predict_gpu.py:97 is exact in bf16 for counts 0..255)
 
-// Same from float32 x [B, T, F] (the operator-level boundary, TransducerModel.py:60).
+// float32 x [B, T, F] (the operator-level boundary, TransducerModel.py:60) -> KB16 fp32 operand tiles
+// xa[tile][pos][kb 24][16][4]; rows of windows past n_windows and features past F are zero.
 __global__ __launch_bounds__(256) void pack_x_f32_kernel(const float* __restrict__ x, int n_windows,
                                                          int T, f32x4* __restrict__ xa,
                                                          long xa_tile_stride) {

@@ -10,8 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from helen_amd.engine import HelenEngine  # noqa: E402
 from helen_amd.weights import make_weights  # noqa: E402
 
-PLAIN = {"HELEN_GRU_HALF8": "0", "HELEN_GRU_QUARTER4": "0", "HELEN_SPLIT": "0", "HELEN_DEC_WSP": "0", "HELEN_ENC_WS8P": "0",
-         "HELEN_GRU_PAIR": "0", "HELEN_GRU_SINGLE8": "0", "HELEN_DEC_WS": "0", "HELEN_ENC_WS8": "0"}
+PLAIN = {"HELEN_GRU_HALF8": "0", "HELEN_GRU_QUARTER4": "0", "HELEN_SPLIT": "0", "HELEN_DEC_WSP": "0",
+         "HELEN_GRU_PAIR": "0", "HELEN_GRU_SINGLE8": "0", "HELEN_DEC_WS": "0"}
 
 
 def main():

@@ -117,14 +117,14 @@ def test_dispatch_table_dry_run(monkeypatch):
     exactly its own column."""
     from helen_amd import _lib
     for k in ("HELEN_GRU_PAIR", "HELEN_GRU_SINGLE8", "HELEN_GRU_HALF8", "HELEN_GRU_QUARTER4", "HELEN_DEC_WS", "HELEN_DEC_WSP",
-              "HELEN_ENC_WS8", "HELEN_ENC_WS8P", "HELEN_SPLIT", "HELEN_SPLIT_AT", "HELEN_BF16_PAIR"):
+              "HELEN_SPLIT", "HELEN_SPLIT_AT", "HELEN_BF16_PAIR"):
         monkeypatch.delenv(k, raising=False)
     want = {1: "gru_quarter4_kernel", 32: "gru_quarter4_kernel", 33: "gru_half8_kernel", 64: "gru_half8_kernel",
             86: "gru_single8_kernel", 128: "gru_single8_kernel", 240: "gru_pair_kernel", 256: "gru_pair_kernel"}
     for tiles, rec in want.items():
         p = _lib.plan_call(256, tiles)
         assert p["recurrence"] == rec and not p["split"], (tiles, p)
-    assert _lib.plan_call(256, 256)["decoder"] == "gemm_dec_ws_kernel" and _lib.plan_call(256, 256)["encoder"] == "gemm_enc_ws8_kernel"
+    assert _lib.plan_call(256, 256)["decoder"] == "gemm_dec_ws_kernel" and _lib.plan_call(256, 256)["encoder_runs"] == 1
     assert _lib.plan_call(256, 16)["decoder"] == "gemm_dec_wsp_kernel" and _lib.plan_call(256, 16)["decoder_runs"] == 7
     assert _lib.plan_call(256, 64)["decoder_runs"] == 2 and _lib.plan_call(256, 100)["decoder"] == "gemm_gi_kernel<16>"
     for tiles, first in ((65, 64), (85, 64), (129, 65), (144, 72), (160, 128), (192, 128), (239, 128)):
@@ -142,7 +142,7 @@ def test_dispatch_table_dry_run(monkeypatch):
         assert _lib.plan_call(cus, cus // 2)["recurrence"] == "gru_single8_kernel" and not _lib.plan_call(cus, cus // 2)["split"]
         assert _lib.plan_call(cus, cus // 2 + 1)["split"]
         assert _lib.plan_call(cus, cus)["recurrence"] == "gru_pair_kernel" and not _lib.plan_call(cus, cus)["split"]
-        assert _lib.plan_call(cus, cus)["decoder"] == "gemm_dec_ws_kernel" and _lib.plan_call(cus, cus)["encoder"] == "gemm_enc_ws8_kernel"
+        assert _lib.plan_call(cus, cus)["decoder"] == "gemm_dec_ws_kernel" and _lib.plan_call(cus, cus)["encoder"] == "gemm_enc_x3_kernel"
         for tiles in range(1, 2 * cus + 1):                  # every size has a plan whose groups are smaller than the call
             p = _lib.plan_call(cus, tiles)
             assert not p["split"] or 0 < p["first_group"] < tiles, (cus, tiles, p)

@@ -8,7 +8,7 @@
     everywhere else the labels are bit-identical;
   * the same run in the fp32x3 mode (fp32-class results on the bf16 matrix cores), same bar;
   * every fp32 kernel the batch size selects -- gru_kernel | gru_pair_kernel, gemm_gi_kernel<16> |
-    gemm_dec_ws_kernel, gemm_gi_kernel<6> | gemm_enc_ws_kernel -- gives the SAME bits: a 4096-window call
+    gemm_dec_ws_kernel, gemm_enc_x3_kernel in one or several position runs -- gives the SAME bits: a 4096-window call
     (pair recurrence, weight-stationary projections) against four 1024-window calls (the fine-grained kernels).
 """
 import os
@@ -270,14 +270,14 @@ def test_part_tile_recurrences_give_the_same_bits(scale_case, monkeypatch):
     h = torch.rand((700, 2, 128), device="cuda") - 0.5
     big = torch.from_numpy(img[8000:8000 + 1500]).cuda()
     got = {}
-    # (the projections of such calls are gemm_dec_wsp_kernel / gemm_enc_ws8p_kernel -- a tile's positions cut into runs --
-    # unless HELEN_DEC_WSP=0 / HELEN_ENC_WS8P=0 send them to gemm_gi_kernel: the fourth configuration)
+    # (the decoder projection of such calls is gemm_dec_wsp_kernel -- a (tile, direction)'s positions cut into runs -- unless
+    # HELEN_DEC_WSP=0 sends it to gemm_gi_kernel: the fourth configuration; the encoder projection is gemm_enc_x3_kernel
+    # at every size, its positions cut into runs by the tile count alone)
     for name, half, quarter, wsp in (("whole", "0", "0", "1"), ("half", "1", "0", "1"), ("quarter", "0", "1", "1"),
                                      ("streaming projection", "0", "0", "0")):
         monkeypatch.setenv("HELEN_GRU_HALF8", half)
         monkeypatch.setenv("HELEN_GRU_QUARTER4", quarter)
         monkeypatch.setenv("HELEN_DEC_WSP", wsp)
-        monkeypatch.setenv("HELEN_ENC_WS8P", wsp)
         monkeypatch.setenv("HELEN_GRU_PAIR", "0")
         eng.reload_overrides()
         got[name] = (eng.polish(dev, want_acc=True), eng.chunk_forward(x, h), eng.chunk_forward(x[:33, :1], h[:33]),
@@ -288,7 +288,7 @@ def test_part_tile_recurrences_give_the_same_bits(scale_case, monkeypatch):
             for u, v_ in zip(a, b):
                 assert torch.equal(u, v_), name
     # the defaults take them for these sizes: 1000 windows the half tiles, 500 the quarter tiles
-    for k in ("HELEN_GRU_HALF8", "HELEN_GRU_QUARTER4", "HELEN_GRU_PAIR", "HELEN_DEC_WSP", "HELEN_ENC_WS8P"):
+    for k in ("HELEN_GRU_HALF8", "HELEN_GRU_QUARTER4", "HELEN_GRU_PAIR", "HELEN_DEC_WSP"):
         monkeypatch.delenv(k)
     eng.reload_overrides()
     for u, v_ in zip(eng.polish(dev, want_acc=True), got["whole"][0]):
@@ -299,9 +299,9 @@ def test_part_tile_recurrences_give_the_same_bits(scale_case, monkeypatch):
 
 
 def test_every_fp32_kernel_choice_gives_the_same_bits(scale_case):
-    """A 4096-window call takes gru_pair_kernel, gemm_dec_ws_kernel and gemm_enc_ws8_kernel; 1024-window calls
-    take gru_kernel, gemm_gi_kernel<16, true> and gemm_gi_kernel<6, false>; 3000 windows (188 tiles) take the
-    pair recurrence with the streaming decoder projection; 2400 windows (150 tiles) gemm_enc_ws_kernel.
+    """A 4096-window call takes gru_pair_kernel, gemm_dec_ws_kernel and gemm_enc_x3_kernel in one run of positions;
+    1024-window calls take gru_kernel, gemm_gi_kernel<16, true> and gemm_enc_x3_kernel in position runs; 3000 windows (188
+    tiles) take the pair recurrence with the streaming decoder projection; 2400 windows (150 tiles) run as two tile groups.
     Accumulators and labels must be EQUAL."""
     from helen_amd.engine import HelenEngine
     w, img, _ = scale_case
@@ -322,7 +322,7 @@ def test_every_fp32_kernel_choice_gives_the_same_bits(scale_case):
     for u, v_ in zip(big.chunk_forward(x, h), (torch.cat(t) for t in zip(small.chunk_forward(x[:1024], h[:1024]),
                                                                           small.chunk_forward(x[1024:], h[1024:])))):
         assert torch.equal(u, v_)
-    # 150 tiles per call: gemm_enc_ws_kernel (three column-set workgroups per tile) with the pair recurrence
+    # 150 tiles per call: two tile groups on two streams (the exact encoder projection on shifted operand pointers)
     sets = HelenEngine(w, device=0, max_windows=2400)
     e3 = sets.polish(dev, want_acc=True)
     torch.cuda.synchronize()
