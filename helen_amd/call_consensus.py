@@ -111,28 +111,27 @@ def call_consensus(image_dir, model_path, batch_size, num_workers, threads, outp
         sys.exit(1)
     vet = None
     if os.environ.get("HELEN_SKIP_IMAGE_CHECK", "") != "1":
-        if callers > 1:
-            vet_image_directory(image_dir)          # before any process is started
-        else:
-            # one rank runs in this process: the schema check of a few images per file runs BESIDE its start-up (the
-            # reader raises the same IMAGE SIZE ERROR itself when it meets such an image; the check's findings are
-            # reported either way).  The check enters libhdf5 from its own thread (helen_amd.hdf5, ctypes): it holds the
-            # lock libhelen_io.so serialises its own library calls with, so a libhdf5 that is not built thread-safe is
-            # never entered from two threads (a reader or writer that needs the library waits for the check to finish;
-            # the direct scanner and emitter never do).
-            import threading
+        # The schema check of a few images per file runs BESIDE the prediction, whatever the number of ranks (the reader
+        # raises the same IMAGE SIZE ERROR itself when it meets such an image; the check's findings are reported either
+        # way).  Listing the images of a whole-genome directory walks every file's group structures -- 4.6 s of one CPU
+        # and 14 KB of mapped file pages per window on 3 M deflated windows (profiles/r06_genome_scale_one_device.txt) --
+        # which until round 6 a multi-rank run spent before its first process started.  With one rank in this process the
+        # check enters libhdf5 from its own thread (helen_amd.hdf5, ctypes): it holds the lock libhelen_io.so serialises
+        # its own library calls with, so a libhdf5 that is not built thread-safe is never entered from two threads (a
+        # reader or writer that needs the library waits for the check to finish; the direct scanner and emitter never do).
+        import threading
 
-            from . import native_io
-            vet = {"error": None}
+        from . import native_io
+        vet = {"error": None}
 
-            def run_vet():
-                try:
-                    with native_io.library_lock():
-                        vet_image_directory(image_dir)
-                except BaseException as e:          # noqa: BLE001 -- re-raised below
-                    vet["error"] = e
-            vet["thread"] = threading.Thread(target=run_vet, daemon=True)
-            vet["thread"].start()
+        def run_vet():
+            try:
+                with native_io.library_lock():
+                    vet_image_directory(image_dir)
+            except BaseException as e:          # noqa: BLE001 -- re-raised below
+                vet["error"] = e
+        vet["thread"] = threading.Thread(target=run_vet, daemon=True)
+        vet["thread"].start()
     streams = None
     try:
         if gpu_mode:
@@ -169,7 +168,7 @@ def _process_age():
 def _report_ranks(run):
     """Several ranks: one line per rank with its stage times (rank 0 alone prints the long line while it runs), and the
     resident-memory high-water marks of the parent, the ranks and the stitch collectors."""
-    from .host_plan import peak_rss_mb
+    from .host_plan import peak_rss_mb, rss_breakdown_mb
     ranks = run.get("ranks") or []
     if len(ranks) > 1:
         for r in ranks:
@@ -179,9 +178,13 @@ def _report_ranks(run):
                              % (r.get("rank"), r.get("windows"), r.get("seconds") or 0.0, st.get("read_wait", 0.0), st.get("device", 0.0),
                                 st.get("write", 0.0), st.get("stitch", 0.0), r.get("reader_workers")))
     collectors = (run.get("stitch_collectors") or {}).get("per_collector") or []
-    sys.stderr.write("INFO: PEAK RESIDENT MEMORY (MB): PARENT %s, RANKS %s%s.\n"
-                     % (peak_rss_mb(), [r.get("peak_rss_mb") for r in ranks],
-                        ", STITCH COLLECTORS %s" % [c.get("peak_rss_mb") for c in collectors] if collectors else ""))
+    # VmHWM, and beside it the anonymous part at the end of each process's work: the rest is pages of mapped image files
+    # (the direct scanner) and of page-locked slots, resident without being heap
+    sys.stderr.write("INFO: PEAK RESIDENT MEMORY (MB; IN BRACKETS THE ANONYMOUS PART AT THE END): PARENT %s (%s), RANKS %s%s.\n"
+                     % (peak_rss_mb(), rss_breakdown_mb()[0],
+                        ", ".join("%s (%s)" % (r.get("peak_rss_mb"), r.get("rss_anon_mb")) for r in ranks),
+                        ", STITCH COLLECTORS " + ", ".join("%s (%s)" % (c.get("peak_rss_mb"), c.get("rss_anon_mb")) for c in collectors)
+                        if collectors else ""))
 
 
 def polish_genome(image_dir, model_path, batch_size, num_workers, threads, output_dir,

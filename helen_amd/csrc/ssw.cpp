@@ -19,6 +19,7 @@
 // the reference's own sources) on randomised inputs: tests/test_stitch.py.
 #include "../../include/helen_io.h"
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -373,6 +374,82 @@ bool surely_saturates(const int8_t* ref, int n, const int8_t* read, int m, int m
     return false;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The common join, without the three passes.  Two neighbouring regions called from the same reads agree base for base
+// where they overlap, so the overlap strings stitch aligns -- the last `ov` bases of the running sequence and the first
+// `ov` of the next region -- usually share ONE long exact run (the left string's head is the right string's middle).
+// For that case the library's answer follows from two facts that are cheap to establish:
+//   (1) L = the length of the longest common SUBSEQUENCE of the two strings (bit-parallel, a few hundred word
+//       operations) bounds the number of match columns of ANY alignment, local or not, gapped or not;
+//   (2) the two strings have a common SUBSTRING of exactly that length L.
+// Then, with match > 0 and mismatch, gap_open, gap_extend > 0 and only A, C, G, T in both strings: every alignment scores
+// at most L * match, and one that reaches it has L match columns and nothing else -- it is an occurrence of a common
+// substring of length L.  The striped pass computes the cells of such a gap-free run exactly (H >= diagonal + match,
+// and its values never exceed the true ones: its one deviation from Smith-Waterman, E taken before the lazy-F fix-up,
+// only loses paths), so its best score is L * match and its best cell -- the first reference column that raises the
+// maximum, smallest query index in it -- is the end of the occurrence with the smallest reference start a, and among
+// those the smallest query start b.  The backward pass over the two prefixes stops at the first column, walking down from
+// that end, whose maximum is the forward score: the occurrence's own start (any other occurrence inside the box starts
+// further left; in that column the smallest reversed query index is the largest start <= b, which is b).  The banded
+// pass over the box aligns two EQUAL strings: all diagonal ("diagonal on ties").  Result: score L * match, reference
+// [a, a + L), query [b, b + L), CIGAR  bS L= tailS, no mismatches.  Checked against the reference library on 2e5
+// randomised and adversarial pairs (tests/test_stitch.py); when either fact fails the three passes run as before.
+// ------------------------------------------------------------------------------------------------
+std::atomic<int> g_fast_path{1};
+std::atomic<long long> g_fast_hits{0}, g_fast_misses{0};
+
+// length of the longest common subsequence of ref[0..n) and read[0..m), codes 0..3 only, n <= 64 * kLcsWords
+constexpr int kLcsWords = 16;
+int lcs_length(const int8_t* ref, int n, const int8_t* read, int m) {
+    const int words = (n + 63) / 64;
+    uint64_t mask[4][kLcsWords];
+    for (int c = 0; c < 4; ++c)
+        for (int w = 0; w < words; ++w) mask[c][w] = 0;
+    for (int i = 0; i < n; ++i) mask[ref[i]][i >> 6] |= 1ull << (i & 63);
+    uint64_t V[kLcsWords];
+    for (int w = 0; w < words; ++w) V[w] = ~0ull;
+    for (int j = 0; j < m; ++j) {
+        const uint64_t* M = mask[read[j]];
+        unsigned carry = 0;
+        for (int w = 0; w < words; ++w) {       // V = (V + (V & M)) | (V & ~M), the sum carried across words
+            const uint64_t v = V[w], u = v & M[w];
+            const uint64_t s1 = v + u;
+            const uint64_t s2 = s1 + carry;
+            carry = (s1 < v) | (s2 < s1);
+            V[w] = s2 | (v & ~M[w]);
+        }
+    }
+    int zeros = 0;
+    for (int w = 0; w < words; ++w) {
+        uint64_t v = ~V[w];
+        if (w == words - 1 && (n & 63)) v &= (1ull << (n & 63)) - 1;
+        zeros += __builtin_popcountll(v);
+    }
+    return zeros;
+}
+
+// -> true and (a, b, L) when the certificate holds
+bool exact_overlap(const int8_t* ref, int n, const int8_t* read, int m, int* a_out, int* b_out, int* len_out) {
+    if (n > 64 * kLcsWords || n < 1 || m < 1) return false;
+    for (int i = 0; i < n; ++i)
+        if (ref[i] > 3) return false;
+    for (int j = 0; j < m; ++j)
+        if (read[j] > 3) return false;
+    const int L = lcs_length(ref, n, read, m);
+    if (L < 1) return false;
+    // smallest a with ref[a, a + L) somewhere in read, and there the smallest b (memmem returns the first occurrence)
+    for (int a = 0; a + L <= n; ++a) {
+        const void* hit = memmem(read, (size_t)m, ref + a, (size_t)L);
+        if (hit) {
+            *a_out = a;
+            *b_out = (int)((const int8_t*)hit - read);
+            *len_out = L;
+            return true;
+        }
+    }
+    return false;
+}
+
 struct Op {
     char op;
     int len;
@@ -494,6 +571,31 @@ int helen_ssw_align(const char* ref_seq, int ref_len, const char* query_seq, int
     for (int k = 0; k < ref_len; ++k) ref[k] = base_code(ref_seq[k]);
     for (int k = 0; k < query_len; ++k) read[k] = base_code(query_seq[k]);
 
+    // the common join: one long exact run shared by the two strings (see exact_overlap)
+    if (g_fast_path.load(std::memory_order_relaxed) && match > 0 && mismatch > 0 && gap_open > 0 && gap_extend >= 0) {
+        int a = 0, b = 0, len = 0;
+        if (exact_overlap(ref.data(), ref_len, read.data(), query_len, &a, &b, &len) &&
+            (long long)len * match + match + mismatch < 32000) {
+            g_fast_hits.fetch_add(1, std::memory_order_relaxed);
+            out[0] = len * match;
+            out[1] = a;
+            out[2] = a + len - 1;
+            out[3] = b;
+            out[4] = b + len - 1;
+            out[5] = 0;
+            if (cigar_cap > 0) {
+                char text[96];
+                int at = 0;
+                if (b > 0) at += snprintf(text + at, sizeof(text) - at, "%dS", b);
+                at += snprintf(text + at, sizeof(text) - at, "%d=", len);
+                const int tail = query_len - (b + len);
+                if (tail > 0) at += snprintf(text + at, sizeof(text) - at, "%dS", tail);
+                snprintf(cigar, cigar_cap, "%s", text);
+            }
+            return 0;
+        }
+        g_fast_misses.fetch_add(1, std::memory_order_relaxed);
+    }
     // 8-bit pass first; the 16-bit pass replaces it when the score saturates
     const int bias = mismatch;  // |most negative matrix entry|
     int lanes = 16;
@@ -575,6 +677,20 @@ int helen_ssw_align(const char* ref_seq, int ref_len, const char* query_seq, int
     out[5] = mism;
     if (cigar_cap > 0) snprintf(cigar, cigar_cap, "%s", s.c_str());
     return 0;
+}
+
+/* The exact-overlap shortcut of helen_ssw_align (on by default): enable = 0 / 1 switches it, anything else only asks;
+ * returns the previous setting.  helen_ssw_fast_path_counts: joins answered by it / handed on to the three passes since
+ * the library was loaded. */
+int helen_ssw_fast_path(int enable) {
+    const int before = g_fast_path.load();
+    if (enable == 0 || enable == 1) g_fast_path.store(enable);
+    return before;
+}
+
+void helen_ssw_fast_path_counts(long long* hits, long long* misses) {
+    if (hits) *hits = g_fast_hits.load();
+    if (misses) *misses = g_fast_misses.load();
 }
 
 }  // extern "C"

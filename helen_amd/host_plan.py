@@ -196,6 +196,22 @@ def peak_rss_mb(status="/proc/self/status"):
     return None
 
 
+def rss_breakdown_mb(status="/proc/self/status"):
+    """(anonymous, file-backed + shared-memory) resident MB of this process NOW -- what VmHWM does not tell apart: the pages
+    of image files the direct scanner has mapped are resident without being anybody's heap."""
+    anon = other = None
+    try:
+        with open(status) as f:
+            for ln in f:
+                if ln.startswith("RssAnon:"):
+                    anon = int(ln.split()[1]) // 1024
+                elif ln.startswith(("RssFile:", "RssShmem:")):
+                    other = (other or 0) + int(ln.split()[1]) // 1024
+    except (OSError, ValueError, IndexError):
+        pass
+    return anon, other
+
+
 def ram_backed_budget_bytes(path="/dev/shm"):
     """What may be PUT into RAM-backed files under `path` by a run: free space of the tmpfs, and no more than half of
     ram_available_bytes() (the other half is for the processes themselves: page-locked slots, page cache, heaps)."""

@@ -87,6 +87,10 @@ def load():
     lib.helen_ssw_join_batch.restype = ctypes.c_int
     lib.helen_ssw_join_batch.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, vp]
+    lib.helen_ssw_fast_path.restype = ctypes.c_int
+    lib.helen_ssw_fast_path.argtypes = [ctypes.c_int]
+    lib.helen_ssw_fast_path_counts.restype = None
+    lib.helen_ssw_fast_path_counts.argtypes = [ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]
     lib.helen_ssw_align.restype = ctypes.c_int
     lib.helen_ssw_align.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -435,6 +439,19 @@ class Alignment(object):
     """What the reference's HELEN.Alignment exposes to Stitch (pybind_api.h:18-31)."""
     __slots__ = ("best_score", "reference_begin", "reference_end", "query_begin", "query_end",
                  "mismatches", "cigar_string")
+
+
+def ssw_fast_path(enable=None):
+    """The aligner's exact-overlap shortcut (include/helen_io.h): True / False switches it, None only asks -> the previous
+    setting."""
+    return bool(load().helen_ssw_fast_path(-1 if enable is None else int(bool(enable))))
+
+
+def ssw_fast_path_counts():
+    """(alignments the shortcut answered, alignments that went through the three passes) since the library was loaded."""
+    hits, misses = ctypes.c_longlong(), ctypes.c_longlong()
+    load().helen_ssw_fast_path_counts(ctypes.byref(hits), ctypes.byref(misses))
+    return int(hits.value), int(misses.value)
 
 
 def ssw_align(reference, query, match, mismatch, gap_open, gap_extend):

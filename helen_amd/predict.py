@@ -28,7 +28,7 @@ import time
 
 
 from .data_store import DataStore
-from .host_plan import peak_rss_mb
+from .host_plan import peak_rss_mb, rss_breakdown_mb
 from .options import ImageSizeOptions
 from .prediction_writer import prediction_file_name, writer_of_region, writer_process  # noqa: F401
 from .sequence_dataset import SequenceDataset, SharedSlot, fill_shared
@@ -834,7 +834,7 @@ def predict(test_file, output_filename, model_path, batch_size, num_workers, ran
         "setup_seconds": round(t_setup - start_time, 3), "close_seconds": round(time.time() - t_loop_end, 3),
         "reader_workers": num_workers, "reader_mode": mode, "slots": n_slots, "device_calls": len(calls),
         "stitch_stream": None if stream is None else dict(LAST_STREAM[0].stats, wait_seconds=round(stitch_wait, 3)),
-        "stitch_failed": stitch_failed, "peak_rss_mb": peak_rss_mb(),
+        "stitch_failed": stitch_failed, "peak_rss_mb": peak_rss_mb(), "rss_anon_mb": rss_breakdown_mb()[0],
         "cpus_pinned": None if plan is None or not plan.cpus else len(plan.cpus),
         "numa_node": None if plan is None else plan.numa_node})
     if rank == 0:

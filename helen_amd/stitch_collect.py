@@ -233,8 +233,9 @@ def _collector_main(bucket, buckets, prefix, prediction_files, threads, run_thre
         t_assembled = time.time()
     finally:
         writer.close()
-    from .host_plan import peak_rss_mb
+    from .host_plan import peak_rss_mb, rss_breakdown_mb
     stats.update({"bucket": bucket, "regions": sum(len(d) for d in per_rank), "from_file": from_file, "peak_rss_mb": peak_rss_mb(),
+                  "rss_anon_mb": rss_breakdown_mb()[0],
                   "joins_submitted": result.stats.get("joins_submitted", 0), "index": index,
                   "seconds": {"following": round(t_last - t0, 3), "accepting": round(busy, 3),
                               "joins_after_the_last_record": round(t_joined - t_last, 3),

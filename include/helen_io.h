@@ -164,6 +164,14 @@ int helen_ssw_join_batch(int n, const char* blob, const int64_t* l_off, const in
 int helen_ssw_align(const char* ref_seq, int ref_len, const char* query_seq, int query_len, int match, int mismatch,
                     int gap_open, int gap_extend, int* out, char* cigar, int cigar_cap);
 
+/* helen_ssw_align answers the common join of stitch -- the two overlap strings share one exact run as long as their longest
+ * common subsequence, A/C/G/T only -- without running the three passes: for such a pair the library's result is determined
+ * (helen_amd/csrc/ssw.cpp: exact_overlap states why), and it is what this returns.  On by default.
+ *   helen_ssw_fast_path(0 | 1)   switches it off / on for the process (any other value only asks); returns the previous setting
+ *   helen_ssw_fast_path_counts   alignments answered that way / handed on to the three passes since the library was loaded */
+int helen_ssw_fast_path(int enable);
+void helen_ssw_fast_path_counts(long long* hits, long long* misses);
+
 #ifdef __cplusplus
 }
 #endif

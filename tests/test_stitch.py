@@ -369,3 +369,114 @@ def test_a_failed_run_fails_the_stitch_and_names_the_incomplete_fasta(tmp_path, 
     monkeypatch.setenv("HELEN_STITCH_KEEP_GOING", "1")
     assert S.perform_stitch(str(bad), str(tmp_path / "out_keep"), "asm", 2).endswith("asm.fa")
     assert len(S.FAILED_RUNS) == 1
+
+
+def _ref_align(ref, r, q, pen=(4, 6, 8, 2), _buf={}):
+    out = _buf.setdefault("out", (ctypes.c_int * 6)())
+    cig = _buf.setdefault("cig", ctypes.create_string_buffer(1 << 16))
+    ref.ssw_ref_align(r, len(r), q, pen[0], pen[1], pen[2], pen[3], out, cig, 1 << 16)
+    return (out[0],) + ((tuple(out[1:6]), cig.value) if out[0] > 0 else ())
+
+
+def _own_align(lib, r, q, pen=(4, 6, 8, 2), _buf={}):
+    out = _buf.setdefault("out", (ctypes.c_int * 6)())
+    cig = _buf.setdefault("cig", ctypes.create_string_buffer(1 << 16))
+    rc = lib.helen_ssw_align(r, len(r), q, len(q), pen[0], pen[1], pen[2], pen[3], out, cig, 1 << 16)
+    assert rc == 0
+    return (out[0],) + ((tuple(out[1:6]), cig.value) if out[0] > 0 else ())
+
+
+def _shortcut_cases(rng):
+    """Pairs shaped like stitch's joins and pairs built to break the shortcut's argument: ties between several exact runs,
+    tandem repeats that offer a LONGER shifted diagonal, homopolymers, periodic strings, runs at either end of either
+    string, one string inside the other, tiny alphabets at tiny lengths (dense in ties)."""
+    def rnd(n, alphabet="ACGT"):
+        return "".join(rng.choice(alphabet) for _ in range(n))
+    kind = rng.random()
+    if kind < 0.40:                         # a join: the left string's head is the right string's tail part
+        ov = rng.choice([20, 60, 110, 220, 220, 220, 330])
+        shared = rng.randrange(max(1, ov // 4), ov + 1)
+        mid = rnd(shared)
+        left = mid + rnd(ov - shared)
+        right = rnd(ov - shared) + mid
+        if rng.random() < 0.15:             # one substitution somewhere: the shortcut must usually step aside
+            k = rng.randrange(len(right))
+            right = right[:k] + rng.choice("ACGT") + right[k + 1:]
+        return left, right
+    if kind < 0.55:                         # tiny alphabet, tiny strings: every kind of tie
+        return rnd(rng.randrange(1, 14), rng.choice(["A", "AC", "ACG", "ACGT"])), rnd(rng.randrange(1, 14), rng.choice(["A", "AC", "ACGT"]))
+    if kind < 0.70:                         # tandem repeats and homopolymers under an exact overlap
+        unit = rnd(rng.randrange(1, 7))
+        rep = unit * rng.randrange(3, 60)
+        a, b = rnd(rng.randrange(0, 40)), rnd(rng.randrange(0, 40))
+        left = (rep + a)[:rng.randrange(8, 260)]
+        right = (b + rep)[-rng.randrange(8, 260):]
+        return left, right
+    if kind < 0.80:                         # one inside the other, and equal strings
+        s = rnd(rng.randrange(1, 300), rng.choice(["ACGT", "AC"]))
+        i = rng.randrange(0, len(s))
+        j = rng.randrange(i + 1, len(s) + 1)
+        return (s, s[i:j]) if rng.random() < 0.5 else (s[i:j], s)
+    if kind < 0.90:                         # two copies of the shared run in one of the strings
+        mid = rnd(rng.randrange(4, 80))
+        gap = rnd(rng.randrange(0, 30))
+        return (mid + gap + mid, rnd(rng.randrange(0, 20)) + mid) if rng.random() < 0.5 else (mid + rnd(rng.randrange(0, 20)), mid + gap + mid)
+    # low-complexity overlap with the shared part in the middle of both
+    mid = rnd(rng.randrange(10, 150), rng.choice(["AC", "ACG", "ACGT"]))
+    return rnd(rng.randrange(0, 50)) + mid + rnd(rng.randrange(0, 50)), rnd(rng.randrange(0, 50)) + mid + rnd(rng.randrange(0, 50))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SSW), reason="oracle/_ref/libssw_ref.so not built (make -C oracle ref)")
+def test_exact_overlap_shortcut_equals_the_reference_library():
+    """helen_ssw_align answers a pair whose longest common SUBSEQUENCE is a common SUBSTRING without running the three
+    passes (helen_amd/csrc/ssw.cpp: exact_overlap).  Every such answer -- score, begin / end cells, CIGAR, mismatch count
+    -- must be the reference library's own: 200,000 pairs on which the shortcut fires (stitch-shaped joins and pairs built
+    against its argument), each also run with the shortcut off."""
+    ref = ctypes.CDLL(REF_SSW)
+    lib = native_io.load()
+    rng = random.Random(20260930)
+    fired = tried = 0
+    before = native_io.ssw_fast_path(True)
+    try:
+        while fired < 200000 and tried < 1200000:
+            r, q = _shortcut_cases(rng)
+            if not r or not q:
+                continue
+            tried += 1
+            rb, qb = r.encode(), q.encode()
+            h0 = native_io.ssw_fast_path_counts()[0]
+            got = _own_align(lib, rb, qb)
+            if native_io.ssw_fast_path_counts()[0] == h0:
+                continue                     # the three passes answered: covered by the tests above
+            fired += 1
+            want = _ref_align(ref, rb, qb)
+            assert got == want, (r, q, got, want)
+            if fired % 16 == 0:              # ... and this library's own three passes say the same
+                native_io.ssw_fast_path(False)
+                slow = _own_align(lib, rb, qb)
+                native_io.ssw_fast_path(True)
+                assert slow == got, (r, q, slow, got)
+    finally:
+        native_io.ssw_fast_path(before)
+    assert fired >= 200000, (fired, tried)
+    print("exact-overlap shortcut: %d of %d pairs answered by it, all equal to the reference library" % (fired, tried))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SSW), reason="oracle/_ref/libssw_ref.so not built (make -C oracle ref)")
+@pytest.mark.parametrize("penalties", [(2, 2, 3, 1), (1, 4, 6, 1), (5, 4, 10, 3), (1, 1, 1, 0)])
+def test_exact_overlap_shortcut_with_other_penalties(penalties):
+    """The argument needs match > 0 and mismatch, gap_open > 0 only: other penalty sets, gap_extend = 0 included."""
+    ref = ctypes.CDLL(REF_SSW)
+    lib = native_io.load()
+    rng = random.Random(sum(penalties) * 7919)
+    fired = 0
+    for _ in range(60000):
+        r, q = _shortcut_cases(rng)
+        if not r or not q:
+            continue
+        h0 = native_io.ssw_fast_path_counts()[0]
+        got = _own_align(lib, r.encode(), q.encode(), penalties)
+        if native_io.ssw_fast_path_counts()[0] != h0:
+            fired += 1
+            assert got == _ref_align(ref, r.encode(), q.encode(), penalties), (penalties, r, q)
+    assert fired > 10000
