@@ -396,7 +396,7 @@ bool surely_saturates(const int8_t* ref, int n, const int8_t* read, int m, int m
 // randomised and adversarial pairs (tests/test_stitch.py); when either fact fails the three passes run as before.
 // ------------------------------------------------------------------------------------------------
 std::atomic<int> g_fast_path{1};
-std::atomic<long long> g_fast_hits{0}, g_fast_misses{0};
+std::atomic<long long> g_fast_hits{0}, g_fast_hits2{0}, g_fast_misses{0};
 
 // length of the longest common subsequence of ref[0..n) and read[0..m), codes 0..3 only, n <= 64 * kLcsWords
 constexpr int kLcsWords = 16;
@@ -572,29 +572,32 @@ int helen_ssw_align(const char* ref_seq, int ref_len, const char* query_seq, int
     for (int k = 0; k < query_len; ++k) read[k] = base_code(query_seq[k]);
 
     // the common join: one long exact run shared by the two strings (see exact_overlap)
-    if (g_fast_path.load(std::memory_order_relaxed) && match > 0 && mismatch > 0 && gap_open > 0 && gap_extend >= 0) {
+    const bool shortcuts = g_fast_path.load(std::memory_order_relaxed) && match > 0 && mismatch > 0 && gap_open > 0 && gap_extend >= 0;
+    auto exact_run_result = [&](int a, int b, int len) {      // reference [a, a + len) == query [b, b + len), nothing else aligned
+        out[0] = len * match;
+        out[1] = a;
+        out[2] = a + len - 1;
+        out[3] = b;
+        out[4] = b + len - 1;
+        out[5] = 0;
+        if (cigar_cap > 0) {
+            char text[96];
+            int at = 0;
+            if (b > 0) at += snprintf(text + at, sizeof(text) - at, "%dS", b);
+            at += snprintf(text + at, sizeof(text) - at, "%d=", len);
+            const int tail = query_len - (b + len);
+            if (tail > 0) at += snprintf(text + at, sizeof(text) - at, "%dS", tail);
+            snprintf(cigar, cigar_cap, "%s", text);
+        }
+    };
+    if (shortcuts) {
         int a = 0, b = 0, len = 0;
         if (exact_overlap(ref.data(), ref_len, read.data(), query_len, &a, &b, &len) &&
             (long long)len * match + match + mismatch < 32000) {
             g_fast_hits.fetch_add(1, std::memory_order_relaxed);
-            out[0] = len * match;
-            out[1] = a;
-            out[2] = a + len - 1;
-            out[3] = b;
-            out[4] = b + len - 1;
-            out[5] = 0;
-            if (cigar_cap > 0) {
-                char text[96];
-                int at = 0;
-                if (b > 0) at += snprintf(text + at, sizeof(text) - at, "%dS", b);
-                at += snprintf(text + at, sizeof(text) - at, "%d=", len);
-                const int tail = query_len - (b + len);
-                if (tail > 0) at += snprintf(text + at, sizeof(text) - at, "%dS", tail);
-                snprintf(cigar, cigar_cap, "%s", text);
-            }
+            exact_run_result(a, b, len);
             return 0;
         }
-        g_fast_misses.fetch_add(1, std::memory_order_relaxed);
     }
     // 8-bit pass first; the 16-bit pass replaces it when the score saturates
     const int bias = mismatch;  // |most negative matrix entry|
@@ -610,6 +613,26 @@ int helen_ssw_align(const char* ref_seq, int ref_len, const char* query_seq, int
         fwd = striped(ref.data(), false, ref_len, read.data(), query_len, gap_open, gap_extend, mat, 8, 0, -1);
     }
     const int score = fwd.score, ref_end = fwd.ref, read_end = fwd.read;
+    // The second shortcut, after the library's own forward pass: the best cell is the end of an exact run of
+    // score / match real bases.  An alignment that scores `score` has at least that many match columns, hence spans at
+    // least that many reference columns; the backward pass, walking down from the end column, therefore meets the score
+    // first in the run's own first column, in the cell of an alignment that spans exactly those columns and pays for
+    // nothing -- the run -- and the banded pass over the box aligns two equal strings.  Begin cell and CIGAR follow.
+    if (shortcuts && score > 0 && score % match == 0) {
+        const int len = score / match;
+        if (len <= ref_end + 1 && len <= read_end + 1) {
+            const int8_t* rp = ref.data() + ref_end - len + 1;
+            const int8_t* qp = read.data() + read_end - len + 1;
+            bool same = memcmp(rp, qp, (size_t)len) == 0;
+            for (int k = 0; same && k < len; ++k) same = rp[k] <= 3;
+            if (same) {
+                g_fast_hits2.fetch_add(1, std::memory_order_relaxed);
+                exact_run_result(ref_end - len + 1, read_end - len + 1, len);
+                return 0;
+            }
+        }
+    }
+    if (shortcuts) g_fast_misses.fetch_add(1, std::memory_order_relaxed);
     // begin cell: reversed query prefix against the reference prefix, walked backwards
     std::vector<int8_t> rq(read.begin(), read.begin() + read_end + 1);
     std::reverse(rq.begin(), rq.end());
@@ -689,8 +712,10 @@ int helen_ssw_fast_path(int enable) {
 }
 
 void helen_ssw_fast_path_counts(long long* hits, long long* misses) {
-    if (hits) *hits = g_fast_hits.load();
+    if (hits) *hits = g_fast_hits.load() + g_fast_hits2.load();
     if (misses) *misses = g_fast_misses.load();
 }
+
+long long helen_ssw_fast_path_after_forward(void) { return g_fast_hits2.load(); }
 
 }  // extern "C"

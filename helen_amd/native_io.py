@@ -91,6 +91,8 @@ def load():
     lib.helen_ssw_fast_path.argtypes = [ctypes.c_int]
     lib.helen_ssw_fast_path_counts.restype = None
     lib.helen_ssw_fast_path_counts.argtypes = [ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]
+    lib.helen_ssw_fast_path_after_forward.restype = ctypes.c_longlong
+    lib.helen_ssw_fast_path_after_forward.argtypes = []
     lib.helen_ssw_align.restype = ctypes.c_int
     lib.helen_ssw_align.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -398,7 +398,7 @@ class CollectorRun(object):
                 f.close()
         finally:
             self.abort()
-        total = {"from_table": 0, "aligned_now": 0, "sliced": 0, "contigs": 0, "late": 0}
+        total = {"from_table": 0, "aligned_now": 0, "sliced": 0, "contigs": 0, "late": 0, "shortcut": 0, "three_passes": 0}
         for stats in got.values():
             for k in total:
                 total[k] += stats[k]

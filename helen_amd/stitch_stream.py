@@ -514,15 +514,22 @@ def assemble_contigs(files, by_file, joins, pair_joins, threads, emit, fast=True
         say("INFO: " + prefix + " FINISHED PROCESSING " + contig + ", POLISHED SEQUENCE LENGTH: " + str(len(sequence)) + ".\n")
         if len(sequence) > 0:
             emit(contig, [b'>' + contig.encode() + b"\n", sequence, b"\n"])
-    return {"from_table": hits[0], "aligned_now": hits[1], "sliced": sliced, "contigs": len(contigs), "late": late}
+    answered, passed_on = native_io.ssw_fast_path_counts() if native_io.available() else (0, 0)
+    return {"from_table": hits[0], "aligned_now": hits[1], "sliced": sliced, "contigs": len(contigs), "late": late,
+            # this PROCESS's alignments so far (the stream's speculation included): answered by the aligner's exact-overlap
+            # shortcut / taken through the three passes
+            "shortcut": answered, "three_passes": passed_on}
 
 
 def report_line(stats, from_file, threads):
     return ("INFO: STITCH PIPELINED BEHIND INFERENCE: %d JOINS FROM THE TABLE, %d ALIGNED NOW, %d REGION(S) READ BACK "
             "FROM THE FILES; %d OF %d CONTIG(S) ASSEMBLED FROM REGION SLICES%s.\n"
             % (stats["from_table"], stats["aligned_now"], from_file, stats["sliced"], stats["contigs"],
-               "" if not stats["late"] else "; %d JOIN(S) BETWEEN REGIONS OF DIFFERENT STREAMS ALIGNED ON %d THREAD(S) FIRST"
-               % (stats["late"], threads)))
+               ("" if not stats["late"] else "; %d JOIN(S) BETWEEN REGIONS OF DIFFERENT STREAMS ALIGNED ON %d THREAD(S) FIRST"
+                % (stats["late"], threads))
+               + ("" if not stats.get("shortcut", 0) + stats.get("three_passes", 0) else
+                  "; %d OF %d ALIGNMENT(S) ANSWERED BY THE EXACT-OVERLAP SHORTCUT"
+                  % (stats["shortcut"], stats["shortcut"] + stats["three_passes"]))))
 
 
 class FastaWriter(object):

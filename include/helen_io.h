@@ -166,11 +166,15 @@ int helen_ssw_align(const char* ref_seq, int ref_len, const char* query_seq, int
 
 /* helen_ssw_align answers the common join of stitch -- the two overlap strings share one exact run as long as their longest
  * common subsequence, A/C/G/T only -- without running the three passes: for such a pair the library's result is determined
- * (helen_amd/csrc/ssw.cpp: exact_overlap states why), and it is what this returns.  On by default.
+ * (helen_amd/csrc/ssw.cpp: exact_overlap states why), and it is what this returns; a pair that fails that test but whose
+ * forward pass ends on an exact run of score / match bases skips the other two passes.  On by default.
  *   helen_ssw_fast_path(0 | 1)   switches it off / on for the process (any other value only asks); returns the previous setting
  *   helen_ssw_fast_path_counts   alignments answered that way / handed on to the three passes since the library was loaded */
 int helen_ssw_fast_path(int enable);
 void helen_ssw_fast_path_counts(long long* hits, long long* misses);
+/* ... of the hits, those answered only after the forward pass: its best cell ends an exact run of score / match bases, which
+ * fixes the begin cell and the CIGAR (the backward and the banded pass are not run). */
+long long helen_ssw_fast_path_after_forward(void);
 
 #ifdef __cplusplus
 }

@@ -429,13 +429,15 @@ def _shortcut_cases(rng):
 @pytest.mark.skipif(not os.path.exists(REF_SSW), reason="oracle/_ref/libssw_ref.so not built (make -C oracle ref)")
 def test_exact_overlap_shortcut_equals_the_reference_library():
     """helen_ssw_align answers a pair whose longest common SUBSEQUENCE is a common SUBSTRING without running the three
-    passes (helen_amd/csrc/ssw.cpp: exact_overlap).  Every such answer -- score, begin / end cells, CIGAR, mismatch count
+    passes (helen_amd/csrc/ssw.cpp: exact_overlap), and one whose forward pass ends on an exact run of score / match bases
+    without the other two.  Every such answer -- score, begin / end cells, CIGAR, mismatch count
     -- must be the reference library's own: 200,000 pairs on which the shortcut fires (stitch-shaped joins and pairs built
     against its argument), each also run with the shortcut off."""
     ref = ctypes.CDLL(REF_SSW)
     lib = native_io.load()
     rng = random.Random(20260930)
     fired = tried = 0
+    after_forward0 = lib.helen_ssw_fast_path_after_forward()
     before = native_io.ssw_fast_path(True)
     try:
         while fired < 200000 and tried < 1200000:
@@ -459,7 +461,10 @@ def test_exact_overlap_shortcut_equals_the_reference_library():
     finally:
         native_io.ssw_fast_path(before)
     assert fired >= 200000, (fired, tried)
-    print("exact-overlap shortcut: %d of %d pairs answered by it, all equal to the reference library" % (fired, tried))
+    second = lib.helen_ssw_fast_path_after_forward() - after_forward0
+    print("exact-overlap shortcuts: %d of %d pairs answered by them (%d only after the forward pass), all equal to the reference "
+          "library" % (fired, tried, second))
+    assert second > 5000 and fired - second > 50000          # both shortcuts are exercised
 
 
 @pytest.mark.skipif(not os.path.exists(REF_SSW), reason="oracle/_ref/libssw_ref.so not built (make -C oracle ref)")
