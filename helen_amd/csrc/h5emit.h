@@ -24,7 +24,9 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <deque>
 #include <map>
 #include <mutex>
@@ -46,6 +48,51 @@ struct Child {
     uint64_t header;   // address of the child's object header
 };
 
+// The file buffer: bytes appended at the end, WITHOUT the value-initialisation a std::vector insists on (a window's 14 KB
+// are written exactly once, by whoever fills them) and with storage that stays put until it is handed to a flusher.
+class Bytes {
+   public:
+    Bytes() = default;
+    Bytes(const Bytes&) = delete;
+    Bytes& operator=(const Bytes&) = delete;
+    Bytes(Bytes&& o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+    Bytes& operator=(Bytes&& o) noexcept {
+        if (this != &o) {
+            free(p_);
+            p_ = o.p_; n_ = o.n_; cap_ = o.cap_;
+            o.p_ = nullptr; o.n_ = o.cap_ = 0;
+        }
+        return *this;
+    }
+    ~Bytes() { free(p_); }
+    uint8_t* data() { return p_; }
+    const uint8_t* data() const { return p_; }
+    size_t size() const { return n_; }
+    size_t capacity() const { return cap_; }
+    bool empty() const { return n_ == 0; }
+    void clear() { n_ = 0; }
+    void reserve(size_t c) {
+        if (c > cap_) {
+            p_ = (uint8_t*)realloc(p_, c);
+            if (!p_) abort();
+            cap_ = c;
+        }
+    }
+    uint8_t* extend(size_t n) {                 // n more bytes, uninitialised
+        if (n_ + n > cap_) reserve(std::max(n_ + n, cap_ + cap_ / 2));
+        uint8_t* q = p_ + n_;
+        n_ += n;
+        return q;
+    }
+    void append(const void* b, size_t n) { memcpy(extend(n), b, n); }
+    void zeros(size_t n) { memset(extend(n), 0, n); }
+    void push_back(uint8_t v) { *extend(1) = v; }
+
+   private:
+    uint8_t* p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
+};
+
 class File {
    public:
     ~File() {
@@ -58,7 +105,8 @@ class File {
         for (int t = 0; t < kFlushers; ++t) flushers_.emplace_back([this]() { flusher_loop(); });
         buf_.reserve(kFlush + (1 << 20));
         // room for the superblock (96 bytes), written last
-        buf_.assign(kDataStart, 0);
+        buf_.clear();
+        buf_.zeros(kDataStart);
         base_ = 0;
         return true;
     }
@@ -72,15 +120,14 @@ class File {
     uint64_t dataset_filled(Fill&& fill, size_t bytes, int elem_size, bool is_signed, int rank, const uint64_t* dims) {
         align8();
         const uint64_t addr = tell();
-        const size_t at = buf_.size();
-        buf_.resize(at + bytes);
-        fill(buf_.data() + at);
+        fill(buf_.extend(bytes));
         if (buf_.size() >= kFlush) flush();
         return dataset_header(addr, bytes, elem_size, is_signed, rank, dims);
     }
     uint64_t dataset(const void* data, size_t bytes, int elem_size, bool is_signed, int rank, const uint64_t* dims) {
         align8();
         const uint64_t addr = tell();
+        last_data_ = addr;
         put(data, bytes);
         return dataset_header(addr, bytes, elem_size, is_signed, rank, dims);
     }
@@ -127,6 +174,89 @@ class File {
         put8(3); put8(0); put16(8); put64((uint64_t)v); pad(4);
         return hdr;
     }
+
+    // ---- stamps ----
+    // A block of objects whose bytes depend on where it lands only through the absolute addresses inside it (a window's three
+    // datasets and their group: fixed names, fixed shapes) is emitted ONCE, into memory, at two different addresses; what
+    // differs between the two copies are the address fields.  Every later use copies the block and adds its address to those
+    // fields (the writer's time per window went into some 200 small appends and a dozen allocations before; now one copy, a
+    // handful of patches and the window's data).  `marks` = offsets the builder asked to remember (where data goes),
+    // `result` = offset of the object header the block is referred to by.
+    struct Stamp {
+        std::vector<uint8_t> bytes;
+        std::vector<uint32_t> patches;
+        std::vector<uint64_t> marks;      // (offset, bytes) pairs of the data areas
+        std::vector<uint64_t> literal;    // (offset, bytes) pairs of everything else
+        uint64_t result = 0;
+    };
+    // emit(File&, std::vector<uint64_t>& marks) -> address of the block's object header; the block must start 8-aligned
+    template <class Emit>
+    static Stamp make_stamp(Emit&& emit) {
+        Stamp s[2];
+        const uint64_t at[2] = {kDataStart, kDataStart + (1ull << 20)};
+        for (int i = 0; i < 2; ++i) {
+            File f;
+            f.memory_ = true;
+            f.base_ = at[i];
+            s[i].result = emit(f, s[i].marks) - at[i];
+            for (auto& m : s[i].marks) m -= at[i];
+            s[i].bytes.assign(f.buf_.data(), f.buf_.data() + f.buf_.size());
+        }
+        const size_t n = s[0].bytes.size();
+        for (size_t p = 0; p < n;) {
+            if (s[0].bytes[p] == s[1].bytes[p]) { ++p; continue; }
+            // the lowest byte that a difference of 1 << 20 changes is byte 2 of the little-endian field
+            const size_t o = p - 2;
+            uint64_t v0, v1;
+            memcpy(&v0, s[0].bytes.data() + o, 8);
+            memcpy(&v1, s[1].bytes.data() + o, 8);
+            if (p < 2 || o + 8 > n || v1 - v0 != (1ull << 20)) { s[0].bytes.clear(); return s[0]; }   // (not a stampable block)
+            v0 -= at[0];
+            memcpy(s[0].bytes.data() + o, &v0, 8);
+            s[0].patches.push_back((uint32_t)o);
+            p = o + 8;
+        }
+        uint64_t at_byte = 0;
+        for (size_t k = 0; k + 1 < s[0].marks.size(); k += 2) {
+            if (s[0].marks[k] > at_byte) { s[0].literal.push_back(at_byte); s[0].literal.push_back(s[0].marks[k] - at_byte); }
+            at_byte = s[0].marks[k] + s[0].marks[k + 1];
+        }
+        if (n > at_byte) { s[0].literal.push_back(at_byte); s[0].literal.push_back(n - at_byte); }
+        return std::move(s[0]);
+    }
+    // Appends the block (8-aligned); -> its bytes in the file buffer, for the caller to fill the marked data areas, and the
+    // address of its object header.  stamped() afterwards hands a full buffer on.
+    uint8_t* stamp(const Stamp& st, uint64_t* header) {
+        uint64_t addr;
+        uint8_t* p = reserve_block(st, &addr, header);
+        fill_block(st, p, addr);
+        return p;
+    }
+    void stamped() {
+        if (buf_.size() >= kFlush) flush();
+    }
+    // The two halves of stamp(), for a caller that fills its blocks LATER and on other threads: room for the block now (the
+    // addresses are final), its bytes whenever -- before the buffer is handed on, which before_flush announces.  The
+    // buffer's storage does not move in between (its reserve covers everything appended between two flush checks).
+    uint8_t* reserve_block(const Stamp& st, uint64_t* addr, uint64_t* header) {
+        align8();
+        *addr = tell();
+        *header = *addr + st.result;
+        return buf_.extend(st.bytes.size());
+    }
+    // (everything outside the marked data areas: `literal` = [offset, length) pairs; thread-safe: touches only the block)
+    static void fill_block(const Stamp& st, uint8_t* p, uint64_t addr) {
+        for (size_t k = 0; k + 1 < st.literal.size(); k += 2) memcpy(p + st.literal[k], st.bytes.data() + st.literal[k], st.literal[k + 1]);
+        for (uint32_t o : st.patches) {
+            uint64_t v;
+            memcpy(&v, p + o, 8);
+            v += addr;
+            memcpy(p + o, &v, 8);
+        }
+    }
+    void set_before_flush(std::function<void()> f) { before_flush_ = std::move(f); }
+    bool full() const { return buf_.size() >= kFlush; }
+    uint64_t last_data_address() const { return last_data_; }   // where the newest dataset()'s raw data begins
 
     // ---- groups ----
     // old-style group over `kids` (any order; sorted here by name, bytewise like strcmp); returns the object
@@ -250,18 +380,21 @@ class File {
     static constexpr int kFlushers = 2;
     static constexpr size_t kInFlight = 3;
     int fd_ = -1;
+    bool memory_ = false;        // make_stamp's scratch files: everything stays in buf_
     std::atomic<bool> failed_{false};
-    std::vector<uint8_t> buf_;
+    Bytes buf_;
+    std::function<void()> before_flush_;   // blocks reserved but not yet filled: fill them now
     uint64_t base_ = 0;   // file offset of buf_[0]
+    uint64_t last_data_ = 0;
     struct Piece {
-        std::vector<uint8_t> bytes;
+        Bytes bytes;
         uint64_t offset;
     };
     std::vector<std::thread> flushers_;
     std::mutex mutex_;
     std::condition_variable work_, room_;
     std::deque<Piece> queue_;
-    std::vector<std::vector<uint8_t>> spare_;
+    std::vector<Bytes> spare_;
     size_t in_flight_ = 0;
     bool stopping_ = false;
 
@@ -304,7 +437,8 @@ class File {
         stopping_ = false;
     }
     void flush() {
-        if (buf_.empty()) return;
+        if (buf_.empty() || memory_) return;
+        if (before_flush_) before_flush_();
         if (flushers_.empty()) {            // (after finish() has stopped them: nothing writes then)
             size_t done = 0;
             while (done < buf_.size() && !failed_.load()) {
@@ -316,7 +450,7 @@ class File {
             buf_.clear();
             return;
         }
-        std::vector<uint8_t> next;
+        Bytes next;
         {
             std::unique_lock<std::mutex> lock(mutex_);
             room_.wait(lock, [this]() { return in_flight_ < kInFlight; });
@@ -334,11 +468,10 @@ class File {
         buf_.reserve(kFlush + (1 << 20));
     }
     void put(const void* p, size_t n) {
-        const uint8_t* b = (const uint8_t*)p;
-        buf_.insert(buf_.end(), b, b + n);
+        buf_.append(p, n);
         if (buf_.size() >= kFlush) flush();
     }
-    void pad(size_t n) { buf_.resize(buf_.size() + n, 0); }
+    void pad(size_t n) { buf_.zeros(n); }
     void align8() { pad((8 - (tell() & 7)) & 7); }
     void put8(uint8_t v) { buf_.push_back(v); }
     void put16(uint16_t v) { put(&v, 2); }

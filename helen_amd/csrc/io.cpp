@@ -459,6 +459,126 @@ struct Region {                      // predictions/<contig>/<contig-start-end>
     uint64_t header = 0;             // its group as last emitted ...
     bool dirty = true;               // ... which lacks members added since
 };
+// The block of one window -- position uint32 [1000, 3], bases uint8 [1000], rles uint8 [1000] and the group over the three
+// (DataStore.py:126-133) -- as h5emit emits it, made once; marks = where the three datasets' data goes.
+const h5emit::File::Stamp& window_stamp() {
+    static const h5emit::File::Stamp stamp = h5emit::File::make_stamp([](h5emit::File& f, std::vector<uint64_t>& marks) {
+        static_assert((kSeq * 3) % 4 == 0 && kSeq % 8 == 0, "the stamped block keeps its datasets 8-aligned");
+        const std::vector<uint8_t> zeros((size_t)kSeq * 12, 0);
+        const uint64_t dp[2] = {(uint64_t)kSeq, 3}, dl[1] = {(uint64_t)kSeq};
+        std::vector<h5emit::Child> kids(3);
+        auto mark = [&](size_t bytes) { marks.push_back(f.last_data_address()); marks.push_back(bytes); };
+        kids[0] = {"position", f.dataset(zeros.data(), (size_t)kSeq * 12, 4, false, 2, dp)};
+        mark((size_t)kSeq * 12);
+        kids[1] = {"bases", f.dataset(zeros.data(), kSeq, 1, false, 1, dl)};
+        mark(kSeq);
+        kids[2] = {"rles", f.dataset(zeros.data(), kSeq, 1, false, 1, dl)};
+        mark(kSeq);
+        return f.group(kids);
+    });
+    return stamp;
+}
+
+// A window's block of the prediction file, reserved by the writer's own thread (which does the bookkeeping and fixes the
+// addresses) and FILLED -- the block's bytes, 3000 positions int64 -> uint32, two label rows -- by that thread and the
+// helpers below, a flush-full of blocks at a time.
+struct FillJob {
+    uint8_t* block;
+    uint64_t addr;
+    const int64_t* positions;
+    const uint8_t *bases, *rles;
+};
+void fill_window(const FillJob& j) {
+    const h5emit::File::Stamp& st = window_stamp();
+    h5emit::File::fill_block(st, j.block, j.addr);
+    // int64 -> uint32: a -1 padding row wraps to 4294967295 (DataStore.py:128); aligned in the FILE, not in memory
+    uint8_t* q = j.block + st.marks[0];
+    const int64_t* p = j.positions;
+    for (int k = 0; k < kSeq * 3; k += 4) {
+        const uint32_t four[4] = {(uint32_t)p[k], (uint32_t)p[k + 1], (uint32_t)p[k + 2], (uint32_t)p[k + 3]};
+        memcpy(q + 4 * k, four, 16);
+    }
+    memcpy(j.block + st.marks[2], j.bases, kSeq);
+    memcpy(j.block + st.marks[4], j.rles, kSeq);
+}
+class FillPool {
+   public:
+    explicit FillPool(int helpers) {
+        for (int t = 0; t < helpers; ++t) threads_.emplace_back([this]() { loop(); });
+    }
+    ~FillPool() {
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            stop_ = true;
+        }
+        wake_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    void add(const FillJob& j) { jobs_.push_back(j); }
+    size_t pending() const { return jobs_.size(); }
+    // every queued block filled when this returns (the caller works too), and no helper still looking at the job list: a
+    // helper that wakes late for a round that is over finds left_ == 0 under the lock and goes back to sleep
+    void run() {
+        if (jobs_.empty()) return;
+        if (threads_.empty() || jobs_.size() < 8) {
+            for (const FillJob& j : jobs_) fill_window(j);
+            jobs_.clear();
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            next_.store(0);
+            left_ = jobs_.size();
+            ++round_;
+        }
+        wake_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lock(mutex_);
+        done_.wait(lock, [this]() { return left_ == 0 && busy_ == 0; });
+        jobs_.clear();
+    }
+
+   private:
+    void work() {
+        size_t mine = 0;
+        const size_t n = jobs_.size();          // (fixed for the round: nobody adds while a round runs)
+        for (;;) {
+            const size_t k = next_.fetch_add(1);
+            if (k >= n) break;
+            fill_window(jobs_[k]);
+            ++mine;
+        }
+        if (mine) {
+            std::lock_guard<std::mutex> lock(mutex_);
+            left_ -= mine;
+            if (left_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        unsigned long seen = 0;
+        std::unique_lock<std::mutex> lock(mutex_);
+        for (;;) {
+            wake_.wait(lock, [&]() { return stop_ || round_ != seen; });
+            if (stop_) return;
+            seen = round_;
+            if (left_ == 0) continue;           // that round is over already
+            ++busy_;
+            lock.unlock();
+            work();
+            lock.lock();
+            if (--busy_ == 0 && left_ == 0) done_.notify_all();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::vector<FillJob> jobs_;
+    std::mutex mutex_;
+    std::condition_variable wake_, done_;
+    std::atomic<size_t> next_{0};
+    size_t left_ = 0, busy_ = 0;
+    unsigned long round_ = 0;
+    bool stop_ = false;
+};
+
 struct Writer {
     hid_t file = -1;
     hid_t lcpl = -1, dcpl = -1;
@@ -468,6 +588,7 @@ struct Writer {
     std::vector<uint32_t> pos32;
     // direct emitter (h5emit.h): the default; $HELEN_IO_WRITER=libhdf5 selects the library path above
     h5emit::File* fast = nullptr;
+    FillPool* pool = nullptr;        // helpers that fill the reserved window blocks ($HELEN_IO_WRITER_THREADS, default 2)
     std::string path;
     std::map<std::string, std::map<std::string, Region>> tree;   // contig -> region name -> members
     Region* open_region = nullptr;   // the region of the newest window: its group is emitted when the next begins
@@ -1048,6 +1169,11 @@ void* helen_io_writer_open(const char* path) {
             delete w;
             return nullptr;
         }
+        int helpers = 2;
+        if (const char* t = getenv("HELEN_IO_WRITER_THREADS")) helpers = std::max(0, std::min(15, atoi(t) - 1));
+        w->pool = new FillPool(helpers);
+        FillPool* pool = w->pool;
+        w->fast->set_before_flush([pool]() { pool->run(); });
         return w;
     }
     std::lock_guard<std::recursive_mutex> lib(g_library_mutex);
@@ -1104,18 +1230,13 @@ int helen_io_write_predictions_sel(void* handle, int n_sel, const int32_t* sel, 
                 reg.dirty = true;
             }
             if (w->images.insert(contig + prefix + suffix).second) {
-                const int64_t* p = positions + (size_t)i * kSeq * 3;
-                const uint64_t dp[2] = {(uint64_t)kSeq, 3}, dl[1] = {(uint64_t)kSeq};
-                std::vector<h5emit::Child> kids(3);
-                // int64 -> uint32 (a -1 padding row wraps to 4294967295, DataStore.py:128) straight into the file buffer
-                kids[0] = {"position", w->fast->dataset_filled([p](uint8_t* dst) {
-                               typedef uint32_t unaligned_u32 __attribute__((aligned(1), may_alias));
-                               unaligned_u32* q = (unaligned_u32*)dst;      // (aligned in the FILE, not in memory)
-                               for (int k = 0; k < kSeq * 3; ++k) q[k] = (uint32_t)p[k];
-                           }, (size_t)kSeq * 12, 4, false, 2, dp)};
-                kids[1] = {"bases", w->fast->dataset(bases + (size_t)i * kSeq, kSeq, 1, false, 1, dl)};
-                kids[2] = {"rles", w->fast->dataset(rles + (size_t)i * kSeq, kSeq, 1, false, 1, dl)};
-                reg.kids.push_back({suffix, w->fast->group(kids)});
+                // a window's three datasets and their group are one stamped block (h5emit.h): the block's bytes, then the
+                // data -- int64 -> uint32 positions (a -1 padding row wraps to 4294967295, DataStore.py:128), bases, rles
+                uint64_t addr, header;
+                uint8_t* block = w->fast->reserve_block(window_stamp(), &addr, &header);
+                w->pool->add({block, addr, positions + (size_t)i * kSeq * 3, bases + (size_t)i * kSeq, rles + (size_t)i * kSeq});
+                w->fast->stamped();          // (a full buffer is handed on: its blocks are filled first, before_flush)
+                reg.kids.push_back({suffix, header});
                 reg.dirty = true;
             }
             if (!w->fast->ok()) return fail("write failed (disk full?)");
@@ -1139,6 +1260,10 @@ int helen_io_write_predictions_sel(void* handle, int n_sel, const int32_t* sel, 
             H5Gclose(g);
             if (bad) return -1;
         }
+    }
+    if (w->fast) {
+        w->pool->run();              // the caller's arrays are only good until this call returns
+        if (!w->fast->ok()) return fail("write failed (disk full?)");
     }
     return 0;
 }
@@ -1628,6 +1753,8 @@ int helen_io_writer_close(void* handle) {
         forget_path(w->path.c_str());
         // the file is complete and closed; what is left is giving back a million small allocations (a 300,000-region
         // run: two name sets and the region table, ~0.1 s): not on the caller's clock
+        delete w->pool;              // (its helpers are idle: every call filled what it reserved)
+        w->pool = nullptr;
         std::thread([w]() {
             delete w->fast;
             delete w;

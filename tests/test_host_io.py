@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from helen_amd import file_manager, hdf5
+from helen_amd import file_manager, hdf5, native_io
 from helen_amd.data_store import DataStore
 from helen_amd.sequence_dataset import SequenceDataset
 from helen_amd.synthetic import write_image_dir, write_image_file
@@ -763,3 +763,41 @@ def test_hdf5_layer_against_libhdf5s_own_tool(tmp_path):
         assert t == "H5T_STD_U8LE" and shape == (1000,) and np.array_equal(np.array(vals), B)
         t, shape, vals = _h5dump_dataset(out, root + "/2/rles")
         assert t == "H5T_STD_U8LE" and np.array_equal(np.array(vals), R)
+
+
+def test_writer_threads_give_the_same_file(tmp_path, monkeypatch):
+    """The prediction writer reserves a window's block on its own thread and fills it -- the block's bytes, 3000 positions
+    int64 -> uint32, two label rows -- on $HELEN_IO_WRITER_THREADS threads, a flush-full at a time (helen_amd/csrc/io.cpp:
+    FillPool).  Any thread count gives the same FILE, byte for byte: many calls of 9 .. 700 windows (hundreds of rounds of
+    the pool, buffers handed on in the middle of a call), duplicates and -1 padding rows included."""
+    import hashlib
+    rng = np.random.default_rng(7)
+    n = 9000
+    names = ["ctg%d" % (i // 2500) for i in range(n)]
+    meta = np.zeros((n, 3), np.int64)
+    region = np.arange(n) // 3
+    meta[:, 0], meta[:, 1], meta[:, 2] = region * 2400, region * 2400 + 2400, np.arange(n) % 3
+    meta[4000:4010] = meta[3990:4000]                       # repeats: skipped silently (DataStore.py:123)
+    names[4000:4010] = names[3990:4000]
+    positions = rng.integers(0, 1 << 40, (n, 1000, 3), dtype=np.int64)
+    positions[::7, 900:] = -1                               # padding rows: 4294967295 in the file
+    bases = rng.integers(0, 5, (n, 1000), dtype=np.uint8)
+    rles = rng.integers(0, 11, (n, 1000), dtype=np.uint8)
+    cuts = [0]
+    while cuts[-1] < n:
+        cuts.append(min(n, cuts[-1] + int(rng.choice([9, 33, 250, 700]))))
+    digests = {}
+    for threads in ("1", "2", "4", "7"):
+        monkeypatch.setenv("HELEN_IO_WRITER_THREADS", threads)
+        path = str(tmp_path / ("p_%s.hdf" % threads))
+        w = native_io.Writer(path)
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            w.write(native_io.pack_contigs(names[lo:hi]), meta[lo:hi], positions[lo:hi], bases[lo:hi], rles[lo:hi])
+        w.close()
+        digests[threads] = hashlib.sha1(open(path, "rb").read()).hexdigest()
+    assert len(set(digests.values())) == 1, digests
+    with hdf5.File(str(tmp_path / "p_4.hdf")) as f:
+        i = 2501
+        got = f.read("predictions/ctg1/ctg1-%d-%d/%d/position" % (meta[i, 0], meta[i, 1], meta[i, 2]))
+        assert got.dtype == np.uint32 and np.array_equal(got, positions[i].astype(np.uint32))
+        assert np.array_equal(f.read("predictions/ctg0/ctg0-0-2400/2/rles"), rles[2])
