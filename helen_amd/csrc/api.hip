@@ -362,14 +362,26 @@ void launch_chunk(HelenModel* m, hipStream_t s, int tiles, int pos0, int T, int 
         return;
     }
     if (m->precision == HELEN_PRECISION_FP32X3) {
-        // encoder output goes out as three bf16 planes only; the projection consumes them directly
-        LAUNCH(HELEN_K_GRU_ENC, gru_x3_kernel, dim3(tiles, 2), dim3(512), m->gi_enc, kGiEncTileStride, pos0,
-               enc_npos - pos0 - T, T, m->w3h_enc, m->bhn_enc, m->hid, m->y1p, kY1pTileStride,
-               (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride);
+        // encoder output goes out as three bf16 planes only; the projection consumes them directly.  Above half the CUs in
+        // tiles the recurrences take two tiles per workgroup (gru_x3_il_kernel: the same bits)
+        const bool two = x3_pair_pays(tiles, m->cus, m->overrides);
+        const dim3 grid2((tiles + 1) / 2, 2);
+        if (two)
+            LAUNCH(HELEN_K_GRU_ENC, gru_x3_il_kernel<false>, grid2, dim3(512), m->gi_enc, kGiEncTileStride, pos0,
+                   enc_npos - pos0 - T, T, m->w3h_enc, m->bhn_enc, m->hid, m->y1p, kY1pTileStride,
+                   (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride, tiles);
+        else
+            LAUNCH(HELEN_K_GRU_ENC, gru_x3_kernel, dim3(tiles, 2), dim3(512), m->gi_enc, kGiEncTileStride, pos0,
+                   enc_npos - pos0 - T, T, m->w3h_enc, m->bhn_enc, m->hid, m->y1p, kY1pTileStride,
+                   (const f32x4*)nullptr, (f32x4*)nullptr, kPlTileStride);
         LAUNCH(HELEN_K_GEMM_DEC, (gemm_dec_x3_kernel<3, 2>), dim3(3 * ((tiles + 7) / 8 * 8)), dim3(512), m->y1p, kY1pTileStride,
                (const f32x4*)m->w3i_dec, m->bias_dec, m->gi_dec, kGiDecTileStride, T, tiles);
-        LAUNCH(HELEN_K_GRU_DEC, gru_x3_kernel, dim3(tiles, 2), dim3(512), m->gi_dec, kGiDecTileStride, 0, 0, T,
-               m->w3h_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kY1pTileStride, m->whd, m->plogit, kPlTileStride);
+        if (two)
+            LAUNCH(HELEN_K_GRU_DEC, gru_x3_il_kernel<true>, grid2, dim3(512), m->gi_dec, kGiDecTileStride, 0, 0, T,
+                   m->w3h_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kY1pTileStride, m->whd, m->plogit, kPlTileStride, tiles);
+        else
+            LAUNCH(HELEN_K_GRU_DEC, gru_x3_kernel, dim3(tiles, 2), dim3(512), m->gi_dec, kGiDecTileStride, 0, 0, T,
+                   m->w3h_dec, m->bhn_dec, m->hid, (f32x4*)nullptr, kY1pTileStride, m->whd, m->plogit, kPlTileStride);
         return;
     }
     // fp32: which recurrence and which decoder projection is dispatch.h's plan_chunk (all the same bits)

@@ -41,6 +41,7 @@ struct Overrides {
     int dec_ws = -1, dec_wsp = -1, dec_wsp_parts = 0;
     int split = -1, split_at = 0;
     int bf16_pair = -1;
+    int x3_pair = -1;                           // fp32x3: 1 / 0 = two tiles per workgroup (gru_x3_il_kernel) / one (gru_x3_kernel)
     int host_lock = -1;                         // helen_polish_host: 0 never page-lock caller memory, 1 ranges that own their pages, 2 all
     bool verbose = false;
 };
@@ -60,6 +61,7 @@ inline Overrides read_overrides() {
     o.split = flag_of("HELEN_SPLIT");
     if (const char* n = getenv("HELEN_SPLIT_AT")) o.split_at = atoi(n);
     o.bf16_pair = flag_of("HELEN_BF16_PAIR");
+    o.x3_pair = flag_of("HELEN_X3_PAIR");
     // exactly none | own | all ("0" = none); anything else is ignored: a typo must not re-open the in-place page-locking
     if (const char* hl = getenv("HELEN_HOST_LOCK")) {
         if (!strcmp(hl, "none") || !strcmp(hl, "0")) o.host_lock = 0;
@@ -154,6 +156,8 @@ inline CallPlan plan_call(int tiles, int cus, bool fp32, const Overrides& o) {
 }
 
 inline bool bf16_pair_pays(int tiles, int cus, const Overrides& o) { return o.bf16_pair >= 0 ? o.bf16_pair == 1 : 2 * tiles > cus; }
+// fp32x3 likewise: above half the CUs in tiles the two-tile kernel (gate math inside the other tile's MFMA stream)
+inline bool x3_pair_pays(int tiles, int cus, const Overrides& o) { return o.x3_pair >= 0 ? o.x3_pair == 1 : 2 * tiles > cus; }
 
 // The table for a device of `cus` compute units: one row per run of tile counts with the same plan.
 inline std::string describe_dispatch(int cus, const Overrides& o, int max_tiles = 0) {

@@ -588,7 +588,7 @@ struct Writer {
     std::vector<uint32_t> pos32;
     // direct emitter (h5emit.h): the default; $HELEN_IO_WRITER=libhdf5 selects the library path above
     h5emit::File* fast = nullptr;
-    FillPool* pool = nullptr;        // helpers that fill the reserved window blocks ($HELEN_IO_WRITER_THREADS, default 2)
+    FillPool* pool = nullptr;        // helpers that fill the reserved window blocks ($HELEN_IO_WRITER_THREADS - 1; default: one)
     std::string path;
     std::map<std::string, std::map<std::string, Region>> tree;   // contig -> region name -> members
     Region* open_region = nullptr;   // the region of the newest window: its group is emitted when the next begins
@@ -1169,7 +1169,7 @@ void* helen_io_writer_open(const char* path) {
             delete w;
             return nullptr;
         }
-        int helpers = 2;
+        int helpers = 1;
         if (const char* t = getenv("HELEN_IO_WRITER_THREADS")) helpers = std::max(0, std::min(15, atoi(t) - 1));
         w->pool = new FillPool(helpers);
         FillPool* pool = w->pool;

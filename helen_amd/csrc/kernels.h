@@ -15,4 +15,5 @@
 #include "kernels_x3.h"
 #include "kernels_fused_bf16.h"
 #include "kernels_fused_bf16_il.h"
+#include "kernels_x3_il.h"
 #include "kernels_heads.h"

@@ -124,7 +124,7 @@ int helen_model_device_bytes(const HelenModel* model, size_t* out_bytes);
  * Which kernels a call takes is one table derived from the device's CU count (helen_amd/csrc/dispatch.h); every
  * choice gives the same bits.  The environment's A/B switches (HELEN_GRU_PAIR, HELEN_GRU_SINGLE8, HELEN_GRU_HALF8,
  * HELEN_GRU_QUARTER4, HELEN_DEC_WS, HELEN_DEC_WSP[_PARTS], HELEN_SPLIT[_AT],
- * HELEN_BF16_PAIR, HELEN_HOST_LOCK, HELEN_VERBOSE = print the table) are read ONCE, when the model is
+ * HELEN_BF16_PAIR, HELEN_X3_PAIR, HELEN_HOST_LOCK, HELEN_VERBOSE = print the table) are read ONCE, when the model is
  * created; helen_reload_overrides reads them again for this model (tests and probes that flip one between calls).
  *   helen_describe_dispatch   the table for a device of `cus` compute units, as text (a dry run: no device needed)
  *   helen_plan_call           out[8] = split?, tiles of the first group, recurrence kernel, decoder projection, its
