@@ -375,6 +375,35 @@ def test_bf16_kernel_choice_gives_the_same_bits(scale_case):
         e.close()
 
 
+def test_fp32x3_kernel_choice_gives_the_same_bits(scale_case):
+    """fp32x3 mode: calls of more than 128 tiles take gru_x3_il_kernel (two tiles per workgroup, the gate math and the
+    three-term split inside the other tile's MFMA stream), smaller ones gru_x3_kernel.  Accumulators, labels, operator-entry
+    logits and hidden state must be EQUAL -- for an odd tile count and for T = 1 .. 5 and 37 too (prologue, steady loop and
+    tail of the region schedule; the decoder's head slice taken while all three planes of its K32 group are in registers)."""
+    from helen_amd.engine import HelenEngine
+    w, img, _ = scale_case
+    dev = torch.from_numpy(img[6144:6144 + 4096]).cuda()
+    big = HelenEngine(w, device=0, max_windows=4096, precision="fp32x3")      # 256 tiles: two per workgroup
+    small = HelenEngine(w, device=0, max_windows=1024, precision="fp32x3")    # 64 tiles: one per workgroup
+    odd = HelenEngine(w, device=0, max_windows=4080, precision="fp32x3")      # 255 tiles
+    a = big.polish(dev, want_acc=True)
+    b = small.polish(dev, want_acc=True)
+    c = odd.polish(dev[:4080], want_acc=True)
+    torch.cuda.synchronize()
+    for name, x, y, z in zip(("bases", "rles", "acc_base", "acc_rle"), a, b, c):
+        assert torch.equal(x, y), name + ": 4096-window fp32x3 call differs from 1024-window calls"
+        assert torch.equal(x[:4080], z), name + ": 255-tile fp32x3 call differs"
+    x = torch.rand((4096, 100, 90), device="cuda") * 255
+    h = torch.rand((4096, 2, 128), device="cuda") - 0.5
+    for T in (1, 2, 3, 4, 5, 37, 100):
+        xs = x[:, :T].contiguous()
+        parts = [small.chunk_forward(xs[i:i + 1024], h[i:i + 1024]) for i in range(0, 4096, 1024)]
+        for name, u, v_ in zip(("base", "rle", "hidden"), big.chunk_forward(xs, h), (torch.cat(t) for t in zip(*parts))):
+            assert torch.equal(u, v_), "T = %d: %s differs between the two-tile and the one-tile kernels" % (T, name)
+    for e in (big, small, odd):
+        e.close()
+
+
 def test_host_path_survives_an_injected_failure(monkeypatch):
     """helen_polish_host: a failure in the middle of the pipeline must leave nothing in flight, leak nothing,
     and the handle must work afterwards; page-locked and pageable callers get the same labels.  The injection
