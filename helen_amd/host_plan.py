@@ -320,9 +320,10 @@ class HostPlan(object):
 
 
 # `polish`: what the stitch stage behind the inference costs the host per rank at the device's rate (measured on the GPU
-# box's host, 81 k windows/s = 27 k regions/s per MI355X): region decode 0.65 of a CPU in the rank, overlap alignments
-# 70 us each = 1.9 CPUs (in the rank itself with one rank, in the collector processes with several)
-STITCH_CPUS_PER_RANK = 2.5
+# box's host, 81 k windows/s = 27 k regions/s per MI355X; profiles/r06_stitch_stage_cpu.txt): 0.93 of a CPU over all its
+# threads -- region decode, and overlap alignments at ~4 us each since the aligner answers the common join without its
+# three passes (70 us and 4.96 CPUs with the shortcuts off; round 5 priced the stage at 2.5)
+STITCH_CPUS_PER_RANK = 1.0
 
 
 def plan_host(devices, num_workers, cap_windows, calls_per_rank=None, usable=None, allowed=None, shm_free=None,
