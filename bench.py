@@ -1040,6 +1040,13 @@ def main():
                                     "chr20-scale image shard resident in HBM") if args.precision != "bf16"
                        else "BASELINE.json configs[3] variant: bf16 gate matmuls, fp32 accumulate/state",
                        "batch": B, "batches_per_step": G, "windows_per_step": call_windows,
+                       "arithmetic": {"fp32": "fp32 operands, products and accumulation on v_mfma_f32_16x16x4_f32 (recurrences, decoder "
+                                              "projection, heads); the encoder's input projection takes EXACT bf16 products -- a pileup "
+                                              "count is one bf16 term, W_ih three -- with fp32 accumulation (roofline.kernels names the "
+                                              "pipe of every kernel class)",
+                                      "bf16": "gate-matmul operands rounded to bf16, fp32 accumulation, state and gate math",
+                                      "fp32x3": "every fp32 product as the six leading products of three-term bf16 splits, fp32 "
+                                                "accumulation, state and gate math"}[args.precision],
                        "positions": 1000, "features": 90, "windows_per_gpu": args.steps * call_windows,
                        "resident_windows_per_gpu": n_res, "sharding": "by rank, no collective"},
             "roofline": {"bound": bound, "kernel": {"fp32": "gru_pair_kernel (GRU recurrence of two window tiles per 8-wave workgroup, fp32 MFMA; "
