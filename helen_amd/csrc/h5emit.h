@@ -206,11 +206,12 @@ class File {
         for (size_t p = 0; p < n;) {
             if (s[0].bytes[p] == s[1].bytes[p]) { ++p; continue; }
             // the lowest byte that a difference of 1 << 20 changes is byte 2 of the little-endian field
+            if (p < 2 || p + 6 > n) { s[0].bytes.clear(); return std::move(s[0]); }                   // (not a stampable block)
             const size_t o = p - 2;
             uint64_t v0, v1;
             memcpy(&v0, s[0].bytes.data() + o, 8);
             memcpy(&v1, s[1].bytes.data() + o, 8);
-            if (p < 2 || o + 8 > n || v1 - v0 != (1ull << 20)) { s[0].bytes.clear(); return s[0]; }   // (not a stampable block)
+            if (v1 - v0 != (1ull << 20)) { s[0].bytes.clear(); return std::move(s[0]); }
             v0 -= at[0];
             memcpy(s[0].bytes.data() + o, &v0, 8);
             s[0].patches.push_back((uint32_t)o);

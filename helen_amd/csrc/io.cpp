@@ -1169,6 +1169,12 @@ void* helen_io_writer_open(const char* path) {
             delete w;
             return nullptr;
         }
+        if (window_stamp().bytes.empty() || window_stamp().marks.size() != 6) {     // (never: the block's layout is fixed)
+            fail("internal: the window block of a prediction file is not stampable");
+            delete w->fast;
+            delete w;
+            return nullptr;
+        }
         int helpers = 1;
         if (const char* t = getenv("HELEN_IO_WRITER_THREADS")) helpers = std::max(0, std::min(15, atoi(t) - 1));
         w->pool = new FillPool(helpers);
