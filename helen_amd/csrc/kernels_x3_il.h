@@ -137,7 +137,6 @@ __global__ __launch_bounds__(512, 1) void gru_x3_il_kernel(
     f32x4 Pr[2], Pz[2], Pn[2];
 #pragma unroll
     for (int x = 0; x < 2; ++x) Pr[x] = Pz[x] = Pn[x] = splat4(0.f);
-    int stores_before = 0;          // VMEM stores this wave issued at the end of the previous region (behind its gi DMAs)
     auto gi_slot = [&](int x) __attribute__((always_inline)) { return smem + x * kPerTile + kGi + v * 192; };
     auto dma_gi = [&](int x, int s_) __attribute__((always_inline)) {      // the three gate fragments of tile x's step s_
         const f32x4* p = gi_p[x] + (size_t)s_ * kPosStride + lane;
@@ -161,12 +160,9 @@ __global__ __launch_bounds__(512, 1) void gru_x3_il_kernel(
         const bool has_prev = steady || s > 0;
         const bool has_prev2 = steady || s > 1;
         f32x4* const base = smem + x * kPerTile;
-        // the gi fragments of tile o's pending step were loaded a region ago, in front of that region's stores
-        if (gates) {
-            if (stores_before == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (stores_before == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        }
+        // the gi fragments of tile o's pending step were DMA'd a region ago (behind that region's output stores: nothing
+        // younger is in the VMEM queue)
+        if (gates) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const f32x4 gr = Pr[o], gz = Pz[o], gnn = Pn[o];
         f32x4 ir = splat4(0.f), iz = splat4(0.f), in_ = splat4(0.f);
         if (gates) {
@@ -174,6 +170,19 @@ __global__ __launch_bounds__(512, 1) void gru_x3_il_kernel(
             ir = gs[0];
             iz = gs[64];
             in_ = gs[128];
+        }
+        // What leaves the workgroup in this region goes FIRST, while the other wave of the SIMD multiplies -- at the end of
+        // the region it would be eight waves' wait at the barrier (the no-barrier timing build: decoder 0.44 -> 0.35 ms).
+        if (!DEC && has_prev) {              // the planes of h_x(s-1) = the layer output of slot s-1: 768 units of 16 B
+            const f32x4* ps = base + cur * 768;
+            f32x4* po = (f32x4*)y_next[x];
+            po[in_block((unsigned)tid)] = ps[tid];
+            if (tid < 256) po[512 + in_block((unsigned)tid)] = ps[512 + tid];
+            y_next[x] += 2 * 768 * 16;
+        }
+        if (DEC && has_prev2) {              // slot s-2: its partials were parked in tile x's region of step s-1
+            if (v < 4) store_logits(x, s & 1, in_block((unsigned)tid * 4u));
+            y_next[x] += 128 * 16;
         }
         dma_gi(x, s);               // this tile's gi of step s, for the gates one region on
         f32x4 ar = splat4(0.f), az = splat4(0.f), ahn = splat4(bn), pl = splat4(0.f);
@@ -259,9 +268,10 @@ __global__ __launch_bounds__(512, 1) void gru_x3_il_kernel(
                 constexpr int c = 2 * (k - 56);
                 b3[c] = bf16_bits(r2[c]);
                 b3[c + 1] = bf16_bits(r2[c + 1]);
-            } else {                                      // the new h becomes the carried state
+            } else {                                      // the new h becomes the carried state; its three planes -> LDS
                 constexpr int c = k - 58;
                 hprev[o][c] = hn[c];
+                store_planes(o, ow, c, b1[c], b2[c], b3[c]);
             }
         };
         auto mfma_item = [&](auto I) __attribute__((always_inline)) {
@@ -291,6 +301,8 @@ __global__ __launch_bounds__(512, 1) void gru_x3_il_kernel(
                     HELEN_PIN(pl);
                 }
             }
+            if constexpr (w18 == 15)                      // the head slice (issued at w18 == 3) is done: parked, read one region of this tile later
+                if (DEC && has_prev && M == Mv) (base + kPart + (((s - 1) & 1) * 8 + v) * 64)[lane] = pl;
             if constexpr (w18 == 6)                       // plane 1: behind it (M + 1, 0), (M + 1, 2)
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(M < 3 ? 2 : 0) : "memory");
             const bf16x8 a_cur = aq[TA[kk] == 0 ? slot0 : TA[kk]];
@@ -310,33 +322,9 @@ __global__ __launch_bounds__(512, 1) void gru_x3_il_kernel(
             if constexpr (i < NS) gate_slot(I);
         });
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (gates) {               // the three planes of tile o's new h -> LDS
-#pragma unroll
-            for (int r = 0; r < 4; ++r) store_planes(o, ow, r, b1[r], b2[r], b3[r]);
-        }
         Pr[x] = ar;
         Pz[x] = az;
         Pn[x] = ahn;
-        int issued = 0;
-        if (!DEC && has_prev) {              // the planes of h_x(s-1) = the layer output of slot s-1: 768 units of 16 B
-            const f32x4* ps = base + cur * 768;
-            f32x4* po = (f32x4*)y_next[x];
-            po[in_block((unsigned)tid)] = ps[tid];
-            if (tid < 256) po[512 + in_block((unsigned)tid)] = ps[512 + tid];
-            y_next[x] += 2 * 768 * 16;
-            issued = v < 4 ? 2 : 1;
-        }
-        if (DEC) {
-            if (has_prev) (base + kPart + (((s - 1) & 1) * 8 + v) * 64)[lane] = pl;   // parked: read one region of this tile later
-            if (has_prev2) {                 // slot s-2: its partials were parked in tile x's region of step s-1
-                if (v < 4) {
-                    store_logits(x, s & 1, in_block((unsigned)tid * 4u));
-                    issued = 1;
-                }
-                y_next[x] += 128 * 16;
-            }
-        }
-        stores_before = issued;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
