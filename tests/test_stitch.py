@@ -431,7 +431,8 @@ def test_exact_overlap_shortcut_equals_the_reference_library():
     """helen_ssw_align answers a pair whose longest common SUBSEQUENCE is a common SUBSTRING without running the three
     passes (helen_amd/csrc/ssw.cpp: exact_overlap), and one whose forward pass ends on an exact run of score / match bases
     without the other two.  Every such answer -- score, begin / end cells, CIGAR, mismatch count
-    -- must be the reference library's own: 200,000 pairs on which the shortcut fires (stitch-shaped joins and pairs built
+    -- must be the reference library's own: 120,000 pairs on which a shortcut fires ($HELEN_TEST_SHORTCUT_PAIRS
+    sets another number; the round's record run over 200,000: profiles/r06_ssw_shortcut_200k.txt) (stitch-shaped joins and pairs built
     against its argument), each also run with the shortcut off."""
     ref = ctypes.CDLL(REF_SSW)
     lib = native_io.load()
@@ -440,7 +441,8 @@ def test_exact_overlap_shortcut_equals_the_reference_library():
     after_forward0 = lib.helen_ssw_fast_path_after_forward()
     before = native_io.ssw_fast_path(True)
     try:
-        while fired < 200000 and tried < 1200000:
+        want = int(os.environ.get("HELEN_TEST_SHORTCUT_PAIRS", "120000"))
+        while fired < want and tried < 8 * want:
             r, q = _shortcut_cases(rng)
             if not r or not q:
                 continue
@@ -460,11 +462,11 @@ def test_exact_overlap_shortcut_equals_the_reference_library():
                 assert slow == got, (r, q, slow, got)
     finally:
         native_io.ssw_fast_path(before)
-    assert fired >= 200000, (fired, tried)
+    assert fired >= want, (fired, tried)
     second = lib.helen_ssw_fast_path_after_forward() - after_forward0
     print("exact-overlap shortcuts: %d of %d pairs answered by them (%d only after the forward pass), all equal to the reference "
           "library" % (fired, tried, second))
-    assert second > 5000 and fired - second > 50000          # both shortcuts are exercised
+    assert second > 5000 and fired - second > 30000          # both shortcuts are exercised
 
 
 @pytest.mark.skipif(not os.path.exists(REF_SSW), reason="oracle/_ref/libssw_ref.so not built (make -C oracle ref)")
@@ -475,7 +477,7 @@ def test_exact_overlap_shortcut_with_other_penalties(penalties):
     lib = native_io.load()
     rng = random.Random(sum(penalties) * 7919)
     fired = 0
-    for _ in range(60000):
+    for _ in range(30000):
         r, q = _shortcut_cases(rng)
         if not r or not q:
             continue
@@ -484,4 +486,4 @@ def test_exact_overlap_shortcut_with_other_penalties(penalties):
         if native_io.ssw_fast_path_counts()[0] != h0:
             fired += 1
             assert got == _ref_align(ref, r.encode(), q.encode(), penalties), (penalties, r, q)
-    assert fired > 10000
+    assert fired > 5000
