@@ -441,8 +441,8 @@ def test_exact_overlap_shortcut_equals_the_reference_library():
     after_forward0 = lib.helen_ssw_fast_path_after_forward()
     before = native_io.ssw_fast_path(True)
     try:
-        want = int(os.environ.get("HELEN_TEST_SHORTCUT_PAIRS", "120000"))
-        while fired < want and tried < 8 * want:
+        target = int(os.environ.get("HELEN_TEST_SHORTCUT_PAIRS", "120000"))
+        while fired < target and tried < 8 * target:
             r, q = _shortcut_cases(rng)
             if not r or not q:
                 continue
@@ -462,7 +462,7 @@ def test_exact_overlap_shortcut_equals_the_reference_library():
                 assert slow == got, (r, q, slow, got)
     finally:
         native_io.ssw_fast_path(before)
-    assert fired >= want, (fired, tried)
+    assert fired >= target, (fired, tried)
     second = lib.helen_ssw_fast_path_after_forward() - after_forward0
     print("exact-overlap shortcuts: %d of %d pairs answered by them (%d only after the forward pass), all equal to the reference "
           "library" % (fired, tried, second))
