@@ -560,7 +560,7 @@ def plan_only(args, rank, world):
     out = {"plan_only": True, "n_gpus": world, "rank": rank, "steps": args.steps, "warmup": args.warmup,
            "windows_per_step": args.batch * args.coalesce, "precision": args.precision,
            "legs": {"cpu_baseline": not args.no_cpu_baseline and world == 1, "host_path": not args.no_host_path,
-                    "modes": not args.no_modes and args.precision == "fp32", "margins": not args.no_margins,
+                    "modes": not args.no_modes and args.precision == "fp32" and world == 1, "margins": not args.no_margins,
                     "end_to_end": e2e_windows > 0},
            "devices": "cuda:0 for every rank (--single-device)" if args.single_device else "cuda:LOCAL_RANK"}
     if e2e_windows > 0:
