@@ -62,9 +62,16 @@ __global__ __launch_bounds__(512, 1) void gru_x3_il_kernel(
     }
     const float bn = bhn[dir * kH + u];
     // decoder: the head weights of K32 group Mv = v & 3 in three bf16 terms (gru_x3_kernel): waves v and v + 4 share the
-    // group, v < 4 takes the three small products, v >= 4 the three large ones
+    // group, v < 4 takes the three small products (h1 w3, h3 w1, h2 w2), v >= 4 the three large ones (h1 w2, h2 w1, h1 w1).
+    // Which plane of h and which term of the weights a product takes are per-wave BYTE OFFSETS, not branches: a branch
+    // inside a region splits its one basic block, and the compiler then sinks the gate math out of its slots into the
+    // block that stores the result (the round-6 build of this kernel had 34 + 9 + 54 VALU instructions in three lumps
+    // between its MFMAs instead of one or two behind each: profiles/r06_region_anatomy.txt).
     const int Mv = v & 3;
     bf16x8* const bh_lds = (bf16x8*)(smem + 2 * kPerTile) + v * 192 + lane;     // (DEC) this wave's Bh3[t] at [t * 64]
+    const unsigned head_a[3] = {(unsigned)(0 * 256 + Mv * 64) * 16u, (unsigned)((v < 4 ? 2 : 1) * 256 + Mv * 64) * 16u,
+                                (unsigned)((v < 4 ? 1 : 0) * 256 + Mv * 64) * 16u};
+    const unsigned head_b[3] = {(unsigned)((v < 4 ? 2 : 1) * 64) * 16u, 0u, (unsigned)((v < 4 ? 1 : 0) * 64) * 16u};
     if (DEC) {
         bf16x8 Bh3[3];
         const f32x4* ws = Whd + (size_t)(dir * 8 + 2 * Mv + (q >> 1)) * 64 + (2 * (q & 1)) * 16 + j;
@@ -160,8 +167,9 @@ __global__ __launch_bounds__(512, 1) void gru_x3_il_kernel(
         const bool has_prev = steady || s > 0;
         const bool has_prev2 = steady || s > 1;
         f32x4* const base = smem + x * kPerTile;
-        // the gi fragments of tile o's pending step were DMA'd a region ago (behind that region's output stores: nothing
-        // younger is in the VMEM queue)
+        // the gi fragments of tile o's pending step were DMA'd a region ago.  (vmcnt(0), not a counted wait: the one younger
+        // entry a decoder wave may have in the VMEM queue is the logit store of the last region's end, and loads and stores
+        // do not retire in order with each other; that store has had the wait at the barrier to complete.)
         if (gates) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const f32x4 gr = Pr[o], gz = Pz[o], gnn = Pn[o];
         f32x4 ir = splat4(0.f), iz = splat4(0.f), in_ = splat4(0.f);
@@ -171,18 +179,13 @@ __global__ __launch_bounds__(512, 1) void gru_x3_il_kernel(
             iz = gs[64];
             in_ = gs[128];
         }
-        // What leaves the workgroup in this region goes FIRST, while the other wave of the SIMD multiplies -- at the end of
-        // the region it would be eight waves' wait at the barrier (the no-barrier timing build: decoder 0.44 -> 0.35 ms).
+        // The encoder's layer output leaves at the region's start (every wave has a share of it).
         if (!DEC && has_prev) {              // the planes of h_x(s-1) = the layer output of slot s-1: 768 units of 16 B
             const f32x4* ps = base + cur * 768;
             f32x4* po = (f32x4*)y_next[x];
             po[in_block((unsigned)tid)] = ps[tid];
             if (tid < 256) po[512 + in_block((unsigned)tid)] = ps[512 + tid];
             y_next[x] += 2 * 768 * 16;
-        }
-        if (DEC && has_prev2) {              // slot s-2: its partials were parked in tile x's region of step s-1
-            if (v < 4) store_logits(x, s & 1, in_block((unsigned)tid * 4u));
-            y_next[x] += 128 * 16;
         }
         dma_gi(x, s);               // this tile's gi of step s, for the gates one region on
         f32x4 ar = splat4(0.f), az = splat4(0.f), ahn = splat4(bn), pl = splat4(0.f);
@@ -284,25 +287,7 @@ __global__ __launch_bounds__(512, 1) void gru_x3_il_kernel(
             }
             if constexpr (w18 == 3) {                     // plane 2: behind it (M, 1), (M + 1, 0)
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(M < 3 ? 2 : 1) : "memory");
-                if (DEC && has_prev && M == Mv) {         // the head slice of h_x(s-1), this wave's three products: while all three
-                                                          // planes of the group sit in their slots (plane 1 is waited for here)
-                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(M < 3 ? 1 : 0) : "memory");
-                    const bf16x8 a0 = aq[slot0], a1 = aq[1], a2 = aq[2];
-                    const bf16x8* bh = (const bf16x8*)bh_lds;
-                    if (v < 4) {             // smallest first: h1 w3, h3 w1, h2 w2
-                        pl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bh[128], splat4(0.f), 0, 0, 0);
-                        pl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bh[0], pl, 0, 0, 0);
-                        pl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bh[64], pl, 0, 0, 0);
-                    } else {                 // h1 w2, h2 w1, h1 w1
-                        pl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bh[64], splat4(0.f), 0, 0, 0);
-                        pl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bh[0], pl, 0, 0, 0);
-                        pl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bh[0], pl, 0, 0, 0);
-                    }
-                    HELEN_PIN(pl);
-                }
             }
-            if constexpr (w18 == 15)                      // the head slice (issued at w18 == 3) is done: parked, read one region of this tile later
-                if (DEC && has_prev && M == Mv) (base + kPart + (((s - 1) & 1) * 8 + v) * 64)[lane] = pl;
             if constexpr (w18 == 6)                       // plane 1: behind it (M + 1, 0), (M + 1, 2)
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(M < 3 ? 2 : 0) : "memory");
             const bf16x8 a_cur = aq[TA[kk] == 0 ? slot0 : TA[kk]];
@@ -313,18 +298,52 @@ __global__ __launch_bounds__(512, 1) void gru_x3_il_kernel(
             if constexpr (w18 == 5) fetch(std::integral_constant<int, M + 1>{}, T2{});      // product 1 done: slot 2 is free
             if constexpr (w18 == 14) fetch(std::integral_constant<int, M + 1>{}, T1{});     // product 4 done: slot 1 is free
         };
+        // (DEC) the head slice of h_x(s-1): this wave's three products on the planes of its K32 group.  The six fragments
+        // are fetched behind MFMA 60 -- the last counted wait of the stream is in front of it, the gate slots are through
+        // and their registers free -- and multiplied behind the last MFMA of the region.
+        bf16x8 ha[3], hb[3];
+        auto head_fetch = [&]() __attribute__((always_inline)) {
+            const unsigned bh0 = lds0 + (unsigned)((2 * kPerTile) * 16) + (unsigned)(v * 192 * 16) + lane16;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                f32x4 ta, tb;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(ta) : "v"(pa_lds + head_a[k]));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(tb) : "v"(bh0 + head_b[k]));
+                ha[k] = __builtin_bit_cast(bf16x8, ta);
+                hb[k] = __builtin_bit_cast(bf16x8, tb);
+            }
+        };
         constexpr int kLead = 2;             // gate slots in front of the first MFMA: they cover the LDS latency of group 0
         static_for<(NM + kLead > NS ? NM + kLead : NS)>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (i >= kLead && i - kLead < NM) mfma_item(std::integral_constant<int, (i >= kLead ? i - kLead : 0)>{});
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (DEC && i - kLead == 60) {
+                static_assert(60 + kLead >= NS, "the gate slots must be through when the head's fragments take their registers");
+                if (has_prev) head_fetch();
+            }
             if constexpr (i < NS) gate_slot(I);
         });
         __builtin_amdgcn_sched_barrier(0);
+        if (DEC && has_prev) {
+            // (the six fragments are operands of the wait: an MFMA that reads one cannot be scheduled in front of it)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ha[0]), "+v"(ha[1]), "+v"(ha[2]), "+v"(hb[0]), "+v"(hb[1]), "+v"(hb[2])::"memory");
+            pl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha[0], hb[0], splat4(0.f), 0, 0, 0);      // smallest first (gru_x3_kernel)
+            pl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha[1], hb[1], pl, 0, 0, 0);
+            pl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha[2], hb[2], pl, 0, 0, 0);
+            (base + kPart + (((s - 1) & 1) * 8 + v) * 64)[lane] = pl;     // parked; summed one region of this tile later
+        }
         Pr[x] = ar;
         Pz[x] = az;
         Pn[x] = ahn;
+        // The sum of slot s-2's eight partials (parked in tile x's region of step s-1) leaves from waves 0-3: the OLDER
+        // wave of each SIMD is through its stream ~1,000 cycles before the younger one and would only wait at the barrier.
+        if (DEC && has_prev2) {
+            if (v < 4) store_logits(x, s & 1, in_block((unsigned)tid * 4u));
+            y_next[x] += 128 * 16;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
