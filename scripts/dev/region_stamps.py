@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""Developer probe (GPU box): where a region of gru_x3_il_kernel goes, per wave.  Needs a library built from a copy of csrc
-patched with s_memtime stamps (build/lib_stamps.so: t0 after the barrier, t1 after the wait for the gi DMA, t2 after the
-slot stream, t3 after the LDS drain, next t0 = after the barrier) and exporting helen_debug_x3.
+"""Developer probe (GPU box): where a region of the two-tile kernels (gru_x3_il_kernel, gru_fused_bf16_il_kernel) goes, per
+wave of workgroup 0.  Needs the stamped library scripts/dev/make_stamp_probe.py builds (build/lib_stamps.so).
     HELEN_HIP_LIB=$PWD/build/lib_stamps.so python scripts/dev/region_stamps.py [windows=4096] [fp32x3|bf16]"""
 import ctypes
 import os
@@ -45,7 +44,8 @@ def main():
             s = a[dec, d]
             base = int(s[:, 0, 0].min())
             print("%s dir %d, workgroup 0, last steady iteration (cycles of s_memtime; region order r0 r1 r2 r3):" % ("decoder" if dec else "encoder", d))
-            print("  wave | per region: start(after barrier, rel.)  gi-wait  stream  lds-drain  barrier-wait")
+            print("  wave | per region: start (after the barrier, relative)  %s  LDS drain  wait at the barrier"
+                  % ("gi wait  slot stream + tail" if precision == "fp32x3" else "slot stream  h stores + outbound + VMEM wait"))
             for v in range(8):
                 parts = []
                 for r in range(4):
