@@ -87,9 +87,38 @@ def patch_bf16(s):
     return s
 
 
+def patch_pair(s):
+    s = sub(s, "template <bool DEC>\n", "__device__ unsigned long long helen_dbg_pair[2][2][8][16];\n"
+            "__device__ unsigned long long helen_dbg_pairf[2][2][8][16];\ntemplate <bool DEC>\n", "pair globals")
+    s = sub(s, "    auto half_step = [&](auto X, auto CUR, auto STEADY, int s) __attribute__((always_inline)) {\n",
+            "    unsigned long long st[16], sf[16];\n#pragma unroll\n    for (int k = 0; k < 16; ++k) st[k] = sf[k] = 0;\n"
+            "    auto half_step = [&](auto X, auto CUR, auto STEADY, int s) __attribute__((always_inline)) {\n", "pair arrays")
+    s = sub(s, "        const f32x4* hb = hx + slane;\n",
+            "        const f32x4* hb = hx + slane;\n        constexpr int ri = cur * 2 + x;\n"
+            "        if constexpr (steady) st[ri * 4 + 0] = __builtin_amdgcn_s_memtime();\n", "pair start")
+    s = sub(s, "            __builtin_amdgcn_sched_barrier(0);\n#pragma unroll\n            for (int e = 0; e < 2; ++e)\n",
+            "            __builtin_amdgcn_sched_barrier(0);\n            if (steady && ri == 0) sf[m] = __builtin_amdgcn_s_memtime();\n"
+            "#pragma unroll\n            for (int e = 0; e < 2; ++e)\n", "pair groups")
+    s = sub(s, "        if (DEC && has_prev2) {\n            if (v == ((s - 2) & 3))",
+            "        if constexpr (steady) st[ri * 4 + 1] = __builtin_amdgcn_s_memtime();\n"
+            "        if (DEC && has_prev2) {\n            if (v == ((s - 2) & 3))", "pair M end")
+    s = sub(s, "        asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n        __builtin_amdgcn_s_barrier();\n        asm volatile(\"\" ::: \"memory\");\n        a_pref",
+            "        asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
+            "        if constexpr (steady) { st[ri * 4 + 2] = __builtin_amdgcn_s_memtime(); asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\"); }\n"
+            "        __builtin_amdgcn_s_barrier();\n        asm volatile(\"\" ::: \"memory\");\n"
+            "        if constexpr (steady) { st[ri * 4 + 3] = __builtin_amdgcn_s_memtime(); asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\"); }\n"
+            "        a_pref", "pair barrier")
+    s = sub(s, "    for (; s < T; ++s) step(No{}, s);                     // the last one or two steps: no step s+1 to feed\n",
+            "    for (; s < T; ++s) step(No{}, s);                     // the last one or two steps: no step s+1 to feed\n"
+            "    if (pair_index == 0 && lane == 0) {\n#pragma unroll\n        for (int k = 0; k < 16; ++k) {\n"
+            "            helen_dbg_pair[DEC][dir][v][k] = st[k];\n            helen_dbg_pairf[DEC][dir][v][k] = sf[k];\n        }\n    }\n",
+            "pair write-out")
+    return s
+
+
 def patch_api(s):
     fn = ""
-    for name in ("x3", "x3f", "bf16", "bf16f"):
+    for name in ("x3", "x3f", "bf16", "bf16f", "pair", "pairf"):
         fn += ("__attribute__((visibility(\"default\"))) int helen_debug_%s(unsigned long long* out) { return (int)hipMemcpyFromSymbol("
                "out, HIP_SYMBOL(helen::helen_dbg_%s), sizeof(unsigned long long) * 2 * 2 * 8 * 16); }\n" % (name, name))
     return sub(s, "const char* helen_last_error(void) { return g_err; }\n", "const char* helen_last_error(void) { return g_err; }\n" + fn, "api")
@@ -101,7 +130,8 @@ def main():
     os.makedirs(os.path.dirname(DST))
     shutil.copytree(SRC, DST, ignore=shutil.ignore_patterns("*.so"))
     shutil.copytree(os.path.join(ROOT, "include"), os.path.join(ROOT, "build", "probe", "include"))
-    for name, fn in (("kernels_x3_il.h", patch_x3), ("kernels_fused_bf16_il.h", patch_bf16), ("api.hip", patch_api)):
+    for name, fn in (("kernels_x3_il.h", patch_x3), ("kernels_fused_bf16_il.h", patch_bf16), ("kernels_gru_pair.h", patch_pair),
+                     ("api.hip", patch_api)):
         path = os.path.join(DST, name)
         with open(path) as f:
             text = f.read()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer probe (GPU box): where a region of the two-tile kernels (gru_x3_il_kernel, gru_fused_bf16_il_kernel) goes, per
 wave of workgroup 0.  Needs the stamped library scripts/dev/make_stamp_probe.py builds (build/lib_stamps.so).
-    HELEN_HIP_LIB=$PWD/build/lib_stamps.so python scripts/dev/region_stamps.py [windows=4096] [fp32x3|bf16]"""
+    HELEN_HIP_LIB=$PWD/build/lib_stamps.so python scripts/dev/region_stamps.py [windows=4096] [fp32x3|bf16|fp32]"""
 import ctypes
 import os
 import sys
@@ -36,6 +36,30 @@ def main():
     print(precision + " %d windows: %.2f ms per call = %.0f windows/s; gru_enc %.4f ms, gru_dec %.4f ms per launch"
           % (n, dt * 1e3, n / dt, st["gru_enc"][0] / st["gru_enc"][1], st["gru_dec"][0] / st["gru_dec"][1]))
     buf = (ctypes.c_ulonglong * (2 * 2 * 8 * 16))()
+    if precision == "fp32":
+        # gru_pair_kernel: a half-step = M phase of one tile (96 fp32 MFMAs per wave) | barrier | that tile's gate math.
+        # [0] half-step start, [1] after the M phase, [2] in front of the barrier, [3] behind it; sf[m] in front of K16 group m
+        lib.helen_debug_pair(buf)
+        a = torch.tensor(list(buf), dtype=torch.int64).reshape(2, 2, 8, 4, 4)
+        lib.helen_debug_pairf(buf)
+        f = torch.tensor(list(buf), dtype=torch.int64).reshape(2, 2, 8, 16)
+        for dec in (0, 1):
+            s = a[dec, 0]
+            base = int(s[:, 0, 0].min())
+            print("%s dir 0, workgroup 0, last steady trip: per half-step  start (relative)  M phase  sums + LDS drain  wait at the barrier  gates (to the next start)"
+                  % ("decoder" if dec else "encoder"))
+            for v in range(8):
+                parts = []
+                for r in range(4):
+                    t = [int(z) for z in s[v, r]]
+                    nxt = int(s[v, r + 1, 0]) if r < 3 else None
+                    parts.append("%6d %5d %4d %5d %5s" % (t[0] - base, t[1] - t[0], t[2] - t[1], t[3] - t[2], "-" if nxt is None else str(nxt - t[3])))
+                print("  %d    | %s" % (v, " | ".join(parts)))
+            print("%s dir 0, half-step r0: start -> group 0 | cycles per K16 group (12 MFMAs each) | last group -> M end" % ("decoder" if dec else "encoder"))
+            for v in range(8):
+                t = [int(z) for z in f[dec, 0, v]]
+                print("  %d    | %4d | %s | %4d" % (v, t[0] - int(s[v, 0, 0]), " ".join("%4d" % (t[k + 1] - t[k]) for k in range(7)), int(s[v, 0, 1]) - t[7]))
+        return
     rc = (lib.helen_debug_x3 if precision == "fp32x3" else lib.helen_debug_bf16)(buf)
     print(precision, "stamps rc", rc)
     a = torch.tensor(list(buf), dtype=torch.int64).reshape(2, 2, 8, 4, 4)      # [dec][dir][wave][region][stamp]
