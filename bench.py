@@ -49,6 +49,97 @@ FP32_MFMA_PEAK = 157.3e12             # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_
 BF16_MFMA_PEAK = 2.5e15               # MI355X_MICROARCH.md: bf16 MFMA, dense
 
 
+NOMINAL_SCLK_MHZ = 2400.0             # MI355X_MICROARCH.md: the clock the MFMA peaks are quoted at
+
+
+def _amdgpu_hwmon():
+    """[(PCI address, hwmon directory)] of every amdgpu card that publishes its shader clock and socket power."""
+    import glob
+    out = []
+    for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+        if os.path.exists(h + "/freq1_input") and os.path.exists(h + "/power1_input"):
+            out.append((os.path.basename(os.path.realpath(os.path.dirname(os.path.dirname(h)))), h))
+    return out
+
+
+def sustained_clock(run, dev, seconds=1.5):
+    """Shader clock and socket power while `run(4)` repeats for `seconds`, read from the amdgpu hwmon files by a side thread
+    every 10 ms (OUTSIDE every timed region).  The bf16-pipe modes sit at the part's power cap and run at a lower clock than
+    the 2.4 GHz their peaks are quoted at (profiles/r06_clock_power.txt): the roofline fractions stay against the nominal
+    peaks, this says what the device sustained under this very load.  Never raises: a box without the files says so."""
+    import threading
+    try:
+        import torch
+        cards = _amdgpu_hwmon()
+        if not cards:
+            return {"error": "no amdgpu hwmon freq1_input / power1_input under /sys/class/drm"}
+        props = torch.cuda.get_device_properties(dev)
+        want = None
+        if hasattr(props, "pci_bus_id"):
+            want = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, getattr(props, "pci_device_id", 0))
+        pick = [c for c in cards if c[0] == want] or cards
+        seen = {c[0]: [] for c in pick}
+        stop = threading.Event()
+
+        def watch():
+            while not stop.is_set():
+                for pci, h in pick:
+                    try:
+                        with open(h + "/freq1_input") as f:
+                            mhz = int(f.read()) / 1e6
+                        with open(h + "/power1_input") as f:
+                            watt = int(f.read()) / 1e6
+                        seen[pci].append((time.perf_counter(), mhz, watt))
+                    except (OSError, ValueError):
+                        pass
+                time.sleep(0.01)
+
+        th = threading.Thread(target=watch, daemon=True)
+        run(4)
+        torch.cuda.synchronize(dev)
+        th.start()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            run(4)
+            torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        stop.set()
+        th.join(timeout=2.0)
+        # the card under this load = the one asked for by PCI address, else the one drawing the most power meanwhile
+        best, rows = None, []
+        for pci, vals in seen.items():
+            vals = [v for v in vals if t0 + 0.3 <= v[0] <= t1]
+            if vals and (best is None or sum(v[2] for v in vals) / len(vals) > sum(v[2] for v in rows) / len(rows)):
+                best, rows = pci, vals
+        if not rows:
+            return {"error": "no readable samples"}
+        mhz = sorted(v[1] for v in rows)[len(rows) // 2]
+        watt = sorted(v[2] for v in rows)[len(rows) // 2]
+        cap = None
+        try:
+            with open(dict(pick)[best] + "/power1_cap") as f:
+                cap = int(f.read()) / 1e6
+        except (OSError, ValueError):
+            pass
+        return {"sclk_mhz": round(mhz, 0), "socket_power_w": round(watt, 0), "power_cap_w": cap, "nominal_mhz": NOMINAL_SCLK_MHZ,
+                "samples": len(rows), "seconds": round(t1 - t0, 2), "card": best,
+                "matched_by": "PCI address" if want is not None and best == want else "highest power draw",
+                "source": "amdgpu hwmon freq1_input (sclk) / power1_input (PPT), medians over back-to-back calls outside the timed region"}
+    except Exception as e:      # noqa: BLE001 -- a side report: it must not be able to take the bench line down
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def with_clock(roofline, clock):
+    """`roofline` + the clock report and the fractions read against the sustained clock instead of the nominal one."""
+    roofline["clock"] = clock
+    mhz = clock.get("sclk_mhz") if isinstance(clock, dict) else None
+    if mhz and roofline.get("bound") == "mfma":
+        roofline["frac_at_sustained_clock"] = round(roofline["frac"] * NOMINAL_SCLK_MHZ / mhz, 4)
+        if roofline.get("path_frac") is not None:
+            roofline["path_frac_at_sustained_clock"] = round(roofline["path_frac"] * NOMINAL_SCLK_MHZ / mhz, 4)
+    return roofline
+
+
 def pmc_traffic(windows_per_launch, precision="fp32"):
     """HBM bytes per recurrence launch from the committed rocprofv3 PMC summary of this same command
     (profiles/*_pmc_summary.json, FETCH_SIZE/WRITE_SIZE passes; see scripts/pmc_summary.py), scaled to this run's
@@ -438,6 +529,7 @@ def mode_report(precision, batch, coalesce, images, dev, fp32_labels, steps=8, w
         torch.cuda.synchronize(dev)
         all_stats = eng.kernel_stats()
         eng.set_profiling([])
+        clock = sustained_clock(run, dev)
         value = steps * call_windows / elapsed
         n_l = stats["gru_enc"][1] + stats["gru_dec"][1]
         avg_ms = (stats["gru_enc"][0] + stats["gru_dec"][0]) / max(n_l, 1)
@@ -468,6 +560,7 @@ def mode_report(precision, batch, coalesce, images, dev, fp32_labels, steps=8, w
                             "path_frac_of_fp32_mfma_peak": round(value * FLOP_PER_WINDOW / FP32_MFMA_PEAK, 4)},
                "label_identity": {"base": round(same_b, 6), "rle": round(same_r, 6), "windows": k,
                                   "against": "the fp32 path's labels of the same windows (the headline run above)"}}
+        with_clock(out["roofline"], clock)
         chk = precision_check(eng, precision, images, dev)
         out["max_abs_logit_diff"] = chk["max_abs_logit_diff"]
         out["max_abs_logit"] = chk["max_abs_logit"]
@@ -961,6 +1054,7 @@ def main():
     all_stats = eng.kernel_stats()
     eng.set_profiling([])
     my_elapsed = elapsed
+    clock = sustained_clock(run, dev) if world == 1 else None
 
     # host path: the same number of windows from page-locked host memory to labels in host memory, ONE
     # helen_polish_host call (it pipelines sub-batches of `call_windows`: upload k+1 | kernels k | download k-1)
@@ -1072,6 +1166,8 @@ def main():
                                             (BF16_MFMA_PEAK if args.precision == "bf16" else FP32_MFMA_PEAK), 4),
                          "kernels": kernel_table(all_stats, table_calls, call_windows, args.precision, my_elapsed * 1e3 / args.steps)},
         }
+        if clock is not None:
+            with_clock(out["roofline"], clock)
         if args.precision != "fp32":
             out["precision_check"] = precision_check(eng, args.precision, images, dev)
         if not args.no_margins:
