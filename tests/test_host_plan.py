@@ -356,3 +356,22 @@ def test_the_plan_prices_the_stitch_stage_of_polish():
     plain = host_plan.plan_host(list(range(8)), 8, 4096, usable=16, allowed=list(range(16)), shm_free=1 << 40,
                                 local_cpus=lookup)
     assert not any("STITCH" in n for n in plain.notes)
+
+
+def test_bench_clock_report_reads_hwmon_and_never_raises(tmp_path, monkeypatch):
+    """bench.py's `roofline.clock`: the fractions re-read at the sustained clock, and a box without the amdgpu hwmon files
+    (this container) reports that instead of taking the bench line down."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_clock", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    r = bench.with_clock({"bound": "mfma", "frac": 0.48, "path_frac": 0.54}, {"sclk_mhz": 1800.0, "socket_power_w": 1400.0})
+    assert r["frac_at_sustained_clock"] == round(0.48 * 2400 / 1800, 4) and r["path_frac_at_sustained_clock"] == round(0.54 * 2400 / 1800, 4)
+    r = bench.with_clock({"bound": "mfma", "frac": 0.48}, {"error": "no files"})
+    assert "frac_at_sustained_clock" not in r and r["clock"] == {"error": "no files"}
+    r = bench.with_clock({"bound": "hbm", "frac": 0.7}, {"sclk_mhz": 1800.0})
+    assert "frac_at_sustained_clock" not in r            # an HBM-bound fraction does not scale with the shader clock
+    calls = []
+    out = bench.sustained_clock(lambda n: calls.append(n), "cuda:0", seconds=0.05)
+    assert isinstance(out, dict) and ("error" in out or "sclk_mhz" in out)
