@@ -24,9 +24,13 @@ namespace helen {
 //   buffers), its carried fp32 state in registers; a wave's gi fragments are DMA'd into its own LDS slot one region ahead
 //   and read back when the gates need them; the decoder's head-weight fragments wait in LDS too (the register file holds
 //   W_hh, two tiles' accumulators and the gate math: 251 / 256 registers).
-//   Encoder launch: the planes of h_x(s-1) leave for gemm_dec_x3_kernel during region (x, s); decoder launch: the head
-//   slice of h_x(s-1) is three bf16 MFMAs on its planes at the wave's K32 group, parked in LDS, summed over the eight
-//   waves (in wave order) one region of the tile later.
+//   Encoder launch: the planes of h_x(s-1) leave for gemm_dec_x3_kernel at the start of region (x, s); decoder launch: the
+//   head slice of h_x(s-1) is three bf16 MFMAs on the planes of the wave's K32 group behind the region's last MFMA (their
+//   fragments fetched behind MFMA 60), parked in LDS, summed over the eight waves (in wave order) by waves 0-3 at the end of
+//   the tile's next region.
+//   NO run-time branch between the first and the last MFMA of a region: one splits the region's basic block, and the
+//   compiler then sinks the gate math out of its slots (sched_barrier binds the machine scheduler, not the IR passes) --
+//   profiles/r06_region_anatomy.txt.  The VALU-between-MFMAs histogram of the disassembly is the check.
 // grid (ceil(tiles / 2), 2 directions); an odd tile count makes the last workgroup walk its one tile twice.
 // ------------------------------------------------------------------------------------------------
 template <bool DEC>
