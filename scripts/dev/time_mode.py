@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Developer probe (GPU box): one precision mode's call time and recurrence launch times, for the library HELEN_HIP_LIB
+names (a timing build) or the tree's -- alternate the two on one box for an A/B (profiles/r06_bf16_head_out_ab.txt).
+    [HELEN_HIP_LIB=$PWD/build/lib_<variant>.so] python scripts/dev/time_mode.py fp32|fp32x3|bf16 <windows per call>"""
 import os, sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from helen_amd.engine import HelenEngine
 from helen_amd.weights import make_weights
 prec, n = sys.argv[1], int(sys.argv[2])
